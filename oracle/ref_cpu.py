@@ -1,0 +1,509 @@
+"""CPU oracle for the UnOpticalFlow ``--mode flow`` hot path.
+
+TEST INFRASTRUCTURE ONLY.  This module is the *checker* for the HIP product in
+``unopticalflow_amd``: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.  The product never routes
+through it (the product raises when its HIP library is missing).
+
+It restates, in plain torch-CPU ops and with this repo's own structure, the
+algorithm of the reference files (paths relative to the upstream repo):
+
+  core/networks/structures/net_utils.py:7-54      conv / deconv / warp_flow
+  core/networks/structures/feature_pyramid.py:8-36  FeaturePyramid
+  core/networks/structures/pwc_tf.py:17-179       PWC_tf (corr_naive, decoder, context)
+  core/networks/pytorch_ssim/ssim.py:4-20         SSIM
+  core/networks/model_flow_paper.py:15-255        Model_flow and its losses
+  core/config/config_utils.py:3-9                 loss weights
+  train.py:33-39,137-152                          one optimisation step
+
+Parity pin: ``tests/golden/*.npz`` were produced by importing the reference
+itself in the build container (``tools/gen_golden.py``); ``tests/test_oracle_*``
+checks every function here against them.  The arithmetic bottoms out in
+PyTorch ATen (pinned upstream at torch==1.2.0, here torch 2.10): the
+``align_corners`` switch reproduces both generations of ``grid_sample``
+(default False == the reference as imported under torch 2.10).
+"""
+from __future__ import annotations
+
+import math
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------
+# net_utils.py:7-14
+# ----------------------------------------------------------------------------
+
+def conv(in_planes, out_planes, kernel_size=3, stride=1, padding=1, dilation=1):
+    """Conv2d(bias) + LeakyReLU(0.1) -- net_utils.py:7-11."""
+    return nn.Sequential(
+        nn.Conv2d(in_planes, out_planes, kernel_size, stride, padding, dilation, bias=True),
+        nn.LeakyReLU(0.1),
+    )
+
+
+def deconv(in_planes, out_planes, kernel_size=4, stride=2, padding=1):
+    """net_utils.py:13-14 (never called on the flow path)."""
+    return nn.ConvTranspose2d(in_planes, out_planes, kernel_size, stride, padding, bias=True)
+
+
+# ----------------------------------------------------------------------------
+# net_utils.py:16-54
+# ----------------------------------------------------------------------------
+
+def pixel_grid(B, H, W, device):
+    """The (x, y) index grid of net_utils.py:29-33, built on the tensor's device."""
+    xs = torch.arange(W, device=device, dtype=torch.float32).view(1, 1, 1, W).expand(B, 1, H, W)
+    ys = torch.arange(H, device=device, dtype=torch.float32).view(1, 1, H, 1).expand(B, 1, H, W)
+    return torch.cat((xs, ys), 1)
+
+
+def warp_flow(x, flow, use_mask=False, align_corners=False):
+    """Backward-warp ``x`` by ``flow`` -- net_utils.py:16-54.
+
+    v = grid + flow; g = 2*v/max(size-1,1) - 1; bilinear ``grid_sample`` with
+    zeros padding.  With ``use_mask`` a ones tensor is sampled the same way,
+    thresholded (<0.9999 -> 0, else 1) and multiplied in (net_utils.py:47-52).
+    """
+    B, C, H, W = x.shape
+    grid = pixel_grid(B, H, W, x.device)
+    if grid.shape != flow.shape:
+        raise ValueError('the shape of grid {0} is not equal to the shape of flow {1}.'.format(
+            grid.shape, flow.shape))
+    v = grid + flow
+    gx = 2.0 * v[:, 0] / max(W - 1, 1) - 1.0
+    gy = 2.0 * v[:, 1] / max(H - 1, 1) - 1.0
+    g = torch.stack((gx, gy), dim=3)
+    out = F.grid_sample(x, g, mode='bilinear', padding_mode='zeros', align_corners=align_corners)
+    if not use_mask:
+        return out
+    mask = F.grid_sample(torch.ones_like(x), g, mode='bilinear', padding_mode='zeros',
+                         align_corners=align_corners)
+    mask = (mask >= 0.9999).to(x.dtype)          # [<0.9999]=0 then [>0]=1
+    return out * mask
+
+
+def warp_mask(shape, flow, align_corners=False):
+    """The binary validity mask of net_utils.py:47-51 on its own ([B,1,H,W], 0/1)."""
+    B, C, H, W = shape
+    ones = torch.ones((B, 1, H, W), dtype=flow.dtype, device=flow.device)
+    grid = pixel_grid(B, H, W, flow.device)
+    v = grid + flow
+    gx = 2.0 * v[:, 0] / max(W - 1, 1) - 1.0
+    gy = 2.0 * v[:, 1] / max(H - 1, 1) - 1.0
+    m = F.grid_sample(ones, torch.stack((gx, gy), 3), mode='bilinear', padding_mode='zeros',
+                      align_corners=align_corners)
+    return (m >= 0.9999).to(torch.uint8)
+
+
+def warp_flow_np(x, flow, use_mask=False, align_corners=False):
+    """Elementwise numpy restatement of ``warp_flow`` (fp32, ATen CPU op order).
+
+    Spells out what ``grid_sample(bilinear, zeros)`` does at the call sites
+    net_utils.py:46,49 so the HIP kernel has a formula to follow:
+      unnormalise  ix = fma(g+1, W/2, -0.5)        (align_corners=False; ATen's CPU
+                                                    kernel contracts the mul+sub, measured)
+                   ix = (g+1)*((W-1)/2)            (align_corners=True)
+      x0 = floor(ix); w = ix-x0; e = 1-w; n = iy-y0; s = 1-n
+      taps nw=s*e ne=s*w sw=n*e se=n*w ; out-of-range taps contribute 0
+      mask = ((nw'+ne')+sw')+se' thresholded at 0.9999
+    Returns (out, mask_u8[B,1,H,W]).
+    """
+    x = np.asarray(x, np.float32)
+    flow = np.asarray(flow, np.float32)
+    B, C, H, W = x.shape
+    f32 = np.float32
+    xs = np.arange(W, dtype=f32)[None, None, :]
+    ys = np.arange(H, dtype=f32)[None, :, None]
+    vx = (xs + flow[:, 0]).astype(f32)
+    vy = (ys + flow[:, 1]).astype(f32)
+    gx = ((f32(2.0) * vx) / f32(max(W - 1, 1)) - f32(1.0)).astype(f32)
+    gy = ((f32(2.0) * vy) / f32(max(H - 1, 1)) - f32(1.0)).astype(f32)
+    if align_corners:
+        ix = ((gx + f32(1)) * f32((W - 1) / 2.0)).astype(f32)
+        iy = ((gy + f32(1)) * f32((H - 1) / 2.0)).astype(f32)
+    else:
+        # single-rounding fma: the fp32 product is exact in fp64
+        ix = ((gx + f32(1)).astype(np.float64) * (W / 2.0) - 0.5).astype(f32)
+        iy = ((gy + f32(1)).astype(np.float64) * (H / 2.0) - 0.5).astype(f32)
+    x0 = np.floor(ix)
+    y0 = np.floor(iy)
+    w = (ix - x0).astype(f32)
+    e = (f32(1) - w).astype(f32)
+    n = (iy - y0).astype(f32)
+    s = (f32(1) - n).astype(f32)
+    taps = ((s * e, 0, 0), (s * w, 0, 1), (n * e, 1, 0), (n * w, 1, 1))
+    out = np.zeros_like(x)
+    msum = np.zeros((B, H, W), f32)
+    bidx = np.arange(B)[:, None, None]
+    for wt, dy, dx in taps:
+        xi = x0 + dx
+        yi = y0 + dy
+        ok = (xi >= 0) & (xi <= W - 1) & (yi >= 0) & (yi <= H - 1)
+        xc = np.clip(xi, 0, W - 1).astype(np.int64)
+        yc = np.clip(yi, 0, H - 1).astype(np.int64)
+        wt0 = np.where(ok, wt, f32(0)).astype(f32)
+        vals = x[bidx, :, yc, xc]                     # [B,H,W,C]
+        out += (np.moveaxis(vals, 3, 1) * wt0[:, None]).astype(f32)
+        msum = (msum + wt0).astype(f32)
+    mask = (msum >= f32(0.9999))
+    if use_mask:
+        out = out * mask[:, None].astype(f32)
+    return out, mask[:, None].astype(np.uint8)
+
+
+# ----------------------------------------------------------------------------
+# pytorch_ssim/ssim.py:4-20
+# ----------------------------------------------------------------------------
+
+def SSIM(x, y):
+    """3x3 zero-padded mean-filter SSIM map, C1=0.01^2, C2=0.03^2 -- ssim.py:4-20."""
+    C1 = 0.01 ** 2
+    C2 = 0.03 ** 2
+    box = lambda t: F.avg_pool2d(t, 3, 1, padding=1)      # divisor 9 everywhere
+    mu_x, mu_y = box(x), box(y)
+    sigma_x = box(x ** 2) - mu_x ** 2
+    sigma_y = box(y ** 2) - mu_y ** 2
+    sigma_xy = box(x * y) - mu_x * mu_y
+    num = (2 * mu_x * mu_y + C1) * (2 * sigma_xy + C2)
+    den = (mu_x ** 2 + mu_y ** 2 + C1) * (sigma_x + sigma_y + C2)
+    return num / den
+
+
+# ----------------------------------------------------------------------------
+# feature_pyramid.py:8-36
+# ----------------------------------------------------------------------------
+
+PYRAMID_CHANNELS = (16, 32, 64, 96, 128, 196)
+
+
+class FeaturePyramid(nn.Module):
+    """Six (stride-2 conv, stride-1 conv) stages -- feature_pyramid.py:10-21,29-36."""
+
+    def __init__(self):
+        super().__init__()
+        cin = 3
+        for lvl, cout in enumerate(PYRAMID_CHANNELS):
+            setattr(self, 'conv%d' % (2 * lvl + 1), conv(cin, cout, 3, 2))
+            setattr(self, 'conv%d' % (2 * lvl + 2), conv(cout, cout, 3, 1))
+            cin = cout
+
+    def forward(self, img):
+        feats, t = [], img
+        for lvl in range(6):
+            t = getattr(self, 'conv%d' % (2 * lvl + 1))(t)
+            t = getattr(self, 'conv%d' % (2 * lvl + 2))(t)
+            feats.append(t)
+        return tuple(feats)
+
+
+# ----------------------------------------------------------------------------
+# pwc_tf.py:17-179
+# ----------------------------------------------------------------------------
+
+DECODER_WIDTHS = (128, 128, 96, 64, 32)       # ``dd`` of pwc_tf.py:25 (non-cumulative)
+
+
+def corr_naive(f1, f2, d=4):
+    """Cost volume, pwc_tf.py:97-106.
+
+    out[b, i*(2d+1)+j, y, x] = mean_c f1[b,c,y,x] * f2pad[b,c,y+i,x+j] with f2
+    zero-padded by d; i walks rows (dy = i-d), j columns (dx = j-d).
+    """
+    assert f1.shape == f2.shape
+    H, W = f1.shape[2:4]
+    f2p = F.pad(f2, (d, d, d, d), value=0)
+    planes = []
+    for i in range(2 * d + 1):
+        for j in range(2 * d + 1):
+            planes.append((f1 * f2p[:, :, i:i + H, j:j + W]).mean(1, keepdim=True))
+    return torch.cat(planes, 1)
+
+
+class PWC_tf(nn.Module):
+    """Coarse-to-fine decoder, pwc_tf.py:17-179."""
+
+    def __init__(self, md=4, align_corners=False):
+        super().__init__()
+        self.corr = self.corr_naive                      # pwc_tf.py:19 plug point
+        self.leakyRELU = nn.LeakyReLU(0.1)
+        self.align_corners = align_corners
+        nd = (2 * md + 1) ** 2
+        dd = DECODER_WIDTHS
+        feat_ch = {6: 0, 5: 128, 4: 96, 3: 64, 2: 32}
+        for lvl in (6, 5, 4, 3, 2):
+            od = nd if lvl == 6 else nd + feat_ch[lvl] + 2
+            ins = (od, dd[0], dd[0] + dd[1], dd[1] + dd[2], dd[2] + dd[3])
+            for k in range(5):
+                setattr(self, 'conv%d_%d' % (lvl, k), conv(ins[k], dd[k], 3, 1))
+            setattr(self, 'predict_flow%d' % lvl, self.predict_flow(dd[3] + dd[4]))
+        ctx = ((dd[4] + 2, 128, 1), (128, 128, 2), (128, 128, 4), (128, 96, 8), (96, 64, 16), (64, 32, 1))
+        for k, (ci, co, dil) in enumerate(ctx):
+            setattr(self, 'dc_conv%d' % (k + 1), conv(ci, co, 3, 1, padding=dil, dilation=dil))
+        self.dc_conv7 = self.predict_flow(32)
+
+    def predict_flow(self, in_planes):
+        return nn.Conv2d(in_planes, 2, kernel_size=3, stride=1, padding=1, bias=True)
+
+    def warp(self, x, flow):
+        return warp_flow(x, flow, use_mask=False, align_corners=self.align_corners)
+
+    def corr_naive(self, input1, input2, d=4):
+        return corr_naive(input1, input2, d)
+
+    def _decode(self, lvl, x):
+        """x0..x4 with the two-wide concat pattern of pwc_tf.py:113-118."""
+        c = [getattr(self, 'conv%d_%d' % (lvl, k)) for k in range(5)]
+        x0 = c[0](x)
+        x1 = c[1](x0)
+        x2 = c[2](torch.cat((x0, x1), 1))
+        x3 = c[3](torch.cat((x1, x2), 1))
+        x4 = c[4](torch.cat((x2, x3), 1))
+        flow = getattr(self, 'predict_flow%d' % lvl)(torch.cat((x3, x4), 1))
+        return flow, x4
+
+    def forward(self, feature_list_1, feature_list_2, img_hw):
+        f1 = dict(zip((1, 2, 3, 4, 5, 6), feature_list_1))
+        f2 = dict(zip((1, 2, 3, 4, 5, 6), feature_list_2))
+        flows = {}
+        flow, _ = self._decode(6, self.corr(f1[6], f2[6]))            # :112-118
+        for lvl in (5, 4, 3, 2):                                      # :119-168
+            up = F.interpolate(flow, scale_factor=2.0, mode='bilinear') * 2.0
+            warped = self.warp(f2[lvl], up)
+            cv = self.corr(f1[lvl], warped)
+            flow, x4 = self._decode(lvl, torch.cat((cv, f1[lvl], up), 1))
+            flow = flow + up
+            flows[lvl] = flow
+        x = self.dc_conv4(self.dc_conv3(self.dc_conv2(self.dc_conv1(torch.cat([flows[2], x4], 1)))))
+        flows[2] = flows[2] + self.dc_conv7(self.dc_conv6(self.dc_conv5(x)))   # :170-171
+        H, W = img_hw[0], img_hw[1]
+        outs = []
+        for k, lvl in enumerate((2, 3, 4, 5)):                        # :173-177
+            outs.append(F.interpolate(flows[lvl] * 4.0, [H // (2 ** k), W // (2 ** k)], mode='bilinear'))
+        return outs
+
+
+# ----------------------------------------------------------------------------
+# model_flow_paper.py:15-255
+# ----------------------------------------------------------------------------
+
+def flow_normalization(flow, p=2):
+    """model_flow_paper.py:44-51."""
+    nrm = torch.norm(flow, p=p, dim=1).unsqueeze(1) + 1e-12
+    return flow / nrm.repeat(1, 2, 1, 1)
+
+
+def img_pyramid(img, n):
+    """model_flow_paper.py:54-60 (detached box means)."""
+    H, W = img.shape[2], img.shape[3]
+    return [F.adaptive_avg_pool2d(img, [int(H / 2 ** s), int(W / 2 ** s)]).detach() for s in range(n)]
+
+
+def diff_weight(img, img_from_l, img_from_r):
+    """One scale of compute_diff_weight, model_flow_paper.py:108-132.
+
+    Returns diff_l, diff_r, weight_bwd, weight_fwd, valid_bwd, valid_fwd.
+    """
+    valid_fwd = 1 - (img_from_r == 0).prod(1, keepdim=True).type_as(img_from_r)
+    valid_bwd = 1 - (img_from_l == 0).prod(1, keepdim=True).type_as(img_from_l)
+    diff_l = torch.abs(img - img_from_l).mean(1, True)
+    diff_r = torch.abs(img - img_from_r).mean(1, True)
+    weight = (1 - F.softmax(torch.cat((diff_l, diff_r), 1), 1)).detach()
+    weight = 2 * torch.exp(-(weight - 0.5) ** 2 / 0.03)
+    w_bwd = weight[:, 0:1] * valid_bwd
+    w_fwd = weight[:, 1:2] * valid_fwd
+    return diff_l, diff_r, w_bwd, w_fwd, valid_bwd, valid_fwd
+
+
+def masked_l1(diff, w):
+    """One scale of compute_loss_with_mask, model_flow_paper.py:93-97 -> [B]."""
+    divider = w.mean((1, 2, 3))
+    return (diff * w.repeat(1, 3, 1, 1)).mean((1, 2, 3)) / (divider + 1e-12)
+
+
+def ssim_loss(img, img_warped, w):
+    """One scale of compute_loss_ssim, model_flow_paper.py:140-146 -> [B]."""
+    divider = w.mean((1, 2, 3))
+    w3 = w.repeat(1, 3, 1, 1)
+    s = SSIM(img * w3, img_warped * w3)
+    return torch.clamp((1.0 - s) / 2.0, 0, 1).mean((1, 2, 3)) / (divider + 1e-12)
+
+
+def grad2_error(flow, img):
+    """cal_grad2_error, model_flow_paper.py:152-167 -> [B] (flow already /20)."""
+    gx = lambda t: t[:, :, :, 1:] - t[:, :, :, :-1]
+    gy = lambda t: t[:, :, 1:, :] - t[:, :, :-1, :]
+    w_x = torch.exp(-10.0 * torch.abs(gx(img)).mean(1).unsqueeze(1))
+    w_y = torch.exp(-10.0 * torch.abs(gy(img)).mean(1).unsqueeze(1))
+    dx2 = gx(gx(flow))
+    dy2 = gy(gy(flow))
+    err = (w_x[:, :, :, 1:] * torch.abs(dx2)).mean((1, 2, 3)) + (w_y[:, :, 1:, :] * torch.abs(dy2)).mean((1, 2, 3))
+    return err / 2.0
+
+
+def consis_loss(fwd_flow, bwd_flow, w_fwd):
+    """One scale of compute_loss_flow_consis, model_flow_paper.py:183-193 -> [B]."""
+    fn = flow_normalization(fwd_flow)
+    bn = flow_normalization(bwd_flow).detach()
+    occ = 1 - w_fwd
+    divider = occ.mean((1, 2, 3))
+    return (torch.abs(fn + bn) * occ).mean((1, 2, 3)) / (divider + 1e-12)
+
+
+class Model_flow(nn.Module):
+    """model_flow_paper.py:14-255."""
+
+    def __init__(self, cfg, align_corners=False):
+        super().__init__()
+        self.fpyramid = FeaturePyramid()
+        self.pwc_model = PWC_tf(align_corners=align_corners)
+        self.align_corners = align_corners
+        if cfg.mode in ('depth', 'flowposenet'):
+            for p in list(self.fpyramid.parameters()) + list(self.pwc_model.parameters()):
+                p.requires_grad = False
+        self.dataset = cfg.dataset
+        self.num_scales = cfg.num_scales
+        self.flow_consist_alpha = cfg.h_flow_consist_alpha
+        self.flow_consist_beta = cfg.h_flow_consist_beta
+
+    def inference_flow(self, img1, img2):
+        hw = [img1.shape[2], img1.shape[3]]
+        return self.pwc_model(self.fpyramid(img1), self.fpyramid(img2), hw)[0]
+
+    def forward(self, inputs, return_aux=False):
+        assert inputs.shape[1] == 3
+        H, W = int(inputs.shape[2] / 3), inputs.shape[3]
+        imgl, img, imgr = inputs[:, :, :H], inputs[:, :, H:2 * H], inputs[:, :, 2 * H:3 * H]
+        fl, fc, fr = self.fpyramid(imgl), self.fpyramid(img), self.fpyramid(imgr)
+        flows_bwd = self.pwc_model(fc, fl, [H, W])
+        flows_fwd = self.pwc_model(fc, fr, [H, W])
+        n = len(flows_fwd)
+        pyr_l, pyr_c, pyr_r = img_pyramid(imgl, n), img_pyramid(img, n), img_pyramid(imgr, n)
+        ac = self.align_corners
+        from_l = [warp_flow(i, f, True, ac) for i, f in zip(pyr_l, flows_bwd)]
+        from_r = [warp_flow(i, f, True, ac) for i, f in zip(pyr_r, flows_fwd)]
+        zero = lambda: inputs.new_zeros(inputs.shape[0])
+        lp, ls, lsm, lc = zero(), zero(), zero(), zero()
+        aux = {'valid_bwd': [], 'valid_fwd': [], 'weight_bwd': [], 'weight_fwd': []}
+        for s in range(self.num_scales):
+            d_l, d_r, w_b, w_f, v_b, v_f = diff_weight(pyr_c[s], from_l[s], from_r[s])
+            lp = lp + masked_l1(d_r, w_f) + masked_l1(d_l, w_b)
+            ls = ls + ssim_loss(pyr_c[s], from_r[s], w_f) + ssim_loss(pyr_c[s], from_l[s], w_b)
+            lsm = lsm + grad2_error(flows_fwd[s] / 20.0, pyr_c[s]) + grad2_error(flows_bwd[s] / 20.0, pyr_c[s])
+            lc = lc + consis_loss(flows_fwd[s], flows_bwd[s], w_f)
+            aux['valid_bwd'].append(v_b); aux['valid_fwd'].append(v_f)
+            aux['weight_bwd'].append(w_b); aux['weight_fwd'].append(w_f)
+        pack = {'loss_pixel': lp, 'loss_ssim': ls, 'loss_flow_smooth': lsm, 'loss_flow_consis': lc}
+        if return_aux:
+            aux.update(flows_fwd=flows_fwd, flows_bwd=flows_bwd, from_l=from_l, from_r=from_r,
+                       feats=fc)
+            return pack, aux
+        return pack
+
+
+def get_model(mode):
+    """core/networks/__init__.py:5-9."""
+    if mode == 'flow':
+        return Model_flow
+    raise ValueError('Mode {} not found.'.format(mode))
+
+
+# ----------------------------------------------------------------------------
+# config_utils.py:3-9, train.py:137-152
+# ----------------------------------------------------------------------------
+
+def default_cfg(**over):
+    cfg = types.SimpleNamespace(mode='flow', dataset='kitti_depth', num_scales=3,
+                                h_flow_consist_alpha=3.0, h_flow_consist_beta=0.05,
+                                w_ssim=0.85, w_flow_smooth=10.0, w_flow_consis=0.01, lr=1e-4)
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def generate_loss_weights_dict(cfg):
+    return {'loss_pixel': 1 - cfg.w_ssim, 'loss_ssim': cfg.w_ssim,
+            'loss_flow_smooth': cfg.w_flow_smooth, 'loss_flow_consis': cfg.w_flow_consis}
+
+
+def total_loss(loss_pack, weights):
+    """train.py:147-150."""
+    return sum(weights[k] * loss_pack[k].mean() for k in loss_pack)
+
+
+def train_step(model, optimizer, inputs, weights):
+    """train.py:139-152: zero_grad, forward, weighted batch-mean loss, backward, Adam step."""
+    optimizer.zero_grad()
+    pack = model(inputs)
+    loss = total_loss(pack, weights)
+    loss.backward()
+    optimizer.step()
+    return loss.detach(), {k: v.detach() for k, v in pack.items()}
+
+
+# ----------------------------------------------------------------------------
+# deterministic parameters shared by the fixture generator, tests and bench
+# ----------------------------------------------------------------------------
+
+def seeded_state_dict(model, seed=1234, flow_gain=1.0):
+    """Fill every parameter from numpy's PCG64 stream, in state-dict order.
+
+    weights ~ N(0, 2/fan_in), biases ~ 0.01*N(0,1).  numpy
+    streams are version-stable, so both sides of a parity test can rebuild the
+    same 5,134,324 numbers without shipping a checkpoint.
+    """
+    rng = np.random.default_rng(seed)
+    sd = model.state_dict()
+    out = {}
+    for name, t in sd.items():
+        shape = tuple(t.shape)
+        if name.endswith('weight'):
+            fan_in = int(np.prod(shape[1:]))
+            a = rng.standard_normal(shape).astype(np.float32) * np.float32(math.sqrt(2.0 / fan_in))
+            if 'predict_flow' in name or 'dc_conv7' in name:
+                a = a * np.float32(flow_gain)
+        else:
+            a = (0.01 * rng.standard_normal(shape)).astype(np.float32)
+        out[name] = torch.from_numpy(a)
+    return out
+
+
+def synthetic_triplets(B, H, W, seed=0, structured=True):
+    """Synthetic [B,3,3H,W] frame triplets (left, centre, right stacked on H).
+
+    structured: a smooth random texture (sum of low-frequency sinusoids) whose
+    left/right frames are the centre shifted by (-3,-1)/(+3,+1) px, with a
+    32x32 black occluder so the ``== 0`` validity test and the border masks are
+    exercised.  Otherwise U[0,1) noise.
+    """
+    rng = np.random.default_rng(seed)
+    if not structured:
+        return torch.from_numpy(rng.random((B, 3, 3 * H, W), dtype=np.float32))
+    pad = 8
+    yy, xx = np.meshgrid(np.arange(H + 2 * pad, dtype=np.float64),
+                         np.arange(W + 2 * pad, dtype=np.float64), indexing='ij')
+    out = np.zeros((B, 3, 3 * H, W), np.float32)
+    for b in range(B):
+        canvas = np.zeros((3, H + 2 * pad, W + 2 * pad))
+        for c in range(3):
+            for _ in range(8):
+                fx, fy = rng.uniform(0.01, 0.12, 2)
+                ph, amp = rng.uniform(0, 2 * np.pi), rng.uniform(0.3, 1.0)
+                canvas[c] += amp * np.sin(2 * np.pi * (fx * xx + fy * yy) + ph)
+        canvas = (canvas - canvas.min()) / (canvas.max() - canvas.min() + 1e-9)
+        canvas = 0.05 + 0.9 * canvas
+        oy, ox = rng.integers(pad, H // 2), rng.integers(pad, W // 2)
+        sh = min(32, H // 4)
+        canvas[:, oy:oy + sh, ox:ox + sh] = 0.0
+        for k, (dx, dy) in enumerate(((-3, -1), (0, 0), (3, 1))):
+            out[b, :, k * H:(k + 1) * H] = canvas[:, pad + dy:pad + dy + H, pad + dx:pad + dx + W]
+    return torch.from_numpy(out)
+
+
+def epe(flow_a, flow_b):
+    """Mean end-point error, the formula of evaluate_flow.py:131-134 without a GT mask."""
+    d = flow_a - flow_b
+    return torch.sqrt(d[:, 0] ** 2 + d[:, 1] ** 2).mean()

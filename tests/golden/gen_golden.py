@@ -1,0 +1,242 @@
+"""Generate the golden fixtures in this directory by running the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference); nothing here is
+imported by the tests or by the product.  The reference is imported unmodified
+with the two harness shims of SURVEY.md section 8c:
+  * an empty ``cv2`` module (model_flow_paper.py:10 imports it, never calls it),
+  * ``Tensor.get_device`` returning the device for CPU tensors (net_utils.py:48).
+``align_corners=True`` fixtures (torch-1.2 semantics of ``grid_sample``) are made
+by wrapping ``nn.functional.grid_sample`` around the reference's call sites
+(net_utils.py:46,49).
+
+Parameters and inputs come from numpy PCG64 streams (``oracle.ref_cpu.
+seeded_state_dict`` / ``synthetic_triplets``) so the fixtures hold only small
+inputs and the reference's outputs.
+
+    python tests/golden/gen_golden.py        # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+sys.modules.setdefault('cv2', types.ModuleType('cv2'))
+_gd = torch.Tensor.get_device
+torch.Tensor.get_device = lambda t: t.device if not t.is_cuda else _gd(t)
+sys.path.insert(0, '/root/reference')
+from core.networks import get_model                      # noqa: E402  (the reference)
+from core.networks.structures import warp_flow, PWC_tf   # noqa: E402
+from core.networks.pytorch_ssim import SSIM              # noqa: E402
+
+from oracle import ref_cpu as R                          # noqa: E402  (seeding helpers only)
+
+_GS = nn.functional.grid_sample
+FLOW_GAIN = 0.25
+
+
+class align_corners_ctx:
+    """Make the reference's bare grid_sample calls use the given align_corners."""
+
+    def __init__(self, ac):
+        self.ac = ac
+
+    def __enter__(self):
+        ac = self.ac
+        nn.functional.grid_sample = lambda x, g, **k: _GS(x, g, align_corners=ac, **k)
+
+    def __exit__(self, *a):
+        nn.functional.grid_sample = _GS
+
+
+def rnd(seed, shape, scale=1.0, uniform=False):
+    rng = np.random.default_rng(seed)
+    a = rng.random(shape, dtype=np.float32) if uniform else rng.standard_normal(shape).astype(np.float32)
+    return torch.from_numpy(a * np.float32(scale))
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, d):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **d)
+    print('%-22s %8.1f KB  %d arrays' % (name, os.path.getsize(path) / 1024, len(d)))
+
+
+# ------------------------------------------------------------------ G1: corr
+def gen_corr():
+    out = {}
+    pwc = PWC_tf()
+    cases = [(2, 5, 7, 11), (4, 32, 9, 13), (8, 196, 5, 7), (4, 196, 4, 13), (4, 7, 16, 20), (1, 3, 3, 5)]
+    out['cases'] = np.array(cases, np.int64)
+    for k, (d, C, h, w) in enumerate(cases):
+        f1 = rnd(100 + k, (2, C, h, w)).requires_grad_()
+        f2 = rnd(200 + k, (2, C, h, w)).requires_grad_()
+        cv = pwc.corr_naive(f1, f2, d=d)
+        g = rnd(300 + k, tuple(cv.shape))
+        cv.backward(g)
+        out.update({'f1_%d' % k: npy(f1), 'f2_%d' % k: npy(f2), 'g_%d' % k: npy(g), 'cv_%d' % k: npy(cv),
+                    'gf1_%d' % k: npy(f1.grad), 'gf2_%d' % k: npy(f2.grad)})
+    save('g1_corr.npz', out)
+
+
+# ------------------------------------------------------------------ G1: warp
+def gen_warp():
+    out = {}
+    cases = [  # C, h, w, flow scale, use_mask
+        (3, 16, 24, 2.0, 1), (3, 16, 24, 9.0, 1), (32, 9, 13, 3.0, 0), (5, 8, 8, 6.0, 0), (3, 1, 1, 0.3, 1),
+        (3, 32, 104, 4.0, 1)]
+    out['cases'] = np.array([(c, h, w, int(s * 10), m) for c, h, w, s, m in cases], np.int64)
+    for k, (C, h, w, s, um) in enumerate(cases):
+        x0 = rnd(400 + k, (2, C, h, w), uniform=True)
+        fl0 = rnd(500 + k, (2, 2, h, w), s)
+        if k == 0:
+            fl0[:, :, :4] = 0.0                      # exact zero flow rows
+            fl0[:, :, 4:6] = torch.round(fl0[:, :, 4:6])   # integer flows
+        g = rnd(600 + k, (2, C, h, w))
+        out['x_%d' % k], out['flow_%d' % k], out['g_%d' % k] = npy(x0), npy(fl0), npy(g)
+        for ac in (0, 1):
+            with align_corners_ctx(bool(ac)):
+                x = x0.clone().requires_grad_()
+                fl = fl0.clone().requires_grad_()
+                y = warp_flow(x, fl, use_mask=bool(um))
+                y.backward(g)
+                tag = '%d_ac%d' % (k, ac)
+                out['y_' + tag], out['gx_' + tag], out['gflow_' + tag] = npy(y), npy(x.grad), npy(fl.grad)
+                if um:   # the mask itself: a ones image comes back non-zero exactly where mask==1
+                    m = warp_flow(torch.ones(2, 1, h, w), fl0, use_mask=True)
+                    out['mask_' + tag] = (npy(m) != 0).astype(np.uint8)
+    save('g1_warp.npz', out)
+
+
+# ------------------------------------------------------------------ G1: losses
+def gen_losses():
+    out = {}
+    cfg = R.default_cfg(num_scales=1)
+    m = get_model('flow')(cfg)
+    B, h, w = 2, 24, 40
+    img = rnd(700, (B, 3, h, w), uniform=True)
+    from_l = (img + rnd(701, (B, 3, h, w), 0.1)).clamp(0, 1)
+    from_r = (img + rnd(702, (B, 3, h, w), 0.1)).clamp(0, 1)
+    from_l[:, :, 3:9, 5:17] = 0.0                   # masked-out (all-zero) pixels
+    from_r[:, :, 10:20, 22:38] = 0.0
+    from_r[0, 0, 0, 0] = 0.0                        # single-channel zero: still valid
+    flow_f = rnd(703, (B, 2, h, w), 3.0)
+    flow_b = rnd(704, (B, 2, h, w), 3.0)
+    out.update(img=npy(img), from_l=npy(from_l), from_r=npy(from_r), flow_f=npy(flow_f), flow_b=npy(flow_b))
+    gl = rnd(705, (B,))                             # upstream d(total)/d(loss[b])
+    out['gl'] = npy(gl)
+
+    fl = from_l.clone().requires_grad_()
+    fr = from_r.clone().requires_grad_()
+    d_b, d_f, w_b, w_f = m.compute_diff_weight([fl], [img], [fr])
+    out.update(diff_l=npy(d_b[0]), diff_r=npy(d_f[0]), w_bwd=npy(w_b[0]), w_fwd=npy(w_f[0]))
+    lp = m.compute_loss_with_mask(d_f, w_f) + m.compute_loss_with_mask(d_b, w_b)
+    ls_f = m.compute_loss_ssim([img], [fr], w_f)
+    ls_b = m.compute_loss_ssim([img], [fl], w_b)
+    out.update(loss_pixel=npy(lp), loss_ssim_f=npy(ls_f), loss_ssim_b=npy(ls_b))
+    (lp * gl).sum().backward(retain_graph=True)
+    out.update(lp_g_from_l=npy(fl.grad), lp_g_from_r=npy(fr.grad))
+    fl.grad = None; fr.grad = None
+    ((ls_f + ls_b) * gl).sum().backward()
+    out.update(ls_g_from_l=npy(fl.grad), ls_g_from_r=npy(fr.grad))
+    w3 = w_f[0].repeat(1, 3, 1, 1)
+    out['ssim_map'] = npy(SSIM(img * w3, from_r * w3))
+
+    ff = flow_f.clone().requires_grad_()
+    lsm = m.compute_loss_flow_smooth([ff], [img])
+    (lsm * gl).sum().backward()
+    out.update(loss_smooth=npy(lsm), lsm_g_flow=npy(ff.grad))
+
+    ff = flow_f.clone().requires_grad_()
+    fb = flow_b.clone().requires_grad_()
+    lc = m.compute_loss_flow_consis([ff], [fb], [w_f[0].detach()])
+    (lc * gl).sum().backward()
+    assert fb.grad is None
+    out.update(loss_consis=npy(lc), lc_g_flow=npy(ff.grad))
+    save('g1_losses.npz', out)
+
+
+# ------------------------------------------------------------------ G2 / G3: modules
+def grad_stats(model):
+    names, s, a = [], [], []
+    for n, p in model.named_parameters():
+        names.append(n); s.append(p.grad.double().sum().item()); a.append(p.grad.double().abs().sum().item())
+    return names, np.array(s), np.array(a)
+
+
+def param_stats(model):
+    return np.array([p.detach().double().sum().item() for p in model.parameters()]), \
+        np.array([p.detach().double().abs().sum().item() for p in model.parameters()])
+
+
+def gen_module(name, B, H, W, steps, full_flows):
+    out = {'B': B, 'H': H, 'W': W, 'flow_gain': FLOW_GAIN}
+    cfg = R.default_cfg()
+    weights = R.generate_loss_weights_dict(cfg)
+    x = R.synthetic_triplets(B, H, W, seed=0, structured=True)
+    for ac in (0, 1):
+        tag = '_ac%d' % ac
+        with align_corners_ctx(bool(ac)):
+            model = get_model('flow')(cfg)
+            model.load_state_dict(R.seeded_state_dict(model, 1234, FLOW_GAIN))
+            opt = torch.optim.Adam([{'params': filter(lambda p: p.requires_grad, model.parameters()),
+                                     'lr': cfg.lr}])
+            # forward pieces (model_flow_paper.py:208-235), for feature / flow / mask fixtures
+            with torch.no_grad():
+                imgl, img, imgr = x[:, :, :H], x[:, :, H:2 * H], x[:, :, 2 * H:]
+                feats = model.fpyramid(img)
+                fb = model.pwc_model(feats, model.fpyramid(imgl), [H, W])
+                ff = model.pwc_model(feats, model.fpyramid(imgr), [H, W])
+                out['feat_sum' + tag] = np.array([f.double().sum().item() for f in feats])
+                out['feat_abs' + tag] = np.array([f.double().abs().sum().item() for f in feats])
+                out['feat5' + tag], out['feat6' + tag] = npy(feats[4]), npy(feats[5])
+                for s in range(4):
+                    for nm, fl in (('fwd', ff[s]), ('bwd', fb[s])):
+                        st = 1 if (full_flows and s >= 1) else max(1, 8 >> s)
+                        out['flow_%s%d%s' % (nm, s, tag)] = npy(fl[:, :, ::st, ::st])
+                        out['flow_%s%d_sum%s' % (nm, s, tag)] = fl.double().sum().item()
+                pyr_l, pyr_r = model.generate_img_pyramid(imgl, 4), model.generate_img_pyramid(imgr, 4)
+                for s in range(4):
+                    for nm, pyr, fl in (('bwd', pyr_l, fb), ('fwd', pyr_r, ff)):
+                        m = warp_flow(torch.ones_like(pyr[s][:, :1]), fl[s], use_mask=True)
+                        out['mask_%s%d%s' % (nm, s, tag)] = np.packbits((npy(m) != 0).astype(np.uint8))
+                out['inference_flow' + tag] = npy(model.inference_flow(img, imgr)[:, :, ::8, ::8])
+            # train steps (train.py:139-152)
+            for it in range(steps):
+                opt.zero_grad()
+                pack = model(x)
+                loss = sum(weights[k] * pack[k].mean() for k in pack)
+                loss.backward()
+                if it == 0:
+                    for k in pack:
+                        out[k + tag] = npy(pack[k])
+                    out['total' + tag] = loss.item()
+                    names, gs, ga = grad_stats(model)
+                    out['grad_sum' + tag], out['grad_abs' + tag] = gs, ga
+                    out['grad_norm' + tag] = float(np.sqrt(sum((p.grad.double() ** 2).sum().item()
+                                                               for p in model.parameters())))
+                opt.step()
+                if it in (0, 2):
+                    ps, pa = param_stats(model)
+                    out['param_sum_step%d%s' % (it + 1, tag)] = ps
+                    out['param_abs_step%d%s' % (it + 1, tag)] = pa
+                out['loss_step%d%s' % (it, tag)] = loss.item()
+    save(name, out)
+
+
+if __name__ == '__main__':
+    torch.manual_seed(0)
+    gen_corr()
+    gen_warp()
+    gen_losses()
+    gen_module('g2_module_128.npz', 2, 128, 128, steps=3, full_flows=True)
+    gen_module('g3_kitti_256x832.npz', 1, 256, 832, steps=1, full_flows=False)
