@@ -1,0 +1,116 @@
+/*
+ * unflow_hip.h -- C ABI of libunflow_hip.so, the MI355X (gfx950) kernels behind the
+ * UnOpticalFlow `--mode flow` hot path.
+ *
+ * The reference (jianfenglihg/UnOpticalFlow) is pure Python on PyTorch and has no FFI;
+ * its operator plug points for this path are Python callables.  Each entry point below
+ * replaces the eager-PyTorch op chain of one of them (reference file:line cited per
+ * function); the Python host side (unopticalflow_amd/ops.py) binds them with ctypes and
+ * wraps them in torch.autograd.Function under the reference's own names.
+ *
+ * Conventions
+ *   - every tensor is a dense fp32 NCHW device buffer (masks: uint8), caller-allocated;
+ *     kernels never allocate, free or synchronise;
+ *   - `stream` is a hipStream_t (NULL = the default stream); work is only enqueued;
+ *   - the return value is the hipError_t of the launch (0 = hipSuccess),
+ *     UNFLOW_EINVAL (-22) for a bad argument (NULL pointer, non-positive size, d < 0);
+ *   - `partials` scratch buffers hold per-workgroup partial sums of the per-sample
+ *     reductions; size them with unflow_partials_per_sample(); results are bitwise
+ *     reproducible run to run (fixed summation order, no float atomics) except
+ *     unflow_warp_bwd's gsrc scatter-add.
+ *   - align_corners selects the grid_sample generation: 0 = torch >= 1.3 default
+ *     (the reference as it runs today), 1 = torch 1.2.0 (the reference's pin).
+ */
+#ifndef UNFLOW_HIP_H
+#define UNFLOW_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNFLOW_EINVAL (-22)
+
+/* ABI version of this header (bumped on any signature change). */
+int unflow_abi_version(void);
+
+/* Number of float slots per sample a `partials` buffer needs for an H x W map
+ * (multiply by B and by the op's K listed below). */
+int unflow_partials_per_sample(int H, int W);
+
+/* ---- cost volume: PWC_tf.corr_naive, core/networks/structures/pwc_tf.py:97-106 ----
+ * cv[b, i*(2d+1)+j, y, x] = (1/C) * sum_c f1[b,c,y,x] * f2[b,c,y+i-d,x+j-d]  (zero outside)
+ * f1,f2: [B,C,H,W]; cv: [B,(2d+1)^2,H,W]. */
+int unflow_corr_fwd(const float* f1, const float* f2, float* cv,
+                    int B, int C, int H, int W, int d, void* stream);
+/* autograd of the above: gcv [B,(2d+1)^2,H,W] -> gf1, gf2 [B,C,H,W] (both written in full). */
+int unflow_corr_bwd(const float* f1, const float* f2, const float* gcv, float* gf1, float* gf2,
+                    int B, int C, int H, int W, int d, void* stream);
+
+/* ---- flow warp: warp_flow, core/networks/structures/net_utils.py:16-54 ----
+ * out[b,c,y,x] = bilinear sample of src[b,c] at (x+u, y+v) through the reference's
+ * normalise -> grid_sample(bilinear, zeros) chain.  mask (may be NULL = use_mask False):
+ * [B,1,H,W] uint8, 1 where the sampled ones-image is >= 0.9999 (net_utils.py:47-51); when
+ * given, out is multiplied by it (net_utils.py:52).  flow: [B,2,H,W], channel 0 = x. */
+int unflow_warp_fwd(const float* src, const float* flow, float* out, uint8_t* mask,
+                    int B, int C, int H, int W, int align_corners, void* stream);
+/* autograd of the above.  mask NULL = unmasked.  gsrc may be NULL (source has no grad, as for
+ * the detached image pyramids, model_flow_paper.py:58); otherwise it is zeroed and
+ * scatter-added with float atomics.  gflow [B,2,H,W] is written in full. */
+int unflow_warp_bwd(const float* src, const float* flow, const float* gout, const uint8_t* mask,
+                    float* gsrc, float* gflow,
+                    int B, int C, int H, int W, int align_corners, void* stream);
+
+/* ---- occlusion weights: Model_flow.compute_diff_weight, model_flow_paper.py:101-134 ----
+ * img, from_l, from_r: [B,3,H,W].  diff_*: mean_c|img-from_*| [B,1,H,W]; w_*: soft occlusion
+ * weight * validity [B,1,H,W]; valid_* (may be NULL): uint8 1 - prod_c[from_* == 0]. */
+int unflow_occ_weight_fwd(const float* img, const float* from_l, const float* from_r,
+                          float* diff_l, float* diff_r, float* w_bwd, float* w_fwd,
+                          uint8_t* valid_bwd, uint8_t* valid_fwd,
+                          int B, int H, int W, void* stream);
+/* grad of diff = mean_c|img-from| w.r.t. from: gfrom[b,c,p] = -sign(img-from) * gdiff[b,p] / 3. */
+int unflow_absdiff_bwd(const float* img, const float* from, const float* gdiff, float* gfrom,
+                       int B, int H, int W, void* stream);
+
+/* ---- masked mean: Model_flow.compute_loss_with_mask (one scale), model_flow_paper.py:93-97 ----
+ * loss[b] = mean_p(diff*w) / (mean_p(w) + 1e-12).  partials: K=2.  sums[b] = {sum diff*w, sum w}
+ * is saved for the backward. */
+int unflow_masked_mean_fwd(const float* diff, const float* w, float* loss, float* sums,
+                           float* partials, int B, int H, int W, void* stream);
+int unflow_masked_mean_bwd(const float* w, const float* sums, const float* gloss, float* gdiff,
+                           int B, int H, int W, void* stream);
+
+/* ---- SSIM loss: SSIM, pytorch_ssim/ssim.py:4-20 + compute_loss_ssim (one scale),
+ * model_flow_paper.py:140-146 ----
+ * x = img*w, y = warped*w; loss[b] = mean_{c,p} clamp((1-SSIM(x,y))/2, 0, 1) / (mean_p(w)+1e-12).
+ * partials: K=2.  sums[b] = {sum clamp(..), sum w}. */
+int unflow_ssim_loss_fwd(const float* img, const float* warped, const float* w, float* loss,
+                         float* sums, float* partials, int B, int H, int W, void* stream);
+/* gradient w.r.t. warped only (img is a detached pyramid, w is detached). */
+int unflow_ssim_loss_bwd(const float* img, const float* warped, const float* w, const float* sums,
+                         const float* gloss, float* gwarped, int B, int H, int W, void* stream);
+/* the bare SSIM map of ssim.py:4-20 for [B,C,H,W] inputs (test/diagnostic surface). */
+int unflow_ssim_map(const float* x, const float* y, float* out, int B, int C, int H, int W,
+                    void* stream);
+
+/* ---- 2nd-order smoothness: cal_grad2_error + compute_loss_flow_smooth (one scale),
+ * model_flow_paper.py:152-177 ----  flow [B,2,H,W] (un-divided; the /20 is inside), img [B,3,H,W].
+ * partials: K=2. */
+int unflow_smooth2_fwd(const float* flow, const float* img, float* loss, float* partials,
+                       int B, int H, int W, void* stream);
+int unflow_smooth2_bwd(const float* flow, const float* img, const float* gloss, float* gflow,
+                       int B, int H, int W, void* stream);
+
+/* ---- forward/backward consistency: compute_loss_flow_consis (one scale),
+ * model_flow_paper.py:44-51,183-193 ----  grad flows to fwd_flow only.  partials: K=2. */
+int unflow_consis_fwd(const float* fwd_flow, const float* bwd_flow, const float* w_fwd, float* loss,
+                      float* sums, float* partials, int B, int H, int W, void* stream);
+int unflow_consis_bwd(const float* fwd_flow, const float* bwd_flow, const float* w_fwd,
+                      const float* sums, const float* gloss, float* gflow,
+                      int B, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNFLOW_HIP_H */

@@ -1,0 +1,73 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, exports every
+symbol include/unflow_hip.h declares with the arity the ctypes binding uses, and the product has no
+CPU fallback.  No compute is launched (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_decls():
+    src = open(os.path.join(ROOT, 'include', 'unflow_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    decls = {}
+    for m in re.finditer(r'\bint\s+(unflow_\w+)\s*\(([^)]*)\)\s*;', src):
+        args = m.group(2).strip()
+        decls[m.group(1)] = 0 if args in ('', 'void') else len(args.split(','))
+    return decls
+
+
+def test_library_builds_loads_and_exports_every_header_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from unopticalflow_amd import _lib
+    lib = _lib.load()
+    decls = _header_decls()
+    assert len(decls) >= 17
+    assert set(decls) == set(_lib.SIGNATURES), set(decls) ^ set(_lib.SIGNATURES)
+    for name, nargs in decls.items():
+        assert hasattr(lib, name), name
+        assert len(_lib.SIGNATURES[name]) == nargs, name
+    assert lib.unflow_abi_version() == _lib.ABI_VERSION
+
+
+def test_argument_validation_without_gpu():
+    from unopticalflow_amd import _lib
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    assert lib.unflow_corr_fwd(null, null, null, 1, 1, 1, 1, 4, null) == -22
+    assert lib.unflow_warp_fwd(null, null, null, null, 1, 3, 8, 8, 0, null) == -22
+    assert lib.unflow_partials_per_sample(0, 5) == -22
+    assert lib.unflow_partials_per_sample(256, 832) > 0
+
+
+def test_no_cpu_fallback():
+    from unopticalflow_amd import ops, get_model
+    from oracle import ref_cpu as R
+    with pytest.raises(RuntimeError):
+        ops.corr(torch.zeros(1, 2, 4, 4), torch.zeros(1, 2, 4, 4))
+    with pytest.raises(RuntimeError):
+        ops.warp_flow(torch.zeros(1, 3, 8, 8), torch.zeros(1, 2, 8, 8))
+    model = get_model('flow')(R.default_cfg())
+    with pytest.raises(RuntimeError):
+        model(torch.rand(1, 3, 192, 64))
+
+
+def test_product_does_not_import_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, 'unopticalflow_amd')
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                text = open(os.path.join(dp, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', text, flags=re.M), os.path.join(dp, f)
+
+
+def test_get_model_unknown_mode():
+    from unopticalflow_amd import get_model
+    with pytest.raises(ValueError):
+        get_model('depth')

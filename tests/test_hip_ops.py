@@ -1,0 +1,256 @@
+"""GPU parity: every HIP operator (through the C ABI) against the CPU oracle and the golden
+fixtures captured from the reference.  Run with ``-m gpu`` on an MI355X.
+
+Bars (BASELINE.json north_star): integer / binary outputs bit-exact; floating point within
+1e-4 relative (the tolerance is written at each assert; op-level checks are usually tighter)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    from unopticalflow_amd import ops as _ops, _lib
+    _lib.load()                       # fail loudly if the HIP library is missing
+    return _ops
+
+
+def dev(a):
+    t = T(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+    return t.to('cuda')
+
+
+def close(a, b, rtol=1e-4, atol=1e-6, what=''):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
+
+
+def rnd(seed, shape, scale=1.0, uniform=False):
+    rng = np.random.default_rng(seed)
+    a = rng.random(shape, dtype=np.float32) if uniform else rng.standard_normal(shape).astype(np.float32)
+    return T(a * np.float32(scale))
+
+
+# ------------------------------------------------------------------------------------ corr
+def test_corr_golden(ops, golden):
+    g = golden('g1_corr.npz')
+    for k, (d, C, h, w) in enumerate(g['cases']):
+        f1 = dev(g['f1_%d' % k]).requires_grad_()
+        f2 = dev(g['f2_%d' % k]).requires_grad_()
+        cv = ops.corr(f1, f2, int(d))
+        close(cv, g['cv_%d' % k], rtol=1e-5, atol=1e-6, what='corr fwd case %d' % k)
+        cv.backward(dev(g['g_%d' % k]))
+        close(f1.grad, g['gf1_%d' % k], rtol=1e-5, atol=2e-6, what='corr gf1 case %d' % k)
+        close(f2.grad, g['gf2_%d' % k], rtol=1e-5, atol=2e-6, what='corr gf2 case %d' % k)
+
+
+@pytest.mark.parametrize('d,C,h,w', [(4, 32, 64, 208), (4, 64, 32, 104), (4, 96, 16, 52), (4, 128, 8, 26),
+                                     (4, 196, 4, 13), (8, 32, 32, 104), (3, 6, 10, 70), (2, 9, 17, 130),
+                                     (1, 4, 5, 5), (0, 3, 4, 6), (4, 3, 23, 97), (4, 17, 9, 129)])
+def test_corr_vs_oracle(ops, d, C, h, w):
+    """Pyramid-level shapes of 832x256 (L2..L6), d=8, odd sizes, generic-radius path."""
+    f1c, f2c = rnd(1, (2, C, h, w)).requires_grad_(), rnd(2, (2, C, h, w)).requires_grad_()
+    cv_ref = R.corr_naive(f1c, f2c, d)
+    gout = rnd(3, tuple(cv_ref.shape))
+    cv_ref.backward(gout)
+    f1, f2 = dev(f1c.detach()).requires_grad_(), dev(f2c.detach()).requires_grad_()
+    cv = ops.corr(f1, f2, d)
+    close(cv, cv_ref, rtol=1e-5, atol=2e-6)
+    cv.backward(dev(gout))
+    close(f1.grad, f1c.grad, rtol=1e-5, atol=5e-6)
+    close(f2.grad, f2c.grad, rtol=1e-5, atol=5e-6)
+
+
+def test_corr_shape_mismatch_asserts(ops):
+    with pytest.raises(AssertionError):                       # pwc_tf.py:99
+        ops.corr(torch.zeros(1, 2, 4, 4, device='cuda'), torch.zeros(1, 2, 4, 5, device='cuda'))
+
+
+def test_corr_full_size_properties(ops):
+    """BASELINE config 2 size (B=8 pairs, level-2 maps 32x64x208): size-independent properties."""
+    f1, f2, f3 = (rnd(s, (8, 32, 64, 208)).cuda() for s in (11, 12, 13))
+    a, b = ops.corr(f1, f2), ops.corr(f1, f3)
+    close(ops.corr(f1, f2 + 2.0 * f3), a + 2.0 * b, rtol=1e-4, atol=1e-5, what='linearity in f2')
+    centre = ops.corr(f1, f1)[:, 40]                          # zero displacement = mean_c f1^2
+    close(centre, (f1 * f1).mean(1), rtol=1e-5, atol=1e-6)
+    # swapping the arguments mirrors the displacement: cv21[(-dy,-dx)](p + (dy,dx)) == cv12[(dy,dx)](p)
+    cv12, cv21 = ops.corr(f1, f2), ops.corr(f2, f1)
+    i, j = 6, 1                                               # dy = +2, dx = -3
+    dy, dx = i - 4, j - 4
+    lhs = cv12[:, i * 9 + j, 0:64 - dy, 3:208]
+    rhs = cv21[:, (8 - i) * 9 + (8 - j), dy:64, 0:208 - 3]
+    close(lhs, rhs, rtol=1e-5, atol=1e-6, what='displacement symmetry')
+
+
+# ------------------------------------------------------------------------------------ warp
+@pytest.mark.parametrize('ac', [0, 1])
+def test_warp_golden(ops, golden, ac):
+    g = golden('g1_warp.npz')
+    for k, (C, h, w, s10, um) in enumerate(g['cases']):
+        tag = '%d_ac%d' % (k, ac)
+        x = dev(g['x_%d' % k]).requires_grad_()
+        fl = dev(g['flow_%d' % k]).requires_grad_()
+        if um:
+            y, m = ops.warp_flow_masked(x, fl, align_corners=bool(ac))
+            assert np.array_equal(m.cpu().numpy(), g['mask_' + tag]), 'mask not bit-exact, case %d' % k
+        else:
+            y = ops.warp_flow(x, fl, use_mask=False, align_corners=bool(ac))
+        close(y, g['y_' + tag], rtol=1e-5, atol=1e-6, what='warp fwd %s' % tag)
+        y.backward(dev(g['g_%d' % k]))
+        close(x.grad, g['gx_' + tag], rtol=1e-4, atol=1e-5, what='warp gsrc %s' % tag)
+        close(fl.grad, g['gflow_' + tag], rtol=1e-4, atol=1e-4, what='warp gflow %s' % tag)
+
+
+@pytest.mark.parametrize('ac', [False, True])
+@pytest.mark.parametrize('hw', [(256, 832), (128, 416), (64, 208), (32, 104), (8, 26), (4, 13), (33, 57)])
+def test_warp_mask_bit_exact(ops, ac, hw):
+    """Binary validity masks (net_utils.py:47-51) must equal the reference CPU path bit for bit,
+    on flows that straddle the borders and land near integer positions."""
+    h, w = hw
+    rng = np.random.default_rng(h * 7 + w + int(ac))
+    fl = (rng.standard_normal((2, 2, h, w)) * 6).astype(np.float32)
+    fl[0, :, : h // 2] *= 1e-3
+    fl[1, :, :, : w // 3] = np.round(fl[1, :, :, : w // 3] * 2) / 2
+    x = rng.random((2, 3, h, w), dtype=np.float32)
+    m_ref = R.warp_mask(x.shape, T(fl), ac).numpy()
+    y_ref = R.warp_flow(T(x), T(fl), True, ac)
+    y, m = ops.warp_flow_masked(dev(x), dev(fl), align_corners=ac)
+    assert np.array_equal(m.cpu().numpy(), m_ref)
+    close(y, y_ref, rtol=1e-5, atol=1e-6)
+
+
+def test_warp_feature_grads_vs_oracle(ops):
+    for (C, h, w, s) in ((32, 64, 208, 2.0), (128, 8, 26, 1.0), (96, 16, 52, 5.0), (7, 9, 11, 3.0)):
+        xc = rnd(5, (2, C, h, w)).requires_grad_()
+        fc = rnd(6, (2, 2, h, w), s).requires_grad_()
+        g = rnd(7, (2, C, h, w))
+        yr = R.warp_flow(xc, fc)
+        yr.backward(g)
+        x, f = dev(xc.detach()).requires_grad_(), dev(fc.detach()).requires_grad_()
+        y = ops.warp_flow(x, f)
+        close(y, yr, rtol=1e-5, atol=1e-6)
+        y.backward(dev(g))
+        close(x.grad, xc.grad, rtol=1e-4, atol=1e-5)
+        scale = fc.grad.abs().max().item()
+        close(f.grad, fc.grad, rtol=1e-4, atol=1e-5 * scale)
+
+
+def test_warp_shape_mismatch_raises(ops):
+    with pytest.raises(ValueError):                           # net_utils.py:35-36
+        ops.warp_flow(torch.zeros(1, 3, 8, 8, device='cuda'), torch.zeros(1, 2, 8, 9, device='cuda'))
+
+
+def test_warp_identity_and_shift_full_size(ops):
+    """Full-size properties: zero flow is the identity under align_corners=True; an integer
+    shift reproduces the shifted image with a mask that only drops the uncovered columns."""
+    x = rnd(21, (8, 3, 256, 832), uniform=True).cuda()
+    z = torch.zeros(8, 2, 256, 832, device='cuda')
+    y, m = ops.warp_flow_masked(x, z, align_corners=True)
+    assert torch.equal(y, x) and bool(m.all())
+    z[:, 0] = 3.0
+    y, m = ops.warp_flow_masked(x, z, align_corners=True)
+    close(y[..., :829], x[..., 3:], rtol=0, atol=2e-6)
+    assert int(m[..., 829:].sum()) == 0 and bool(m[..., :828].all())
+
+
+# ------------------------------------------------------------------------------------ losses
+def _loss_inputs(g):
+    return (dev(g['img']), dev(g['from_l']).requires_grad_(), dev(g['from_r']).requires_grad_(), dev(g['gl']))
+
+
+def test_occ_weight_and_losses_golden(ops, golden):
+    g = golden('g1_losses.npz')
+    img, fl, fr, gl = _loss_inputs(g)
+    d_l, d_r, w_b, w_f, v_b, v_f = ops.occ_weight(img, fl, fr)
+    close(d_l, g['diff_l'], rtol=1e-6, atol=1e-7); close(d_r, g['diff_r'], rtol=1e-6, atol=1e-7)
+    close(w_b, g['w_bwd'], rtol=1e-5, atol=1e-6); close(w_f, g['w_fwd'], rtol=1e-5, atol=1e-6)
+    assert np.array_equal(v_b.cpu().numpy() != 0, g['w_bwd'] != 0)
+    assert np.array_equal(v_f.cpu().numpy() != 0, g['w_fwd'] != 0)
+    lp = ops.masked_mean(d_r, w_f) + ops.masked_mean(d_l, w_b)
+    close(lp, g['loss_pixel'], rtol=1e-5)
+    ls_f, ls_b = ops.ssim_loss(img, fr, w_f), ops.ssim_loss(img, fl, w_b)
+    close(ls_f, g['loss_ssim_f'], rtol=1e-5); close(ls_b, g['loss_ssim_b'], rtol=1e-5)
+    (lp * gl).sum().backward(retain_graph=True)
+    close(fl.grad, g['lp_g_from_l'], rtol=1e-4, atol=1e-8); close(fr.grad, g['lp_g_from_r'], rtol=1e-4, atol=1e-8)
+    fl.grad = None; fr.grad = None
+    ((ls_f + ls_b) * gl).sum().backward()
+    s = np.abs(g['ls_g_from_l']).max()
+    close(fl.grad, g['ls_g_from_l'], rtol=1e-3, atol=1e-4 * s); close(fr.grad, g['ls_g_from_r'], rtol=1e-3, atol=1e-4 * s)
+    w3 = w_f.repeat(1, 3, 1, 1)
+    close(ops.ssim_map(img * w3, fr.detach() * w3), g['ssim_map'], rtol=1e-4, atol=1e-5)
+
+    ff = dev(g['flow_f']).requires_grad_()
+    lsm = ops.smooth2_loss(ff, img)
+    close(lsm, g['loss_smooth'], rtol=1e-5)
+    (lsm * gl).sum().backward()
+    close(ff.grad, g['lsm_g_flow'], rtol=1e-4, atol=1e-9)
+
+    ff = dev(g['flow_f']).requires_grad_()
+    fb = dev(g['flow_b']).requires_grad_()
+    lc = ops.consis_loss(ff, fb, w_f)
+    close(lc, g['loss_consis'], rtol=1e-5)
+    (lc * gl).sum().backward()
+    close(ff.grad, g['lc_g_flow'], rtol=1e-4, atol=1e-8)
+    assert fb.grad is None
+
+
+@pytest.mark.parametrize('hw', [(64, 208), (32, 104), (13, 61), (128, 416)])
+def test_losses_vs_oracle_random(ops, hw):
+    h, w = hw
+    B = 2
+    img = rnd(31, (B, 3, h, w), uniform=True)
+    from_l = (img + rnd(32, (B, 3, h, w), 0.1)).clamp(0, 1)
+    from_r = (img + rnd(33, (B, 3, h, w), 0.1)).clamp(0, 1)
+    from_l[:, :, 2:7, 3:19] = 0.0
+    from_r[:, :, h // 2:, w // 2:] = 0.0
+    flf, flb = rnd(34, (B, 2, h, w), 3.0), rnd(35, (B, 2, h, w), 3.0)
+    gl = rnd(36, (B,))
+    # oracle
+    l_c, r_c = from_l.clone().requires_grad_(), from_r.clone().requires_grad_()
+    ff_c = flf.clone().requires_grad_()
+    d_l, d_r, w_b, w_f, v_b, v_f = R.diff_weight(img, l_c, r_c)
+    tot_c = (R.masked_l1(d_r, w_f) + R.masked_l1(d_l, w_b)) * 0.15 + \
+        (R.ssim_loss(img, r_c, w_f) + R.ssim_loss(img, l_c, w_b)) * 0.85 + \
+        R.grad2_error(ff_c / 20.0, img) * 10.0 + R.consis_loss(ff_c, flb, w_f) * 0.01
+    (tot_c * gl).sum().backward()
+    # HIP
+    img_g, gl_g = img.cuda(), gl.cuda()
+    l_g, r_g = from_l.cuda().requires_grad_(), from_r.cuda().requires_grad_()
+    ff_g = flf.cuda().requires_grad_()
+    D_l, D_r, W_b, W_f, V_b, V_f = ops.occ_weight(img_g, l_g, r_g)
+    assert np.array_equal(V_b.cpu().numpy(), v_b.numpy().astype(np.uint8))
+    assert np.array_equal(V_f.cpu().numpy(), v_f.numpy().astype(np.uint8))
+    close(W_b, w_b, rtol=1e-5, atol=1e-6); close(W_f, w_f, rtol=1e-5, atol=1e-6)
+    tot_g = (ops.masked_mean(D_r, W_f) + ops.masked_mean(D_l, W_b)) * 0.15 + \
+        (ops.ssim_loss(img_g, r_g, W_f) + ops.ssim_loss(img_g, l_g, W_b)) * 0.85 + \
+        ops.smooth2_loss(ff_g, img_g) * 10.0 + ops.consis_loss(ff_g, flb.cuda(), W_f) * 0.01
+    close(tot_g, tot_c, rtol=1e-5)
+    (tot_g * gl_g).sum().backward()
+    for a, b in ((l_g.grad, l_c.grad), (r_g.grad, r_c.grad), (ff_g.grad, ff_c.grad)):
+        close(a, b, rtol=1e-3, atol=1e-4 * b.abs().max().item())
+
+
+def test_ssim_map_vs_oracle(ops):
+    for (C, h, w) in ((3, 64, 208), (1, 5, 7), (4, 33, 130), (3, 256, 832)):
+        x, y = rnd(41, (2, C, h, w), uniform=True), rnd(42, (2, C, h, w), uniform=True)
+        y[:, :, : h // 2] = x[:, :, : h // 2]                    # SSIM == 1 region
+        close(ops.ssim_map(x.cuda(), y.cuda()), R.SSIM(x, y), rtol=1e-4, atol=1e-5)
+
+
+def test_reductions_are_reproducible(ops):
+    """Per-sample reductions use fixed-order partial sums: two launches agree bitwise."""
+    img = rnd(51, (8, 3, 256, 832), uniform=True).cuda()
+    wp = rnd(52, (8, 3, 256, 832), uniform=True).cuda()
+    w = rnd(53, (8, 1, 256, 832), uniform=True).cuda()
+    a, b = ops.ssim_loss(img, wp, w), ops.ssim_loss(img, wp, w)
+    assert torch.equal(a, b)
+    fl = rnd(54, (8, 2, 256, 832), 5.0).cuda()
+    assert torch.equal(ops.smooth2_loss(fl, img), ops.smooth2_loss(fl, img))

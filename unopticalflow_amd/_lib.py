@@ -1,0 +1,75 @@
+"""ctypes binding of libunflow_hip.so (include/unflow_hip.h).
+
+There is no CPU fallback: if the library is missing or a symbol is absent, importing the ops
+fails loudly.  Signatures here are the single source of truth for the Python side and are
+checked against the header by tests/test_abi.py.
+"""
+import ctypes
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, 'libunflow_hip.so')
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+
+# name -> argument types (all return int)
+SIGNATURES = {
+    'unflow_abi_version': [],
+    'unflow_partials_per_sample': [_I, _I],
+    'unflow_corr_fwd': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'unflow_corr_bwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'unflow_warp_fwd': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'unflow_warp_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'unflow_occ_weight_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    'unflow_absdiff_bwd': [_P, _P, _P, _P, _I, _I, _I, _P],
+    'unflow_masked_mean_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    'unflow_masked_mean_bwd': [_P, _P, _P, _P, _I, _I, _I, _P],
+    'unflow_ssim_loss_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    'unflow_ssim_loss_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    'unflow_ssim_map': [_P, _P, _P, _I, _I, _I, _I, _P],
+    'unflow_smooth2_fwd': [_P, _P, _P, _P, _I, _I, _I, _P],
+    'unflow_smooth2_bwd': [_P, _P, _P, _P, _I, _I, _I, _P],
+    'unflow_consis_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    'unflow_consis_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class UnflowLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises UnflowLibraryError if it cannot be used."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UnflowLibraryError(
+            'libunflow_hip.so is not built (%s). Run `python -m unopticalflow_amd.build` '
+            '(needs hipcc, targets gfx950). There is no CPU fallback.' % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise UnflowLibraryError('cannot load %s: %s' % (LIB_PATH, e))
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise UnflowLibraryError('%s does not export %s (stale build?)' % (LIB_PATH, name))
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    if lib.unflow_abi_version() != ABI_VERSION:
+        raise UnflowLibraryError('ABI version mismatch: library %d, binding %d'
+                                 % (lib.unflow_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(status, name):
+    if status != 0:
+        raise RuntimeError('%s failed with status %d%s' % (
+            name, status, ' (invalid argument)' if status == -22 else ' (hipError_t)'))

@@ -1,0 +1,156 @@
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import ops
+from .structures import FeaturePyramid, PWC_tf, warp_flow
+
+
+class Model_flow(nn.Module):
+    """Flow-stage model + unsupervised losses (reference core/networks/model_flow_paper.py:14-255).
+
+    Same constructor, attributes (``fpyramid``, ``pwc_model`` -> same checkpoint keys), methods and
+    return values as the reference.  What changed underneath:
+      * the three frames go through the pyramid as ONE 3B batch and the two directed pairs
+        (centre->left, centre->right) through the decoder as ONE 2B batch (the weights are
+        shared, samples are independent), so every conv / corr / warp launch is 2-3x larger;
+      * corr, warp(+mask), occlusion weights, masked-L1, SSIM, smoothness and consistency
+        are HIP kernels (``unopticalflow_amd.ops``) instead of eager op chains;
+      * the 1/8-scale image warp the reference computes and discards
+        (model_flow_paper.py:62-66 with num_scales=3) is not computed.
+    ``cfg.align_corners`` (optional, default False) selects the grid_sample generation.
+    """
+
+    def __init__(self, cfg):
+        super(Model_flow, self).__init__()
+        self.align_corners = bool(getattr(cfg, 'align_corners', False))
+        self.fpyramid = FeaturePyramid()
+        self.pwc_model = PWC_tf(align_corners=self.align_corners)
+        if cfg.mode == 'depth' or cfg.mode == 'flowposenet':
+            # Stage 2 training
+            for param in self.fpyramid.parameters():
+                param.requires_grad = False
+            for param in self.pwc_model.parameters():
+                param.requires_grad = False
+
+        # hyperparameters
+        self.dataset = cfg.dataset
+        self.num_scales = cfg.num_scales
+        self.flow_consist_alpha = cfg.h_flow_consist_alpha
+        self.flow_consist_beta = cfg.h_flow_consist_beta
+
+    # ---- small helpers kept for surface parity (reference :36-60) ----
+    def get_flow_norm(self, flow, p=2):
+        return torch.norm(flow, p=p, dim=1).unsqueeze(1) + 1e-12
+
+    def get_flow_normalization(self, flow, p=2):
+        flow_norm = torch.norm(flow, p=p, dim=1).unsqueeze(1) + 1e-12
+        return flow / flow_norm.repeat(1, 2, 1, 1)
+
+    def generate_img_pyramid(self, img, num_pyramid):
+        img_h, img_w = img.shape[2], img.shape[3]
+        return [F.adaptive_avg_pool2d(img, [int(img_h / (2 ** s)), int(img_w / (2 ** s))]).data
+                for s in range(num_pyramid)]
+
+    def warp_flow_pyramid(self, img_pyramid, flow_pyramid):
+        return [warp_flow(img, flow, use_mask=True, align_corners=self.align_corners)
+                for img, flow in zip(img_pyramid, flow_pyramid)]
+
+    # ---- losses (one HIP op per scale each) ----
+    def compute_loss_with_mask(self, diff_list, occ_mask_list):
+        """reference :90-99"""
+        loss = 0
+        for scale in range(self.num_scales):
+            loss = loss + ops.masked_mean(diff_list[scale], occ_mask_list[scale])
+        return loss
+
+    def compute_diff_weight(self, img_pyramid_from_l, img_pyramid, img_pyramid_from_r):
+        """reference :101-134 -> diff_bwd, diff_fwd, weight_bwd, weight_fwd (lists over scales)"""
+        diff_fwd, diff_bwd, weight_fwd, weight_bwd = [], [], [], []
+        for scale in range(self.num_scales):
+            d_l, d_r, w_b, w_f, _, _ = ops.occ_weight(img_pyramid[scale], img_pyramid_from_l[scale],
+                                                      img_pyramid_from_r[scale])
+            diff_bwd.append(d_l); diff_fwd.append(d_r)
+            weight_bwd.append(w_b); weight_fwd.append(w_f)
+        return diff_bwd, diff_fwd, weight_bwd, weight_fwd
+
+    def compute_loss_ssim(self, img_pyramid, img_warped_pyramid, occ_mask_list):
+        """reference :137-148"""
+        loss = 0
+        for scale in range(self.num_scales):
+            loss = loss + ops.ssim_loss(img_pyramid[scale], img_warped_pyramid[scale], occ_mask_list[scale])
+        return loss
+
+    def gradients(self, img):
+        dy = img[:, :, 1:, :] - img[:, :, :-1, :]
+        dx = img[:, :, :, 1:] - img[:, :, :, :-1]
+        return dx, dy
+
+    def cal_grad2_error(self, flow, img):
+        """reference :157-167; ``flow`` is already divided by 20 as at the call site :174."""
+        return ops.smooth2_loss(flow * 20.0, img)
+
+    def compute_loss_flow_smooth(self, optical_flows, img_pyramid):
+        """reference :169-177 (the /20 of :174 happens inside the kernel)"""
+        loss = 0
+        for scale in range(self.num_scales):
+            loss = loss + ops.smooth2_loss(optical_flows[scale], img_pyramid[scale])
+        return loss
+
+    def compute_loss_flow_consis(self, fwd_flow_pyramid, bwd_flow_pyramid, occ_mask_list):
+        """reference :180-195"""
+        loss = 0
+        for scale in range(self.num_scales):
+            loss = loss + ops.consis_loss(fwd_flow_pyramid[scale], bwd_flow_pyramid[scale], occ_mask_list[scale])
+        return loss
+
+    # ---- network passes ----
+    def inference_flow(self, img1, img2):
+        """reference :198-202 -> full-resolution flow [B,2,H,W]"""
+        img_hw = [img1.shape[2], img1.shape[3]]
+        B = img1.shape[0]
+        feats = self.fpyramid(torch.cat((img1, img2), 0))
+        feature_list_1 = [f[:B] for f in feats]
+        feature_list_2 = [f[B:] for f in feats]
+        return self.pwc_model(feature_list_1, feature_list_2, img_hw)[0]
+
+    def _flows(self, imgl, img, imgr):
+        """Both directed flow pyramids with one 3B pyramid pass and one 2B decoder pass."""
+        B, _, img_h, img_w = img.shape
+        feats = self.fpyramid(torch.cat((imgl, img, imgr), 0))           # [3B, ...] per level
+        feat_c2 = [torch.cat((f[B:2 * B], f[B:2 * B]), 0) for f in feats]
+        feat_lr = [torch.cat((f[:B], f[2 * B:]), 0) for f in feats]
+        flows = self.pwc_model(feat_c2, feat_lr, [img_h, img_w])         # [2B, 2, h, w] per scale
+        return [f[:B] for f in flows], [f[B:] for f in flows]            # bwd (centre->left), fwd
+
+    def forward(self, inputs, output_flow=False, use_flow_loss=True, is_second_phase=False):
+        images = inputs
+        assert (images.shape[1] == 3)
+        img_h, img_w = int(images.shape[2] / 3), images.shape[3]
+        imgl, img, imgr = images[:, :, :img_h, :], images[:, :, img_h:2 * img_h, :], images[:, :, 2 * img_h:3 * img_h, :]
+
+        optical_flows_bwd, optical_flows_fwd = self._flows(imgl, img, imgr)
+
+        loss_pack = {}
+        n = self.num_scales          # the reference also builds the unused 4th level
+        imgl_pyramid = self.generate_img_pyramid(imgl, n)
+        img_pyramid = self.generate_img_pyramid(img, n)
+        imgr_pyramid = self.generate_img_pyramid(imgr, n)
+
+        img_warped_pyramid_from_l = self.warp_flow_pyramid(imgl_pyramid, optical_flows_bwd)
+        img_warped_pyramid_from_r = self.warp_flow_pyramid(imgr_pyramid, optical_flows_fwd)
+
+        diff_bwd, diff_fwd, weight_bwd, weight_fwd = self.compute_diff_weight(
+            img_warped_pyramid_from_l, img_pyramid, img_warped_pyramid_from_r)
+        loss_pack['loss_pixel'] = self.compute_loss_with_mask(diff_fwd, weight_fwd) + \
+            self.compute_loss_with_mask(diff_bwd, weight_bwd)
+
+        loss_pack['loss_ssim'] = self.compute_loss_ssim(img_pyramid, img_warped_pyramid_from_r, weight_fwd) + \
+            self.compute_loss_ssim(img_pyramid, img_warped_pyramid_from_l, weight_bwd)
+
+        loss_pack['loss_flow_smooth'] = self.compute_loss_flow_smooth(optical_flows_fwd, img_pyramid) + \
+            self.compute_loss_flow_smooth(optical_flows_bwd, img_pyramid)
+
+        loss_pack['loss_flow_consis'] = self.compute_loss_flow_consis(optical_flows_fwd, optical_flows_bwd, weight_fwd)
+
+        return loss_pack

@@ -1,0 +1,28 @@
+import torch.nn as nn
+
+from .... import ops
+
+
+def conv(in_planes, out_planes, kernel_size=3, stride=1, padding=1, dilation=1):
+    """Conv2d(bias) + LeakyReLU(0.1) (reference net_utils.py:7-11).  The contraction runs on MFMA
+    through PyTorch-ROCm; the Sequential keeps the reference's ``<name>.0.weight`` state-dict keys."""
+    return nn.Sequential(
+        nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride,
+                  padding=padding, dilation=dilation, bias=True),
+        nn.LeakyReLU(0.1))
+
+
+def deconv(in_planes, out_planes, kernel_size=4, stride=2, padding=1):
+    """reference net_utils.py:13-14 -- kept for the symbol; unused on the flow path."""
+    return nn.ConvTranspose2d(in_planes, out_planes, kernel_size, stride, padding, bias=True)
+
+
+def warp_flow(x, flow, use_mask=False, align_corners=False):
+    """Warp x (im2) back to im1 by the optical flow (reference net_utils.py:16-54).
+
+    x: [B, C, H, W], flow: [B, 2, H, W] -> [B, C, H, W].  One HIP kernel (csrc/warp.hip); with
+    ``use_mask`` the binary validity mask of net_utils.py:47-52 is produced in the same pass and
+    multiplied in.  ``align_corners`` picks the grid_sample generation (False: torch >= 1.3, the
+    reference as it runs today; True: its torch==1.2.0 pin).
+    """
+    return ops.warp_flow(x, flow, use_mask=use_mask, align_corners=align_corners)

@@ -1,0 +1,71 @@
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .... import ops
+from .net_utils import conv, warp_flow
+
+_DD = (128, 128, 96, 64, 32)                       # decoder widths (reference pwc_tf.py:25)
+_FEAT = {6: 0, 5: 128, 4: 96, 3: 64, 2: 32}        # channels of the pyramid level fed to each decoder
+
+
+class PWC_tf(nn.Module):
+    """PWC-style coarse-to-fine flow decoder (reference pwc_tf.py:17-179).
+
+    ``self.corr`` is the reference's own plug point (pwc_tf.py:19-20); here it is the HIP cost
+    volume.  Parameter names (conv{6..2}_{0..4}, predict_flow{6..2}, dc_conv{1..7}) match the
+    reference checkpoint.
+    """
+
+    def __init__(self, md=4, align_corners=False):
+        super(PWC_tf, self).__init__()
+        self.corr = self.corr_naive
+        self.leakyRELU = nn.LeakyReLU(0.1)
+        self.align_corners = align_corners
+        nd = (2 * md + 1) ** 2
+        for lvl in (6, 5, 4, 3, 2):
+            od = nd if lvl == 6 else nd + _FEAT[lvl] + 2
+            cins = (od, _DD[0], _DD[0] + _DD[1], _DD[1] + _DD[2], _DD[2] + _DD[3])
+            for k, cin in enumerate(cins):
+                self.add_module('conv%d_%d' % (lvl, k), conv(cin, _DD[k], kernel_size=3, stride=1))
+            self.add_module('predict_flow%d' % lvl, self.predict_flow(_DD[3] + _DD[4]))
+        ctx = ((_DD[4] + 2, 128, 1), (128, 128, 2), (128, 128, 4), (128, 96, 8), (96, 64, 16), (64, 32, 1))
+        for k, (cin, cout, dil) in enumerate(ctx):
+            self.add_module('dc_conv%d' % (k + 1), conv(cin, cout, kernel_size=3, stride=1, padding=dil, dilation=dil))
+        self.dc_conv7 = self.predict_flow(32)
+
+    def predict_flow(self, in_planes):
+        return nn.Conv2d(in_planes, 2, kernel_size=3, stride=1, padding=1, bias=True)
+
+    def warp(self, x, flow):
+        return warp_flow(x, flow, use_mask=False, align_corners=self.align_corners)
+
+    def corr_naive(self, input1, input2, d=4):
+        """Same contract as the reference's corr_naive (pwc_tf.py:97-106); one HIP kernel."""
+        return ops.corr(input1, input2, d)
+
+    def _decoder(self, lvl, x):
+        c = [getattr(self, 'conv%d_%d' % (lvl, k)) for k in range(5)]
+        x0 = c[0](x)
+        x1 = c[1](x0)
+        x2 = c[2](torch.cat((x0, x1), 1))
+        x3 = c[3](torch.cat((x1, x2), 1))
+        x4 = c[4](torch.cat((x2, x3), 1))
+        return getattr(self, 'predict_flow%d' % lvl)(torch.cat((x3, x4), 1)), x4
+
+    def forward(self, feature_list_1, feature_list_2, img_hw):
+        f1 = dict(zip(range(1, 7), feature_list_1))
+        f2 = dict(zip(range(1, 7), feature_list_2))
+        flow, _ = self._decoder(6, self.corr(f1[6], f2[6]))
+        level_flow = {}
+        for lvl in (5, 4, 3, 2):
+            up = F.interpolate(flow, scale_factor=2.0, mode='bilinear') * 2.0
+            cv = self.corr(f1[lvl], self.warp(f2[lvl], up))
+            flow, x4 = self._decoder(lvl, torch.cat((cv, f1[lvl], up), 1))
+            flow = flow + up
+            level_flow[lvl] = flow
+        x = self.dc_conv4(self.dc_conv3(self.dc_conv2(self.dc_conv1(torch.cat([level_flow[2], x4], 1)))))
+        level_flow[2] = level_flow[2] + self.dc_conv7(self.dc_conv6(self.dc_conv5(x)))
+        img_h, img_w = img_hw[0], img_hw[1]
+        return [F.interpolate(level_flow[lvl] * 4.0, [img_h // (1 << k), img_w // (1 << k)], mode='bilinear')
+                for k, lvl in enumerate((2, 3, 4, 5))]

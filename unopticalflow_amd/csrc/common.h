@@ -1,0 +1,55 @@
+// Shared device helpers for the gfx950 kernels of libunflow_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/unflow_hip.h"
+
+#define UNFLOW_WAVE 64
+
+#define UNFLOW_REQUIRE(cond) do { if (!(cond)) return UNFLOW_EINVAL; } while (0)
+
+static inline int unflow_launch_status() { return (int)hipGetLastError(); }
+
+__host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// 64-lane butterfly sum (DPP/ds_swizzle shuffles, no LDS).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, UNFLOW_WAVE);
+    return v;
+}
+
+// Sum K values over a 256-thread workgroup; result valid in thread 0.  `red` is K*4 floats of LDS.
+template <int K>
+__device__ __forceinline__ void block_sum_256(float (&v)[K], float* red) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) red[wid * K + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = (red[k] + red[K + k]) + (red[2 * K + k] + red[3 * K + k]);
+    }
+}
+
+// Per-sample reductions: every workgroup stores its K partial sums, a second one-workgroup-per-
+// sample kernel adds them in a fixed order (bitwise reproducible; no float atomics).
+// Layout partials[b][blk][K]; blocks per sample = unflow_partials_per_sample(H, W).
+#define UNFLOW_RED_TILE 2048   /* pixels per workgroup in the flat per-sample reductions */
+
+__device__ __forceinline__ float sum_partials(const float* p, int n, int K, int k, float* red) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += p[i * K + k];
+    s = wave_sum(s);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = s;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    return t;
+}

@@ -1,0 +1,383 @@
+// Occlusion-aware photometric terms for gfx950: occlusion weights, masked mean, and the flow
+// regularisers (2nd-order smoothness, forward/backward consistency).
+//
+// Each kernel replaces a chain of ~10-20 eager elementwise / reduction launches of the
+// reference (core/networks/model_flow_paper.py, lines cited per kernel) with one pass over the
+// pixels: coalesced reads along x, per-sample sums reduced with wave shuffles -> LDS -> one
+// partial per workgroup -> fixed-order finalize (bitwise reproducible, no float atomics).
+// Built with -ffp-contract=off: the elementwise algebra follows the reference op by op.
+#include "common.h"
+
+namespace {
+
+constexpr int TILE = UNFLOW_RED_TILE;
+
+// ---------------------------------------------------------------------------------------------
+// compute_diff_weight, model_flow_paper.py:108-132 (one scale)
+// ---------------------------------------------------------------------------------------------
+__global__ void occ_weight_fwd_kernel(const float* __restrict__ img, const float* __restrict__ from_l,
+                                      const float* __restrict__ from_r, float* __restrict__ diff_l,
+                                      float* __restrict__ diff_r, float* __restrict__ w_bwd,
+                                      float* __restrict__ w_fwd, uint8_t* __restrict__ valid_bwd,
+                                      uint8_t* __restrict__ valid_fwd, int B, int HW) {
+    const size_t n = (size_t)B * HW;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = t / HW, p = t - b * HW;
+        const size_t base = b * 3 * HW + p;
+        float dl = 0.f, dr = 0.f;
+        bool zl = true, zr = true;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float i = img[base + (size_t)c * HW];
+            const float l = from_l[base + (size_t)c * HW];
+            const float r = from_r[base + (size_t)c * HW];
+            dl = dl + fabsf(i - l);
+            dr = dr + fabsf(i - r);
+            zl = zl && (l == 0.f);
+            zr = zr && (r == 0.f);
+        }
+        dl = dl / 3.0f;                                   // :117-118  mean over the 3 channels
+        dr = dr / 3.0f;
+        const float vb = zl ? 0.f : 1.f;                  // :112  valid_bwd  <- img_from_l
+        const float vf = zr ? 0.f : 1.f;                  // :111  valid_fwd  <- img_from_r
+        const float mx = fmaxf(dl, dr);                   // :121  softmax over (diff_l, diff_r)
+        const float el = expf(dl - mx), er = expf(dr - mx);
+        const float den = el + er;
+        const float wl = 1.0f - el / den, wr = 1.0f - er / den;
+        const float tl = wl - 0.5f, tr = wr - 0.5f;       // :126
+        const float gl = 2.0f * expf(-(tl * tl) / 0.03f);
+        const float gr = 2.0f * expf(-(tr * tr) / 0.03f);
+        diff_l[t] = dl; diff_r[t] = dr;
+        w_bwd[t] = gl * vb;                               // :128
+        w_fwd[t] = gr * vf;                               // :129
+        if (valid_bwd) valid_bwd[t] = zl ? 0 : 1;
+        if (valid_fwd) valid_fwd[t] = zr ? 0 : 1;
+    }
+}
+
+// d mean_c|img - from| / d from  (torch: abs' = sign, with sign(0) = 0)
+__global__ void absdiff_bwd_kernel(const float* __restrict__ img, const float* __restrict__ from,
+                                   const float* __restrict__ gdiff, float* __restrict__ gfrom, int B, int HW) {
+    const size_t n = (size_t)B * 3 * HW;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = t / ((size_t)3 * HW), p = t % HW;
+        const float d = img[t] - from[t];
+        const float sg = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+        gfrom[t] = -(gdiff[b * HW + p] / 3.0f) * sg;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// compute_loss_with_mask, model_flow_paper.py:93-97 (one scale)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void masked_mean_partial_kernel(const float* __restrict__ diff,
+                                                                  const float* __restrict__ w,
+                                                                  float* __restrict__ partials, int HW) {
+    __shared__ float red[8];
+    const int b = blockIdx.y;
+    float acc[2] = {0.f, 0.f};
+    const int p0 = blockIdx.x * TILE;
+#pragma unroll
+    for (int k = 0; k < TILE / 256; ++k) {
+        const int p = p0 + k * 256 + threadIdx.x;
+        if (p < HW) {
+            const float wv = w[(size_t)b * HW + p];
+            acc[0] += diff[(size_t)b * HW + p] * wv;
+            acc[1] += wv;
+        }
+    }
+    block_sum_256<2>(acc, red);
+    if (threadIdx.x == 0) {
+        float* o = partials + ((size_t)b * gridDim.x + blockIdx.x) * 2;
+        o[0] = acc[0]; o[1] = acc[1];
+    }
+}
+
+// generic finalize for loss = (s0 / n0) / (s1 / n1 + 1e-12)
+__global__ void ratio_finalize_kernel(const float* __restrict__ partials, int nblk, float* __restrict__ loss,
+                                      float* __restrict__ sums, float n0, float n1) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float* p = partials + (size_t)b * nblk * 2;
+    const float s0 = sum_partials(p, nblk, 2, 0, red);
+    const float s1 = sum_partials(p, nblk, 2, 1, red);
+    if (threadIdx.x == 0) {
+        loss[b] = (s0 / n0) / (s1 / n1 + 1e-12f);
+        if (sums) { sums[b * 2] = s0; sums[b * 2 + 1] = s1; }
+    }
+}
+
+__global__ void masked_mean_bwd_kernel(const float* __restrict__ w, const float* __restrict__ sums,
+                                       const float* __restrict__ gloss, float* __restrict__ gdiff,
+                                       int B, int HW) {
+    const size_t n = (size_t)B * HW;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = t / HW;
+        const float k = gloss[b] / (float)HW / (sums[b * 2 + 1] / (float)HW + 1e-12f);
+        gdiff[t] = k * w[t];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cal_grad2_error / compute_loss_flow_smooth, model_flow_paper.py:152-177 (one scale)
+//   err = ( mean_{2,H,W-2}( wx[x+1] * |f[x+2]-2f[x+1]+f[x]| ) + mean_{2,H-2,W}( wy[y+1] * |...| ) ) / 2
+//   wx[x] = exp(-10 * mean_c|img[x+1]-img[x]|), f = flow / 20
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float edge_w(const float* __restrict__ im, size_t hw, size_t i0, size_t i1) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s = s + fabsf(im[c * hw + i1] - im[c * hw + i0]);
+    return expf(-10.0f * (s / 3.0f));
+}
+
+__device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(256) void smooth2_partial_kernel(const float* __restrict__ flow,
+                                                              const float* __restrict__ img,
+                                                              float* __restrict__ partials, int H, int W) {
+    __shared__ float red[8];
+    const int b = blockIdx.y;
+    const int HW = H * W;
+    const float* f = flow + (size_t)b * 2 * HW;
+    const float* im = img + (size_t)b * 3 * HW;
+    float acc[2] = {0.f, 0.f};
+    const int p0 = blockIdx.x * TILE;
+#pragma unroll 2
+    for (int k = 0; k < TILE / 256; ++k) {
+        const int p = p0 + k * 256 + threadIdx.x;
+        if (p >= HW) break;
+        const int y = p / W, x = p - y * W;
+        if (x + 2 < W) {                                 // dx2 at x, weight w_x[x+1]
+            const float wx = edge_w(im, HW, p + 1, p + 2);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float a = f[c * HW + p] / 20.0f, m = f[c * HW + p + 1] / 20.0f, z = f[c * HW + p + 2] / 20.0f;
+                acc[0] += wx * fabsf((z - m) - (m - a));
+            }
+        }
+        if (y + 2 < H) {
+            const float wy = edge_w(im, HW, p + W, p + 2 * W);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float a = f[c * HW + p] / 20.0f, m = f[c * HW + p + W] / 20.0f, z = f[c * HW + p + 2 * W] / 20.0f;
+                acc[1] += wy * fabsf((z - m) - (m - a));
+            }
+        }
+    }
+    block_sum_256<2>(acc, red);
+    if (threadIdx.x == 0) {
+        float* o = partials + ((size_t)b * gridDim.x + blockIdx.x) * 2;
+        o[0] = acc[0]; o[1] = acc[1];
+    }
+}
+
+__global__ void smooth2_finalize_kernel(const float* __restrict__ partials, int nblk, float* __restrict__ loss,
+                                        int H, int W) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float* p = partials + (size_t)b * nblk * 2;
+    const float s0 = sum_partials(p, nblk, 2, 0, red);
+    const float s1 = sum_partials(p, nblk, 2, 1, red);
+    if (threadIdx.x == 0) {
+        const float nx = 2.0f * (float)H * (float)(W - 2), ny = 2.0f * (float)(H - 2) * (float)W;
+        loss[b] = (s0 / nx + s1 / ny) / 2.0f;     // empty means (W<3 or H<3) are NaN, as in torch
+    }
+}
+
+// gather form of the backward: pixel q collects the three second differences it takes part in.
+__global__ void smooth2_bwd_kernel(const float* __restrict__ flow, const float* __restrict__ img,
+                                   const float* __restrict__ gloss, float* __restrict__ gflow,
+                                   int B, int H, int W) {
+    const int HW = H * W;
+    const size_t n = (size_t)B * HW;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(t / HW), p = (int)(t - (size_t)b * HW);
+        const int y = p / W, x = p - y * W;
+        const float* f = flow + (size_t)b * 2 * HW;
+        const float* im = img + (size_t)b * 3 * HW;
+        const float kx = gloss[b] / (2.0f * (2.0f * (float)H * (float)(W - 2))) / 20.0f;
+        const float ky = gloss[b] / (2.0f * (2.0f * (float)(H - 2) * (float)W)) / 20.0f;
+        float g[2] = {0.f, 0.f};
+        // x direction: second difference starting at x0 = x-2, x-1, x with coefficient +1, -2, +1
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int x0 = x - 2 + k;
+            if (x0 < 0 || x0 + 2 >= W) continue;
+            const int q = p - 2 + k;
+            const float wx = edge_w(im, HW, q + 1, q + 2);
+            const float coef = (k == 1) ? -2.f : 1.f;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float a = f[c * HW + q] / 20.0f, m = f[c * HW + q + 1] / 20.0f, z = f[c * HW + q + 2] / 20.0f;
+                g[c] += kx * wx * coef * sgn((z - m) - (m - a));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int y0 = y - 2 + k;
+            if (y0 < 0 || y0 + 2 >= H) continue;
+            const int q = p + (k - 2) * W;
+            const float wy = edge_w(im, HW, q + W, q + 2 * W);
+            const float coef = (k == 1) ? -2.f : 1.f;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float a = f[c * HW + q] / 20.0f, m = f[c * HW + q + W] / 20.0f, z = f[c * HW + q + 2 * W] / 20.0f;
+                g[c] += ky * wy * coef * sgn((z - m) - (m - a));
+            }
+        }
+        gflow[(size_t)b * 2 * HW + p] = g[0];
+        gflow[(size_t)b * 2 * HW + HW + p] = g[1];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// get_flow_normalization + compute_loss_flow_consis, model_flow_paper.py:44-51,183-193 (one scale)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void consis_partial_kernel(const float* __restrict__ ff,
+                                                             const float* __restrict__ fb,
+                                                             const float* __restrict__ w_fwd,
+                                                             float* __restrict__ partials, int HW) {
+    __shared__ float red[8];
+    const int b = blockIdx.y;
+    const float* f = ff + (size_t)b * 2 * HW;
+    const float* g = fb + (size_t)b * 2 * HW;
+    float acc[2] = {0.f, 0.f};
+    const int p0 = blockIdx.x * TILE;
+#pragma unroll
+    for (int k = 0; k < TILE / 256; ++k) {
+        const int p = p0 + k * 256 + threadIdx.x;
+        if (p < HW) {
+            const float fu = f[p], fv = f[HW + p], gu = g[p], gv = g[HW + p];
+            const float nf = sqrtf(fu * fu + fv * fv) + 1e-12f;
+            const float ng = sqrtf(gu * gu + gv * gv) + 1e-12f;
+            const float occ = 1.0f - w_fwd[(size_t)b * HW + p];
+            acc[0] += fabsf(fu / nf + gu / ng) * occ + fabsf(fv / nf + gv / ng) * occ;
+            acc[1] += occ;
+        }
+    }
+    block_sum_256<2>(acc, red);
+    if (threadIdx.x == 0) {
+        float* o = partials + ((size_t)b * gridDim.x + blockIdx.x) * 2;
+        o[0] = acc[0]; o[1] = acc[1];
+    }
+}
+
+__global__ void consis_bwd_kernel(const float* __restrict__ ff, const float* __restrict__ fb,
+                                  const float* __restrict__ w_fwd, const float* __restrict__ sums,
+                                  const float* __restrict__ gloss, float* __restrict__ gflow, int B, int HW) {
+    const size_t n = (size_t)B * HW;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = t / HW, p = t - b * HW;
+        const float* f = ff + b * 2 * HW;
+        const float* g = fb + b * 2 * HW;
+        const float fu = f[p], fv = f[HW + p], gu = g[p], gv = g[HW + p];
+        const float n0 = sqrtf(fu * fu + fv * fv), nf = n0 + 1e-12f;
+        const float ng = sqrtf(gu * gu + gv * gv) + 1e-12f;
+        const float occ = 1.0f - w_fwd[t];
+        const float k = gloss[b] / (2.0f * (float)HW) / (sums[b * 2 + 1] / (float)HW + 1e-12f) * occ;
+        const float tu = k * sgn(fu / nf + gu / ng), tv = k * sgn(fv / nf + gv / ng);
+        // f_hat = f / (|f| + eps):  d f_hat_c / d f_j = delta_cj / nf - f_c f_j / (nf^2 |f|)
+        const float dot = tu * fu + tv * fv;
+        const float r = (n0 > 0.f) ? dot / (nf * nf * n0) : 0.f;
+        gflow[b * 2 * HW + p] = tu / nf - r * fu;
+        gflow[b * 2 * HW + HW + p] = tv / nf - r * fv;
+    }
+}
+
+inline int flat_blocks(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (int)(b < 8192 ? (b ? b : 1) : 8192);
+}
+
+}  // namespace
+
+int unflow_ssim_blocks(int H, int W);   // ssim.hip
+
+extern "C" int unflow_abi_version(void) { return 1; }
+
+extern "C" int unflow_partials_per_sample(int H, int W) {
+    if (H <= 0 || W <= 0) return UNFLOW_EINVAL;
+    const int flat = ceil_div(H * W, TILE);
+    const int ss = unflow_ssim_blocks(H, W);
+    return 2 * (flat > ss ? flat : ss);     // floats per sample (K = 2 everywhere)
+}
+
+extern "C" int unflow_occ_weight_fwd(const float* img, const float* from_l, const float* from_r,
+                                     float* diff_l, float* diff_r, float* w_bwd, float* w_fwd,
+                                     uint8_t* valid_bwd, uint8_t* valid_fwd, int B, int H, int W, void* stream) {
+    UNFLOW_REQUIRE(img && from_l && from_r && diff_l && diff_r && w_bwd && w_fwd && B > 0 && H > 0 && W > 0);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(occ_weight_fwd_kernel, dim3(flat_blocks((size_t)B * H * W)), dim3(256), 0, s, img, from_l,
+                       from_r, diff_l, diff_r, w_bwd, w_fwd, valid_bwd, valid_fwd, B, H * W);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_absdiff_bwd(const float* img, const float* from, const float* gdiff, float* gfrom,
+                                  int B, int H, int W, void* stream) {
+    UNFLOW_REQUIRE(img && from && gdiff && gfrom && B > 0 && H > 0 && W > 0);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(absdiff_bwd_kernel, dim3(flat_blocks((size_t)B * 3 * H * W)), dim3(256), 0, s, img, from,
+                       gdiff, gfrom, B, H * W);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_masked_mean_fwd(const float* diff, const float* w, float* loss, float* sums,
+                                      float* partials, int B, int H, int W, void* stream) {
+    UNFLOW_REQUIRE(diff && w && loss && sums && partials && B > 0 && H > 0 && W > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = ceil_div(H * W, TILE);
+    hipLaunchKernelGGL(masked_mean_partial_kernel, dim3(nblk, B), dim3(256), 0, s, diff, w, partials, H * W);
+    hipLaunchKernelGGL(ratio_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, sums,
+                       (float)H * (float)W, (float)H * (float)W);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_masked_mean_bwd(const float* w, const float* sums, const float* gloss, float* gdiff,
+                                      int B, int H, int W, void* stream) {
+    UNFLOW_REQUIRE(w && sums && gloss && gdiff && B > 0 && H > 0 && W > 0);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(masked_mean_bwd_kernel, dim3(flat_blocks((size_t)B * H * W)), dim3(256), 0, s, w, sums,
+                       gloss, gdiff, B, H * W);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_smooth2_fwd(const float* flow, const float* img, float* loss, float* partials,
+                                  int B, int H, int W, void* stream) {
+    UNFLOW_REQUIRE(flow && img && loss && partials && B > 0 && H > 0 && W > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = ceil_div(H * W, TILE);
+    hipLaunchKernelGGL(smooth2_partial_kernel, dim3(nblk, B), dim3(256), 0, s, flow, img, partials, H, W);
+    hipLaunchKernelGGL(smooth2_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, H, W);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_smooth2_bwd(const float* flow, const float* img, const float* gloss, float* gflow,
+                                  int B, int H, int W, void* stream) {
+    UNFLOW_REQUIRE(flow && img && gloss && gflow && B > 0 && H > 0 && W > 0);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(smooth2_bwd_kernel, dim3(flat_blocks((size_t)B * H * W)), dim3(256), 0, s, flow, img, gloss,
+                       gflow, B, H, W);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_consis_fwd(const float* fwd_flow, const float* bwd_flow, const float* w_fwd, float* loss,
+                                 float* sums, float* partials, int B, int H, int W, void* stream) {
+    UNFLOW_REQUIRE(fwd_flow && bwd_flow && w_fwd && loss && sums && partials && B > 0 && H > 0 && W > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = ceil_div(H * W, TILE);
+    hipLaunchKernelGGL(consis_partial_kernel, dim3(nblk, B), dim3(256), 0, s, fwd_flow, bwd_flow, w_fwd, partials,
+                       H * W);
+    hipLaunchKernelGGL(ratio_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, sums,
+                       2.0f * (float)H * (float)W, (float)H * (float)W);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_consis_bwd(const float* fwd_flow, const float* bwd_flow, const float* w_fwd,
+                                 const float* sums, const float* gloss, float* gflow, int B, int H, int W,
+                                 void* stream) {
+    UNFLOW_REQUIRE(fwd_flow && bwd_flow && w_fwd && sums && gloss && gflow && B > 0 && H > 0 && W > 0);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(consis_bwd_kernel, dim3(flat_blocks((size_t)B * H * W)), dim3(256), 0, s, fwd_flow, bwd_flow,
+                       w_fwd, sums, gloss, gflow, B, H * W);
+    return unflow_launch_status();
+}

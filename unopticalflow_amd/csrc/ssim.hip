@@ -1,0 +1,264 @@
+// SSIM loss forward / backward for gfx950 -- wavefront sliding window, no LDS tiles.
+//
+// Replaces SSIM (reference core/networks/pytorch_ssim/ssim.py:4-20: five AvgPool2d(3,1,1) plus
+// ~15 elementwise launches, each a full HBM round trip) and the surrounding
+// compute_loss_ssim scale body (model_flow_paper.py:140-146).
+//
+// One wave owns a 64-column strip and walks down the rows.  Lanes hold one column each; the
+// x-1 / x+1 neighbours come from DPP lane shuffles, the y-1 / y+1 neighbours from a 3-row
+// register ring, so every input element is read from HBM once per strip (strips overlap by the
+// 1- or 2-lane halo).  The 3x3 sums are accumulated in the same tap order as ATen's
+// avg_pool2d (row-major over the window, then / 9) and the SSIM algebra follows ssim.py
+// operation by operation (this file is built with -ffp-contract=off), so the map agrees with
+// the CPU reference to rounding of the final divide.
+//
+// Backward (w.r.t. the warped image only; img is a detached pyramid level and w is detached,
+// model_flow_paper.py:58,122): a second ring carries the per-pixel coefficients
+//   a = gS*dS/dmu_y, b = gS*dS/dE[yy], c = gS*dS/dE[xy]
+// whose 3x3 box sum gives  d/dy_q = (A + 2*y_q*B + x_q*C) / 9.
+#include "common.h"
+
+namespace {
+
+constexpr float kC1 = 0.0001f;   // 0.01**2
+constexpr float kC2 = 0.0009f;   // 0.03**2
+
+struct Stats { float mu_x, mu_y, sig_x, sig_y, sig_xy, n1, n2, d1, d2, ssim; };
+
+// X/Y: [row][col] raw 3x3 neighbourhood in ATen's pooling order.
+__device__ __forceinline__ Stats window_stats(const float (&X)[3][3], const float (&Y)[3][3]) {
+    float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float x = X[r][k], y = Y[r][k];
+            sx = sx + x; sy = sy + y;
+            sxx = sxx + x * x; syy = syy + y * y; sxy = sxy + x * y;
+        }
+    Stats s;
+    s.mu_x = sx / 9.0f; s.mu_y = sy / 9.0f;
+    s.sig_x = sxx / 9.0f - s.mu_x * s.mu_x;
+    s.sig_y = syy / 9.0f - s.mu_y * s.mu_y;
+    s.sig_xy = sxy / 9.0f - s.mu_x * s.mu_y;
+    s.n1 = 2.0f * s.mu_x * s.mu_y + kC1;
+    s.n2 = 2.0f * s.sig_xy + kC2;
+    s.d1 = s.mu_x * s.mu_x + s.mu_y * s.mu_y + kC1;
+    s.d2 = s.sig_x + s.sig_y + kC2;
+    s.ssim = (s.n1 * s.n2) / (s.d1 * s.d2);
+    return s;
+}
+
+// Strip geometry shared by host and device.
+constexpr int RS = 32;                  // output rows per wave
+__host__ __device__ inline int strips(int W, int halo) { return ceil_div(W, 64 - 2 * halo); }
+__host__ __device__ inline int chunks(int H) { return ceil_div(H, RS); }
+
+// NC channels share one weight plane (NC = 3, WEIGHTED: the loss; NC = 1, !WEIGHTED: the bare map).
+// grid = (ceil(strips*chunks / 4), groups) with groups = B (loss) or B*C (map); block = 256.
+template <int NC, bool WEIGHTED, bool MAP>
+__global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__ img,
+                                                       const float* __restrict__ warped,
+                                                       const float* __restrict__ wgt,
+                                                       float* __restrict__ map_out,
+                                                       float* __restrict__ partials, int H, int W) {
+    __shared__ float red[8];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int grp = blockIdx.y;
+    const int nsx = strips(W, 1), nch = chunks(H);
+    const int job = blockIdx.x * 4 + wid;
+    float acc[2] = {0.f, 0.f};
+    if (job < nsx * nch) {
+        const int sx = job % nsx, cy = job / nsx;
+        const int x = sx * 62 - 1 + lane;
+        const int ys = cy * RS, ye = min(ys + RS, H);
+        const bool xin = (x >= 0 && x < W);
+        const bool xout = xin && lane >= 1 && lane <= 62;
+        const size_t plane = (size_t)H * W;
+        const float* ip = img + (size_t)grp * NC * plane;
+        const float* wp = warped + (size_t)grp * NC * plane;
+        const float* mp = WEIGHTED ? wgt + (size_t)grp * plane : nullptr;
+        float X[NC][3][3], Y[NC][3][3];       // [channel][ring row][left, centre, right]
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { X[c][r][k] = 0.f; Y[c][r][k] = 0.f; }
+        for (int r = ys - 1; r <= ye; ++r) {
+            const bool rin = (r >= 0 && r < H) && xin;
+            const size_t off = (size_t)(rin ? r : 0) * W + (xin ? x : 0);
+            const float m = WEIGHTED ? (rin ? mp[off] : 0.f) : 1.f;
+            if (WEIGHTED && r >= ys && r < ye && xout) acc[1] += m;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float xv = rin ? ip[(size_t)c * plane + off] * m : 0.f;
+                const float yv = rin ? wp[(size_t)c * plane + off] * m : 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {   // slide the ring
+                    X[c][0][k] = X[c][1][k]; X[c][1][k] = X[c][2][k];
+                    Y[c][0][k] = Y[c][1][k]; Y[c][1][k] = Y[c][2][k];
+                }
+                X[c][2][0] = __shfl_up(xv, 1, 64); X[c][2][1] = xv; X[c][2][2] = __shfl_down(xv, 1, 64);
+                Y[c][2][0] = __shfl_up(yv, 1, 64); Y[c][2][1] = yv; Y[c][2][2] = __shfl_down(yv, 1, 64);
+            }
+            const int ro = r - 1;               // the row whose window is now complete
+            if (ro >= ys && ro < ye && xout) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const Stats s = window_stats(X[c], Y[c]);
+                    if (MAP) {
+                        map_out[((size_t)grp * NC + c) * plane + (size_t)ro * W + x] = s.ssim;
+                    } else {
+                        const float v = (1.0f - s.ssim) / 2.0f;
+                        acc[0] += fminf(fmaxf(v, 0.f), 1.f);
+                    }
+                }
+            }
+        }
+    }
+    if (!MAP) {
+        block_sum_256<2>(acc, red);
+        if (threadIdx.x == 0) {
+            float* p = partials + ((size_t)grp * gridDim.x + blockIdx.x) * 2;
+            p[0] = acc[0]; p[1] = acc[1];
+        }
+    }
+}
+
+// loss[b] = (sum clamp / (3*H*W)) / (sum w / (H*W) + 1e-12); sums[b] = {sum clamp, sum w}
+__global__ void ssim_finalize_kernel(const float* __restrict__ partials, int nblk, float* __restrict__ loss,
+                                     float* __restrict__ sums, int H, int W) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float* p = partials + (size_t)b * nblk * 2;
+    const float s0 = sum_partials(p, nblk, 2, 0, red);
+    const float s1 = sum_partials(p, nblk, 2, 1, red);
+    if (threadIdx.x == 0) {
+        const float hw = (float)H * (float)W;
+        loss[b] = (s0 / (3.0f * hw)) / (s1 / hw + 1e-12f);
+        sums[b * 2] = s0; sums[b * 2 + 1] = s1;
+    }
+}
+
+// grid = (ceil(strips2*chunks/4), B); 2-lane halo per side -> 60 output columns per wave.
+__global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__ img,
+                                                       const float* __restrict__ warped,
+                                                       const float* __restrict__ wgt,
+                                                       const float* __restrict__ sums,
+                                                       const float* __restrict__ gloss,
+                                                       float* __restrict__ gwarped, int H, int W) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int nsx = strips(W, 2), nch = chunks(H);
+    const int job = blockIdx.x * 4 + wid;
+    if (job >= nsx * nch) return;
+    const int sx = job % nsx, cy = job / nsx;
+    const int x = sx * 60 - 2 + lane;
+    const int ys = cy * RS, ye = min(ys + RS, H);
+    const bool xin = (x >= 0 && x < W);
+    const bool xout = xin && lane >= 2 && lane <= 61;
+    const size_t plane = (size_t)H * W;
+    const float* ip = img + (size_t)b * 3 * plane;
+    const float* wp = warped + (size_t)b * 3 * plane;
+    const float* mp = wgt + (size_t)b * plane;
+    float* gp = gwarped + (size_t)b * 3 * plane;
+    const float hw = (float)H * (float)W;
+    // d loss[b] / d clamp-sum, times d clamp / d SSIM = -1/2 inside the clamp range
+    const float kb = gloss[b] / (3.0f * hw) / (sums[b * 2 + 1] / hw + 1e-12f) * -0.5f;
+
+    float X[3][3][3], Y[3][3][3];      // raw ring  [channel][row][l,c,r]
+    float Q[3][3][3];                  // coefficient ring [channel][row][a,b,c], already summed over x-1..x+1
+    float M[3];                        // weight ring (centre lane)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { X[c][r][k] = 0.f; Y[c][r][k] = 0.f; Q[c][r][k] = 0.f; }
+    M[0] = M[1] = M[2] = 0.f;
+
+    // r: newest raw row; r-1: row whose stats complete; r-2: row whose gradient completes.
+    for (int r = ys - 2; r <= ye + 1; ++r) {
+        const bool rin = (r >= 0 && r < H) && xin;
+        const size_t off = (size_t)(rin ? r : 0) * W + (xin ? x : 0);
+        const float m = rin ? mp[off] : 0.f;
+        M[0] = M[1]; M[1] = M[2]; M[2] = m;
+        const int rs = r - 1;
+        const bool sin = (rs >= 0 && rs < H) && xin;        // stats pixel inside the image?
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float xv = rin ? ip[(size_t)c * plane + off] * m : 0.f;
+            const float yv = rin ? wp[(size_t)c * plane + off] * m : 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                X[c][0][k] = X[c][1][k]; X[c][1][k] = X[c][2][k];
+                Y[c][0][k] = Y[c][1][k]; Y[c][1][k] = Y[c][2][k];
+                Q[c][0][k] = Q[c][1][k]; Q[c][1][k] = Q[c][2][k];
+            }
+            X[c][2][0] = __shfl_up(xv, 1, 64); X[c][2][1] = xv; X[c][2][2] = __shfl_down(xv, 1, 64);
+            Y[c][2][0] = __shfl_up(yv, 1, 64); Y[c][2][1] = yv; Y[c][2][2] = __shfl_down(yv, 1, 64);
+            float a = 0.f, bq = 0.f, cq = 0.f;
+            if (sin) {
+                const Stats s = window_stats(X[c], Y[c]);
+                const float v = (1.0f - s.ssim) / 2.0f;
+                if (v >= 0.f && v <= 1.f) {                 // clamp passes gradient on [min, max]
+                    const float inv = 1.0f / (s.d1 * s.d2);
+                    a = kb * (2.0f * s.mu_x * (s.n2 - s.n1) * inv -
+                              2.0f * s.mu_y * s.ssim * (1.0f / s.d1 - 1.0f / s.d2));
+                    bq = kb * (-s.ssim / s.d2);
+                    cq = kb * (2.0f * s.n1 * inv);
+                }
+            }
+            Q[c][2][0] = __shfl_up(a, 1, 64) + a + __shfl_down(a, 1, 64);
+            Q[c][2][1] = __shfl_up(bq, 1, 64) + bq + __shfl_down(bq, 1, 64);
+            Q[c][2][2] = __shfl_up(cq, 1, 64) + cq + __shfl_down(cq, 1, 64);
+        }
+        const int ro = r - 2;
+        if (ro >= ys && ro < ye && xout) {
+            const float mo = M[0];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float A = Q[c][0][0] + Q[c][1][0] + Q[c][2][0];
+                const float Bq = Q[c][0][1] + Q[c][1][1] + Q[c][2][1];
+                const float Cq = Q[c][0][2] + Q[c][1][2] + Q[c][2][2];
+                const float gy = (A + 2.0f * Y[c][0][1] * Bq + X[c][0][1] * Cq) / 9.0f;
+                gp[(size_t)c * plane + (size_t)ro * W + x] = gy * mo;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int unflow_ssim_blocks(int H, int W) { return ceil_div(strips(W, 1) * chunks(H), 4); }
+
+extern "C" int unflow_ssim_loss_fwd(const float* img, const float* warped, const float* w, float* loss,
+                                    float* sums, float* partials, int B, int H, int W, void* stream) {
+    UNFLOW_REQUIRE(img && warped && w && loss && sums && partials && B > 0 && H > 0 && W > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = unflow_ssim_blocks(H, W);
+    hipLaunchKernelGGL((ssim_fwd_kernel<3, true, false>), dim3(nblk, B), dim3(256), 0, s, img, warped, w,
+                       (float*)nullptr, partials, H, W);
+    hipLaunchKernelGGL(ssim_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, sums, H, W);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_ssim_loss_bwd(const float* img, const float* warped, const float* w, const float* sums,
+                                    const float* gloss, float* gwarped, int B, int H, int W, void* stream) {
+    UNFLOW_REQUIRE(img && warped && w && sums && gloss && gwarped && B > 0 && H > 0 && W > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = ceil_div(strips(W, 2) * chunks(H), 4);
+    hipLaunchKernelGGL(ssim_bwd_kernel, dim3(nblk, B), dim3(256), 0, s, img, warped, w, sums, gloss, gwarped, H, W);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_ssim_map(const float* x, const float* y, float* out, int B, int C, int H, int W,
+                               void* stream) {
+    UNFLOW_REQUIRE(x && y && out && B > 0 && C > 0 && H > 0 && W > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = unflow_ssim_blocks(H, W);
+    hipLaunchKernelGGL((ssim_fwd_kernel<1, false, true>), dim3(nblk, B * C), dim3(256), 0, s, x, y,
+                       (const float*)nullptr, out, (float*)nullptr, H, W);
+    return unflow_launch_status();
+}

@@ -1,0 +1,321 @@
+"""Autograd operators over libunflow_hip.so.
+
+Each operator replaces one eager op chain of the reference (file:line in the docstrings) with
+the hand-written gfx950 kernels of ``csrc/``.  Tensors must live on a HIP device: there is no
+CPU path here (the CPU restatement used for parity lives in ``oracle/`` and is test-only).
+PyTorch supplies device memory (caching allocator) and the current stream; the kernels are
+called through the plain-C ABI of ``include/unflow_hip.h`` with raw pointers.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+__all__ = ['corr', 'warp_flow', 'warp_flow_masked', 'occ_weight', 'masked_mean', 'ssim_loss',
+           'ssim_map', 'smooth2_loss', 'consis_loss']
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(*tensors):
+    """All operands must be fp32 tensors on one HIP device."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError('unopticalflow_amd ops run on an MI355X (HIP) device only; got a %s tensor. '
+                               'There is no CPU fallback.' % t.device)
+        if t.dtype != torch.float32:
+            raise TypeError('unopticalflow_amd ops compute in fp32; got %s' % t.dtype)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError('operands on different devices: %s vs %s' % (dev, t.device))
+    return dev
+
+
+def _call(name, *args):
+    lib = _lib.load()
+    _lib.check(getattr(lib, name)(*args), name)
+
+
+def _partials(B, H, W, dev):
+    n = _lib.load().unflow_partials_per_sample(H, W)
+    return torch.empty(B * n, dtype=torch.float32, device=dev)
+
+
+# ------------------------------------------------------------------------------------------
+# cost volume
+# ------------------------------------------------------------------------------------------
+class _Corr(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f1, f2, d):
+        _dev(f1, f2)
+        f1, f2 = f1.contiguous(), f2.contiguous()
+        B, C, H, W = f1.shape
+        cv = torch.empty((B, (2 * d + 1) ** 2, H, W), dtype=f1.dtype, device=f1.device)
+        with torch.cuda.device(f1.device):
+            _call('unflow_corr_fwd', _ptr(f1), _ptr(f2), _ptr(cv), B, C, H, W, d, _stream())
+        ctx.save_for_backward(f1, f2)
+        ctx.d = d
+        return cv
+
+    @staticmethod
+    def backward(ctx, g):
+        f1, f2 = ctx.saved_tensors
+        B, C, H, W = f1.shape
+        g = g.contiguous()
+        gf1, gf2 = torch.empty_like(f1), torch.empty_like(f2)
+        with torch.cuda.device(f1.device):
+            _call('unflow_corr_bwd', _ptr(f1), _ptr(f2), _ptr(g), _ptr(gf1), _ptr(gf2), B, C, H, W, ctx.d,
+                  _stream())
+        return gf1, gf2, None
+
+
+def corr(input1, input2, d=4):
+    """Cost volume, PWC_tf.corr_naive (pwc_tf.py:97-106): [B,C,H,W] x2 -> [B,(2d+1)^2,H,W]."""
+    assert (input1.shape == input2.shape)            # pwc_tf.py:99
+    return _Corr.apply(input1, input2, int(d))
+
+
+# ------------------------------------------------------------------------------------------
+# warp
+# ------------------------------------------------------------------------------------------
+class _Warp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, flow, use_mask, align_corners):
+        _dev(x, flow)
+        x, flow = x.contiguous(), flow.contiguous()
+        B, C, H, W = x.shape
+        out = torch.empty_like(x)
+        mask = torch.empty((B, 1, H, W), dtype=torch.uint8, device=x.device) if use_mask else None
+        with torch.cuda.device(x.device):
+            _call('unflow_warp_fwd', _ptr(x), _ptr(flow), _ptr(out), _ptr(mask), B, C, H, W,
+                  int(align_corners), _stream())
+        ctx.save_for_backward(x, flow, mask)
+        ctx.ac = int(align_corners)
+        if use_mask:
+            ctx.mark_non_differentiable(mask)
+            return out, mask
+        return out, None
+
+    @staticmethod
+    def backward(ctx, g, _gmask):
+        x, flow, mask = ctx.saved_tensors
+        B, C, H, W = x.shape
+        g = g.contiguous()
+        gsrc = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gflow = torch.empty_like(flow)
+        with torch.cuda.device(x.device):
+            _call('unflow_warp_bwd', _ptr(x), _ptr(flow), _ptr(g), _ptr(mask), _ptr(gsrc), _ptr(gflow),
+                  B, C, H, W, ctx.ac, _stream())
+        return gsrc, (gflow if ctx.needs_input_grad[1] else None), None, None
+
+
+def _check_flow_shape(x, flow):
+    B, C, H, W = x.size()
+    if tuple(flow.shape) != (B, 2, H, W):            # net_utils.py:35-36
+        raise ValueError('the shape of grid {0} is not equal to the shape of flow {1}.'.format(
+            torch.Size((B, 2, H, W)), flow.shape))
+
+
+def warp_flow(x, flow, use_mask=False, align_corners=False):
+    """warp_flow (net_utils.py:16-54): backward-warp x [B,C,H,W] by flow [B,2,H,W]."""
+    _check_flow_shape(x, flow)
+    out, _ = _Warp.apply(x, flow, bool(use_mask), bool(align_corners))
+    return out
+
+
+def warp_flow_masked(x, flow, align_corners=False):
+    """warp_flow(..., use_mask=True) that also returns the binary uint8 mask of net_utils.py:47-51."""
+    _check_flow_shape(x, flow)
+    return _Warp.apply(x, flow, True, bool(align_corners))
+
+
+# ------------------------------------------------------------------------------------------
+# occlusion weights + photometric terms
+# ------------------------------------------------------------------------------------------
+class _OccWeight(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, from_l, from_r):
+        dev = _dev(img, from_l, from_r)
+        img, from_l, from_r = img.contiguous(), from_l.contiguous(), from_r.contiguous()
+        B, C, H, W = img.shape
+        assert C == 3
+        f = lambda: torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        u = lambda: torch.empty((B, 1, H, W), dtype=torch.uint8, device=dev)
+        diff_l, diff_r, w_bwd, w_fwd, v_bwd, v_fwd = f(), f(), f(), f(), u(), u()
+        with torch.cuda.device(dev):
+            _call('unflow_occ_weight_fwd', _ptr(img), _ptr(from_l), _ptr(from_r), _ptr(diff_l), _ptr(diff_r),
+                  _ptr(w_bwd), _ptr(w_fwd), _ptr(v_bwd), _ptr(v_fwd), B, H, W, _stream())
+        ctx.save_for_backward(img, from_l, from_r)
+        ctx.mark_non_differentiable(w_bwd, w_fwd, v_bwd, v_fwd)     # weight is .data (:122)
+        return diff_l, diff_r, w_bwd, w_fwd, v_bwd, v_fwd
+
+    @staticmethod
+    def backward(ctx, g_l, g_r, *_):
+        img, from_l, from_r = ctx.saved_tensors
+        B, C, H, W = img.shape
+        out = [None, None, None]
+        with torch.cuda.device(img.device):
+            for k, (src, g) in enumerate(((from_l, g_l), (from_r, g_r))):
+                if ctx.needs_input_grad[k + 1] and g is not None:
+                    gs = torch.empty_like(src)
+                    _call('unflow_absdiff_bwd', _ptr(img), _ptr(src), _ptr(g.contiguous()), _ptr(gs), B, H, W,
+                          _stream())
+                    out[k + 1] = gs
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError('occ_weight: the centre image is a detached pyramid level '
+                               '(model_flow_paper.py:58); no gradient is defined for it')
+        return tuple(out)
+
+
+def occ_weight(img, img_from_l, img_from_r):
+    """One scale of compute_diff_weight (model_flow_paper.py:108-132).
+
+    Returns (diff_l, diff_r, weight_bwd, weight_fwd, valid_bwd_u8, valid_fwd_u8)."""
+    return _OccWeight.apply(img, img_from_l, img_from_r)
+
+
+class _MaskedMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, diff, w):
+        dev = _dev(diff, w)
+        diff, w = diff.contiguous(), w.contiguous()
+        B, _, H, W = diff.shape
+        loss = torch.empty(B, dtype=torch.float32, device=dev)
+        sums = torch.empty((B, 2), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _call('unflow_masked_mean_fwd', _ptr(diff), _ptr(w), _ptr(loss), _ptr(sums),
+                  _ptr(_partials(B, H, W, dev)), B, H, W, _stream())
+        ctx.save_for_backward(w, sums)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        w, sums = ctx.saved_tensors
+        B, _, H, W = w.shape
+        gdiff = torch.empty_like(w)
+        with torch.cuda.device(w.device):
+            _call('unflow_masked_mean_bwd', _ptr(w), _ptr(sums), _ptr(gl.contiguous()), _ptr(gdiff), B, H, W,
+                  _stream())
+        return gdiff, None
+
+
+def masked_mean(diff, w):
+    """One scale of compute_loss_with_mask (model_flow_paper.py:93-97): [B,1,H,W] x2 -> [B]."""
+    return _MaskedMean.apply(diff, w.detach())
+
+
+class _SsimLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, warped, w):
+        dev = _dev(img, warped, w)
+        img, warped, w = img.contiguous(), warped.contiguous(), w.contiguous()
+        B, C, H, W = img.shape
+        assert C == 3
+        loss = torch.empty(B, dtype=torch.float32, device=dev)
+        sums = torch.empty((B, 2), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _call('unflow_ssim_loss_fwd', _ptr(img), _ptr(warped), _ptr(w), _ptr(loss), _ptr(sums),
+                  _ptr(_partials(B, H, W, dev)), B, H, W, _stream())
+        ctx.save_for_backward(img, warped, w, sums)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        img, warped, w, sums = ctx.saved_tensors
+        B, C, H, W = img.shape
+        gw = torch.empty_like(warped)
+        with torch.cuda.device(img.device):
+            _call('unflow_ssim_loss_bwd', _ptr(img), _ptr(warped), _ptr(w), _ptr(sums), _ptr(gl.contiguous()),
+                  _ptr(gw), B, H, W, _stream())
+        return None, gw, None
+
+
+def ssim_loss(img, img_warped, w):
+    """One scale of compute_loss_ssim (model_flow_paper.py:140-146) -> [B]; grad to img_warped."""
+    return _SsimLoss.apply(img.detach(), img_warped, w.detach())
+
+
+def ssim_map(x, y):
+    """SSIM(x, y) map of pytorch_ssim/ssim.py:4-20 (forward only)."""
+    dev = _dev(x, y)
+    if x.requires_grad or y.requires_grad:
+        raise RuntimeError('ssim_map is forward-only; the differentiable path is ssim_loss')
+    x, y = x.contiguous(), y.contiguous()
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        _call('unflow_ssim_map', _ptr(x), _ptr(y), _ptr(out), B, C, H, W, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# flow regularisers
+# ------------------------------------------------------------------------------------------
+class _Smooth2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flow, img):
+        dev = _dev(flow, img)
+        flow, img = flow.contiguous(), img.contiguous()
+        B, _, H, W = flow.shape
+        loss = torch.empty(B, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _call('unflow_smooth2_fwd', _ptr(flow), _ptr(img), _ptr(loss), _ptr(_partials(B, H, W, dev)),
+                  B, H, W, _stream())
+        ctx.save_for_backward(flow, img)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        flow, img = ctx.saved_tensors
+        B, _, H, W = flow.shape
+        gflow = torch.empty_like(flow)
+        with torch.cuda.device(flow.device):
+            _call('unflow_smooth2_bwd', _ptr(flow), _ptr(img), _ptr(gl.contiguous()), _ptr(gflow), B, H, W,
+                  _stream())
+        return gflow, None
+
+
+def smooth2_loss(flow, img):
+    """cal_grad2_error(flow/20, img) (model_flow_paper.py:152-167,174) -> [B]; flow is un-divided."""
+    return _Smooth2.apply(flow, img.detach())
+
+
+class _Consis(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ff, fb, w):
+        dev = _dev(ff, fb, w)
+        ff, fb, w = ff.contiguous(), fb.contiguous(), w.contiguous()
+        B, _, H, W = ff.shape
+        loss = torch.empty(B, dtype=torch.float32, device=dev)
+        sums = torch.empty((B, 2), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _call('unflow_consis_fwd', _ptr(ff), _ptr(fb), _ptr(w), _ptr(loss), _ptr(sums),
+                  _ptr(_partials(B, H, W, dev)), B, H, W, _stream())
+        ctx.save_for_backward(ff, fb, w, sums)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        ff, fb, w, sums = ctx.saved_tensors
+        B, _, H, W = ff.shape
+        g = torch.empty_like(ff)
+        with torch.cuda.device(ff.device):
+            _call('unflow_consis_bwd', _ptr(ff), _ptr(fb), _ptr(w), _ptr(sums), _ptr(gl.contiguous()), _ptr(g),
+                  B, H, W, _stream())
+        return g, None, None
+
+
+def consis_loss(fwd_flow, bwd_flow, w_fwd):
+    """One scale of compute_loss_flow_consis (model_flow_paper.py:183-193) -> [B]; grad to fwd_flow."""
+    return _Consis.apply(fwd_flow, bwd_flow.detach(), w_fwd.detach())
