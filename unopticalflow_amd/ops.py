@@ -47,6 +47,45 @@ def _call(name, *args):
     _lib.check(getattr(lib, name)(*args), name)
 
 
+class _KernelTimer:
+    """HIP-event timing of one C entry point on the stream it is launched on (bench.py's roofline
+    leg).  Disabled by default: no events, no overhead."""
+
+    def __init__(self):
+        self.name = None
+        self.min_width = 0
+        self.pairs = []
+        self.bytes = 0
+
+    def enable(self, name, min_width=0):
+        self.name, self.min_width, self.pairs, self.bytes = name, min_width, [], 0
+
+    def disable(self):
+        self.name = None
+
+    def wants(self, name, width):
+        return self.name == name and width >= self.min_width
+
+    def start(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()                       # torch's current stream == the stream handed to the kernel
+        return ev
+
+    def stop(self, ev0, nbytes):
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        self.pairs.append((ev0, ev1))
+        self.bytes += nbytes
+
+    def summary(self):
+        """(launches, total ms, total algorithmic bytes); call after a device synchronize."""
+        ms = sum(a.elapsed_time(b) for a, b in self.pairs)
+        return len(self.pairs), ms, self.bytes
+
+
+kernel_timer = _KernelTimer()
+
+
 def _partials(B, H, W, dev):
     n = _lib.load().unflow_partials_per_sample(H, W)
     return torch.empty(B * n, dtype=torch.float32, device=dev)
@@ -63,7 +102,11 @@ class _Corr(torch.autograd.Function):
         B, C, H, W = f1.shape
         cv = torch.empty((B, (2 * d + 1) ** 2, H, W), dtype=f1.dtype, device=f1.device)
         with torch.cuda.device(f1.device):
+            timed = kernel_timer.wants('unflow_corr_fwd', W)
+            ev = kernel_timer.start() if timed else None
             _call('unflow_corr_fwd', _ptr(f1), _ptr(f2), _ptr(cv), B, C, H, W, d, _stream())
+            if timed:                     # algorithmic bytes: read f1, f2 once, write cv once
+                kernel_timer.stop(ev, 4 * B * H * W * (2 * C + (2 * d + 1) ** 2))
         ctx.save_for_backward(f1, f2)
         ctx.d = d
         return cv

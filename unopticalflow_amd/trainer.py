@@ -1,0 +1,69 @@
+"""The --mode flow optimisation step (reference train.py:33-39,137-152) as a reusable object.
+
+    zero_grad -> loss_pack = model(inputs) -> loss = sum_k w_k * mean_B(loss_pack[k])
+    -> backward -> [all-reduce mean over ranks] -> Adam(lr).step()
+
+The model is any module with the ``Model_flow`` contract (forward([B,3,3H,W]) -> dict of four [B]
+tensors); on a GPU that is ``unopticalflow_amd.Model_flow`` (HIP kernels).  The trainer itself
+holds no kernel code, which lets the multi-process logic be exercised on CPU with gloo.
+"""
+import torch
+
+from .core.config import generate_loss_weights_dict
+from .parallel import FlatGradients, broadcast_parameters
+
+
+class FlowTrainer:
+    def __init__(self, cfg, model, distributed=False, allreduce_chunks=4, fused_adam=None):
+        self.cfg = cfg
+        self.model = model
+        self.loss_weights = generate_loss_weights_dict(cfg)
+        params = [p for p in model.parameters() if p.requires_grad]      # train.py:39
+        if distributed:
+            broadcast_parameters(model)
+        self.grads = FlatGradients(params, chunks=allreduce_chunks)
+        self.distributed = distributed
+        kw = {}
+        if fused_adam is None:
+            fused_adam = params[0].is_cuda
+        if fused_adam:
+            kw['fused'] = True
+        self.optimizer = torch.optim.Adam([{'params': params, 'lr': cfg.lr}], **kw)
+        self.iteration = 0
+
+    def total_loss(self, loss_pack):
+        """train.py:147-150"""
+        loss = None
+        for key in loss_pack:
+            term = self.loss_weights[key] * loss_pack[key].mean()
+            loss = term if loss is None else loss + term
+        return loss
+
+    def step(self, inputs):
+        """One optimisation step on this rank's shard.  Returns (loss, loss_pack) (detached)."""
+        self.model.train()
+        self.grads.zero()
+        loss_pack = self.model(inputs)
+        loss = self.total_loss(loss_pack)
+        loss.backward()
+        if self.distributed:
+            self.grads.all_reduce_mean()
+        self.optimizer.step()
+        self.iteration += 1
+        return loss.detach(), {k: v.detach() for k, v in loss_pack.items()}
+
+    # ---- checkpoint format of train.py:23-31 (keys unwrapped, so 1-GPU and N-GPU files interchange)
+    def state(self):
+        return {'iteration': self.iteration, 'model_state_dict': self.model.state_dict(),
+                'optimizer_state_dict': self.optimizer.state_dict()}
+
+    def save(self, path):
+        torch.save(self.state(), path)
+
+    def load(self, path, map_location=None):
+        data = torch.load(path, map_location=map_location)
+        sd = {k[len('module.'):] if k.startswith('module.') else k: v for k, v in data['model_state_dict'].items()}
+        self.model.load_state_dict(sd)
+        self.optimizer.load_state_dict(data['optimizer_state_dict'])
+        self.iteration = data['iteration']
+        return self.iteration
