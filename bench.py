@@ -46,11 +46,23 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(sample_b):
     """The oracle's train step (same op graph as the reference: 81-offset corr loop, grid_sample,
     AvgPool SSIM) on this box's host cores: 1 untimed + 2 timed steps of `sample_b` triplets."""
     from oracle import ref_cpu as R
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     cfg = R.default_cfg()
     model = R.Model_flow(cfg)
