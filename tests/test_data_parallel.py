@@ -1,0 +1,120 @@
+"""Data-parallel path on CPU: 2 processes over gloo.  The trainer / flat-gradient all-reduce are
+model-agnostic, so they are exercised here with the CPU oracle model (tests may import oracle/);
+on the GPU box the same code runs with the HIP Model_flow over RCCL (bench.py --gpus N).
+
+Property: averaging the gradients of equal per-rank shards reproduces the
+reference's DataParallel global-batch mean, so N ranks x B/N samples == 1 process x B samples."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ref_cpu as R
+from unopticalflow_amd.parallel import FlatGradients, init_distributed, shard_batch
+from unopticalflow_amd.trainer import FlowTrainer
+
+H = W = 64
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _make(seed_params=1234):
+    cfg = R.default_cfg()
+    model = R.Model_flow(cfg)
+    model.load_state_dict(R.seeded_state_dict(model, seed_params, 0.25))
+    return cfg, model
+
+
+def _worker(rank, world, port, steps, out_path):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    r, lr, w = init_distributed('gloo')
+    assert (r, w) == (rank, world)
+    cfg, model = _make(seed_params=1234 if rank == 0 else 999)   # rank 0's weights must win
+    trainer = FlowTrainer(cfg, model, distributed=True, fused_adam=False)
+    x = R.synthetic_triplets(2 * world, H, W, seed=5, structured=True)
+    mine = shard_batch(x, rank, world)
+    for _ in range(steps):
+        loss, _ = trainer.step(mine)
+    trainer.grads.check_views()
+    if rank == 0:
+        torch.save({'grad': trainer.grads.flat.clone(), 'params': [p.detach().clone() for p in model.parameters()],
+                    'loss': loss}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('steps', [1, 2])
+def test_two_ranks_match_single_process(tmp_path, steps):
+    world = 2
+    out = str(tmp_path / 'rank0.pt')
+    mp.spawn(_worker, args=(world, _free_port(), steps, out), nprocs=world, join=True)
+    got = torch.load(out)
+
+    torch.set_num_threads(4)
+    cfg, model = _make()
+    trainer = FlowTrainer(cfg, model, distributed=False, fused_adam=False)
+    x = R.synthetic_triplets(2 * world, H, W, seed=5, structured=True)
+    for _ in range(steps):
+        trainer.step(x)
+    g_ref = trainer.grads.flat
+    scale = g_ref.abs().max().item()
+    np.testing.assert_allclose(got['grad'].numpy(), g_ref.numpy(), rtol=1e-4, atol=1e-5 * scale)
+    for a, b in zip(got['params'], model.parameters()):
+        np.testing.assert_allclose(a.numpy(), b.detach().numpy(), rtol=1e-4, atol=2e-5)  # Adam: |update| <= lr = 1e-4
+
+
+def test_flat_gradients_alias_and_zero():
+    cfg, model = _make()
+    fg = FlatGradients(model.parameters())
+    assert fg.numel == 5134324
+    x = R.synthetic_triplets(1, H, W, seed=1)
+    R.total_loss(model(x), R.generate_loss_weights_dict(cfg)).backward()
+    fg.check_views()
+    assert fg.flat.abs().sum() > 0
+    n0 = sum(p.grad.abs().sum() for p in model.parameters())
+    assert torch.allclose(n0, fg.flat.abs().sum(), rtol=1e-5)
+    fg.zero()
+    assert all(float(p.grad.abs().sum()) == 0.0 for p in model.parameters())
+    model.zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError):
+        fg.check_views()
+
+
+def test_shard_batch_requires_divisible():
+    with pytest.raises(ValueError):
+        shard_batch(torch.zeros(3, 1), 0, 2)
+    assert shard_batch(torch.arange(8).view(8, 1), 1, 4).flatten().tolist() == [2, 3]
+
+
+def test_checkpoint_roundtrip_and_module_prefix(tmp_path):
+    """Checkpoint dict of train.py:23-31; DataParallel-style 'module.' keys load too."""
+    cfg, model = _make()
+    tr = FlowTrainer(cfg, model, fused_adam=False)
+    x = R.synthetic_triplets(1, H, W, seed=2)
+    tr.step(x)
+    path = str(tmp_path / 'last.pth')
+    tr.save(path)
+    data = torch.load(path)
+    assert set(data) == {'iteration', 'model_state_dict', 'optimizer_state_dict'} and data['iteration'] == 1
+    data['model_state_dict'] = {'module.' + k: v for k, v in data['model_state_dict'].items()}
+    torch.save(data, path)
+    cfg2, model2 = _make(seed_params=7)
+    tr2 = FlowTrainer(cfg2, model2, fused_adam=False)
+    assert tr2.load(path) == 1
+    for a, b in zip(model.parameters(), model2.parameters()):
+        assert torch.equal(a, b)
+    l1, _ = tr.step(x)
+    l2, _ = tr2.step(x)
+    assert torch.allclose(l1, l2, rtol=1e-6)

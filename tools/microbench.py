@@ -1,0 +1,96 @@
+"""Time individual HIP operators on the pyramid-level shapes of the 832x256, B=8 step (2B=16 for
+corr / feature warp).  GPU only.  python tools/microbench.py [op ...]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from unopticalflow_amd import ops, _lib   # noqa: E402
+
+LEVELS = {'L2': (32, 64, 208), 'L3': (64, 32, 104), 'L4': (96, 16, 52), 'L5': (128, 8, 26), 'L6': (196, 4, 13)}
+
+
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3   # us
+
+
+def corr(B=16):
+    for name, (C, h, w) in LEVELS.items():
+        f1 = torch.randn(B, C, h, w, device='cuda')
+        f2 = torch.randn(B, C, h, w, device='cuda')
+        g = torch.randn(B, 81, h, w, device='cuda')
+        cv = torch.empty(B, 81, h, w, device='cuda')
+        gf1, gf2 = torch.empty_like(f1), torch.empty_like(f2)
+        lib = _lib.load()
+        P = ops._ptr
+        fb = 4 * B * h * w * (2 * C + 81)
+        bb = 4 * B * h * w * (4 * C + 81)
+        tf = timeit(lambda: lib.unflow_corr_fwd(P(f1), P(f2), P(cv), B, C, h, w, 4, ops._stream()))
+        tb = timeit(lambda: lib.unflow_corr_bwd(P(f1), P(f2), P(g), P(gf1), P(gf2), B, C, h, w, 4, ops._stream()))
+        print('corr %s [%d,%d,%d,%d] variant=%s  fwd %7.1f us (%6.0f GB/s)   bwd %7.1f us (%6.0f GB/s)' % (
+            name, B, C, h, w, os.environ.get('UNFLOW_CORR_VARIANT', 'auto'), tf, fb / tf / 1e3, tb, bb / tb / 1e3), flush=True)
+
+
+def warp(B=16):
+    for name, (C, h, w) in list(LEVELS.items())[:4]:
+        x = torch.randn(B, C, h, w, device='cuda', requires_grad=True)
+        fl = (torch.randn(B, 2, h, w, device='cuda') * 2).requires_grad_()
+        g = torch.randn(B, C, h, w, device='cuda')
+        tf = timeit(lambda: ops.warp_flow(x.detach(), fl.detach()))
+        y = ops.warp_flow(x, fl)
+        tb = timeit(lambda: torch.autograd.grad(y, (x, fl), g, retain_graph=True))
+        fb, bb = 4 * B * h * w * (2 * C + 2), 4 * B * h * w * (3 * C + 4)
+        print('warp %s [%d,%d,%d,%d] fwd %7.1f us (%6.0f GB/s)   bwd %7.1f us (%6.0f GB/s)' % (
+            name, B, C, h, w, tf, fb / tf / 1e3, tb, bb / tb / 1e3), flush=True)
+    for s in range(3):
+        h, w = 256 >> s, 832 >> s
+        x = torch.rand(8, 3, h, w, device='cuda')
+        fl = (torch.randn(8, 2, h, w, device='cuda') * 2).requires_grad_()
+        g = torch.randn(8, 3, h, w, device='cuda')
+        tf = timeit(lambda: ops.warp_flow_masked(x, fl.detach()))
+        y, _ = ops.warp_flow_masked(x, fl)
+        tb = timeit(lambda: torch.autograd.grad(y, (fl,), g, retain_graph=True))
+        fb, bb = 8 * h * w * 33, 4 * 8 * h * w * 10
+        print('imgwarp s%d [8,3,%d,%d] fwd %7.1f us (%6.0f GB/s)   bwd %7.1f us (%6.0f GB/s)' % (
+            s, h, w, tf, fb / tf / 1e3, tb, bb / tb / 1e3), flush=True)
+
+
+def losses(B=8):
+    for s in range(3):
+        h, w = 256 >> s, 832 >> s
+        img = torch.rand(B, 3, h, w, device='cuda')
+        wp = torch.rand(B, 3, h, w, device='cuda').requires_grad_()
+        wp2 = torch.rand(B, 3, h, w, device='cuda').requires_grad_()
+        wt = torch.rand(B, 1, h, w, device='cuda')
+        fl = (torch.randn(B, 2, h, w, device='cuda') * 3).requires_grad_()
+        fb = torch.randn(B, 2, h, w, device='cuda') * 3
+        gl = torch.ones(B, device='cuda')
+        n = B * h * w
+        for nm, fwd, inp, bytes_f, bytes_b in (
+                ('ssim', lambda: ops.ssim_loss(img, wp, wt), (wp,), 4 * n * 7, 4 * n * 10),
+                ('occ_weight', lambda: ops.occ_weight(img, wp, wp2)[0], (wp,), 4 * n * 13 + 2 * n, 4 * n * 10),
+                ('smooth2', lambda: ops.smooth2_loss(fl, img), (fl,), 4 * n * 5, 4 * n * 7),
+                ('consis', lambda: ops.consis_loss(fl, fb, wt), (fl,), 4 * n * 5, 4 * n * 7),
+                ('masked_mean', lambda: ops.masked_mean(wt.requires_grad_(), wt.detach()), (wt,), 4 * n * 2, 4 * n * 2)):
+            tf = timeit(fwd)
+            y = fwd()
+            tb = timeit(lambda: torch.autograd.grad(y, inp, gl, retain_graph=True))
+            print('%-11s s%d [%d,.,%d,%d] fwd %7.1f us (%6.0f GB/s)   bwd %7.1f us (%6.0f GB/s)' % (
+                nm, s, B, h, w, tf, bytes_f / tf / 1e3, tb, bytes_b / tb / 1e3), flush=True)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['corr', 'warp', 'losses']
+    for w_ in which:
+        globals()[w_]()

@@ -13,11 +13,15 @@
 // gf2 = sum_ij g[ij](shifted back) * f1(shifted back), written as a gather -- no atomics
 // (except when the displacement rows are split over workgroups, R > 4).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int TXT = 32;   // lanes along x
 constexpr int TY = 8;     // rows per workgroup
+#ifndef BWD_PIN
+#define BWD_PIN 0
+#endif
 
 template <int R, int PX, int DG, int CC>
 struct CorrCfg {
@@ -28,12 +32,28 @@ struct CorrCfg {
     static constexpr int NG = (DD + DG - 1) / DG;                // displacement-row groups
 };
 
-// Stage CC channels of the (LH x LW) halo tile of `src` (sample b, channels c0..) whose top-left
-// pixel is (ytop, xleft); zero outside the image / channel range.
+// Stage CC channels of an (LH x LW) tile of `src` (sample b, channels c0..) whose top-left pixel is
+// (ytop, xleft); zero outside the image / channel range.  When rows are 16-byte aligned
+// (W % 4 == 0, xleft % 4 == 0, LW % 4 == 0) the copy runs as global_load_dwordx4 -> ds_write_b128.
 template <int LH, int LW, int CC>
 __device__ __forceinline__ void stage_tile(float (*tile)[LH][LW], const float* __restrict__ src,
                                            int b, int C, int H, int W, int c0, int ytop, int xleft) {
     constexpr int PLANE = LH * LW;
+    if ((LW % 4 == 0) && ((W & 3) == 0) && ((xleft & 3) == 0)) {
+        constexpr int LW4 = LW / 4, PLANE4 = LH * LW4;
+        for (int idx = threadIdx.x; idx < CC * PLANE4; idx += 256) {
+            const int c = idx / PLANE4;
+            const int r = idx - c * PLANE4;
+            const int ly = r / LW4;
+            const int lx = (r - ly * LW4) * 4;
+            const int gy = ytop + ly, gx = xleft + lx, gc = c0 + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gc < C && gy >= 0 && gy < H && gx >= 0 && gx < W)      // gx % 4 == 0 and W % 4 == 0: all or nothing
+                v = *reinterpret_cast<const float4*>(src + ((size_t)(b * C + gc) * H + gy) * W + gx);
+            *reinterpret_cast<float4*>(&tile[c][ly][lx]) = v;
+        }
+        return;
+    }
     for (int idx = threadIdx.x; idx < CC * PLANE; idx += 256) {
         const int c = idx / PLANE;
         const int r = idx - c * PLANE;
@@ -59,20 +79,58 @@ __device__ __forceinline__ void load_row(float (&v)[N], const float* row) {
     }
 }
 
+
+// A lane's window into one LDS row: NROW consecutive floats starting at its first pixel.
+// PX == 2: the window is only 8-byte aligned for odd lanes, so it must be read as NROW/2
+// separate ds_read_b64.  Left to itself hipcc fuses neighbouring reads into ds_read2_b64 /
+// ds_read2_b32 (half the LDS rate); laundering one base pointer per float2 column through an
+// empty asm hides the adjacency, and the row / channel displacement folds into the offset field.
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const v2f lds_cfloat2;
+
+template <int NROW, int PX>
+struct RowReader {
+    static constexpr int NP = (PX == 2) ? NROW / 2 : NROW;
+    lds_cfloat* col[NP];
+    __device__ __forceinline__ explicit RowReader(const float* first) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            lds_cfloat* p = (lds_cfloat*)(first + (PX == 2 ? 2 * k : k));   // generic -> LDS address space
+            asm volatile("" : "+v"(p));
+            col[k] = p;
+        }
+    }
+    // floats [off, off + NROW) relative to `first`
+    __device__ __forceinline__ void read(float (&v)[NROW], int off) const {
+        if constexpr (PX == 2) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const v2f t = *(lds_cfloat2*)(col[k] + off);
+                v[2 * k] = t.x; v[2 * k + 1] = t.y;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) v[k] = col[k][off];
+        }
+    }
+};
+
 template <int R, int PX, int DG, int CC>
-__global__ __launch_bounds__(256) void corr_fwd_kernel(const float* __restrict__ f1,
+__global__ __launch_bounds__(256, 2) void corr_fwd_kernel(const float* __restrict__ f1,
                                                        const float* __restrict__ f2,
                                                        float* __restrict__ cv, int C, int H, int W,
                                                        float inv_c) {
     using K = CorrCfg<R, PX, DG, CC>;
-    constexpr int DD = K::DD, LW = K::LW, LH = K::LH, NG = K::NG;
-    constexpr int NROW = PX + 2 * R + ((PX + 2 * R) & (PX == 2 ? 1 : 0));
-    __shared__ __attribute__((aligned(16))) float tile[CC][LH][LW];
+    constexpr int DD = K::DD, LW = K::LW, LH = K::LH, NG = K::NG, TW = K::TW;
+    constexpr int NROW = PX + 2 * R;
+    __shared__ __attribute__((aligned(16))) float tile[CC][LH][LW];     // f2 with halo
+    __shared__ __attribute__((aligned(16))) float own[CC][TY][TW];      // f1
 
     const int tx = threadIdx.x & (TXT - 1), ty = threadIdx.x >> 5;
     const int b = blockIdx.z / NG, grp = blockIdx.z - b * NG;
     const int i0 = grp * DG;
-    const int x0 = blockIdx.x * K::TW, y0 = blockIdx.y * TY;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TY;
     const int px = x0 + tx * PX, py = y0 + ty;
 
     float acc[DG][DD][PX];
@@ -83,26 +141,29 @@ __global__ __launch_bounds__(256) void corr_fwd_kernel(const float* __restrict__
 #pragma unroll
             for (int p = 0; p < PX; ++p) acc[i][j][p] = 0.f;
 
+    const RowReader<NROW, PX> rows(&tile[0][ty][tx * PX]);
     for (int c0 = 0; c0 < C; c0 += CC) {
-        float a[CC][PX];
-#pragma unroll
-        for (int c = 0; c < CC; ++c)
-#pragma unroll
-            for (int p = 0; p < PX; ++p)
-                a[c][p] = (c0 + c < C && py < H && px + p < W)
-                              ? f1[((size_t)(b * C + c0 + c) * H + py) * W + px + p] : 0.f;
         stage_tile<LH, LW, CC>(tile, f2, b, C, H, W, c0, y0 - R + i0, x0 - R);
+        stage_tile<TY, TW, CC>(own, f1, b, C, H, W, c0, y0, x0);
         __syncthreads();
-#pragma unroll
+        // One channel per trip keeps the loop body (DG*DD*PX FMAs + DG row reads) inside the
+        // instruction cache; fully unrolled over CC it ran fetch-bound.
+#pragma unroll 1
         for (int c = 0; c < CC; ++c) {
+            float a[PX];
+            load_row<PX, PX>(a, &own[c][ty][tx * PX]);
+            // rows are double-buffered by hand and pinned with sched_barrier: left alone the
+            // scheduler hoists all DG row reads (DG*NROW VGPRs) and drops to one wave per SIMD
+            float row[2][NROW];
+            rows.read(row[0], c * (LH * LW));
 #pragma unroll
             for (int i = 0; i < DG; ++i) {
-                float row[NROW];
-                load_row<NROW, PX>(row, &tile[c][ty + i][tx * PX]);
+                if (i + 1 < DG) rows.read(row[(i + 1) & 1], c * (LH * LW) + (i + 1) * LW);
 #pragma unroll
                 for (int j = 0; j < DD; ++j)
 #pragma unroll
-                    for (int p = 0; p < PX; ++p) acc[i][j][p] = fmaf(a[c][p], row[j + p], acc[i][j][p]);
+                    for (int p = 0; p < PX; ++p) acc[i][j][p] = fmaf(a[p], row[i & 1][j + p], acc[i][j][p]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
@@ -132,13 +193,13 @@ __global__ __launch_bounds__(256) void corr_fwd_kernel(const float* __restrict__
 // MODE 1: gf2[b,c,q] = (1/C) sum_ij g[ij][q-(i-R,j-R)] * f1[c][q - (i-R, j-R)]
 //   rewritten with i' = 2R-i, j' = 2R-j so both read F at q + (i'-R, j'-R).
 template <int R, int PX, int DG, int CC, int MODE>
-__global__ __launch_bounds__(256) void corr_bwd_kernel(const float* __restrict__ F,
+__global__ __launch_bounds__(256, 2) void corr_bwd_kernel(const float* __restrict__ F,
                                                        const float* __restrict__ g,
                                                        float* __restrict__ out, int C, int H, int W,
                                                        float inv_c) {
     using K = CorrCfg<R, PX, DG, CC>;
     constexpr int DD = K::DD, LW = K::LW, LH = K::LH, NG = K::NG;
-    constexpr int NROW = PX + 2 * R + ((PX + 2 * R) & (PX == 2 ? 1 : 0));
+    constexpr int NROW = PX + 2 * R;
     __shared__ __attribute__((aligned(16))) float tile[CC][LH][LW];
 
     const int tx = threadIdx.x & (TXT - 1), ty = threadIdx.x >> 5;
@@ -170,35 +231,184 @@ __global__ __launch_bounds__(256) void corr_bwd_kernel(const float* __restrict__
                 wr[i][j][p] = v;
             }
 
+    const RowReader<NROW, PX> rows(&tile[0][ty][tx * PX]);
     for (int c0 = 0; c0 < C; c0 += CC) {
         stage_tile<LH, LW, CC>(tile, F, b, C, H, W, c0, y0 - R + i0, x0 - R);
         __syncthreads();
-#pragma unroll
+#pragma unroll 1
         for (int c = 0; c < CC; ++c) {
             float acc[PX];
 #pragma unroll
             for (int p = 0; p < PX; ++p) acc[p] = 0.f;
+            float row[2][NROW];
+            rows.read(row[0], c * (LH * LW));
 #pragma unroll
             for (int i = 0; i < DG; ++i) {
-                float row[NROW];
-                load_row<NROW, PX>(row, &tile[c][ty + i][tx * PX]);
+                if (i + 1 < DG) rows.read(row[(i + 1) & 1], c * (LH * LW) + (i + 1) * LW);
 #pragma unroll
                 for (int j = 0; j < DD; ++j)
 #pragma unroll
-                    for (int p = 0; p < PX; ++p) acc[p] = fmaf(wr[i][j][p], row[j + p], acc[p]);
+                    for (int p = 0; p < PX; ++p) acc[p] = fmaf(wr[i][j][p], row[i & 1][j + p], acc[p]);
+                if (BWD_PIN) __builtin_amdgcn_sched_barrier(0);
             }
             if (c0 + c < C && py < H) {
                 float* o = out + ((size_t)(b * C + c0 + c) * H + py) * W + px;
+                if (NG == 1 && PX == 2 && px + 1 < W && (W & 1) == 0) {
+                    *reinterpret_cast<float2*>(o) = make_float2(acc[0] * inv_c, acc[PX - 1] * inv_c);
+                } else {
 #pragma unroll
-                for (int p = 0; p < PX; ++p)
-                    if (px + p < W) {
-                        if (NG == 1) o[p] = acc[p] * inv_c;
-                        else atomicAdd(o + p, acc[p] * inv_c);
-                    }
+                    for (int p = 0; p < PX; ++p)
+                        if (px + p < W) {
+                            if (NG == 1) o[p] = acc[p] * inv_c;
+                            else atomicAdd(o + p, acc[p] * inv_c);
+                        }
+                }
             }
         }
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Large-map forward: 4 pixels per lane, displacement rows in NG passes, LDS-DMA double buffer.
+//
+// The level-2/3 maps of a 832x256 batch fit on the chip in a single round of workgroups, so
+// load / compute / store phases of all workgroups line up unless a workgroup overlaps them
+// itself.  Here a 256-thread workgroup owns a 64x16 pixel tile and walks the DD displacement
+// rows in NG passes of DG rows: a pass keeps DG*DD*4 accumulators per lane (108 for d=4), streams
+// the channels through a 2-deep LDS ring filled by global_load_lds_dwordx4 (no staging
+// registers; out-of-image slots read a zero line), and its 27 output planes are stored with
+// dwordx4 while the next pass is already computing.  Lanes read their 4+2R f2 floats as three
+// aligned ds_read_b128 (16 lanes = one 256-byte row: conflict-free) for 36 FMAs: VALU-bound,
+// not LDS-bound.  Re-staging f2 per pass comes from L2 / Infinity Cache, not HBM.
+// Requires W % 4 == 0 (16-byte rows).
+// ---------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) float kZeroLine[4] = {0.f, 0.f, 0.f, 0.f};
+
+typedef __attribute__((address_space(1))) const void* gas_ptr;
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+template <int R, int DG, int CC>
+struct Px4Cfg {
+    static constexpr int DD = 2 * R + 1;
+    static constexpr int NG = (DD + DG - 1) / DG;
+    static constexpr int TW = 64, TYB = 16;
+    static constexpr int LW = TW + 2 * R;              // floats; 2R % 4 == 0 required
+    static constexpr int LH = TYB + DG - 1;
+    static constexpr int S2 = LH * LW / 4;             // float4 slots of the f2 halo tile
+    static constexpr int S1 = TYB * TW / 4;            // float4 slots of the f1 tile
+    static constexpr int SC = S2 + S1;                 // per channel
+    static constexpr int SLOTS = ((CC * SC + 255) / 256) * 256;   // per ring stage, whole wave-instructions
+    static constexpr int ITER = SLOTS / 256;
+};
+
+template <int R, int DG, int CC>
+__device__ __forceinline__ void px4_stage(float* stage, const float* __restrict__ f1,
+                                          const float* __restrict__ f2, int b, int C, int H, int W,
+                                          int c0, int y0, int x0, int i0) {
+    using K = Px4Cfg<R, DG, CC>;
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int it = 0; it < K::ITER; ++it) {
+        const int s = it * 256 + threadIdx.x;
+        const int c = s / K::SC;
+        int r = s - c * K::SC;
+        const float* src;
+        int gy, gx;
+        if (r < K::S2) {
+            const int ly = r / (K::LW / 4);
+            gy = y0 - R + i0 + ly;
+            gx = x0 - R + (r - ly * (K::LW / 4)) * 4;
+            src = f2;
+        } else {
+            r -= K::S2;
+            const int ly = r / (K::TW / 4);
+            gy = y0 + ly;
+            gx = x0 + (r - ly * (K::TW / 4)) * 4;
+            src = f1;
+        }
+        const int gc = c0 + c;
+        const bool in = (c < CC) && (gc < C) && (gy >= 0) && (gy < H) && (gx >= 0) && (gx < W);
+        const float* g = in ? src + ((size_t)(b * C + gc) * H + gy) * W + gx : kZeroLine;
+        // wave-uniform LDS base; lane l lands at base + 16*l
+        __builtin_amdgcn_global_load_lds((gas_ptr)g, (lds_ptr)(stage + (it * 256 + wave * 64) * 4), 16, 0, 0);
+    }
+}
+
+template <int R, int DG, int CC>
+__global__ __launch_bounds__(256, 2) void corr_fwd_px4_kernel(const float* __restrict__ f1,
+                                                              const float* __restrict__ f2,
+                                                              float* __restrict__ cv, int C, int H, int W,
+                                                              float inv_c) {
+    using K = Px4Cfg<R, DG, CC>;
+    constexpr int DD = K::DD, LW = K::LW, NG = K::NG;
+    __shared__ __attribute__((aligned(16))) float ring[2][K::SLOTS * 4];
+
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * K::TW, y0 = blockIdx.y * K::TYB;
+    const int px = x0 + tx * 4, py = y0 + ty;
+    const int nchunk = (C + CC - 1) / CC;
+    const size_t plane = (size_t)H * W;
+
+    for (int g = 0; g < NG; ++g) {
+        const int i0 = g * DG;
+        float acc[DG][DD][4];
+#pragma unroll
+        for (int i = 0; i < DG; ++i)
+#pragma unroll
+            for (int j = 0; j < DD; ++j)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[i][j][p] = 0.f;
+
+        px4_stage<R, DG, CC>(ring[0], f1, f2, b, C, H, W, 0, y0, x0, i0);
+        __syncthreads();                                   // drains the DMA (vmcnt(0)) + barrier
+        for (int k = 0; k < nchunk; ++k) {
+            if (k + 1 < nchunk) px4_stage<R, DG, CC>(ring[(k + 1) & 1], f1, f2, b, C, H, W, (k + 1) * CC, y0, x0, i0);
+            const float* st = ring[k & 1];
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                const float* t2 = st + c * K::SC * 4;
+                const float4 a4 = *reinterpret_cast<const float4*>(t2 + K::S2 * 4 + ty * K::TW + tx * 4);
+                const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int i = 0; i < DG; ++i) {
+                    const float4* rp = reinterpret_cast<const float4*>(t2 + (ty + i) * LW + tx * 4);
+                    float row[4 + 2 * R];
+#pragma unroll
+                    for (int q = 0; q < (4 + 2 * R) / 4; ++q) {
+                        const float4 v = rp[q];
+                        row[4 * q] = v.x; row[4 * q + 1] = v.y; row[4 * q + 2] = v.z; row[4 * q + 3] = v.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < DD; ++j)
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) acc[i][j][p] = fmaf(a[p], row[j + p], acc[i][j][p]);
+                    __builtin_amdgcn_sched_barrier(0);      // keep one row of reads in flight, not all
+                }
+            }
+            __syncthreads();
+        }
+        if (py < H && px < W) {
+            float* out = cv + ((size_t)b * DD * DD) * plane + (size_t)py * W + px;
+#pragma unroll
+            for (int i = 0; i < DG; ++i) {
+                if (i0 + i >= DD) break;
+#pragma unroll
+                for (int j = 0; j < DD; ++j)
+                    *reinterpret_cast<float4*>(out + (size_t)((i0 + i) * DD + j) * plane) =
+                        make_float4(acc[i][j][0] * inv_c, acc[i][j][1] * inv_c, acc[i][j][2] * inv_c, acc[i][j][3] * inv_c);
+            }
+        }
+    }
+}
+
+template <int R, int DG, int CC>
+int launch_fwd_px4(const float* f1, const float* f2, float* cv, int B, int C, int H, int W, hipStream_t s) {
+    using K = Px4Cfg<R, DG, CC>;
+    dim3 grid(ceil_div(W, K::TW), ceil_div(H, K::TYB), B);
+    hipLaunchKernelGGL((corr_fwd_px4_kernel<R, DG, CC>), grid, dim3(256), 0, s, f1, f2, cv, C, H, W, 1.0f / C);
+    return unflow_launch_status();
 }
 
 // ---- any-radius fallback (one thread per output element, direct global reads) ----
@@ -211,9 +421,13 @@ __global__ void corr_fwd_generic(const float* __restrict__ f1, const float* __re
         const int b = t / ((size_t)W * H * DD * DD);
         const int sy = y + ij / DD - R, sx = x + ij % DD - R;
         float s = 0.f;
-        if (sy >= 0 && sy < H && sx >= 0 && sx < W)
-            for (int c = 0; c < C; ++c)
-                s = fmaf(f1[((size_t)(b * C + c) * H + y) * W + x], f2[((size_t)(b * C + c) * H + sy) * W + sx], s);
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
+            const float* p1 = f1 + ((size_t)b * C * H + y) * W + x;
+            const float* p2 = f2 + ((size_t)b * C * H + sy) * W + sx;
+            const size_t plane = (size_t)H * W;
+#pragma unroll 8
+            for (int c = 0; c < C; ++c) s = fmaf(p1[c * plane], p2[c * plane], s);
+        }
         cv[t] = s * inv_c;
     }
 }
@@ -270,21 +484,48 @@ int launch_bwd(const float* f1, const float* f2, const float* g, float* gf1, flo
 
 }  // namespace
 
+// Tuning knob (diagnostic): UNFLOW_CORR_VARIANT=1..4 forces a d=4 code path
+//   1: 64x8 tiles, 2 px/lane, all 81 displacements per lane      (large maps)
+//   2: 32x8 tiles, 1 px/lane, all 81 displacements per lane
+//   3: 32x8 tiles, 1 px/lane, displacement rows split over 3 workgroups
+//   4: one lane per output element, direct (cached) global reads    (tiny maps, many channels)
+static int forced_variant() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("UNFLOW_CORR_VARIANT"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
+static int pick_variant(int B, int C, int H, int W) {
+    const int f = forced_variant();
+    if (f) return f;
+    // measured on MI355X at the 832x256 pyramid shapes (tools/microbench.py corr)
+    const long px = (long)B * H * W;
+    if (W >= 96 && px >= 131072) return 1;
+    if (px >= 32768) return 3;
+    return 4;
+}
+
 extern "C" int unflow_corr_fwd(const float* f1, const float* f2, float* cv, int B, int C, int H, int W,
                                int d, void* stream) {
     UNFLOW_REQUIRE(f1 && f2 && cv && B > 0 && C > 0 && H > 0 && W > 0 && d >= 0);
     hipStream_t s = (hipStream_t)stream;
-    const bool wide = (W >= 96);          // 64-pixel tiles only where they fill
+    int variant = 4;
     switch (d) {
         case 1: return launch_fwd<1, 2, 3, 8>(f1, f2, cv, B, C, H, W, s);
         case 2: return launch_fwd<2, 2, 5, 8>(f1, f2, cv, B, C, H, W, s);
-        case 4: return wide ? launch_fwd<4, 2, 9, 8>(f1, f2, cv, B, C, H, W, s)
-                            : launch_fwd<4, 1, 9, 8>(f1, f2, cv, B, C, H, W, s);
+        case 4: variant = pick_variant(B, C, H, W);
+                if (variant == 1) return launch_fwd<4, 2, 9, 8>(f1, f2, cv, B, C, H, W, s);
+                if (variant == 2) return launch_fwd<4, 1, 9, 8>(f1, f2, cv, B, C, H, W, s);
+                if (variant == 3) return launch_fwd<4, 1, 3, 8>(f1, f2, cv, B, C, H, W, s);
+                if (variant == 5 && (W & 3) == 0) return launch_fwd_px4<4, 3, 2>(f1, f2, cv, B, C, H, W, s);
+                if (variant == 6 && (W & 3) == 0) return launch_fwd_px4<4, 3, 4>(f1, f2, cv, B, C, H, W, s);
+                if (variant == 5 || variant == 6) return launch_fwd<4, 2, 9, 8>(f1, f2, cv, B, C, H, W, s);
+                break;
         case 8: return launch_fwd<8, 1, 6, 8>(f1, f2, cv, B, C, H, W, s);
         default: break;
     }
     const size_t n = (size_t)B * (2 * d + 1) * (2 * d + 1) * H * W;
-    const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    const int blocks = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
     hipLaunchKernelGGL(corr_fwd_generic, dim3(blocks), dim3(256), 0, s, f1, f2, cv, B, C, H, W, d, 1.0f / C);
     return unflow_launch_status();
 }
@@ -293,17 +534,19 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                                int B, int C, int H, int W, int d, void* stream) {
     UNFLOW_REQUIRE(f1 && f2 && gcv && gf1 && gf2 && B > 0 && C > 0 && H > 0 && W > 0 && d >= 0);
     hipStream_t s = (hipStream_t)stream;
-    const bool wide = (W >= 96);
+    int variant = 4;
     switch (d) {
         case 1: return launch_bwd<1, 2, 3, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
         case 2: return launch_bwd<2, 2, 5, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-        case 4: return wide ? launch_bwd<4, 2, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s)
-                            : launch_bwd<4, 1, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+        case 4: variant = pick_variant(B, C, H, W);
+                if (variant == 1) return launch_bwd<4, 2, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                if (variant == 2 || variant == 3) return launch_bwd<4, 1, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                break;
         case 8: return launch_bwd<8, 1, 6, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
         default: break;
     }
     const size_t n = (size_t)B * C * H * W;
-    const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    const int blocks = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
     hipLaunchKernelGGL(corr_bwd_generic, dim3(blocks), dim3(256), 0, s, f1, f2, gcv, gf1, gf2, B, C, H, W, d, 1.0f / C);
     return unflow_launch_status();
 }
