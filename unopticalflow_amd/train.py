@@ -1,0 +1,160 @@
+"""Drop-in for the reference's ``train.py --mode flow`` (train.py:33-226) on MI355X.
+
+    python -m unopticalflow_amd.train -c unopticalflow_amd/config/kitti.yaml --gpu 0 --mode flow \
+        --prepared_save_dir data_s1 --model_dir models [--synthetic]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        -m unopticalflow_amd.train -c ... --gpu 0,1,2,3,4,5,6,7 --multi_gpu
+
+Same flags and yaml keys as the reference.  ``--multi_gpu`` keeps its meaning -- the global batch is
+batch_size x num_gpus and num_iterations / num_gpus (train.py:211-213) -- but runs one process per
+GPU with gradients all-reduced over RCCL instead of single-process DataParallel.  Checkpoints keep
+the reference's dict (train.py:23-24) with unwrapped keys.
+"""
+import argparse
+import os
+import pickle
+import shutil
+import time
+
+import torch
+import yaml
+
+from .core.networks import get_model
+from .data import PreparedTriplets, SyntheticTriplets
+from .parallel import init_distributed
+from .trainer import FlowTrainer
+
+
+def print_loss(loss_pack, iter_=None, extra=''):
+    """Same line as the reference's Visualizer.print_loss (core/visualize/visualizer.py:32-48)."""
+    v = {k: loss_pack[k].mean().detach().cpu().numpy() for k in loss_pack}
+    print('iter: {4}, loss_pixel: {0:.6f}, loss_ssim: {1:.6f}, loss_flow_smooth: {2:.6f}, loss_flow_consis: {3:.6f}'
+          .format(v['loss_pixel'], v['loss_ssim'], v['loss_flow_smooth'], v['loss_flow_consis'], iter_) + extra, flush=True)
+
+
+def train(cfg):
+    rank, local_rank, world = init_distributed('nccl')
+    if not torch.cuda.is_available():
+        raise RuntimeError('unopticalflow_amd.train needs an MI355X; there is no CPU path')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    model = get_model(cfg.mode)(cfg).to(dev)
+    trainer = FlowTrainer(cfg, model, distributed=(world > 1))
+    if cfg.resume:                                                     # train.py:42-46
+        name = 'iter_{}.pth'.format(cfg.iter_start) if cfg.iter_start > 0 else 'last.pth'
+        cfg.iter_start = trainer.load(os.path.join(cfg.model_dir, name), map_location=dev)
+    elif cfg.flow_pretrained_model:                                    # train.py:47-61 (flow-mode keys are bare)
+        data = torch.load(cfg.flow_pretrained_model, map_location=dev)['model_state_dict']
+        data = {k[len('module.'):] if k.startswith('module.') else k: v for k, v in data.items()}
+        missing, unexpected = model.load_state_dict(data, strict=False)
+        print(missing); print(unexpected)
+        print('Load Flow Pretrained Model from ' + cfg.flow_pretrained_model)
+
+    per_rank = cfg.batch_size // world
+    if cfg.synthetic:
+        batches = SyntheticTriplets(per_rank, cfg.img_hw, dev, seed=rank)
+    else:
+        data_dir = os.path.join(cfg.prepared_base_dir, cfg.prepared_save_dir)
+        if not os.path.exists(os.path.join(data_dir, 'train.txt')):
+            raise FileNotFoundError('no prepared triplets under {} (raw-dataset preparation is outside this '
+                                    'package: run the reference\'s prepare_data_mp once, or use --synthetic)'.format(data_dir))
+        ds = PreparedTriplets(data_dir, cfg.num_scales, cfg.img_hw, (cfg.num_iterations - cfg.iter_start) * per_rank)
+        sampler = torch.utils.data.distributed.DistributedSampler(ds, world, rank, shuffle=True) if world > 1 else None
+        loader = torch.utils.data.DataLoader(ds, batch_size=per_rank, shuffle=(sampler is None), sampler=sampler,
+                                             num_workers=cfg.num_workers, drop_last=False, pin_memory=True)
+        batches = (b.to(dev, non_blocking=True) for b in loader)
+
+    if rank == 0:
+        print('starting iteration: {}.'.format(cfg.iter_start))
+    t_last, n_last = time.perf_counter(), 0
+    for iter_, inputs in enumerate(batches):
+        iter_ = iter_ + cfg.iter_start
+        if iter_ >= cfg.num_iterations:
+            break
+        loss, loss_pack = trainer.step(inputs)                         # train.py:137-152
+        n_last += 1
+        if rank == 0 and iter_ % cfg.log_interval == 0:
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t_last
+            rate = n_last * cfg.batch_size / dt
+            print_loss(loss_pack, iter_=iter_, extra=', samples/s: {:.1f}, pairs/s: {:.1f}'.format(rate, 2 * rate))
+            t_last, n_last = time.perf_counter(), 0
+        if rank == 0 and (iter_ + 1) % cfg.save_interval == 0:         # train.py:153-155
+            trainer.iteration = iter_
+            trainer.save(os.path.join(cfg.model_dir, 'iter_{}.pth'.format(iter_)))
+            trainer.save(os.path.join(cfg.model_dir, 'last.pth'))
+    return trainer
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description='UnOpticalFlow flow-stage training on MI355X.')
+    ap.add_argument('-c', '--config_file', default=None, help='config file.')
+    ap.add_argument('-g', '--gpu', type=str, default='0', help='gpu id.')
+    ap.add_argument('--batch_size', type=int, default=8, help='batch size.')
+    ap.add_argument('--iter_start', type=int, default=0, help='starting iteration.')
+    ap.add_argument('--lr', type=float, default=0.0001, help='learning rate')
+    ap.add_argument('--num_workers', type=int, default=4, help='number of workers.')
+    ap.add_argument('--log_interval', type=int, default=100, help='interval for printing loss.')
+    ap.add_argument('--test_interval', type=int, default=2000, help='interval for evaluation.')
+    ap.add_argument('--save_interval', type=int, default=2000, help='interval for saving models.')
+    ap.add_argument('--mode', type=str, default='flow', help='training mode.')
+    ap.add_argument('--model_dir', type=str, default=None, help='directory for saving models')
+    ap.add_argument('--prepared_save_dir', type=str, default='data_s1', help='directory name for generated training dataset')
+    ap.add_argument('--flow_pretrained_model', type=str, default=None, help='directory for loading flow pretrained models')
+    ap.add_argument('--depth_pretrained_model', type=str, default=None, help='(unsupported: depth stage is out of scope)')
+    ap.add_argument('--resume', action='store_true', help='to resume training.')
+    ap.add_argument('--multi_gpu', action='store_true', help='to use multiple gpu for training.')
+    ap.add_argument('--no_test', action='store_true', help='without evaluation.')
+    # additions
+    ap.add_argument('--synthetic', action='store_true', help='train on on-device synthetic triplets (no dataset).')
+    ap.add_argument('--align_corners', type=int, default=0, help='grid_sample generation: 0 torch>=1.3, 1 torch 1.2.0.')
+    ap.add_argument('--num_iterations', type=int, default=None, help='override the yaml value.')
+    args = ap.parse_args(argv)
+    if args.config_file is None:
+        raise ValueError('config file needed. -c --config_file.')
+    if not os.path.exists(args.config_file):
+        raise ValueError('config file not found.')
+    if args.depth_pretrained_model:
+        raise ValueError('--depth_pretrained_model belongs to the depth stage, which this package does not cover')
+    if args.model_dir is None:
+        args.model_dir = os.path.join('models', os.path.splitext(os.path.split(args.config_file)[1])[0])
+    args.model_dir = os.path.join(os.getcwd(), args.model_dir, args.mode)
+    os.makedirs(args.model_dir, exist_ok=True)
+    with open(args.config_file, 'r') as f:
+        cfg = yaml.safe_load(f)
+    cfg['img_hw'] = (cfg['img_hw'][0], cfg['img_hw'][1])
+    cfg['log_dump_dir'] = os.path.join(args.model_dir, 'log.pkl')
+    if int(os.environ.get('RANK', '0')) == 0:
+        shutil.copy(args.config_file, args.model_dir)
+    num_iter_override = args.num_iterations
+    for attr, val in vars(args).items():                               # CLI attrs overwrite yaml keys (train.py:203-205)
+        if attr == 'num_iterations' and val is None:
+            continue
+        cfg[attr] = val
+    num_gpus = len(str(args.gpu).split(','))
+    if (args.multi_gpu and num_gpus <= 1) or ((not args.multi_gpu) and num_gpus > 1):
+        raise ValueError('Error! the number of gpus used in the --gpu argument does not match the argument --multi_gpu.')
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.multi_gpu:
+        if world != num_gpus:
+            raise ValueError('--multi_gpu with {} gpus needs {} processes: launch with '
+                             'python -m torch.distributed.run --nproc-per-node {} -m unopticalflow_amd.train ...'
+                             .format(num_gpus, num_gpus, num_gpus))
+        cfg['batch_size'] = cfg['batch_size'] * num_gpus               # train.py:211-213
+        if num_iter_override is None:
+            cfg['num_iterations'] = int(cfg['num_iterations'] / num_gpus)
+
+    class pObject(object):
+        pass
+    cfg_new = pObject()
+    for k, v in cfg.items():
+        setattr(cfg_new, k, v)
+    if int(os.environ.get('RANK', '0')) == 0:
+        with open(os.path.join(args.model_dir, 'config.pkl'), 'wb') as f:
+            pickle.dump(cfg, f)
+    return train(cfg_new)
+
+
+if __name__ == '__main__':
+    main()
