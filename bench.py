@@ -100,7 +100,11 @@ def main():
                                 h_flow_consist_beta=0.05, w_ssim=0.85, w_flow_smooth=10.0, w_flow_consis=0.01,
                                 lr=1e-4, align_corners=False)
     torch.manual_seed(1234)                       # same random init on every rank
+    if os.environ.get('UNFLOW_MIOPEN_FIND', '0') == '1':
+        torch.backends.cudnn.benchmark = True     # MIOpen exhaustive find per conv shape
     model = get_model('flow')(cfg).to(dev)
+    if os.environ.get('UNFLOW_CHANNELS_LAST', '0') == '1':
+        model = model.to(memory_format=torch.channels_last)
     trainer = FlowTrainer(cfg, model, distributed=(world > 1))
     gen = torch.Generator(device=dev)
     gen.manual_seed(rank)                         # distinct synthetic data per rank
@@ -114,7 +118,7 @@ def main():
     for _ in range(args.warmup):
         trainer.step(inputs)
     if not args.no_kernel_timing:
-        ops.kernel_timer.enable('unflow_corr_fwd', min_width=96)
+        ops.kernel_timer.enable('unflow_corr_fwd', min_width=200)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -138,7 +142,7 @@ def main():
                 gbs = nbytes / (ms * 1e-3) / 1e9
                 roof = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None,
-                        'kernel': 'corr_fwd_kernel<R=4,PX=2> (cost volume fwd, levels 2-3, [2B,C,h,w])',
+                        'kernel': 'corr_fwd_ring_kernel<R=4,CC=2> (cost volume fwd, level 2, [2B=16,32,64,208])',
                         'launches': nl, 'avg_us': round(ms * 1e3 / nl, 2),
                         'algorithmic_bytes_per_launch': int(nbytes / nl)}
         base = None

@@ -15,7 +15,8 @@ LIB = os.path.join(PKG, 'libunflow_hip.so')
 SOURCES = ('corr.hip', 'warp.hip', 'ssim.hip', 'photo.hip')
 # -ffp-contract=off: mask / SSIM arithmetic must follow the reference op by op; the kernels call
 # fmaf() explicitly where a fused multiply-add is wanted.
-FLAGS = ('-O3', '--offload-arch=gfx950', '-fPIC', '-shared', '-std=c++17', '-ffp-contract=off')
+FLAGS = ('-O3', '--offload-arch=gfx950', '-fPIC', '-shared', '-std=c++17', '-ffp-contract=off',
+         '-fno-slp-vectorize')   # SLP packs the 2-px FMAs into v_pk_fma_f32 + a v_mov per pair: slower than plain v_fmac
 
 
 def _stale():

@@ -411,6 +411,206 @@ int launch_fwd_px4(const float* f1, const float* f2, float* cv, int B, int C, in
     return unflow_launch_status();
 }
 
+// Hand-issued LDS reads with hand-counted waits.  hipcc tracks its own ds_reads with lgkmcnt(0)
+// whenever a register buffer is re-used, which exposes the full LDS latency every few rows at two
+// waves per SIMD; here the row stream is software-pipelined PF row-steps deep and every step waits
+// only for its own rows (lgkmcnt is a 4-bit in-order counter: <= 15 reads are kept in flight).
+template <int OFF>
+__device__ __forceinline__ v2f lds_read_b64(unsigned addr) {
+    v2f v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);      // nothing that consumes the rows may move above the wait
+}
+
+// One row-step of the forward pipeline: ST = c * DD + i  (channel-in-stage, displacement row).
+template <int ST, int STEPS, int PF, int DD, int NCOL, int CH_BYTES, int ROW_BYTES>
+struct FwdStep {
+    template <int Q>
+    static __device__ __forceinline__ void load(v2f (&row)[PF + 1][NCOL], unsigned addr) {
+        if constexpr (Q < STEPS) {
+            constexpr int off = (Q / DD) * CH_BYTES + (Q % DD) * ROW_BYTES;
+            row[Q % (PF + 1)][0] = lds_read_b64<off>(addr);
+            row[Q % (PF + 1)][1] = lds_read_b64<off + 8>(addr);
+            row[Q % (PF + 1)][2] = lds_read_b64<off + 16>(addr);
+            row[Q % (PF + 1)][3] = lds_read_b64<off + 24>(addr);
+            row[Q % (PF + 1)][4] = lds_read_b64<off + 32>(addr);
+            static_assert(NCOL == 5, "2 px + 2*4 halo floats = 5 float2 columns");
+        }
+    }
+    template <int CC>
+    static __device__ __forceinline__ void run(float (&acc)[DD][DD][2], v2f (&row)[PF + 1][NCOL],
+                                               const v2f (&a)[CC], unsigned addr) {
+        if constexpr (ST < STEPS) {
+            load<ST + PF>(row, addr);
+            constexpr int newer = (STEPS - 1 - ST < PF ? STEPS - 1 - ST : PF) * NCOL;
+            lds_wait<newer>();
+            constexpr int c = ST / DD, i = ST % DD, rb = ST % (PF + 1);
+            float r[2 * NCOL];
+#pragma unroll
+            for (int k = 0; k < NCOL; ++k) { r[2 * k] = row[rb][k].x; r[2 * k + 1] = row[rb][k].y; }
+#pragma unroll
+            for (int j = 0; j < DD; ++j) {
+                acc[i][j][0] = fmaf(a[c].x, r[j], acc[i][j][0]);
+                acc[i][j][1] = fmaf(a[c].y, r[j + 1], acc[i][j][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            FwdStep<ST + 1, STEPS, PF, DD, NCOL, CH_BYTES, ROW_BYTES>::template run<CC>(acc, row, a, addr);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Large-map forward, LDS-DMA ring: same 64x8 tile / 2 px per lane / all displacements per lane as
+// corr_fwd_kernel<R,2,DD,*>, but the channels stream through a 4-slot LDS ring filled by
+// global_load_lds_dwordx4 (no staging VGPRs, no ds_write) with THREE stages in flight behind a
+// counted s_waitcnt vmcnt, one raw s_barrier per stage, and an XCD-aware tile order so the halo
+// rows/columns shared by neighbouring tiles are served by one XCD's L2.
+// Requires W % 4 == 0.
+// ---------------------------------------------------------------------------------------------
+template <int R, int CC>
+struct RingCfg {
+    static constexpr int DD = 2 * R + 1;
+    static constexpr int TW = 64, TYB = 8, NS = 4;
+    static constexpr int LW = TW + 2 * R, LH = TYB + 2 * R;
+    static constexpr int S2 = LH * LW / 4, S1 = TYB * TW / 4, SC = S2 + S1;     // float4 slots per channel
+    static constexpr int ITER = (CC * SC + 255) / 256;
+    static constexpr int STAGE = ITER * 256 * 4;                                // floats per ring slot
+};
+
+// Bijective remap of the linear workgroup id so that consecutive tiles share an XCD (workgroups
+// are dealt round-robin over the 8 XCDs): speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int lin, int total) {
+    const int q = total >> 3, r = total & 7;          // XCD x gets q (+1 if x < r) workgroups
+    const int xcd = lin & 7, k = lin >> 3;
+    return xcd * q + (xcd < r ? xcd : r) + k;
+}
+
+template <int R, int CC>
+__global__ __launch_bounds__(256, 2) void corr_fwd_ring_kernel(const float* __restrict__ f1,
+                                                               const float* __restrict__ f2,
+                                                               float* __restrict__ cv, int C, int H, int W,
+                                                               int tiles_x, int tiles_y, float inv_c, int dbg) {
+    using K = RingCfg<R, CC>;
+    constexpr int DD = K::DD, LW = K::LW, NROW = 2 + 2 * R;
+    __shared__ __attribute__((aligned(16))) float ring[K::NS * K::STAGE];
+
+    const int total = gridDim.x;
+    int t = xcd_remap(blockIdx.x, total);
+    const int bx = t % tiles_x; t /= tiles_x;
+    const int by = t % tiles_y;
+    const int b = t / tiles_y;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, wave = threadIdx.x >> 6;
+    const int x0 = bx * K::TW, y0 = by * K::TYB;
+    const int px = x0 + tx * 2, py = y0 + ty;
+    const size_t plane = (size_t)H * W;
+    const int nchunk = (C + CC - 1) / CC;
+
+    // per-lane, per-slot source description (loop invariant): channel within the stage and the
+    // element offset inside a channel plane, or -1 for slots outside the image / padding
+    int soff[K::ITER], sch[K::ITER], ssel[K::ITER];
+#pragma unroll
+    for (int it = 0; it < K::ITER; ++it) {
+        const int s = it * 256 + threadIdx.x;
+        const int c = s / K::SC;
+        int r = s - c * K::SC;
+        int gy, gx, sel;
+        if (r < K::S2) { const int ly = r / (LW / 4); gy = y0 - R + ly; gx = x0 - R + (r - ly * (LW / 4)) * 4; sel = 1; }
+        else { r -= K::S2; const int ly = r / (K::TW / 4); gy = y0 + ly; gx = x0 + (r - ly * (K::TW / 4)) * 4; sel = 0; }
+        const bool in = (c < CC) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        soff[it] = in ? gy * W + gx : -1;
+        sch[it] = c;
+        ssel[it] = sel;
+    }
+    const float* base1 = f1 + (size_t)b * C * plane;
+    const float* base2 = f2 + (size_t)b * C * plane;
+
+    auto issue = [&](int stage_idx) {
+        float* dst = ring + (stage_idx & (K::NS - 1)) * K::STAGE;
+        const int c0 = stage_idx * CC;
+#pragma unroll
+        for (int it = 0; it < K::ITER; ++it) {
+            const int gc = c0 + sch[it];
+            const bool in = soff[it] >= 0 && gc < C;
+            const float* g = in ? (ssel[it] ? base2 : base1) + (size_t)gc * plane + soff[it] : kZeroLine;
+            __builtin_amdgcn_global_load_lds((gas_ptr)g, (lds_ptr)(dst + (it * 256 + wave * 64) * 4), 16, 0, 0);
+        }
+    };
+
+    float acc[DD][DD][2];
+#pragma unroll
+    for (int i = 0; i < DD; ++i)
+#pragma unroll
+        for (int j = 0; j < DD; ++j) { acc[i][j][0] = 0.f; acc[i][j][1] = 0.f; }
+
+    const unsigned rows_addr = (unsigned)(size_t)(lds_cfloat*)(ring + ty * LW + tx * 2);
+    const unsigned own_addr = (unsigned)(size_t)(lds_cfloat*)(ring + K::S2 * 4 + ty * K::TW + tx * 2);
+
+#pragma unroll
+    for (int st = 0; st < K::NS - 1; ++st) if (!(dbg & 4)) issue(st);       // stages beyond nchunk read the zero line
+
+    for (int k = 0; k < nchunk; ++k) {
+        // all but the newest (NS-2) stages have landed -> stage k is complete for this wave ...
+        if constexpr (K::ITER * (K::NS - 2) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (K::ITER * (K::NS - 2) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // ... and for every wave; slot (k-1) is free
+        if (!(dbg & 4)) issue(k + K::NS - 1);
+        const int sbase = (k & (K::NS - 1)) * K::STAGE;
+        if (dbg & 2) continue;
+        // CC*DD row-steps per stage as one software pipeline (FwdStep): reads of step s+PF are in
+        // flight behind the FMAs of step s.
+        constexpr int PF = 2, STEPS = CC * DD, NCOL = NROW / 2;
+        const unsigned abase = rows_addr + (unsigned)sbase * 4u;
+        v2f a[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            if (c == 0) a[c] = lds_read_b64<0>(own_addr + (unsigned)sbase * 4u);
+            else a[c] = lds_read_b64<K::SC * 16>(own_addr + (unsigned)sbase * 4u);
+        }
+        static_assert(CC <= 2, "a[] reads are spelled out for CC <= 2");
+        v2f row[PF + 1][NCOL];
+        using Step0 = FwdStep<0, STEPS, PF, DD, NCOL, K::SC * 16, LW * 4>;
+        Step0::template load<0>(row, abase);
+        Step0::template load<1>(row, abase);
+        Step0::template run<CC>(acc, row, a, abase);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // drain the zero-line tail loads
+
+    if (py >= H || px >= W) return;
+    float* out = cv + ((size_t)b * DD * DD) * plane + (size_t)py * W + px;
+    if (dbg & 1) {      // timing experiment: keep the accumulators alive, store one plane
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < DD; ++i)
+#pragma unroll
+            for (int j = 0; j < DD; ++j) sum += acc[i][j][0] + acc[i][j][1];
+        out[0] = sum;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < DD; ++i)
+#pragma unroll
+        for (int j = 0; j < DD; ++j)
+            *reinterpret_cast<float2*>(out + (size_t)(i * DD + j) * plane) =
+                make_float2(acc[i][j][0] * inv_c, acc[i][j][1] * inv_c);
+}
+
+template <int R, int CC>
+int launch_fwd_ring(const float* f1, const float* f2, float* cv, int B, int C, int H, int W, hipStream_t s) {
+    using K = RingCfg<R, CC>;
+    const int tx = ceil_div(W, K::TW), ty = ceil_div(H, K::TYB);
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("UNFLOW_CORR_DEBUG"); dbg = e ? atoi(e) : 0; }   // timing experiments only
+    hipLaunchKernelGGL((corr_fwd_ring_kernel<R, CC>), dim3(tx * ty * B), dim3(256), 0, s, f1, f2, cv, C, H, W,
+                       tx, ty, 1.0f / C, dbg);
+    return unflow_launch_status();
+}
+
 // ---- any-radius fallback (one thread per output element, direct global reads) ----
 __global__ void corr_fwd_generic(const float* __restrict__ f1, const float* __restrict__ f2,
                                  float* __restrict__ cv, int B, int C, int H, int W, int R, float inv_c) {
@@ -500,7 +700,7 @@ static int pick_variant(int B, int C, int H, int W) {
     if (f) return f;
     // measured on MI355X at the 832x256 pyramid shapes (tools/microbench.py corr)
     const long px = (long)B * H * W;
-    if (W >= 96 && px >= 131072) return 1;
+    if (W >= 96 && px >= 131072) return ((W & 3) == 0) ? 7 : 1;
     if (px >= 32768) return 3;
     return 4;
 }
@@ -520,6 +720,8 @@ extern "C" int unflow_corr_fwd(const float* f1, const float* f2, float* cv, int 
                 if (variant == 5 && (W & 3) == 0) return launch_fwd_px4<4, 3, 2>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 6 && (W & 3) == 0) return launch_fwd_px4<4, 3, 4>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 5 || variant == 6) return launch_fwd<4, 2, 9, 8>(f1, f2, cv, B, C, H, W, s);
+                if (variant == 7 && (W & 3) == 0) return launch_fwd_ring<4, 2>(f1, f2, cv, B, C, H, W, s);
+                if (variant == 7) return launch_fwd<4, 2, 9, 8>(f1, f2, cv, B, C, H, W, s);
                 break;
         case 8: return launch_fwd<8, 1, 6, 8>(f1, f2, cv, B, C, H, W, s);
         default: break;
@@ -539,7 +741,7 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
         case 1: return launch_bwd<1, 2, 3, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
         case 2: return launch_bwd<2, 2, 5, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
         case 4: variant = pick_variant(B, C, H, W);
-                if (variant == 1) return launch_bwd<4, 2, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                if (variant == 1 || variant == 7) return launch_bwd<4, 2, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (variant == 2 || variant == 3) return launch_bwd<4, 1, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 break;
         case 8: return launch_bwd<8, 1, 6, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
