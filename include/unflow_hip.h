@@ -35,8 +35,8 @@ extern "C" {
 /* ABI version of this header (bumped on any signature change). */
 int unflow_abi_version(void);
 
-/* Number of float slots per sample a `partials` buffer needs for an H x W map
- * (multiply by B and by the op's K listed below). */
+/* Number of float slots per sample a `partials` buffer needs for an H x W map (K = 2 included;
+ * multiply by B). */
 int unflow_partials_per_sample(int H, int W);
 
 /* ---- cost volume: PWC_tf.corr_naive, core/networks/structures/pwc_tf.py:97-106 ----
@@ -109,6 +109,23 @@ int unflow_consis_fwd(const float* fwd_flow, const float* bwd_flow, const float*
 int unflow_consis_bwd(const float* fwd_flow, const float* bwd_flow, const float* w_fwd,
                       const float* sums, const float* gloss, float* gflow,
                       int B, int H, int W, void* stream);
+
+/* ---- conv() epilogue: Conv2d bias + LeakyReLU(0.1), core/networks/structures/net_utils.py:7-11 ----
+ * y [N,C,H,W] is a bias-free convolution output, updated in place: y = leaky_relu(y + bias[c]). */
+int unflow_bias_leaky_fwd(float* y, const float* bias, int N, int C, int H, int W, float slope,
+                          void* stream);
+/* floats of `partials` scratch the backward needs. */
+int unflow_bias_leaky_partials(int N, int C, int H, int W);
+/* y: the activation output; gin = gout * (y > 0 ? 1 : slope) (may alias gout); gbias[c] = sum gin,
+ * reduced in a fixed order (bitwise reproducible). */
+int unflow_bias_leaky_bwd(const float* y, const float* gout, float* gin, float* gbias, float* partials,
+                          int N, int C, int H, int W, float slope, void* stream);
+
+/* ---- image pyramid: Model_flow.generate_img_pyramid scales 1 and 2, model_flow_paper.py:54-60 ----
+ * img [planes,H,W] (planes = B*C, any leading layout) -> half [planes,H/2,W/2] (2x2 box means) and
+ * quarter [planes,H/4,W/4] (4x4 box means of img).  H, W multiples of 4. */
+int unflow_img_pyramid(const float* img, float* half, float* quarter, int planes, int H, int W,
+                       void* stream);
 
 #ifdef __cplusplus
 }

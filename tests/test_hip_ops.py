@@ -256,3 +256,52 @@ def test_reductions_are_reproducible(ops):
     assert torch.equal(a, b)
     fl = rnd(54, (8, 2, 256, 832), 5.0).cuda()
     assert torch.equal(ops.smooth2_loss(fl, img), ops.smooth2_loss(fl, img))
+
+
+# ------------------------------------------------------------------------------------ conv epilogue / pyramid
+@pytest.mark.parametrize('shape', [(16, 128, 64, 208), (24, 16, 128, 416), (2, 196, 4, 13), (3, 5, 7, 9), (1, 2, 1, 1)])
+def test_bias_leaky_relu_vs_torch(ops, shape):
+    """conv() epilogue (net_utils.py:7-11): in-place bias + LeakyReLU(0.1) and its backward incl. bias grad."""
+    N, C, H, W = shape
+    y0 = rnd(61, shape)
+    bias = rnd(62, (C,), 0.3)
+    g = rnd(63, shape)
+    yc = y0.clone().requires_grad_()
+    bc = bias.clone().requires_grad_()
+    ref = torch.nn.functional.leaky_relu(yc + bc.view(1, C, 1, 1), 0.1)
+    ref.backward(g)
+    yg = y0.cuda().requires_grad_()
+    bg = bias.cuda().requires_grad_()
+    out = ops.bias_leaky_relu_(yg * 1.0, bg, 0.1)          # * 1.0: the op works in place on a non-leaf
+    assert torch.equal(out.cpu(), ref.detach())
+    out.backward(g.cuda())
+    assert torch.equal(yg.grad.cpu(), yc.grad)
+    close(bg.grad, bc.grad, rtol=1e-4, atol=1e-4 * bc.grad.abs().max().item())
+
+
+def test_conv_block_matches_reference_block(ops):
+    from unopticalflow_amd import conv as conv_hip
+    torch.manual_seed(0)
+    blk = conv_hip(7, 12, kernel_size=3, stride=2).cuda()
+    ref = R.conv(7, 12, kernel_size=3, stride=2)
+    ref.load_state_dict({k: v.cpu() for k, v in blk.state_dict().items()})     # same keys: 0.weight, 0.bias
+    x = rnd(64, (2, 7, 20, 36))
+    xc, xg = x.clone().requires_grad_(), x.cuda().requires_grad_()
+    yr, yg = ref(xc), blk(xg)
+    close(yg, yr, rtol=1e-4, atol=1e-5)
+    go = rnd(65, tuple(yr.shape))
+    yr.backward(go); yg.backward(go.cuda())
+    close(xg.grad, xc.grad, rtol=1e-4, atol=1e-5)
+    for (n, pg), (_, pr) in zip(blk.named_parameters(), ref.named_parameters()):
+        close(pg.grad, pr.grad, rtol=1e-4, atol=1e-4 * pr.grad.abs().max().item(), what=n)
+
+
+@pytest.mark.parametrize('shape', [(24, 3, 256, 832), (3, 3, 64, 128), (2, 1, 4, 4), (1, 3, 12, 20)])
+def test_img_pyramid_vs_oracle(ops, shape):
+    """generate_img_pyramid scales 1, 2 (model_flow_paper.py:54-60): box means; a few ulps of fp32
+    summation-order difference vs ATen's adaptive_avg_pool2d are allowed (values are in [0,1))."""
+    x = rnd(66, shape, uniform=True)
+    ref = R.img_pyramid(x, 3)
+    half, quarter = ops.img_pyramid(x.cuda())
+    close(half, ref[1], rtol=0, atol=2e-7)
+    close(quarter, ref[2], rtol=0, atol=3e-7)

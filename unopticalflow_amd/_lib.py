@@ -32,6 +32,10 @@ SIGNATURES = {
     'unflow_smooth2_bwd': [_P, _P, _P, _P, _I, _I, _I, _P],
     'unflow_consis_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     'unflow_consis_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    'unflow_bias_leaky_fwd': [_P, _P, _I, _I, _I, _I, ctypes.c_float, _P],
+    'unflow_bias_leaky_partials': [_I, _I, _I, _I],
+    'unflow_bias_leaky_bwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, _P],
+    'unflow_img_pyramid': [_P, _P, _P, _I, _I, _I, _P],
 }
 
 ABI_VERSION = 1

@@ -114,10 +114,12 @@ class Model_flow(nn.Module):
         feature_list_2 = [f[B:] for f in feats]
         return self.pwc_model(feature_list_1, feature_list_2, img_hw)[0]
 
-    def _flows(self, imgl, img, imgr):
+    def _flows(self, imgl, img, imgr, frames=None):
         """Both directed flow pyramids with one 3B pyramid pass and one 2B decoder pass."""
         B, _, img_h, img_w = img.shape
-        feats = self.fpyramid(torch.cat((imgl, img, imgr), 0))           # [3B, ...] per level
+        if frames is None:
+            frames = torch.cat((imgl, img, imgr), 0)
+        feats = self.fpyramid(frames)                                    # [3B, ...] per level
         feat_c2 = [torch.cat((f[B:2 * B], f[B:2 * B]), 0) for f in feats]
         feat_lr = [torch.cat((f[:B], f[2 * B:]), 0) for f in feats]
         flows = self.pwc_model(feat_c2, feat_lr, [img_h, img_w])         # [2B, 2, h, w] per scale
@@ -129,13 +131,23 @@ class Model_flow(nn.Module):
         img_h, img_w = int(images.shape[2] / 3), images.shape[3]
         imgl, img, imgr = images[:, :, :img_h, :], images[:, :, img_h:2 * img_h, :], images[:, :, 2 * img_h:3 * img_h, :]
 
-        optical_flows_bwd, optical_flows_fwd = self._flows(imgl, img, imgr)
+        B = images.shape[0]
+        # the three frames as one contiguous [3B,3,H,W] batch (left, centre, right): feeds the 3B
+        # pyramid pass and, through one HIP pooling kernel, all three image pyramids
+        frames = images[:, :, :3 * img_h].reshape(B, 3, 3, img_h, img_w).permute(2, 0, 1, 3, 4).reshape(3 * B, 3, img_h, img_w)
+        optical_flows_bwd, optical_flows_fwd = self._flows(imgl, img, imgr, frames)
 
         loss_pack = {}
         n = self.num_scales          # the reference also builds the unused 4th level
-        imgl_pyramid = self.generate_img_pyramid(imgl, n)
-        img_pyramid = self.generate_img_pyramid(img, n)
-        imgr_pyramid = self.generate_img_pyramid(imgr, n)
+        if n <= 3 and img_h % 4 == 0 and img_w % 4 == 0:
+            scales = (frames.detach(),) + ops.img_pyramid(frames)
+            imgl_pyramid = [t[:B] for t in scales[:n]]
+            img_pyramid = [t[B:2 * B] for t in scales[:n]]
+            imgr_pyramid = [t[2 * B:] for t in scales[:n]]
+        else:
+            imgl_pyramid = self.generate_img_pyramid(imgl, n)
+            img_pyramid = self.generate_img_pyramid(img, n)
+            imgr_pyramid = self.generate_img_pyramid(imgr, n)
 
         img_warped_pyramid_from_l = self.warp_flow_pyramid(imgl_pyramid, optical_flows_bwd)
         img_warped_pyramid_from_r = self.warp_flow_pyramid(imgr_pyramid, optical_flows_fwd)

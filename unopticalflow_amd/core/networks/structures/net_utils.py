@@ -1,12 +1,24 @@
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .... import ops
 
 
+class ConvLeaky(nn.Sequential):
+    """The reference's conv() block, Sequential(Conv2d(bias=True), LeakyReLU(0.1)): same children, same
+    ``<name>.0.weight`` / ``<name>.0.bias`` state-dict keys.  On a HIP tensor the forward runs the
+    contraction bias-free on MFMA (PyTorch-ROCm / MIOpen) and applies bias + LeakyReLU in one in-place
+    HIP pass (csrc/elementwise.hip); the backward of that pass also produces the bias gradient."""
+
+    def forward(self, x):
+        c = self[0]
+        y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
+        return ops.bias_leaky_relu_(y, c.bias, self[1].negative_slope)
+
+
 def conv(in_planes, out_planes, kernel_size=3, stride=1, padding=1, dilation=1):
-    """Conv2d(bias) + LeakyReLU(0.1) (reference net_utils.py:7-11).  The contraction runs on MFMA
-    through PyTorch-ROCm; the Sequential keeps the reference's ``<name>.0.weight`` state-dict keys."""
-    return nn.Sequential(
+    """Conv2d(bias) + LeakyReLU(0.1) (reference net_utils.py:7-11)."""
+    return ConvLeaky(
         nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride,
                   padding=padding, dilation=dilation, bias=True),
         nn.LeakyReLU(0.1))

@@ -1,0 +1,146 @@
+// HBM-bound glue around the convolutions, fused for gfx950.
+//
+//  * bias + LeakyReLU(0.1) applied in place to a bias-free convolution output, and its backward
+//    fused with the bias-gradient reduction.  The reference's conv() block (net_utils.py:7-11,
+//    Conv2d(bias=True) + LeakyReLU) costs, per convolution, a bias-add pass and an activation pass
+//    forward, and an activation-backward pass plus a reduction pass backward -- each a full
+//    read+write of the activation (109 MB at level 2).  Here: one pass forward, one backward.
+//  * the image pyramid of Model_flow.generate_img_pyramid (model_flow_paper.py:54-60,
+//    adaptive_avg_pool2d to H/2, H/4): both scales from one read of the full-resolution frames.
+//
+// Layout NCHW fp32; lanes along the contiguous H*W axis, 16 bytes per lane when H*W % 4 == 0.
+#include "common.h"
+
+namespace {
+
+constexpr int EW_TILE = 4096;      // elements of one (n, c) plane per workgroup
+
+__global__ __launch_bounds__(256) void bias_leaky_fwd_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                             int C, int HW, float slope) {
+    const int c = blockIdx.y, n = blockIdx.z;
+    const float b = bias[c];
+    float* p = y + ((size_t)n * C + c) * HW;
+    const int e0 = blockIdx.x * EW_TILE;
+    if ((HW & 3) == 0) {
+#pragma unroll
+        for (int k = 0; k < EW_TILE / 1024; ++k) {
+            const int e = e0 + (k * 256 + threadIdx.x) * 4;
+            if (e < HW) {
+                float4 v = *reinterpret_cast<float4*>(p + e);
+                v.x += b; v.y += b; v.z += b; v.w += b;
+                v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+                v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+                *reinterpret_cast<float4*>(p + e) = v;
+            }
+        }
+    } else {
+        for (int e = e0 + threadIdx.x; e < min(e0 + EW_TILE, HW); e += 256) {
+            float v = p[e] + b;
+            p[e] = v > 0.f ? v : v * slope;
+        }
+    }
+}
+
+// gin = gout * (y > 0 ? 1 : slope)   (y is the activation OUTPUT; LeakyReLU keeps the sign)
+// partials[(c * N + n) * nchunk + chunk] = sum of gin over the workgroup's elements
+__global__ __launch_bounds__(256) void bias_leaky_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gout,
+                                                             float* __restrict__ gin, float* __restrict__ partials,
+                                                             int C, int HW, float slope) {
+    __shared__ float red[4];
+    const int c = blockIdx.y, n = blockIdx.z, N = gridDim.z;
+    const size_t base = ((size_t)n * C + c) * HW;
+    const int e0 = blockIdx.x * EW_TILE;
+    float acc[1] = {0.f};
+    if ((HW & 3) == 0) {
+#pragma unroll
+        for (int k = 0; k < EW_TILE / 1024; ++k) {
+            const int e = e0 + (k * 256 + threadIdx.x) * 4;
+            if (e < HW) {
+                const float4 v = *reinterpret_cast<const float4*>(y + base + e);
+                float4 g = *reinterpret_cast<const float4*>(gout + base + e);
+                g.x = v.x > 0.f ? g.x : g.x * slope; g.y = v.y > 0.f ? g.y : g.y * slope;
+                g.z = v.z > 0.f ? g.z : g.z * slope; g.w = v.w > 0.f ? g.w : g.w * slope;
+                *reinterpret_cast<float4*>(gin + base + e) = g;
+                acc[0] += (g.x + g.y) + (g.z + g.w);
+            }
+        }
+    } else {
+        for (int e = e0 + threadIdx.x; e < min(e0 + EW_TILE, HW); e += 256) {
+            float g = gout[base + e];
+            g = y[base + e] > 0.f ? g : g * slope;
+            gin[base + e] = g;
+            acc[0] += g;
+        }
+    }
+    block_sum_256<1>(acc, red);
+    if (threadIdx.x == 0) partials[((size_t)c * N + n) * gridDim.x + blockIdx.x] = acc[0];
+}
+
+__global__ void bias_grad_finalize_kernel(const float* __restrict__ partials, int per_channel, float* __restrict__ gbias) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    const float s = sum_partials(partials + (size_t)c * per_channel, per_channel, 1, 0, red);
+    if (threadIdx.x == 0) gbias[c] = s;
+}
+
+// one lane = one 4x4 input block: 4 float4 row reads -> four 2x2 means and one 4x4 mean, summed in
+// ATen's adaptive_avg_pool2d order (row-major over the window, then * 1/count: exact for 4 and 16).
+__global__ void img_pyramid_kernel(const float* __restrict__ img, float* __restrict__ s1, float* __restrict__ s2,
+                                   int planes, int H, int W) {
+    const int H4 = H >> 2, W4 = W >> 2;
+    const size_t n = (size_t)planes * H4 * W4;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const int x4 = (int)(t % W4), y4 = (int)((t / W4) % H4);
+        const size_t pl = t / ((size_t)W4 * H4);
+        const float* p = img + (pl * H + (size_t)y4 * 4) * W + (size_t)x4 * 4;
+        float4 r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = *reinterpret_cast<const float4*>(p + (size_t)k * W);
+        float* o1 = s1 + (pl * (H >> 1) + (size_t)y4 * 2) * (W >> 1) + (size_t)x4 * 2;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float a = ((r[2 * k].x + r[2 * k].y) + r[2 * k + 1].x) + r[2 * k + 1].y;
+            const float b = ((r[2 * k].z + r[2 * k].w) + r[2 * k + 1].z) + r[2 * k + 1].w;
+            *reinterpret_cast<float2*>(o1 + (size_t)k * (W >> 1)) = make_float2(a * 0.25f, b * 0.25f);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s = (((s + r[k].x) + r[k].y) + r[k].z) + r[k].w;
+        s2[(pl * H4 + y4) * W4 + x4] = s * 0.0625f;
+    }
+}
+
+}  // namespace
+
+extern "C" int unflow_bias_leaky_fwd(float* y, const float* bias, int N, int C, int H, int W, float slope,
+                                     void* stream) {
+    UNFLOW_REQUIRE(y && bias && N > 0 && C > 0 && H > 0 && W > 0 && N <= 65535 && C <= 65535);
+    const int HW = H * W;
+    hipLaunchKernelGGL(bias_leaky_fwd_kernel, dim3(ceil_div(HW, EW_TILE), C, N), dim3(256), 0, (hipStream_t)stream,
+                       y, bias, C, HW, slope);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_bias_leaky_partials(int N, int C, int H, int W) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return UNFLOW_EINVAL;
+    return N * C * ceil_div(H * W, EW_TILE);
+}
+
+extern "C" int unflow_bias_leaky_bwd(const float* y, const float* gout, float* gin, float* gbias, float* partials,
+                                     int N, int C, int H, int W, float slope, void* stream) {
+    UNFLOW_REQUIRE(y && gout && gin && gbias && partials && N > 0 && C > 0 && H > 0 && W > 0 && N <= 65535 && C <= 65535);
+    const int HW = H * W, nchunk = ceil_div(HW, EW_TILE);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bias_leaky_bwd_kernel, dim3(nchunk, C, N), dim3(256), 0, s, y, gout, gin, partials, C, HW, slope);
+    hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3(C), dim3(256), 0, s, partials, N * nchunk, gbias);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_img_pyramid(const float* img, float* half, float* quarter, int planes, int H, int W,
+                                  void* stream) {
+    UNFLOW_REQUIRE(img && half && quarter && planes > 0 && H > 0 && W > 0 && (H & 3) == 0 && (W & 3) == 0);
+    const size_t n = (size_t)planes * (H >> 2) * (W >> 2);
+    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(img_pyramid_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, half, quarter, planes, H, W);
+    return unflow_launch_status();
+}

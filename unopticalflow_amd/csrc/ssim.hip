@@ -25,6 +25,15 @@ constexpr float kC2 = 0.0009f;   // 0.03**2
 
 struct Stats { float mu_x, mu_y, sig_x, sig_y, sig_xy, n1, n2, d1, d2, ssim; };
 
+// x / 9.0f, correctly rounded, in 3 instructions (Markstein: q0 = x*y, r = x - 9*q0 exact by fma,
+// q = q0 + r*y with y = RN(1/9)) instead of the ~12-instruction IEEE divide expansion.
+__device__ __forceinline__ float div9(float x) {
+    const float y = 0.111111111f;
+    const float q0 = x * y;
+    const float r = fmaf(-9.0f, q0, x);
+    return fmaf(r, y, q0);
+}
+
 // X/Y: [row][col] raw 3x3 neighbourhood in ATen's pooling order.
 __device__ __forceinline__ Stats window_stats(const float (&X)[3][3], const float (&Y)[3][3]) {
     float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
@@ -37,10 +46,10 @@ __device__ __forceinline__ Stats window_stats(const float (&X)[3][3], const floa
             sxx = sxx + x * x; syy = syy + y * y; sxy = sxy + x * y;
         }
     Stats s;
-    s.mu_x = sx / 9.0f; s.mu_y = sy / 9.0f;
-    s.sig_x = sxx / 9.0f - s.mu_x * s.mu_x;
-    s.sig_y = syy / 9.0f - s.mu_y * s.mu_y;
-    s.sig_xy = sxy / 9.0f - s.mu_x * s.mu_y;
+    s.mu_x = div9(sx); s.mu_y = div9(sy);
+    s.sig_x = div9(sxx) - s.mu_x * s.mu_x;
+    s.sig_y = div9(syy) - s.mu_y * s.mu_y;
+    s.sig_xy = div9(sxy) - s.mu_x * s.mu_y;
     s.n1 = 2.0f * s.mu_x * s.mu_y + kC1;
     s.n2 = 2.0f * s.sig_xy + kC2;
     s.d1 = s.mu_x * s.mu_x + s.mu_y * s.mu_y + kC1;
@@ -50,7 +59,7 @@ __device__ __forceinline__ Stats window_stats(const float (&X)[3][3], const floa
 }
 
 // Strip geometry shared by host and device.
-constexpr int RS = 32;                  // output rows per wave
+constexpr int RS = 8;                   // output rows per wave (all RS+2 / RS+4 input rows are loaded up front)
 __host__ __device__ inline int strips(int W, int halo) { return ceil_div(W, 64 - 2 * halo); }
 __host__ __device__ inline int chunks(int H) { return ceil_div(H, RS); }
 
@@ -78,6 +87,22 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
         const float* ip = img + (size_t)grp * NC * plane;
         const float* wp = warped + (size_t)grp * NC * plane;
         const float* mp = WEIGHTED ? wgt + (size_t)grp * plane : nullptr;
+        // all RS+2 input rows are requested before the first one is used: the strip costs one
+        // memory round trip instead of one per row
+        constexpr int NR = RS + 2;
+        float mv[NR], xv[NR][NC], yv[NR][NC];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int r = ys - 1 + k;
+            const bool rin = (r >= 0 && r < H && r <= ye) && xin;
+            const size_t off = (size_t)(rin ? r : 0) * W + (xin ? x : 0);
+            mv[k] = WEIGHTED ? (rin ? mp[off] : 0.f) : 1.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                xv[k][c] = rin ? ip[(size_t)c * plane + off] : 0.f;
+                yv[k][c] = rin ? wp[(size_t)c * plane + off] : 0.f;
+            }
+        }
         float X[NC][3][3], Y[NC][3][3];       // [channel][ring row][left, centre, right]
 #pragma unroll
         for (int c = 0; c < NC; ++c)
@@ -85,32 +110,31 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { X[c][r][k] = 0.f; Y[c][r][k] = 0.f; }
-        for (int r = ys - 1; r <= ye; ++r) {
-            const bool rin = (r >= 0 && r < H) && xin;
-            const size_t off = (size_t)(rin ? r : 0) * W + (xin ? x : 0);
-            const float m = WEIGHTED ? (rin ? mp[off] : 0.f) : 1.f;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int r = ys - 1 + k;
+            const float m = mv[k];
             if (WEIGHTED && r >= ys && r < ye && xout) acc[1] += m;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const float xv = rin ? ip[(size_t)c * plane + off] * m : 0.f;
-                const float yv = rin ? wp[(size_t)c * plane + off] * m : 0.f;
+                const float xs = xv[k][c] * m, ysv = yv[k][c] * m;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {   // slide the ring
-                    X[c][0][k] = X[c][1][k]; X[c][1][k] = X[c][2][k];
-                    Y[c][0][k] = Y[c][1][k]; Y[c][1][k] = Y[c][2][k];
+                for (int q = 0; q < 3; ++q) {   // slide the ring
+                    X[c][0][q] = X[c][1][q]; X[c][1][q] = X[c][2][q];
+                    Y[c][0][q] = Y[c][1][q]; Y[c][1][q] = Y[c][2][q];
                 }
-                X[c][2][0] = __shfl_up(xv, 1, 64); X[c][2][1] = xv; X[c][2][2] = __shfl_down(xv, 1, 64);
-                Y[c][2][0] = __shfl_up(yv, 1, 64); Y[c][2][1] = yv; Y[c][2][2] = __shfl_down(yv, 1, 64);
+                X[c][2][0] = __shfl_up(xs, 1, 64); X[c][2][1] = xs; X[c][2][2] = __shfl_down(xs, 1, 64);
+                Y[c][2][0] = __shfl_up(ysv, 1, 64); Y[c][2][1] = ysv; Y[c][2][2] = __shfl_down(ysv, 1, 64);
             }
             const int ro = r - 1;               // the row whose window is now complete
             if (ro >= ys && ro < ye && xout) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const Stats s = window_stats(X[c], Y[c]);
+                    const Stats st = window_stats(X[c], Y[c]);
                     if (MAP) {
-                        map_out[((size_t)grp * NC + c) * plane + (size_t)ro * W + x] = s.ssim;
+                        map_out[((size_t)grp * NC + c) * plane + (size_t)ro * W + x] = st.ssim;
                     } else {
-                        const float v = (1.0f - s.ssim) / 2.0f;
+                        const float v = (1.0f - st.ssim) / 2.0f;
                         acc[0] += fminf(fmaxf(v, 0.f), 1.f);
                     }
                 }
@@ -178,36 +202,50 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__
             for (int k = 0; k < 3; ++k) { X[c][r][k] = 0.f; Y[c][r][k] = 0.f; Q[c][r][k] = 0.f; }
     M[0] = M[1] = M[2] = 0.f;
 
-    // r: newest raw row; r-1: row whose stats complete; r-2: row whose gradient completes.
-    for (int r = ys - 2; r <= ye + 1; ++r) {
-        const bool rin = (r >= 0 && r < H) && xin;
+    // k-th loaded row r = ys-2+k is the newest raw row; r-1: row whose stats complete; r-2: row whose
+    // gradient completes.  All RS+4 rows are requested up front (one memory round trip per strip).
+    constexpr int NR = RS + 4;
+    float mv[NR], xv[NR][3], yv[NR][3];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int r = ys - 2 + k;
+        const bool rin = (r >= 0 && r < H && r <= ye + 1) && xin;
         const size_t off = (size_t)(rin ? r : 0) * W + (xin ? x : 0);
-        const float m = rin ? mp[off] : 0.f;
+        mv[k] = rin ? mp[off] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            xv[k][c] = rin ? ip[(size_t)c * plane + off] : 0.f;
+            yv[k][c] = rin ? wp[(size_t)c * plane + off] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int r = ys - 2 + k;
+        const float m = mv[k];
         M[0] = M[1]; M[1] = M[2]; M[2] = m;
         const int rs = r - 1;
         const bool sin = (rs >= 0 && rs < H) && xin;        // stats pixel inside the image?
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float xv = rin ? ip[(size_t)c * plane + off] * m : 0.f;
-            const float yv = rin ? wp[(size_t)c * plane + off] * m : 0.f;
+            const float xs = xv[k][c] * m, ysv = yv[k][c] * m;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                X[c][0][k] = X[c][1][k]; X[c][1][k] = X[c][2][k];
-                Y[c][0][k] = Y[c][1][k]; Y[c][1][k] = Y[c][2][k];
-                Q[c][0][k] = Q[c][1][k]; Q[c][1][k] = Q[c][2][k];
+            for (int q = 0; q < 3; ++q) {
+                X[c][0][q] = X[c][1][q]; X[c][1][q] = X[c][2][q];
+                Y[c][0][q] = Y[c][1][q]; Y[c][1][q] = Y[c][2][q];
+                Q[c][0][q] = Q[c][1][q]; Q[c][1][q] = Q[c][2][q];
             }
-            X[c][2][0] = __shfl_up(xv, 1, 64); X[c][2][1] = xv; X[c][2][2] = __shfl_down(xv, 1, 64);
-            Y[c][2][0] = __shfl_up(yv, 1, 64); Y[c][2][1] = yv; Y[c][2][2] = __shfl_down(yv, 1, 64);
+            X[c][2][0] = __shfl_up(xs, 1, 64); X[c][2][1] = xs; X[c][2][2] = __shfl_down(xs, 1, 64);
+            Y[c][2][0] = __shfl_up(ysv, 1, 64); Y[c][2][1] = ysv; Y[c][2][2] = __shfl_down(ysv, 1, 64);
             float a = 0.f, bq = 0.f, cq = 0.f;
             if (sin) {
-                const Stats s = window_stats(X[c], Y[c]);
-                const float v = (1.0f - s.ssim) / 2.0f;
+                const Stats st = window_stats(X[c], Y[c]);
+                const float v = (1.0f - st.ssim) / 2.0f;
                 if (v >= 0.f && v <= 1.f) {                 // clamp passes gradient on [min, max]
-                    const float inv = 1.0f / (s.d1 * s.d2);
-                    a = kb * (2.0f * s.mu_x * (s.n2 - s.n1) * inv -
-                              2.0f * s.mu_y * s.ssim * (1.0f / s.d1 - 1.0f / s.d2));
-                    bq = kb * (-s.ssim / s.d2);
-                    cq = kb * (2.0f * s.n1 * inv);
+                    const float inv = 1.0f / (st.d1 * st.d2);
+                    a = kb * (2.0f * st.mu_x * (st.n2 - st.n1) * inv -
+                              2.0f * st.mu_y * st.ssim * (1.0f / st.d1 - 1.0f / st.d2));
+                    bq = kb * (-st.ssim / st.d2);
+                    cq = kb * (2.0f * st.n1 * inv);
                 }
             }
             Q[c][2][0] = __shfl_up(a, 1, 64) + a + __shfl_down(a, 1, 64);

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 
 __all__ = ['corr', 'warp_flow', 'warp_flow_masked', 'occ_weight', 'masked_mean', 'ssim_loss',
-           'ssim_map', 'smooth2_loss', 'consis_loss']
+           'ssim_map', 'smooth2_loss', 'consis_loss', 'bias_leaky_relu_', 'img_pyramid']
 
 
 def _ptr(t):
@@ -362,3 +362,56 @@ class _Consis(torch.autograd.Function):
 def consis_loss(fwd_flow, bwd_flow, w_fwd):
     """One scale of compute_loss_flow_consis (model_flow_paper.py:183-193) -> [B]; grad to fwd_flow."""
     return _Consis.apply(fwd_flow, bwd_flow.detach(), w_fwd.detach())
+
+
+# ------------------------------------------------------------------------------------------
+# conv() epilogue and image pyramid
+# ------------------------------------------------------------------------------------------
+class _BiasLeaky(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, bias, slope):
+        _dev(y, bias)
+        if not y.is_contiguous():
+            raise RuntimeError('bias_leaky_relu_ works in place on a contiguous NCHW convolution output')
+        N, C, H, W = y.shape
+        with torch.cuda.device(y.device):
+            _call('unflow_bias_leaky_fwd', _ptr(y), _ptr(bias), N, C, H, W, ctypes.c_float(slope), _stream())
+        ctx.mark_dirty(y)
+        ctx.save_for_backward(y)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        N, C, H, W = y.shape
+        g = g.contiguous()
+        gin = torch.empty_like(g)
+        gbias = torch.empty(C, dtype=torch.float32, device=y.device)
+        npart = _lib.load().unflow_bias_leaky_partials(N, C, H, W)
+        part = torch.empty(npart, dtype=torch.float32, device=y.device)
+        with torch.cuda.device(y.device):
+            _call('unflow_bias_leaky_bwd', _ptr(y), _ptr(g), _ptr(gin), _ptr(gbias), _ptr(part), N, C, H, W,
+                  ctypes.c_float(ctx.slope), _stream())
+        return gin, gbias, None
+
+
+def bias_leaky_relu_(y, bias, negative_slope=0.1):
+    """In-place ``leaky_relu(y + bias[None,:,None,None])`` on a bias-free conv output: the epilogue of the
+    reference's conv() block (net_utils.py:7-11) in one pass; its backward also reduces the bias gradient."""
+    return _BiasLeaky.apply(y, bias, float(negative_slope))
+
+
+def img_pyramid(img):
+    """Scales 1 and 2 of generate_img_pyramid (model_flow_paper.py:54-60) for a contiguous [N,C,H,W]
+    image batch: (2x2 box means [N,C,H/2,W/2], 4x4 box means [N,C,H/4,W/4]).  No gradient (``.data``)."""
+    dev = _dev(img)
+    img = img.detach().contiguous()
+    N, C, H, W = img.shape
+    if H % 4 or W % 4:
+        raise ValueError('img_pyramid needs H and W to be multiples of 4, got %dx%d' % (H, W))
+    half = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=dev)
+    quarter = torch.empty((N, C, H // 4, W // 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _call('unflow_img_pyramid', _ptr(img), _ptr(half), _ptr(quarter), N * C, H, W, _stream())
+    return half, quarter
