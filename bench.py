@@ -43,6 +43,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=2, help='triplets in the CPU-baseline sample step')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--graph', type=int, default=0, help='1: replay the step as a hipGraph (kernel timing events are then off)')
     return ap.parse_args()
 
 
@@ -100,12 +101,15 @@ def main():
                                 h_flow_consist_beta=0.05, w_ssim=0.85, w_flow_smooth=10.0, w_flow_consis=0.01,
                                 lr=1e-4, align_corners=False)
     torch.manual_seed(1234)                       # same random init on every rank
-    if os.environ.get('UNFLOW_MIOPEN_FIND', '0') == '1':
-        torch.backends.cudnn.benchmark = True     # MIOpen exhaustive find per conv shape
+    if os.environ.get('UNFLOW_MIOPEN_FIND', '1') == '1':
+        from unopticalflow_amd.tuning import enable_miopen_tuning
+        enable_miopen_tuning()                    # shipped find-db for exactly these conv shapes (tuning.py)
     model = get_model('flow')(cfg).to(dev)
     if os.environ.get('UNFLOW_CHANNELS_LAST', '0') == '1':
         model = model.to(memory_format=torch.channels_last)
-    trainer = FlowTrainer(cfg, model, distributed=(world > 1))
+    trainer = FlowTrainer(cfg, model, distributed=(world > 1), use_graph=bool(args.graph))
+    if args.graph:
+        args.no_kernel_timing = True
     gen = torch.Generator(device=dev)
     gen.manual_seed(rank)                         # distinct synthetic data per rank
     inputs = torch.rand((args.batch, 3, 3 * H, W), generator=gen, device=dev, dtype=torch.float32)

@@ -39,8 +39,11 @@ def train(cfg):
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
+    if getattr(cfg, 'miopen_find', 1):
+        from .tuning import enable_miopen_tuning
+        enable_miopen_tuning()
     model = get_model(cfg.mode)(cfg).to(dev)
-    trainer = FlowTrainer(cfg, model, distributed=(world > 1))
+    trainer = FlowTrainer(cfg, model, distributed=(world > 1), use_graph=bool(getattr(cfg, 'graph', 0)))
     if cfg.resume:                                                     # train.py:42-46
         name = 'iter_{}.pth'.format(cfg.iter_start) if cfg.iter_start > 0 else 'last.pth'
         cfg.iter_start = trainer.load(os.path.join(cfg.model_dir, name), map_location=dev)
@@ -110,6 +113,8 @@ def main(argv=None):
     ap.add_argument('--synthetic', action='store_true', help='train on on-device synthetic triplets (no dataset).')
     ap.add_argument('--align_corners', type=int, default=0, help='grid_sample generation: 0 torch>=1.3, 1 torch 1.2.0.')
     ap.add_argument('--num_iterations', type=int, default=None, help='override the yaml value.')
+    ap.add_argument('--miopen_find', type=int, default=1, help='1: use the shipped MIOpen find-db + benchmark mode.')
+    ap.add_argument('--graph', type=int, default=0, help='1: replay the train step as a hipGraph.')
     args = ap.parse_args(argv)
     if args.config_file is None:
         raise ValueError('config file needed. -c --config_file.')

@@ -14,7 +14,7 @@ from .parallel import FlatGradients, broadcast_parameters
 
 
 class FlowTrainer:
-    def __init__(self, cfg, model, distributed=False, allreduce_chunks=4, fused_adam=None):
+    def __init__(self, cfg, model, distributed=False, allreduce_chunks=4, fused_adam=None, use_graph=False):
         self.cfg = cfg
         self.model = model
         self.loss_weights = generate_loss_weights_dict(cfg)
@@ -28,8 +28,15 @@ class FlowTrainer:
             fused_adam = params[0].is_cuda
         if fused_adam:
             kw['fused'] = True
+        if use_graph:
+            kw['capturable'] = True                    # step counters live on the device
         self.optimizer = torch.optim.Adam([{'params': params, 'lr': cfg.lr}], **kw)
         self.iteration = 0
+        # hipGraph replay of the step (forward + loss + backward [+ Adam]): ~3000 kernel launches per
+        # step become one graph launch, so the host never starves the GPU.  Built lazily from the first
+        # batch; inputs are copied into a static buffer.
+        self.use_graph = use_graph
+        self._graph = None
 
     def total_loss(self, loss_pack):
         """train.py:147-150"""
@@ -39,9 +46,48 @@ class FlowTrainer:
             loss = term if loss is None else loss + term
         return loss
 
+    def _eager_fwd_bwd(self, inputs):
+        self.grads.zero()
+        loss_pack = self.model(inputs)
+        loss = self.total_loss(loss_pack)
+        loss.backward()
+        return loss, loss_pack
+
+    def _build_graph(self, inputs):
+        self._static_in = inputs.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                  # warm-up off the capture: MIOpen picks its solvers here
+            for _ in range(3):
+                self._eager_fwd_bwd(self._static_in)
+                if not self.distributed:
+                    self.optimizer.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            loss, pack = self._eager_fwd_bwd(self._static_in)
+            if not self.distributed:                   # with several ranks the all-reduce stays outside the graph
+                self.optimizer.step()
+            self._static_loss = loss.detach()
+            self._static_pack = {k: v.detach() for k, v in pack.items()}
+
+    def _graph_step(self, inputs):
+        if self._graph is None:
+            self._build_graph(inputs)
+        self._static_in.copy_(inputs)
+        self._graph.replay()
+        if self.distributed:
+            self.grads.all_reduce_mean()
+            self.optimizer.step()
+        self.iteration += 1
+        return self._static_loss, self._static_pack
+
     def step(self, inputs):
         """One optimisation step on this rank's shard.  Returns (loss, loss_pack) (detached)."""
         self.model.train()
+        if self.use_graph:
+            return self._graph_step(inputs)
         self.grads.zero()
         loss_pack = self.model(inputs)
         loss = self.total_loss(loss_pack)
