@@ -143,9 +143,13 @@ def main():
         if not args.no_kernel_timing:
             nl, ms, nbytes = ops.kernel_timer.summary()
             if nl:
+                traffic = None        # HBM bytes/launch from the PMC passes (profiles/, collected separately)
+                pmc = os.path.join(ROOT, 'profiles', 'r1_corr_fwd_ring_pmc.json')
+                if os.path.exists(pmc):
+                    traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
                 gbs = nbytes / (ms * 1e-3) / 1e9
                 roof = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None,
+                        'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic,
                         'kernel': 'corr_fwd_ring_kernel<R=4,CC=2> (cost volume fwd, level 2, [2B=16,32,64,208])',
                         'launches': nl, 'avg_us': round(ms * 1e3 / nl, 2),
                         'algorithmic_bytes_per_launch': int(nbytes / nl)}

@@ -128,3 +128,16 @@ def test_input_size_must_be_multiple_of_64():
     cfg, model = _build()
     with pytest.raises(ValueError):
         model(torch.rand(1, 3, 300, 140, device='cuda'))
+
+
+def test_sintel_1024x448_matches_oracle():
+    """BASELINE config 4 resolution (Sintel 1024x448, large-map tiles): one sample vs the CPU oracle."""
+    cfg, model = _build()
+    x = R.synthetic_triplets(1, 448, 1024, seed=4, structured=True)
+    ref = R.Model_flow(R.default_cfg())
+    ref.load_state_dict(R.seeded_state_dict(ref, 1234, 0.25))
+    with torch.no_grad():
+        pack = model(x.cuda())
+        pr = ref(x)
+    for k in pr:
+        close(pack[k], pr[k], rtol=1e-4, what=k)

@@ -69,6 +69,22 @@ def test_corr_vs_oracle(ops, d, C, h, w):
     close(f2.grad, f2c.grad, rtol=1e-5, atol=5e-6)
 
 
+@pytest.mark.parametrize('C,h,w', [(32, 64, 208), (64, 32, 104), (96, 16, 52), (128, 8, 26), (196, 4, 13)])
+def test_corr_d8_full_pyramid(ops, C, h, w):
+    """BASELINE config 5: d=8 cost volume (289 planes) on every pyramid-level shape of 832x256."""
+    f1c, f2c = rnd(8, (2, C, h, w)).requires_grad_(), rnd(9, (2, C, h, w)).requires_grad_()
+    cv_ref = R.corr_naive(f1c, f2c, 8)
+    gout = rnd(10, tuple(cv_ref.shape))
+    cv_ref.backward(gout)
+    f1, f2 = dev(f1c.detach()).requires_grad_(), dev(f2c.detach()).requires_grad_()
+    cv = ops.corr(f1, f2, 8)
+    assert cv.shape[1] == 289
+    close(cv, cv_ref, rtol=1e-5, atol=2e-6)
+    cv.backward(dev(gout))
+    close(f1.grad, f1c.grad, rtol=1e-4, atol=1e-5)          # gf uses float atomics across row groups at d=8
+    close(f2.grad, f2c.grad, rtol=1e-4, atol=1e-5)
+
+
 def test_corr_shape_mismatch_asserts(ops):
     with pytest.raises(AssertionError):                       # pwc_tf.py:99
         ops.corr(torch.zeros(1, 2, 4, 4, device='cuda'), torch.zeros(1, 2, 4, 5, device='cuda'))

@@ -79,7 +79,7 @@ def losses(B=8):
         n = B * h * w
         for nm, fwd, inp, bytes_f, bytes_b in (
                 ('ssim', lambda: ops.ssim_loss(img, wp, wt), (wp,), 4 * n * 7, 4 * n * 10),
-                ('occ_weight', lambda: ops.occ_weight(img, wp, wp2)[0], (wp,), 4 * n * 13 + 2 * n, 4 * n * 10),
+                ('occ_weight', lambda: ops.occ_weight(img, wp, wp2)[0].sum((1, 2, 3)), (wp,), 4 * n * 13 + 2 * n, 4 * n * 10),
                 ('smooth2', lambda: ops.smooth2_loss(fl, img), (fl,), 4 * n * 5, 4 * n * 7),
                 ('consis', lambda: ops.consis_loss(fl, fb, wt), (fl,), 4 * n * 5, 4 * n * 7),
                 ('masked_mean', lambda: ops.masked_mean(wt.requires_grad_(), wt.detach()), (wt,), 4 * n * 2, 4 * n * 2)):
