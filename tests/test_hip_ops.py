@@ -85,6 +85,22 @@ def test_corr_d8_full_pyramid(ops, C, h, w):
     close(f2.grad, f2c.grad, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize('B,C,h,w', [(16, 32, 64, 208), (8, 32, 112, 256), (5, 7, 100, 268), (12, 64, 32, 104)])
+def test_corr_large_map_paths(ops, B, C, h, w):
+    """Shapes that take the LDS-DMA ring kernel (level 2 of the 832x256 B=8 step and of 1024x448 B=4;
+    a ragged one with partial tiles, odd B and C) and the level-3 tile kernel, vs the oracle."""
+    f1c, f2c = rnd(14, (B, C, h, w)).requires_grad_(), rnd(15, (B, C, h, w)).requires_grad_()
+    cv_ref = R.corr_naive(f1c, f2c, 4)
+    gout = rnd(16, tuple(cv_ref.shape))
+    cv_ref.backward(gout)
+    f1, f2 = dev(f1c.detach()).requires_grad_(), dev(f2c.detach()).requires_grad_()
+    cv = ops.corr(f1, f2, 4)
+    close(cv, cv_ref, rtol=1e-5, atol=2e-6)
+    cv.backward(dev(gout))
+    close(f1.grad, f1c.grad, rtol=1e-5, atol=5e-6)
+    close(f2.grad, f2c.grad, rtol=1e-5, atol=5e-6)
+
+
 def test_corr_shape_mismatch_asserts(ops):
     with pytest.raises(AssertionError):                       # pwc_tf.py:99
         ops.corr(torch.zeros(1, 2, 4, 4, device='cuda'), torch.zeros(1, 2, 4, 5, device='cuda'))

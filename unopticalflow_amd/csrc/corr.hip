@@ -67,6 +67,23 @@ __device__ __forceinline__ void stage_tile(float (*tile)[LH][LW], const float* _
     }
 }
 
+// Bijective remap of the linear workgroup id so that consecutive tiles share an XCD (workgroups
+// are dealt round-robin over the 8 XCDs): speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int lin, int total) {
+    const int q = total >> 3, r = total & 7;          // XCD x gets q (+1 if x < r) workgroups
+    const int xcd = lin & 7, k = lin >> 3;
+    return xcd * q + (xcd < r ? xcd : r) + k;
+}
+
+// 3-D grid -> XCD-remapped (bx, by, bz): neighbouring tiles of one sample share an XCD's L2 (halo reuse).
+__device__ __forceinline__ void remapped_block(int& bx, int& by, int& bz) {
+    const int total = gridDim.x * gridDim.y * gridDim.z;
+    int t = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), total);
+    bx = t % gridDim.x; t /= gridDim.x;
+    by = t % gridDim.y;
+    bz = t / gridDim.y;
+}
+
 template <int N, int PX>
 __device__ __forceinline__ void load_row(float (&v)[N], const float* row) {
     if constexpr (PX == 2) {
@@ -128,9 +145,11 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(const float* __restric
     __shared__ __attribute__((aligned(16))) float own[CC][TY][TW];      // f1
 
     const int tx = threadIdx.x & (TXT - 1), ty = threadIdx.x >> 5;
-    const int b = blockIdx.z / NG, grp = blockIdx.z - b * NG;
+    int bx, by, bz;
+    remapped_block(bx, by, bz);
+    const int b = bz / NG, grp = bz - b * NG;
     const int i0 = grp * DG;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TY;
+    const int x0 = bx * TW, y0 = by * TY;
     const int px = x0 + tx * PX, py = y0 + ty;
 
     float acc[DG][DD][PX];
@@ -203,9 +222,11 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_kernel(const float* __restric
     __shared__ __attribute__((aligned(16))) float tile[CC][LH][LW];
 
     const int tx = threadIdx.x & (TXT - 1), ty = threadIdx.x >> 5;
-    const int b = blockIdx.z / NG, grp = blockIdx.z - b * NG;
+    int bx, by, bz;
+    remapped_block(bx, by, bz);
+    const int b = bz / NG, grp = bz - b * NG;
     const int i0 = grp * DG;
-    const int x0 = blockIdx.x * K::TW, y0 = blockIdx.y * TY;
+    const int x0 = bx * K::TW, y0 = by * TY;
     const int px = x0 + tx * PX, py = y0 + ty;
     const size_t plane = (size_t)H * W;
 
@@ -481,14 +502,6 @@ struct RingCfg {
     static constexpr int ITER = (CC * SC + 255) / 256;
     static constexpr int STAGE = ITER * 256 * 4;                                // floats per ring slot
 };
-
-// Bijective remap of the linear workgroup id so that consecutive tiles share an XCD (workgroups
-// are dealt round-robin over the 8 XCDs): speed only, never correctness.
-__device__ __forceinline__ int xcd_remap(int lin, int total) {
-    const int q = total >> 3, r = total & 7;          // XCD x gets q (+1 if x < r) workgroups
-    const int xcd = lin & 7, k = lin >> 3;
-    return xcd * q + (xcd < r ? xcd : r) + k;
-}
 
 template <int R, int CC>
 __global__ __launch_bounds__(256, 2) void corr_fwd_ring_kernel(const float* __restrict__ f1,
