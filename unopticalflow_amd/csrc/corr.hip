@@ -448,13 +448,16 @@ __device__ __forceinline__ void lds_wait() {
     __builtin_amdgcn_sched_barrier(0);      // nothing that consumes the rows may move above the wait
 }
 
-// One row-step of the forward pipeline: ST = c * DD + i  (channel-in-stage, displacement row).
-template <int ST, int STEPS, int PF, int DD, int NCOL, int CH_BYTES, int ROW_BYTES>
+template <int N>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// One row-step of the forward pipeline: ST = c * DG + i  (channel-in-stage, displacement row of the group).
+template <int ST, int STEPS, int PF, int DG, int DD, int NCOL, int CH_BYTES, int ROW_BYTES>
 struct FwdStep {
     template <int Q>
     static __device__ __forceinline__ void load(v2f (&row)[PF + 1][NCOL], unsigned addr) {
         if constexpr (Q < STEPS) {
-            constexpr int off = (Q / DD) * CH_BYTES + (Q % DD) * ROW_BYTES;
+            constexpr int off = (Q / DG) * CH_BYTES + (Q % DG) * ROW_BYTES;
             row[Q % (PF + 1)][0] = lds_read_b64<off>(addr);
             row[Q % (PF + 1)][1] = lds_read_b64<off + 8>(addr);
             row[Q % (PF + 1)][2] = lds_read_b64<off + 16>(addr);
@@ -464,13 +467,13 @@ struct FwdStep {
         }
     }
     template <int CC>
-    static __device__ __forceinline__ void run(float (&acc)[DD][DD][2], v2f (&row)[PF + 1][NCOL],
+    static __device__ __forceinline__ void run(float (&acc)[DG][DD][2], v2f (&row)[PF + 1][NCOL],
                                                const v2f (&a)[CC], unsigned addr) {
         if constexpr (ST < STEPS) {
             load<ST + PF>(row, addr);
             constexpr int newer = (STEPS - 1 - ST < PF ? STEPS - 1 - ST : PF) * NCOL;
             lds_wait<newer>();
-            constexpr int c = ST / DD, i = ST % DD, rb = ST % (PF + 1);
+            constexpr int c = ST / DG, i = ST % DG, rb = ST % (PF + 1);
             float r[2 * NCOL];
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) { r[2 * k] = row[rb][k].x; r[2 * k + 1] = row[rb][k].y; }
@@ -480,35 +483,37 @@ struct FwdStep {
                 acc[i][j][1] = fmaf(a[c].y, r[j + 1], acc[i][j][1]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            FwdStep<ST + 1, STEPS, PF, DD, NCOL, CH_BYTES, ROW_BYTES>::template run<CC>(acc, row, a, addr);
+            FwdStep<ST + 1, STEPS, PF, DG, DD, NCOL, CH_BYTES, ROW_BYTES>::template run<CC>(acc, row, a, addr);
         }
     }
 };
 
 // ---------------------------------------------------------------------------------------------
-// Large-map forward, LDS-DMA ring: same 64x8 tile / 2 px per lane / all displacements per lane as
-// corr_fwd_kernel<R,2,DD,*>, but the channels stream through a 4-slot LDS ring filled by
-// global_load_lds_dwordx4 (no staging VGPRs, no ds_write) with THREE stages in flight behind a
-// counted s_waitcnt vmcnt, one raw s_barrier per stage, and an XCD-aware tile order so the halo
-// rows/columns shared by neighbouring tiles are served by one XCD's L2.
+// Large-map forward, LDS-DMA ring: 64x8 pixel tile, 2 px per lane, DG of the DD displacement rows
+// per workgroup (blockIdx.y picks the group; DG = DD: all 81 displacements in one workgroup).  The
+// channels stream through a 4-slot LDS ring filled by global_load_lds_dwordx4 (no staging VGPRs, no
+// ds_write) with THREE stages in flight behind a counted s_waitcnt vmcnt, one raw s_barrier per
+// stage; rows are read with hand-issued ds_read_b64 two row-steps ahead of their FMAs; the tile
+// order is XCD-aware so the halos shared by neighbouring tiles are served by one XCD's L2.
 // Requires W % 4 == 0.
 // ---------------------------------------------------------------------------------------------
-template <int R, int CC>
+template <int R, int CC, int DG>
 struct RingCfg {
     static constexpr int DD = 2 * R + 1;
+    static constexpr int NG = (DD + DG - 1) / DG;
     static constexpr int TW = 64, TYB = 8, NS = 4;
-    static constexpr int LW = TW + 2 * R, LH = TYB + 2 * R;
+    static constexpr int LW = TW + 2 * R, LH = TYB + DG - 1;
     static constexpr int S2 = LH * LW / 4, S1 = TYB * TW / 4, SC = S2 + S1;     // float4 slots per channel
     static constexpr int ITER = (CC * SC + 255) / 256;
     static constexpr int STAGE = ITER * 256 * 4;                                // floats per ring slot
+    static constexpr int WAVES = (DG * DD * 2 <= 96) ? 3 : 2;                   // occupancy the registers allow
 };
 
-template <int R, int CC>
-__global__ __launch_bounds__(256, 2) void corr_fwd_ring_kernel(const float* __restrict__ f1,
-                                                               const float* __restrict__ f2,
-                                                               float* __restrict__ cv, int C, int H, int W,
-                                                               int tiles_x, int tiles_y, float inv_c, int dbg) {
-    using K = RingCfg<R, CC>;
+template <int R, int CC, int DG>
+__global__ __launch_bounds__(256, (RingCfg<R, CC, DG>::WAVES)) void corr_fwd_ring_kernel(
+    const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ cv, int C, int H, int W,
+    int tiles_x, int tiles_y, float inv_c, int dbg) {
+    using K = RingCfg<R, CC, DG>;
     constexpr int DD = K::DD, LW = K::LW, NROW = 2 + 2 * R;
     __shared__ __attribute__((aligned(16))) float ring[K::NS * K::STAGE];
 
@@ -517,6 +522,7 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_ring_kernel(const float* __re
     const int bx = t % tiles_x; t /= tiles_x;
     const int by = t % tiles_y;
     const int b = t / tiles_y;
+    const int i0 = blockIdx.y * DG;                          // first displacement row of this workgroup
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, wave = threadIdx.x >> 6;
     const int x0 = bx * K::TW, y0 = by * K::TYB;
     const int px = x0 + tx * 2, py = y0 + ty;
@@ -532,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_ring_kernel(const float* __re
         const int c = s / K::SC;
         int r = s - c * K::SC;
         int gy, gx, sel;
-        if (r < K::S2) { const int ly = r / (LW / 4); gy = y0 - R + ly; gx = x0 - R + (r - ly * (LW / 4)) * 4; sel = 1; }
+        if (r < K::S2) { const int ly = r / (LW / 4); gy = y0 - R + i0 + ly; gx = x0 - R + (r - ly * (LW / 4)) * 4; sel = 1; }
         else { r -= K::S2; const int ly = r / (K::TW / 4); gy = y0 + ly; gx = x0 + (r - ly * (K::TW / 4)) * 4; sel = 0; }
         const bool in = (c < CC) && gy >= 0 && gy < H && gx >= 0 && gx < W;
         soff[it] = in ? gy * W + gx : -1;
@@ -554,9 +560,9 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_ring_kernel(const float* __re
         }
     };
 
-    float acc[DD][DD][2];
+    float acc[DG][DD][2];
 #pragma unroll
-    for (int i = 0; i < DD; ++i)
+    for (int i = 0; i < DG; ++i)
 #pragma unroll
         for (int j = 0; j < DD; ++j) { acc[i][j][0] = 0.f; acc[i][j][1] = 0.f; }
 
@@ -568,16 +574,14 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_ring_kernel(const float* __re
 
     for (int k = 0; k < nchunk; ++k) {
         // all but the newest (NS-2) stages have landed -> stage k is complete for this wave ...
-        if constexpr (K::ITER * (K::NS - 2) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if constexpr (K::ITER * (K::NS - 2) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        vm_wait<K::ITER * (K::NS - 2)>();
         __builtin_amdgcn_s_barrier();                        // ... and for every wave; slot (k-1) is free
         if (!(dbg & 4)) issue(k + K::NS - 1);
         const int sbase = (k & (K::NS - 1)) * K::STAGE;
         if (dbg & 2) continue;
-        // CC*DD row-steps per stage as one software pipeline (FwdStep): reads of step s+PF are in
+        // CC*DG row-steps per stage as one software pipeline (FwdStep): reads of step s+PF are in
         // flight behind the FMAs of step s.
-        constexpr int PF = 2, STEPS = CC * DD, NCOL = NROW / 2;
+        constexpr int PF = 2, STEPS = CC * DG, NCOL = NROW / 2;
         const unsigned abase = rows_addr + (unsigned)sbase * 4u;
         v2f a[CC];
 #pragma unroll
@@ -587,39 +591,41 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_ring_kernel(const float* __re
         }
         static_assert(CC <= 2, "a[] reads are spelled out for CC <= 2");
         v2f row[PF + 1][NCOL];
-        using Step0 = FwdStep<0, STEPS, PF, DD, NCOL, K::SC * 16, LW * 4>;
+        using Step0 = FwdStep<0, STEPS, PF, DG, DD, NCOL, K::SC * 16, LW * 4>;
         Step0::template load<0>(row, abase);
         Step0::template load<1>(row, abase);
         Step0::template run<CC>(acc, row, a, abase);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // drain the zero-line tail loads
+    vm_wait<0>();                                            // drain the zero-line tail loads
 
     if (py >= H || px >= W) return;
     float* out = cv + ((size_t)b * DD * DD) * plane + (size_t)py * W + px;
     if (dbg & 1) {      // timing experiment: keep the accumulators alive, store one plane
         float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < DD; ++i)
+        for (int i = 0; i < DG; ++i)
 #pragma unroll
             for (int j = 0; j < DD; ++j) sum += acc[i][j][0] + acc[i][j][1];
         out[0] = sum;
         return;
     }
 #pragma unroll
-    for (int i = 0; i < DD; ++i)
+    for (int i = 0; i < DG; ++i) {
+        if (i0 + i >= DD) break;
 #pragma unroll
         for (int j = 0; j < DD; ++j)
-            *reinterpret_cast<float2*>(out + (size_t)(i * DD + j) * plane) =
+            *reinterpret_cast<float2*>(out + (size_t)((i0 + i) * DD + j) * plane) =
                 make_float2(acc[i][j][0] * inv_c, acc[i][j][1] * inv_c);
+    }
 }
 
-template <int R, int CC>
+template <int R, int CC, int DG>
 int launch_fwd_ring(const float* f1, const float* f2, float* cv, int B, int C, int H, int W, hipStream_t s) {
-    using K = RingCfg<R, CC>;
+    using K = RingCfg<R, CC, DG>;
     const int tx = ceil_div(W, K::TW), ty = ceil_div(H, K::TYB);
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("UNFLOW_CORR_DEBUG"); dbg = e ? atoi(e) : 0; }   // timing experiments only
-    hipLaunchKernelGGL((corr_fwd_ring_kernel<R, CC>), dim3(tx * ty * B), dim3(256), 0, s, f1, f2, cv, C, H, W,
+    hipLaunchKernelGGL((corr_fwd_ring_kernel<R, CC, DG>), dim3(tx * ty * B, K::NG), dim3(256), 0, s, f1, f2, cv, C, H, W,
                        tx, ty, 1.0f / C, dbg);
     return unflow_launch_status();
 }
@@ -697,11 +703,13 @@ int launch_bwd(const float* f1, const float* f2, const float* g, float* gf1, flo
 
 }  // namespace
 
-// Tuning knob (diagnostic): UNFLOW_CORR_VARIANT=1..4 forces a d=4 code path
-//   1: 64x8 tiles, 2 px/lane, all 81 displacements per lane      (large maps)
+// Tuning knob (diagnostic): UNFLOW_CORR_VARIANT=1..9 forces a d=4 forward code path
+//   1: 64x8 tiles, 2 px/lane, all 81 displacements per lane, register-staged LDS tiles
 //   2: 32x8 tiles, 1 px/lane, all 81 displacements per lane
 //   3: 32x8 tiles, 1 px/lane, displacement rows split over 3 workgroups
 //   4: one lane per output element, direct (cached) global reads    (tiny maps, many channels)
+//   5, 6: 4 px/lane, displacement passes, 2-deep LDS-DMA ring (experimental)
+//   7, 8, 9: LDS-DMA ring kernel with 9 / 5 / 3 displacement rows per workgroup
 static int forced_variant() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("UNFLOW_CORR_VARIANT"); v = e ? atoi(e) : 0; }
@@ -711,9 +719,14 @@ static int forced_variant() {
 static int pick_variant(int B, int C, int H, int W) {
     const int f = forced_variant();
     if (f) return f;
-    // measured on MI355X at the 832x256 pyramid shapes (tools/microbench.py corr)
+    // measured on MI355X at the 832x256 pyramid shapes (tools/microbench.py corr):
+    //   level 2 [16,32,64,208]: ring, all 81 displacements per workgroup (7)   37 us
+    //   level 3 [16,64,32,104], level 4 [16,96,16,52]: ring, 3 displacement rows per workgroup (9)  29 / 30 us
+    //   levels 5, 6: one lane per output element (4)   14 / 11 us
     const long px = (long)B * H * W;
-    if (W >= 96 && px >= 131072) return ((W & 3) == 0) ? 7 : 1;
+    const bool dma_ok = ((W & 3) == 0);
+    if (W >= 96 && px >= 131072) return dma_ok ? 7 : 1;
+    if (px >= 8192 && dma_ok) return 9;
     if (px >= 32768) return 3;
     return 4;
 }
@@ -733,8 +746,10 @@ extern "C" int unflow_corr_fwd(const float* f1, const float* f2, float* cv, int 
                 if (variant == 5 && (W & 3) == 0) return launch_fwd_px4<4, 3, 2>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 6 && (W & 3) == 0) return launch_fwd_px4<4, 3, 4>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 5 || variant == 6) return launch_fwd<4, 2, 9, 8>(f1, f2, cv, B, C, H, W, s);
-                if (variant == 7 && (W & 3) == 0) return launch_fwd_ring<4, 2>(f1, f2, cv, B, C, H, W, s);
-                if (variant == 7) return launch_fwd<4, 2, 9, 8>(f1, f2, cv, B, C, H, W, s);
+                if (variant == 7 && (W & 3) == 0) return launch_fwd_ring<4, 2, 9>(f1, f2, cv, B, C, H, W, s);
+                if (variant == 8 && (W & 3) == 0) return launch_fwd_ring<4, 2, 5>(f1, f2, cv, B, C, H, W, s);
+                if (variant == 9 && (W & 3) == 0) return launch_fwd_ring<4, 2, 3>(f1, f2, cv, B, C, H, W, s);
+                if (variant >= 7) return launch_fwd<4, 2, 9, 8>(f1, f2, cv, B, C, H, W, s);
                 break;
         case 8: return launch_fwd<8, 1, 6, 8>(f1, f2, cv, B, C, H, W, s);
         default: break;
@@ -754,8 +769,9 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
         case 1: return launch_bwd<1, 2, 3, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
         case 2: return launch_bwd<2, 2, 5, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
         case 4: variant = pick_variant(B, C, H, W);
-                if (variant == 1 || variant == 7) return launch_bwd<4, 2, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                if (variant == 2 || variant == 3) return launch_bwd<4, 1, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                if (variant == 1 || variant == 7 || variant == 8) return launch_bwd<4, 2, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                if (variant == 2 || variant == 3 || (variant == 9 && (long)B * H * W >= 32768))
+                    return launch_bwd<4, 1, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 break;
         case 8: return launch_bwd<8, 1, 6, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
         default: break;
