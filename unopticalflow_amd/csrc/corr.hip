@@ -630,6 +630,233 @@ int launch_fwd_ring(const float* f1, const float* f2, float* cv, int B, int C, i
     return unflow_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Large-map backward, "group split" ring kernel.  blockIdx.y selects the gradient:
+//   0: gf1[c][q] = (1/C) sum_ij g[ij][q]             * f2[c][q + (i-R, j-R)]
+//   1: gf2[c][q] = (1/C) sum_ij g[ij][q - (i-R,j-R)] * f1[c][q - (i-R, j-R)]   (a gather: no atomics)
+// Holding all DD*DD*2 upstream-gradient values of a lane's two pixels costs 162 VGPRs and leaves no
+// room for a software pipeline (2 waves/SIMD, spills).  Here a 384-thread workgroup owns a 64x4
+// pixel tile THREE times: wave pair g keeps only displacement rows [3g, 3g+3) (54 VGPRs) and
+// produces a partial dot product per channel; pairs 1 and 2 hand theirs to pair 0 through a
+// double-buffered LDS slab one stage later (no extra barrier), pair 0 adds them in a fixed order
+// and issues the 8-byte stores.  ~100 VGPRs -> 4-5 waves per SIMD, so LDS latency, DMA latency and
+// stores overlap across waves.  F streams through the same 4-slot global_load_lds ring as the
+// forward kernel.  Requires W % 4 == 0 and DD == 9 (R == 4).
+// ---------------------------------------------------------------------------------------------
+template <int R, int CC>
+struct BwdGsCfg {
+    static constexpr int DD = 2 * R + 1, DG = 3, NGRP = 3;
+    static constexpr int TW = 64, TYB = 4, NS = 3, THREADS = 128 * NGRP;       // 3 slots: 44 KB -> 3 workgroups per CU
+    static constexpr int LW = TW + 2 * R, LH = TYB + 2 * R;
+    static constexpr int SC = LH * LW / 4;                                      // float4 slots per channel
+    static constexpr int ITER = (CC * SC + THREADS - 1) / THREADS;
+    static constexpr int STAGE = ITER * THREADS * 4;                            // floats per ring slot
+    static constexpr int RED = 2 * CC * 128 * 2;                                // floats per hand-off buffer (pairs 1, 2)
+};
+
+// One row-step of the backward pipeline: ST = c * 3 + i.
+template <int ST, int STEPS, int PF, int DD, int NCOL, int CH_BYTES, int ROW_BYTES>
+struct GsStep {
+    template <int Q>
+    static __device__ __forceinline__ void load(v2f (&row)[PF + 1][NCOL], unsigned addr) {
+        if constexpr (Q < STEPS) {
+            constexpr int off = (Q / 3) * CH_BYTES + (Q % 3) * ROW_BYTES;
+            row[Q % (PF + 1)][0] = lds_read_b64<off>(addr);
+            row[Q % (PF + 1)][1] = lds_read_b64<off + 8>(addr);
+            row[Q % (PF + 1)][2] = lds_read_b64<off + 16>(addr);
+            row[Q % (PF + 1)][3] = lds_read_b64<off + 24>(addr);
+            row[Q % (PF + 1)][4] = lds_read_b64<off + 32>(addr);
+            static_assert(NCOL == 5, "2 px + 2*4 halo floats = 5 float2 columns");
+        }
+    }
+    template <int CC>
+    static __device__ __forceinline__ void run(const float (&wr)[3][DD][2], float (&acc)[CC][2][2],
+                                               v2f (&row)[PF + 1][NCOL], unsigned addr) {
+        if constexpr (ST < STEPS) {
+            load<ST + PF>(row, addr);
+            constexpr int newer = (STEPS - 1 - ST < PF ? STEPS - 1 - ST : PF) * NCOL;
+            lds_wait<newer>();
+            constexpr int c = ST / 3, i = ST % 3, rb = ST % (PF + 1);
+#pragma unroll
+            for (int j = 0; j < DD; ++j) {
+                const float r0 = (j & 1) ? row[rb][j / 2].y : row[rb][j / 2].x;
+                const float r1 = ((j + 1) & 1) ? row[rb][(j + 1) / 2].y : row[rb][(j + 1) / 2].x;
+                acc[c][j & 1][0] = fmaf(wr[i][j][0], r0, acc[c][j & 1][0]);
+                acc[c][j & 1][1] = fmaf(wr[i][j][1], r1, acc[c][j & 1][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            GsStep<ST + 1, STEPS, PF, DD, NCOL, CH_BYTES, ROW_BYTES>::template run<CC>(wr, acc, row, addr);
+        }
+    }
+};
+
+template <int R, int CC>
+__global__ __launch_bounds__(384) void corr_bwd_gs_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                         const float* __restrict__ g, float* __restrict__ gf1,
+                                                         float* __restrict__ gf2, int C, int H, int W,
+                                                         int tiles_x, int tiles_y, float inv_c) {
+    using K = BwdGsCfg<R, CC>;
+    constexpr int DD = K::DD, LW = K::LW, NROW = 2 + 2 * R, NCOL = NROW / 2;
+    static_assert(K::NS == 3 || K::NS == 4, "ring depth");
+    __shared__ __attribute__((aligned(16))) float lds[K::NS * K::STAGE + 2 * K::RED];
+    float* ring = lds;
+    float* red = lds + K::NS * K::STAGE;
+
+    const int mode = blockIdx.y;
+    const float* __restrict__ F = mode ? f1 : f2;
+    float* __restrict__ out = mode ? gf2 : gf1;
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = t % tiles_x; t /= tiles_x;
+    const int by = t % tiles_y;
+    const int b = t / tiles_y;
+    const int l = threadIdx.x & 127, wave = threadIdx.x >> 6;
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);     // wave-uniform: branches on it are scalar
+    const int tx = l & 31, ty = l >> 5;
+    const int x0 = bx * K::TW, y0 = by * K::TYB;
+    const int px = x0 + tx * 2, py = y0 + ty;
+    const size_t plane = (size_t)H * W;
+    const int nchunk = (C + CC - 1) / CC;
+    const bool live = (py < H && px < W);
+
+    // this wave pair's 3 displacement rows of the upstream gradient -> registers
+    // (mode 1: displacement-flipped and gathered from q + (i'-R, j'-R))
+    float wr[3][DD][2];
+    {
+        const float* gb = g + (size_t)b * DD * DD * plane;
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+            for (int j = 0; j < DD; ++j)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int i = grp * 3 + ii;
+                    // branch-free: clamp the gather position, load unconditionally, zero afterwards, so the
+                    // 54 loads of a lane go out back to back instead of as 54 exec-masked blocks
+                    const int sy = mode ? py + i - R : py, sx = mode ? px + p + j - R : px + p;
+                    const int pl = mode ? (2 * R - i) * DD + (2 * R - j) : i * DD + j;
+                    const bool ok = (py < H) && (px + p < W) && sy >= 0 && sy < H && sx >= 0 && sx < W;
+                    const int cy = min(max(sy, 0), H - 1), cx = min(max(sx, 0), W - 1);
+                    float v = gb[(size_t)pl * plane + (size_t)cy * W + cx];
+                    v = ok ? v : 0.f;
+                    wr[ii][j][p] = v * inv_c;
+                }
+    }
+
+    const float* baseF = F + (size_t)b * C * plane;
+    auto issue = [&](int stage_idx) {
+        float* dst = ring + (stage_idx % K::NS) * K::STAGE;
+        const int c0 = stage_idx * CC;
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));            // opaque per call: keeps hipcc from hoisting (and spilling) the slot math
+#pragma unroll
+        for (int it = 0; it < K::ITER; ++it) {
+            const int s = it * K::THREADS + tid;
+            const int c = s / K::SC;
+            const int r = s - c * K::SC;
+            const int ly = r / (LW / 4);
+            const int gy = y0 - R + ly, gx = x0 - R + (r - ly * (LW / 4)) * 4;
+            const int gc = c0 + c;
+            const bool in = (c < CC) && gc < C && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const float* gp = in ? baseF + (size_t)gc * plane + (gy * W + gx) : kZeroLine;
+            __builtin_amdgcn_global_load_lds((gas_ptr)gp, (lds_ptr)(dst + (it * K::THREADS + wave * 64) * 4), 16, 0, 0);
+        }
+    };
+
+    // rows of this pair start 3*grp below the tile's first halo row
+    const unsigned rows_addr = (unsigned)(size_t)(lds_cfloat*)(ring + (ty + 3 * grp) * LW + tx * 2);
+    float* op = out + ((size_t)b * C * H + py) * W + px;
+
+    // pair 0: add the partials pairs 1 and 2 left for stage `st` and store its CC channels
+    // (the slab is read and written with hand-issued ds ops: compiler-visible LDS accesses next to an
+    // in-flight LDS-DMA make hipcc drain vmcnt(0))
+    const unsigned red_addr = (unsigned)(size_t)(lds_cfloat*)(red + l * 2);
+    auto finish = [&](int st, const float (&mine)[CC][2]) {
+        const unsigned ra = red_addr + (unsigned)((st & 1) * K::RED) * 4u;
+        v2f q1[CC], q2[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            if (c == 0) { q1[c] = lds_read_b64<0>(ra); q2[c] = lds_read_b64<CC * 128 * 8>(ra); }
+            else { q1[c] = lds_read_b64<128 * 8>(ra); q2[c] = lds_read_b64<CC * 128 * 8 + 128 * 8>(ra); }
+        }
+        static_assert(CC <= 2, "slab reads are spelled out for CC <= 2");
+        lds_wait<0>();
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            const v2f p1 = q1[c], p2 = q2[c];
+            const int gc = st * CC + c;
+            // exactly one store instruction per channel per wave (lanes masked by EXEC): the vmcnt counts below rely on it
+            if (live && gc < C)
+                *reinterpret_cast<float2*>(op + (size_t)gc * plane) = make_float2((mine[c][0] + p1.x) + p2.x, (mine[c][1] + p1.y) + p2.y);
+        }
+    };
+
+    vm_wait<0>();                                    // the gradient loads are done before the first DMA goes out
+#pragma unroll
+    for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+        for (int j = 0; j < DD; ++j) {               // pin their consumers here too (else hipcc sinks them into the
+            asm volatile("" : "+v"(wr[ii][j][0]));   // loop and drains vmcnt(0) with the DMA in flight)
+            asm volatile("" : "+v"(wr[ii][j][1]));
+        }
+#pragma unroll
+    for (int st = 0; st < K::NS - 1; ++st) issue(st);
+
+    float keep[CC][2];                               // pair 0: its own partials of the previous stage
+#pragma unroll
+    for (int c = 0; c < CC; ++c) { keep[c][0] = 0.f; keep[c][1] = 0.f; }
+
+    for (int k = 0; k < nchunk; ++k) {
+        // vmcnt is in-order over DMA loads AND stores.  Newer than stage k's DMA when we get here:
+        // NS-2 later DMA stages, plus (pair 0 only) the stores of the last min(NS-2, k-1) finished stages.
+        if (grp != 0 || k < 2) vm_wait<(K::NS - 2) * K::ITER>();
+        else if (k == 2 || K::NS == 3) vm_wait<(K::NS - 2) * K::ITER + CC>();
+        else vm_wait<(K::NS - 2) * K::ITER + 2 * CC>();
+        __builtin_amdgcn_s_barrier();                // stage k landed for all; slot k-1 and red[(k-1)&1] are complete
+        if (grp == 0 && k > 0) finish(k - 1, keep);
+        issue(k + K::NS - 1);
+
+        constexpr int PF = 2, STEPS = CC * 3;
+        const unsigned abase = rows_addr + (unsigned)((k % K::NS) * K::STAGE) * 4u;
+        float acc[CC][2][2];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) { acc[c][0][0] = 0.f; acc[c][0][1] = 0.f; acc[c][1][0] = 0.f; acc[c][1][1] = 0.f; }
+        v2f row[PF + 1][NCOL];
+        using Step0 = GsStep<0, STEPS, PF, DD, NCOL, K::SC * 16, LW * 4>;
+        Step0::template load<0>(row, abase);
+        Step0::template load<1>(row, abase);
+        Step0::template run<CC>(wr, acc, row, abase);
+
+        if (grp == 0) {
+#pragma unroll
+            for (int c = 0; c < CC; ++c) { keep[c][0] = acc[c][0][0] + acc[c][1][0]; keep[c][1] = acc[c][0][1] + acc[c][1][1]; }
+        } else {
+            const unsigned wa = red_addr + (unsigned)((k & 1) * K::RED + (grp - 1) * CC * 128 * 2) * 4u;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                v2f v;
+                v.x = acc[c][0][0] + acc[c][1][0];
+                v.y = acc[c][0][1] + acc[c][1][1];
+                if (c == 0) asm volatile("ds_write_b64 %0, %1" ::"v"(wa), "v"(v) : "memory");
+                else asm volatile("ds_write_b64 %0, %1 offset:1024" ::"v"(wa), "v"(v) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slab written before the next barrier
+        }
+    }
+    vm_wait<0>();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 0) finish(nchunk - 1, keep);
+}
+
+template <int R, int CC>
+int launch_bwd_gs(const float* f1, const float* f2, const float* g, float* gf1, float* gf2,
+                  int B, int C, int H, int W, hipStream_t s) {
+    using K = BwdGsCfg<R, CC>;
+    const int tx = ceil_div(W, K::TW), ty = ceil_div(H, K::TYB);
+    hipLaunchKernelGGL((corr_bwd_gs_kernel<R, CC>), dim3(tx * ty * B, 2), dim3(K::THREADS), 0, s, f1, f2, g, gf1, gf2,
+                       C, H, W, tx, ty, 1.0f / C);
+    return unflow_launch_status();
+}
+
 // ---- any-radius fallback (one thread per output element, direct global reads) ----
 __global__ void corr_fwd_generic(const float* __restrict__ f1, const float* __restrict__ f2,
                                  float* __restrict__ cv, int B, int C, int H, int W, int R, float inv_c) {
@@ -716,6 +943,12 @@ static int forced_variant() {
     return v;
 }
 
+static int forced_bwd() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("UNFLOW_CORR_BWD"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 static int pick_variant(int B, int C, int H, int W) {
     const int f = forced_variant();
     if (f) return f;
@@ -769,6 +1002,9 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
         case 1: return launch_bwd<1, 2, 3, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
         case 2: return launch_bwd<2, 2, 5, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
         case 4: variant = pick_variant(B, C, H, W);
+                // group-split ring kernel: measured best for mid-size maps (levels 3, 4); level 2 stays on the tile kernel
+                if ((W & 3) == 0 && (forced_bwd() == 1 || (forced_bwd() == 0 && variant == 9)))
+                    return launch_bwd_gs<4, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (variant == 1 || variant == 7 || variant == 8) return launch_bwd<4, 2, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (variant == 2 || variant == 3 || (variant == 9 && (long)B * H * W >= 32768))
                     return launch_bwd<4, 1, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
