@@ -646,7 +646,8 @@ int launch_fwd_ring(const float* f1, const float* f2, float* cv, int B, int C, i
 template <int R, int CC>
 struct BwdGsCfg {
     static constexpr int DD = 2 * R + 1, DG = 3, NGRP = 3;
-    static constexpr int TW = 64, TYB = 4, NS = 3, THREADS = 128 * NGRP;       // 3 slots: 44 KB -> 3 workgroups per CU
+    static constexpr int TW = 64, TYB = 4, NS = 3, THREADS = 128 * NGRP;       // 3 slots (44 KB, 3 workgroups per CU) measured
+                                                                               // best: 6 slots (80 KB) halves the residency
     static constexpr int LW = TW + 2 * R, LH = TYB + 2 * R;
     static constexpr int SC = LH * LW / 4;                                      // float4 slots per channel
     static constexpr int ITER = (CC * SC + THREADS - 1) / THREADS;
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(384) void corr_bwd_gs_kernel(const float* __restric
                                                          int tiles_x, int tiles_y, float inv_c) {
     using K = BwdGsCfg<R, CC>;
     constexpr int DD = K::DD, LW = K::LW, NROW = 2 + 2 * R, NCOL = NROW / 2;
-    static_assert(K::NS == 3 || K::NS == 4, "ring depth");
+    static_assert(K::NS >= 3 && K::NS <= 6, "ring depth (the counted vmcnt waits cover NS-2 <= 4 store groups)");
     __shared__ __attribute__((aligned(16))) float lds[K::NS * K::STAGE + 2 * K::RED];
     float* ring = lds;
     float* red = lds + K::NS * K::STAGE;
@@ -743,21 +744,30 @@ __global__ __launch_bounds__(384) void corr_bwd_gs_kernel(const float* __restric
     }
 
     const float* baseF = F + (size_t)b * C * plane;
+    // per-lane DMA slot descriptors, computed once: plane offset of the slot's 16 bytes (or -1 outside the
+    // image / in the padding) and its channel within the stage.  (Recomputing them per stage cost ~70 %
+    // extra VALU instructions; with ~100 VGPRs there is room to keep them.)
+    int soff[K::ITER], sch[K::ITER];
+#pragma unroll
+    for (int it = 0; it < K::ITER; ++it) {
+        const int s = it * K::THREADS + (int)threadIdx.x;
+        const int c = s / K::SC;
+        const int r = s - c * K::SC;
+        const int ly = r / (LW / 4);
+        const int gy = y0 - R + ly, gx = x0 - R + (r - ly * (LW / 4)) * 4;
+        const bool in = (c < CC) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        soff[it] = in ? gy * W + gx : -1;
+        sch[it] = c;
+        asm volatile("" : "+v"(soff[it]), "+v"(sch[it]));      // materialise once; do not re-derive in the loop
+    }
     auto issue = [&](int stage_idx) {
         float* dst = ring + (stage_idx % K::NS) * K::STAGE;
         const int c0 = stage_idx * CC;
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));            // opaque per call: keeps hipcc from hoisting (and spilling) the slot math
 #pragma unroll
         for (int it = 0; it < K::ITER; ++it) {
-            const int s = it * K::THREADS + tid;
-            const int c = s / K::SC;
-            const int r = s - c * K::SC;
-            const int ly = r / (LW / 4);
-            const int gy = y0 - R + ly, gx = x0 - R + (r - ly * (LW / 4)) * 4;
-            const int gc = c0 + c;
-            const bool in = (c < CC) && gc < C && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const float* gp = in ? baseF + (size_t)gc * plane + (gy * W + gx) : kZeroLine;
+            const int gc = c0 + sch[it];
+            const bool in = soff[it] >= 0 && gc < C;
+            const float* gp = in ? baseF + (size_t)gc * plane + soff[it] : kZeroLine;
             __builtin_amdgcn_global_load_lds((gas_ptr)gp, (lds_ptr)(dst + (it * K::THREADS + wave * 64) * 4), 16, 0, 0);
         }
     };
@@ -808,9 +818,15 @@ __global__ __launch_bounds__(384) void corr_bwd_gs_kernel(const float* __restric
     for (int k = 0; k < nchunk; ++k) {
         // vmcnt is in-order over DMA loads AND stores.  Newer than stage k's DMA when we get here:
         // NS-2 later DMA stages, plus (pair 0 only) the stores of the last min(NS-2, k-1) finished stages.
-        if (grp != 0 || k < 2) vm_wait<(K::NS - 2) * K::ITER>();
-        else if (k == 2 || K::NS == 3) vm_wait<(K::NS - 2) * K::ITER + CC>();
-        else vm_wait<(K::NS - 2) * K::ITER + 2 * CC>();
+        {
+            constexpr int D = (K::NS - 2) * K::ITER;
+            const int nst = (grp != 0) ? 0 : min(K::NS - 2, max(0, k - 1));     // wave-uniform
+            if (nst == 0) vm_wait<D>();
+            else if (nst == 1) vm_wait<D + CC>();
+            else if (nst == 2) vm_wait<D + 2 * CC>();
+            else if (nst == 3) vm_wait<D + 3 * CC>();
+            else vm_wait<D + 4 * CC>();
+        }
         __builtin_amdgcn_s_barrier();                // stage k landed for all; slot k-1 and red[(k-1)&1] are complete
         if (grp == 0 && k > 0) finish(k - 1, keep);
         issue(k + K::NS - 1);
