@@ -127,6 +127,11 @@ int unflow_bias_leaky_bwd(const float* y, const float* gout, float* gin, float* 
 int unflow_img_pyramid(const float* img, float* half, float* quarter, int planes, int H, int W,
                        void* stream);
 
+/* ---- host helper of the evaluation path (KITTI 16-bit flow PNGs, core/evaluation/flowlib.py:107-127) ----
+ * rows: height x (1 + stride) host bytes (filter byte + filtered scanline per row), decoded in place.
+ * Runs on the CPU; no GPU work. */
+int unflow_png_unfilter(uint8_t* rows, int height, int stride, int bpp);
+
 #ifdef __cplusplus
 }
 #endif

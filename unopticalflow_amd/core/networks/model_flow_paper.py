@@ -56,6 +56,21 @@ class Model_flow(nn.Module):
         return [warp_flow(img, flow, use_mask=True, align_corners=self.align_corners)
                 for img, flow in zip(img_pyramid, flow_pyramid)]
 
+    def compute_loss_pixel(self, img_pyramid, img_warped_pyramid, occ_mask_list):
+        """reference :68-77 (not called by forward(); kept for surface parity, same HIP masked mean)"""
+        loss = 0
+        for scale in range(self.num_scales):
+            diff = torch.abs(img_pyramid[scale] - img_warped_pyramid[scale]).mean(1, True)
+            loss = loss + ops.masked_mean(diff, occ_mask_list[scale])
+        return loss
+
+    def compute_loss_pixel_without_mask(self, img_pyramid, img_warped_pyramid):
+        """reference :79-87 (not called by forward())"""
+        loss = 0
+        for scale in range(self.num_scales):
+            loss = loss + torch.abs(img_pyramid[scale] - img_warped_pyramid[scale]).mean((1, 2, 3))
+        return loss
+
     # ---- losses (one HIP op per scale each) ----
     def compute_loss_with_mask(self, diff_list, occ_mask_list):
         """reference :90-99"""

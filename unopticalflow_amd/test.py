@@ -3,10 +3,12 @@
     python -m unopticalflow_amd.test -c cfg.yaml --gpu 0 --mode flow --task synthetic_flow \
         --pretrained_model models/.../last.pth
 
-``--task kitti_flow`` needs the KITTI 2012/2015 flow PNGs and their decoder, the evaluation stage
-listed as the next row (N1) in SURVEY.md section 8f; it is not implemented in this round and says
-so.  ``--task synthetic_flow`` runs ``inference_flow`` on synthetic pairs with a known translation
-and reports the end-point error with the reference's EPE formula (evaluate_flow.py:131-134).
+``--task kitti_flow`` evaluates on KITTI 2015 (``gt_2015_dir`` of the yaml, or ``--gt_dir``) exactly as
+the reference's test_kitti_2015 (test.py:43-76): per pair ``inference_flow`` at ``img_hw``, then
+``eval_flow_avg`` (EPE / noc / occ / Fl, moving-object split) from ``unopticalflow_amd.evaluation``.
+``--task kitti_flow_2012`` is test_kitti_2012 (test.py:16-41).  ``--task synthetic_flow`` needs no
+dataset: synthetic pairs with a known translation, EPE with the reference's formula
+(evaluate_flow.py:131-134).
 """
 import argparse
 import os
@@ -15,11 +17,42 @@ import torch
 import yaml
 
 from .core.networks import Model_flow
+from . import evaluation as ev
 
 
 def epe(flow, gt):
     d = flow - gt
     return torch.sqrt(d[:, 0] ** 2 + d[:, 1] ** 2).mean()
+
+
+def _predict(cfg, model, dataset):
+    flows = []
+    for idx in range(len(dataset)):
+        img = dataset[idx][None].cuda()
+        img_h = int(img.shape[2] / 2)
+        with torch.no_grad():
+            flow = model.inference_flow(img[:, :, :img_h, :], img[:, :, img_h:, :])
+        flows.append(flow[0].detach().cpu().numpy().transpose(1, 2, 0))
+    return flows
+
+
+def test_kitti_2012(cfg, model, gt_flows, noc_masks, num=None):
+    """reference test.py:16-41"""
+    res = ev.eval_flow_avg(gt_flows, noc_masks, _predict(cfg, model, ev.KITTI_2012(cfg.gt_2012_dir, cfg.img_hw, num)), cfg)
+    print('CONFIG: {0}, mode: {1}'.format(getattr(cfg, 'config_file', None), cfg.mode))
+    print('[EVAL] [KITTI 2012]')
+    print(res)
+    return res
+
+
+def test_kitti_2015(cfg, model, gt_flows, noc_masks, gt_masks, depth_save_dir=None, num=None):
+    """reference test.py:43-76"""
+    res = ev.eval_flow_avg(gt_flows, noc_masks, _predict(cfg, model, ev.KITTI_2015(cfg.gt_2015_dir, cfg.img_hw, num)), cfg,
+                           moving_masks=gt_masks)
+    print('CONFIG: {0}, mode: {1}'.format(getattr(cfg, 'config_file', None), cfg.mode))
+    print('[EVAL] [KITTI 2015]')
+    print(res)
+    return res
 
 
 def test_synthetic_flow(cfg, model, n=8, shift=(3.0, 1.0)):
@@ -48,6 +81,8 @@ def main(argv=None):
     ap.add_argument('--pretrained_model', type=str, default=None, help='directory for loading flow pretrained models')
     ap.add_argument('--result_dir', type=str, default=None, help='directory for saving predictions')
     ap.add_argument('--align_corners', type=int, default=0)
+    ap.add_argument('--gt_dir', type=str, default=None, help='KITTI training dir (overrides gt_2015_dir / gt_2012_dir of the yaml)')
+    ap.add_argument('--num_eval', type=int, default=None, help='evaluate only the first N pairs')
     args = ap.parse_args(argv)
     if not os.path.exists(args.config_file):
         raise ValueError('config file not found.')
@@ -75,8 +110,16 @@ def main(argv=None):
     if args.task == 'synthetic_flow':
         return test_synthetic_flow(cfg_new, model)
     if args.task == 'kitti_flow':
-        raise NotImplementedError('KITTI flow evaluation (dataset loader + flow-PNG decode + eval_flow_avg) is the '
-                                  'next row after the hot path (SURVEY.md 8f N1); not part of this round')
+        if args.gt_dir:
+            cfg_new.gt_2015_dir = args.gt_dir
+        gt_flows, noc_masks = ev.load_gt_flow_kitti(cfg_new.gt_2015_dir, 'kitti_2015', args.num_eval)
+        gt_masks = ev.load_gt_mask(cfg_new.gt_2015_dir, args.num_eval or 200)
+        return test_kitti_2015(cfg_new, model, gt_flows, noc_masks, gt_masks, num=args.num_eval)
+    if args.task == 'kitti_flow_2012':
+        if args.gt_dir:
+            cfg_new.gt_2012_dir = args.gt_dir
+        gt_flows, noc_masks = ev.load_gt_flow_kitti(cfg_new.gt_2012_dir, 'kitti_2012', args.num_eval)
+        return test_kitti_2012(cfg_new, model, gt_flows, noc_masks, num=args.num_eval)
     raise ValueError('unknown task {}'.format(args.task))
 
 
