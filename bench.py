@@ -43,6 +43,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=2, help='triplets in the CPU-baseline sample step')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'], help='conv-stack precision (bf16: BASELINE config 3; the headline metric is fp32)')
     ap.add_argument('--graph', type=int, default=0, help='1: replay the step as a hipGraph (kernel timing events are then off)')
     return ap.parse_args()
 
@@ -99,7 +100,7 @@ def main():
 
     cfg = types.SimpleNamespace(mode='flow', dataset='kitti_depth', num_scales=3, h_flow_consist_alpha=3.0,
                                 h_flow_consist_beta=0.05, w_ssim=0.85, w_flow_smooth=10.0, w_flow_consis=0.01,
-                                lr=1e-4, align_corners=False)
+                                lr=1e-4, align_corners=False, precision=args.precision)
     torch.manual_seed(1234)                       # same random init on every rank
     if os.environ.get('UNFLOW_MIOPEN_FIND', '1') == '1':
         from unopticalflow_amd.tuning import enable_miopen_tuning
@@ -161,9 +162,9 @@ def main():
             'metric': 'frame-pairs/s (train step) at 832x256 bs=8',
             'value': round(pairs / dt, 2), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'KITTI 832x256 triplets, bs=%d per GPU, fp32, corr d=4 + warp + occlusion losses, '
-                                   'fwd+bwd+Adam (BASELINE configs[1])' % args.batch,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'KITTI 832x256 triplets, bs=%d per GPU, %s, corr d=4 + warp + occlusion losses, '
+                                   'fwd+bwd+Adam (BASELINE configs[%d])' % (args.batch, args.precision, 1 if args.precision == 'fp32' else 2),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                        'triplets_per_s': round(pairs / 2 / dt, 2)},
             'roofline': roof, 'cpu_baseline': base,

@@ -18,12 +18,18 @@ class Model_flow(nn.Module):
         are HIP kernels (``unopticalflow_amd.ops``) instead of eager op chains;
       * the 1/8-scale image warp the reference computes and discards
         (model_flow_paper.py:62-66 with num_scales=3) is not computed.
-    ``cfg.align_corners`` (optional, default False) selects the grid_sample generation.
+    ``cfg.align_corners`` (optional, default False) selects the grid_sample generation;
+    ``cfg.precision`` (optional, 'fp32' | 'bf16') the conv-stack precision.
     """
 
     def __init__(self, cfg):
         super(Model_flow, self).__init__()
         self.align_corners = bool(getattr(cfg, 'align_corners', False))
+        # 'fp32' (default, the parity configuration) or 'bf16': the conv stacks run under bf16 autocast (MFMA
+        # bf16), cost volume / warp / losses keep fp32 inputs and accumulation (BASELINE config 3)
+        self.precision = getattr(cfg, 'precision', 'fp32')
+        if self.precision not in ('fp32', 'bf16'):
+            raise ValueError('precision must be fp32 or bf16, got {}'.format(self.precision))
         self.fpyramid = FeaturePyramid()
         self.pwc_model = PWC_tf(align_corners=self.align_corners)
         if cfg.mode == 'depth' or cfg.mode == 'flowposenet':
@@ -124,20 +130,26 @@ class Model_flow(nn.Module):
         """reference :198-202 -> full-resolution flow [B,2,H,W]"""
         img_hw = [img1.shape[2], img1.shape[3]]
         B = img1.shape[0]
-        feats = self.fpyramid(torch.cat((img1, img2), 0))
-        feature_list_1 = [f[:B] for f in feats]
-        feature_list_2 = [f[B:] for f in feats]
-        return self.pwc_model(feature_list_1, feature_list_2, img_hw)[0]
+        with self._autocast():
+            feats = self.fpyramid(torch.cat((img1, img2), 0))
+            feature_list_1 = [f[:B] for f in feats]
+            feature_list_2 = [f[B:] for f in feats]
+            return self.pwc_model(feature_list_1, feature_list_2, img_hw)[0].float()
+
+    def _autocast(self):
+        return torch.autocast('cuda', dtype=torch.bfloat16, enabled=(self.precision == 'bf16'))
 
     def _flows(self, imgl, img, imgr, frames=None):
         """Both directed flow pyramids with one 3B pyramid pass and one 2B decoder pass."""
         B, _, img_h, img_w = img.shape
         if frames is None:
             frames = torch.cat((imgl, img, imgr), 0)
-        feats = self.fpyramid(frames)                                    # [3B, ...] per level
-        feat_c2 = [torch.cat((f[B:2 * B], f[B:2 * B]), 0) for f in feats]
-        feat_lr = [torch.cat((f[:B], f[2 * B:]), 0) for f in feats]
-        flows = self.pwc_model(feat_c2, feat_lr, [img_h, img_w])         # [2B, 2, h, w] per scale
+        with self._autocast():
+            feats = self.fpyramid(frames)                                    # [3B, ...] per level
+            feat_c2 = [torch.cat((f[B:2 * B], f[B:2 * B]), 0) for f in feats]
+            feat_lr = [torch.cat((f[:B], f[2 * B:]), 0) for f in feats]
+            flows = self.pwc_model(feat_c2, feat_lr, [img_h, img_w])         # [2B, 2, h, w] per scale
+        flows = [f.float() for f in flows]
         return [f[:B] for f in flows], [f[B:] for f in flows]            # bwd (centre->left), fwd
 
     def forward(self, inputs, output_flow=False, use_flow_loss=True, is_second_phase=False):

@@ -1,3 +1,4 @@
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -13,6 +14,8 @@ class ConvLeaky(nn.Sequential):
     def forward(self, x):
         c = self[0]
         y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
+        if y.dtype != torch.float32:       # bf16 autocast run (cfg.precision == 'bf16'): unfused torch epilogue
+            return F.leaky_relu(y + c.bias.to(y.dtype).view(1, -1, 1, 1), self[1].negative_slope)
         return ops.bias_leaky_relu_(y, c.bias, self[1].negative_slope)
 
 

@@ -38,11 +38,12 @@ class PWC_tf(nn.Module):
         return nn.Conv2d(in_planes, 2, kernel_size=3, stride=1, padding=1, bias=True)
 
     def warp(self, x, flow):
-        return warp_flow(x, flow, use_mask=False, align_corners=self.align_corners)
+        return warp_flow(x.float(), flow.float(), use_mask=False, align_corners=self.align_corners)
 
     def corr_naive(self, input1, input2, d=4):
-        """Same contract as the reference's corr_naive (pwc_tf.py:97-106); one HIP kernel."""
-        return ops.corr(input1, input2, d)
+        """Same contract as the reference's corr_naive (pwc_tf.py:97-106); one HIP kernel (fp32 accumulation;
+        bf16 features of an autocast run are widened first)."""
+        return ops.corr(input1.float(), input2.float(), d)
 
     def _decoder(self, lvl, x):
         c = [getattr(self, 'conv%d_%d' % (lvl, k)) for k in range(5)]
@@ -51,7 +52,7 @@ class PWC_tf(nn.Module):
         x2 = c[2](torch.cat((x0, x1), 1))
         x3 = c[3](torch.cat((x1, x2), 1))
         x4 = c[4](torch.cat((x2, x3), 1))
-        return getattr(self, 'predict_flow%d' % lvl)(torch.cat((x3, x4), 1)), x4
+        return getattr(self, 'predict_flow%d' % lvl)(torch.cat((x3, x4), 1)).float(), x4
 
     def forward(self, feature_list_1, feature_list_2, img_hw):
         f1 = dict(zip(range(1, 7), feature_list_1))
@@ -65,7 +66,7 @@ class PWC_tf(nn.Module):
             flow = flow + up
             level_flow[lvl] = flow
         x = self.dc_conv4(self.dc_conv3(self.dc_conv2(self.dc_conv1(torch.cat([level_flow[2], x4], 1)))))
-        level_flow[2] = level_flow[2] + self.dc_conv7(self.dc_conv6(self.dc_conv5(x)))
+        level_flow[2] = level_flow[2] + self.dc_conv7(self.dc_conv6(self.dc_conv5(x))).float()
         img_h, img_w = img_hw[0], img_hw[1]
         return [F.interpolate(level_flow[lvl] * 4.0, [img_h // (1 << k), img_w // (1 << k)], mode='bilinear')
                 for k, lvl in enumerate((2, 3, 4, 5))]
