@@ -85,10 +85,12 @@ def test_corr_d8_full_pyramid(ops, C, h, w):
     close(f2.grad, f2c.grad, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize('B,C,h,w', [(16, 32, 64, 208), (8, 32, 112, 256), (5, 7, 100, 268), (12, 64, 32, 104)])
+@pytest.mark.parametrize('B,C,h,w', [(16, 32, 64, 208), (8, 32, 112, 256), (5, 7, 100, 268), (12, 64, 32, 104),
+                                     (2, 1, 256, 256), (2, 3, 260, 256), (3, 2, 40, 72), (1, 5, 12, 700)])
 def test_corr_large_map_paths(ops, B, C, h, w):
-    """Shapes that take the LDS-DMA ring kernel (level 2 of the 832x256 B=8 step and of 1024x448 B=4;
-    a ragged one with partial tiles, odd B and C) and the level-3 tile kernel, vs the oracle."""
+    """Shapes that take the LDS-DMA ring kernels (level 2 of the 832x256 B=8 step and of 1024x448 B=4;
+    ragged ones with partial tiles, odd B; fewer channels than ring stages, C not a multiple of the
+    stage size) and the mid-size group kernels, vs the oracle."""
     f1c, f2c = rnd(14, (B, C, h, w)).requires_grad_(), rnd(15, (B, C, h, w)).requires_grad_()
     cv_ref = R.corr_naive(f1c, f2c, 4)
     gout = rnd(16, tuple(cv_ref.shape))
