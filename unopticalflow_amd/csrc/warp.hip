@@ -107,29 +107,47 @@ __global__ void warp_bwd_kernel(const float* __restrict__ src, const float* __re
     const bool live = (x < W);
     const size_t plane = (size_t)H * W, pix = (size_t)y * W + (live ? x : 0);
     float gix = 0.f, giy = 0.f;
-    if (live) {
-        const float u = flow[((size_t)b * 2) * plane + pix];
-        const float v = flow[((size_t)b * 2 + 1) * plane + pix];
-        const Taps t = make_taps(u, v, x, y, H, W, ac);
-        const bool keep = !MASKED || (mask[(size_t)b * plane + pix] != 0);
-        if (keep) {
+    {
+        // dead lanes (x >= W) run the loop too, with keep == false: the in-wave shuffles below need every lane
+        const float u = live ? flow[((size_t)b * 2) * plane + pix] : 0.f;
+        const float v = live ? flow[((size_t)b * 2 + 1) * plane + pix] : 0.f;
+        const Taps t = make_taps(u, v, live ? x : 0, y, H, W, ac);
+        const bool keep = live && (!MASKED || (mask[(size_t)b * plane + pix] != 0));
+        // Scatter-add of the source gradient.  With a locally smooth flow, lane l's right-hand taps (ne, se) hit
+        // the same source pixels as lane l+1's left-hand taps (nw, sw): the pair is summed in-wave (one DPP
+        // shuffle per row) and issued as ONE atomic by lane l+1, which halves the float atomics -- the op runs
+        // at the chip-wide atomic rate (~1.3 TB/s of added bytes), not at HBM rate.
+        const int lane = threadIdx.x;                      // blockDim.x == 64: one wave per threadIdx.y
+        const int my_nw = (keep && t.v_nw) ? t.o_nw : -1, my_sw = (keep && t.v_sw) ? t.o_sw : -1;
+        const int my_ne = (keep && t.v_ne) ? t.o_ne : -2, my_se = (keep && t.v_se) ? t.o_se : -2;
+        const int left_ne = __shfl_up(my_ne, 1, 64), left_se = __shfl_up(my_se, 1, 64);
+        // take over the left neighbour's ne / se contribution when it targets my nw / sw pixel
+        const bool take_n = WITH_GSRC && lane > 0 && left_ne == my_nw && my_nw >= 0;
+        const bool take_s = WITH_GSRC && lane > 0 && left_se == my_sw && my_sw >= 0;
+        const bool give_n = __shfl_down((int)take_n, 1, 64) && lane < 63;   // my ne is handled by lane+1
+        const bool give_s = __shfl_down((int)take_s, 1, 64) && lane < 63;
+        {
             const float* sp = src + (size_t)b * C * plane;
             const float* gp = gout + (size_t)b * C * plane + pix;
             float* dp = WITH_GSRC ? gsrc + (size_t)b * C * plane : nullptr;
-#pragma unroll 2
+#pragma unroll 4
             for (int c = threadIdx.y; c < C; c += NY) {
                 const float* p = sp + (size_t)c * plane;
-                const float g = gp[(size_t)c * plane];
-                const float a = t.v_nw ? p[t.o_nw] : 0.f, bq = t.v_ne ? p[t.o_ne] : 0.f;
-                const float cq = t.v_sw ? p[t.o_sw] : 0.f, dq = t.v_se ? p[t.o_se] : 0.f;
-                gix += g * ((bq - a) * t.s + (dq - cq) * t.n);
-                giy += g * ((cq - a) * t.e + (dq - bq) * t.w);
+                const float g = keep ? gp[(size_t)c * plane] : 0.f;
+                if (keep) {
+                    const float a = t.v_nw ? p[t.o_nw] : 0.f, bq = t.v_ne ? p[t.o_ne] : 0.f;
+                    const float cq = t.v_sw ? p[t.o_sw] : 0.f, dq = t.v_se ? p[t.o_se] : 0.f;
+                    gix += g * ((bq - a) * t.s + (dq - cq) * t.n);
+                    giy += g * ((cq - a) * t.e + (dq - bq) * t.w);
+                }
                 if (WITH_GSRC) {
                     float* d = dp + (size_t)c * plane;
-                    if (t.v_nw) atomicAdd(d + t.o_nw, g * t.nw);
-                    if (t.v_ne) atomicAdd(d + t.o_ne, g * t.ne);
-                    if (t.v_sw) atomicAdd(d + t.o_sw, g * t.sw);
-                    if (t.v_se) atomicAdd(d + t.o_se, g * t.se);
+                    const float c_ne = g * t.ne, c_se = g * t.se;           // all lanes shuffle (no divergence here)
+                    const float from_n = __shfl_up(c_ne, 1, 64), from_s = __shfl_up(c_se, 1, 64);
+                    if (my_nw >= 0) atomicAdd(d + my_nw, g * t.nw + (take_n ? from_n : 0.f));
+                    if (my_sw >= 0) atomicAdd(d + my_sw, g * t.sw + (take_s ? from_s : 0.f));
+                    if (my_ne >= 0 && !give_n) atomicAdd(d + my_ne, c_ne);
+                    if (my_se >= 0 && !give_s) atomicAdd(d + my_se, c_se);
                 }
             }
         }

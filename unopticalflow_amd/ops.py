@@ -42,8 +42,15 @@ def _dev(*tensors):
     return dev
 
 
-def _call(name, *args):
+def _call(name, *args, nbytes=0, shape=None):
+    """Call one C entry point.  ``nbytes`` = algorithmic HBM bytes of the launch (include/unflow_hip.h,
+    DESIGN.md section 3); only used when bench.py's kernel survey is on."""
     lib = _lib.load()
+    if kernel_timer.survey:
+        ev0 = kernel_timer.start()
+        _lib.check(getattr(lib, name)(*args), name)
+        kernel_timer.stop_survey(name, shape, ev0, nbytes)
+        return
     _lib.check(getattr(lib, name)(*args), name)
 
 
@@ -56,6 +63,29 @@ class _KernelTimer:
         self.min_width = 0
         self.pairs = []
         self.bytes = 0
+        self.survey = False
+        self.table = {}
+
+    def start_survey(self):
+        self.survey, self.table = True, {}
+
+    def stop_survey(self, name, shape, ev0, nbytes):
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        self.table.setdefault((name, shape), []).append((ev0, ev1, nbytes))
+
+    def end_survey(self):
+        """-> list of dicts (entry point, shape, launches, mean us, algorithmic GB/s); call after a synchronize."""
+        self.survey = False
+        rows = []
+        for (name, shape), v in self.table.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in v)
+            nb = sum(n for _, _, n in v)
+            rows.append({'entry': name, 'shape': list(shape) if shape else None, 'launches': len(v),
+                         'avg_us': round(ms * 1e3 / len(v), 2),
+                         'algorithmic_GBps': round(nb / (ms * 1e-3) / 1e9, 1) if ms > 0 and nb else None})
+        rows.sort(key=lambda r: -r['avg_us'] * r['launches'])
+        return rows
 
     def enable(self, name, min_width=0):
         self.name, self.min_width, self.pairs, self.bytes = name, min_width, [], 0
@@ -104,7 +134,8 @@ class _Corr(torch.autograd.Function):
         with torch.cuda.device(f1.device):
             timed = kernel_timer.wants('unflow_corr_fwd', W)
             ev = kernel_timer.start() if timed else None
-            _call('unflow_corr_fwd', _ptr(f1), _ptr(f2), _ptr(cv), B, C, H, W, d, _stream())
+            _call('unflow_corr_fwd', _ptr(f1), _ptr(f2), _ptr(cv), B, C, H, W, d, _stream(),
+                  nbytes=4 * B * H * W * (2 * C + (2 * d + 1) ** 2), shape=(B, C, H, W))
             if timed:                     # algorithmic bytes: read f1, f2 once, write cv once
                 kernel_timer.stop(ev, 4 * B * H * W * (2 * C + (2 * d + 1) ** 2))
         ctx.save_for_backward(f1, f2)
@@ -119,7 +150,7 @@ class _Corr(torch.autograd.Function):
         gf1, gf2 = torch.empty_like(f1), torch.empty_like(f2)
         with torch.cuda.device(f1.device):
             _call('unflow_corr_bwd', _ptr(f1), _ptr(f2), _ptr(g), _ptr(gf1), _ptr(gf2), B, C, H, W, ctx.d,
-                  _stream())
+                  _stream(), nbytes=4 * B * H * W * (4 * C + (2 * ctx.d + 1) ** 2), shape=(B, C, H, W))
         return gf1, gf2, None
 
 
@@ -142,7 +173,8 @@ class _Warp(torch.autograd.Function):
         mask = torch.empty((B, 1, H, W), dtype=torch.uint8, device=x.device) if use_mask else None
         with torch.cuda.device(x.device):
             _call('unflow_warp_fwd', _ptr(x), _ptr(flow), _ptr(out), _ptr(mask), B, C, H, W,
-                  int(align_corners), _stream())
+                  int(align_corners), _stream(), nbytes=B * H * W * (8 * C + 8 + (1 if use_mask else 0)),
+                  shape=(B, C, H, W))
         ctx.save_for_backward(x, flow, mask)
         ctx.ac = int(align_corners)
         if use_mask:
@@ -159,7 +191,8 @@ class _Warp(torch.autograd.Function):
         gflow = torch.empty_like(flow)
         with torch.cuda.device(x.device):
             _call('unflow_warp_bwd', _ptr(x), _ptr(flow), _ptr(g), _ptr(mask), _ptr(gsrc), _ptr(gflow),
-                  B, C, H, W, ctx.ac, _stream())
+                  B, C, H, W, ctx.ac, _stream(),
+                  nbytes=4 * B * H * W * ((3 * C + 4) if gsrc is not None else (2 * C + 4)), shape=(B, C, H, W))
         return gsrc, (gflow if ctx.needs_input_grad[1] else None), None, None
 
 
@@ -198,7 +231,8 @@ class _OccWeight(torch.autograd.Function):
         diff_l, diff_r, w_bwd, w_fwd, v_bwd, v_fwd = f(), f(), f(), f(), u(), u()
         with torch.cuda.device(dev):
             _call('unflow_occ_weight_fwd', _ptr(img), _ptr(from_l), _ptr(from_r), _ptr(diff_l), _ptr(diff_r),
-                  _ptr(w_bwd), _ptr(w_fwd), _ptr(v_bwd), _ptr(v_fwd), B, H, W, _stream())
+                  _ptr(w_bwd), _ptr(w_fwd), _ptr(v_bwd), _ptr(v_fwd), B, H, W, _stream(),
+                  nbytes=B * H * W * (4 * 13 + 2), shape=(B, 3, H, W))
         ctx.save_for_backward(img, from_l, from_r)
         ctx.mark_non_differentiable(w_bwd, w_fwd, v_bwd, v_fwd)     # weight is .data (:122)
         return diff_l, diff_r, w_bwd, w_fwd, v_bwd, v_fwd
@@ -269,7 +303,7 @@ class _SsimLoss(torch.autograd.Function):
         sums = torch.empty((B, 2), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _call('unflow_ssim_loss_fwd', _ptr(img), _ptr(warped), _ptr(w), _ptr(loss), _ptr(sums),
-                  _ptr(_partials(B, H, W, dev)), B, H, W, _stream())
+                  _ptr(_partials(B, H, W, dev)), B, H, W, _stream(), nbytes=4 * B * H * W * 7, shape=(B, 3, H, W))
         ctx.save_for_backward(img, warped, w, sums)
         return loss
 
@@ -280,7 +314,7 @@ class _SsimLoss(torch.autograd.Function):
         gw = torch.empty_like(warped)
         with torch.cuda.device(img.device):
             _call('unflow_ssim_loss_bwd', _ptr(img), _ptr(warped), _ptr(w), _ptr(sums), _ptr(gl.contiguous()),
-                  _ptr(gw), B, H, W, _stream())
+                  _ptr(gw), B, H, W, _stream(), nbytes=4 * B * H * W * 10, shape=(B, 3, H, W))
         return None, gw, None
 
 
@@ -375,7 +409,8 @@ class _BiasLeaky(torch.autograd.Function):
             raise RuntimeError('bias_leaky_relu_ works in place on a contiguous NCHW convolution output')
         N, C, H, W = y.shape
         with torch.cuda.device(y.device):
-            _call('unflow_bias_leaky_fwd', _ptr(y), _ptr(bias), N, C, H, W, ctypes.c_float(slope), _stream())
+            _call('unflow_bias_leaky_fwd', _ptr(y), _ptr(bias), N, C, H, W, ctypes.c_float(slope), _stream(),
+                  nbytes=8 * N * C * H * W, shape=(N, C, H, W))
         ctx.mark_dirty(y)
         ctx.save_for_backward(y)
         ctx.slope = slope
@@ -392,7 +427,7 @@ class _BiasLeaky(torch.autograd.Function):
         part = torch.empty(npart, dtype=torch.float32, device=y.device)
         with torch.cuda.device(y.device):
             _call('unflow_bias_leaky_bwd', _ptr(y), _ptr(g), _ptr(gin), _ptr(gbias), _ptr(part), N, C, H, W,
-                  ctypes.c_float(ctx.slope), _stream())
+                  ctypes.c_float(ctx.slope), _stream(), nbytes=12 * N * C * H * W, shape=(N, C, H, W))
         return gin, gbias, None
 
 
@@ -413,5 +448,6 @@ def img_pyramid(img):
     half = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=dev)
     quarter = torch.empty((N, C, H // 4, W // 4), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _call('unflow_img_pyramid', _ptr(img), _ptr(half), _ptr(quarter), N * C, H, W, _stream())
+        _call('unflow_img_pyramid', _ptr(img), _ptr(half), _ptr(quarter), N * C, H, W, _stream(),
+              nbytes=N * C * H * W * 4 * 21 // 16, shape=(N, C, H, W))
     return half, quarter
