@@ -71,3 +71,24 @@ def test_get_model_unknown_mode():
     from unopticalflow_amd import get_model
     with pytest.raises(ValueError):
         get_model('depth')
+
+
+def test_dma_ring_kernels_do_not_spill():
+    """The LDS-DMA ring kernels wait with counted s_waitcnt vmcnt(N); scratch (spill) traffic shares that
+    counter, so a spilling build would under-wait.  Guard: those kernels must compile without scratch."""
+    import subprocess
+    from unopticalflow_amd import build as b
+    src = os.path.join(b.CSRC, 'corr.hip')
+    flags = [f for f in b.FLAGS if f not in ('-shared', '-fPIC')]
+    out = subprocess.run([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), *flags, '--cuda-device-only', '-c', src,
+                          '-o', os.devnull, '-Rpass-analysis=kernel-resource-usage'],
+                         capture_output=True, text=True).stderr
+    names = re.findall(r'Function Name: (\S+)', out)
+    scratch = [int(x) for x in re.findall(r'ScratchSize \[bytes/lane\]: (\d+)', out)]
+    assert len(names) == len(scratch) and names
+    checked = 0
+    for n, s in zip(names, scratch):
+        if 'ring_kernel' in n or 'gs_kernel' in n:
+            assert s == 0, (n, s)
+            checked += 1
+    assert checked >= 4
