@@ -92,3 +92,18 @@ def test_dma_ring_kernels_do_not_spill():
             assert s == 0, (n, s)
             checked += 1
     assert checked >= 4
+
+
+def test_c_program_links_against_the_abi(tmp_path):
+    """tools/capi_bench.cpp uses include/unflow_hip.h from plain C++ (no torch, no Python): it must compile and
+    link against the in-tree library (it is only run on the GPU box)."""
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build()
+    exe = str(tmp_path / 'capi_bench')
+    r = subprocess.run([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '-O1', '--offload-arch=gfx950',
+                        os.path.join(ROOT, 'tools', 'capi_bench.cpp'), '-I' + os.path.join(ROOT, 'include'),
+                        '-L' + os.path.join(ROOT, 'unopticalflow_amd'), '-lunflow_hip',
+                        '-Wl,-rpath,' + os.path.join(ROOT, 'unopticalflow_amd'), '-o', exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert os.path.exists(exe)
