@@ -40,6 +40,8 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=B_PER_GPU, help='triplets per GPU (8 = BASELINE config)')
+    ap.add_argument('--hw', type=int, nargs=2, default=[H, W], metavar=('H', 'W'),
+                    help='frame size (default 256 832 = the BASELINE metric; 448 1024 = config 4, not in the shipped find-db)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=2, help='triplets in the CPU-baseline sample step')
     ap.add_argument('--no-kernel-timing', action='store_true')
@@ -113,7 +115,8 @@ def main():
         args.no_kernel_timing = True
     gen = torch.Generator(device=dev)
     gen.manual_seed(rank)                         # distinct synthetic data per rank
-    inputs = torch.rand((args.batch, 3, 3 * H, W), generator=gen, device=dev, dtype=torch.float32)
+    fh, fw = args.hw
+    inputs = torch.rand((args.batch, 3, 3 * fh, fw), generator=gen, device=dev, dtype=torch.float32)
 
     def barrier():
         if world > 1:
@@ -174,12 +177,13 @@ def main():
             base = cpu_baseline(args.cpu_sample)
         pairs = 2 * args.batch * world * args.steps
         out = {
-            'metric': 'frame-pairs/s (train step) at 832x256 bs=8',
+            'metric': 'frame-pairs/s (train step) at %dx%d bs=%d' % (fw, fh, args.batch),
             'value': round(pairs / dt, 2), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'bf16', 'data': 'synthetic',
-            'config': {'workload': 'KITTI 832x256 triplets, bs=%d per GPU, %s, corr d=4 + warp + occlusion losses, '
-                                   'fwd+bwd+Adam (BASELINE configs[%d])' % (args.batch, args.precision, 1 if args.precision == 'fp32' else 2),
+            'config': {'workload': '%dx%d triplets, bs=%d per GPU, %s, corr d=4 + warp + occlusion losses, '
+                                   'fwd+bwd+Adam (BASELINE configs[%d])' % (fw, fh, args.batch, args.precision,
+                                                                            (1 if args.precision == 'fp32' else 2) if (fh, fw) == (H, W) else 3),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                        'triplets_per_s': round(pairs / 2 / dt, 2)},
             'roofline': roof, 'cpu_baseline': base, 'kernel_survey': survey,
