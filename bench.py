@@ -43,7 +43,7 @@ def parse():
     ap.add_argument('--hw', type=int, nargs=2, default=[H, W], metavar=('H', 'W'),
                     help='frame size (default 256 832 = the BASELINE metric; 448 1024 = config 4, not in the shipped find-db)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=2, help='triplets in the CPU-baseline sample step')
+    ap.add_argument('--cpu-sample', type=int, default=8, help='triplets in the CPU-baseline sample step (8 = the bench batch)')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'], help='conv-stack precision (bf16: BASELINE config 3; the headline metric is fp32)')
     ap.add_argument('--graph', type=int, default=0, help='1: replay the step as a hipGraph (kernel timing events are then off)')
@@ -80,10 +80,18 @@ def cpu_baseline(sample_b):
     for _ in range(n):
         R.train_step(model, opt, x, weights)
     dt = time.perf_counter() - t0
+    cpu = 'unknown CPU'
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                cpu = ln.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {'value': round(2 * sample_b * n / dt, 4), 'unit': 'pairs/s', 'cores': torch.get_num_threads(),
             'kind': 'port',
-            'sample': '%d timed train steps (+1 untimed) of %d synthetic 832x256 triplets, fp32, torch CPU oracle'
-                      % (n, sample_b)}
+            'sample': '%d timed train steps (+1 untimed) of %d synthetic 832x256 triplets (%.1f s), fp32, torch CPU '
+                      'oracle on %s' % (n, sample_b, dt, cpu)}
 
 
 def main():
