@@ -339,3 +339,40 @@ def test_img_pyramid_vs_oracle(ops, shape):
     half, quarter = ops.img_pyramid(x.cuda())
     close(half, ref[1], rtol=0, atol=2e-7)
     close(quarter, ref[2], rtol=0, atol=3e-7)
+
+
+# ------------------------------------------------------------------------------------ randomised shapes
+def test_fuzz_shapes_against_oracle(ops):
+    """30 random (B, C, H, W, d) draws: every kernel-selection branch (tile / ring / group / generic paths,
+    W % 4 != 0, W < 64, C < ring stage) must agree with the oracle, forward and backward."""
+    rng = np.random.default_rng(2024)
+    for trial in range(30):
+        B = int(rng.integers(1, 5))
+        C = int(rng.choice([1, 2, 3, 5, 8, 17, 32, 40]))
+        H = int(rng.choice([3, 8, 9, 16, 31, 64, 100]))
+        W = int(rng.choice([4, 13, 52, 64, 97, 104, 208, 260]))
+        d = int(rng.choice([1, 2, 4, 4, 4, 8]))
+        if B * C * H * W * (2 * d + 1) ** 2 > 6e7:
+            continue
+        f1c = rnd(1000 + trial, (B, C, H, W)).requires_grad_()
+        f2c = rnd(2000 + trial, (B, C, H, W)).requires_grad_()
+        cv_ref = R.corr_naive(f1c, f2c, d)
+        gout = rnd(3000 + trial, tuple(cv_ref.shape))
+        cv_ref.backward(gout)
+        f1, f2 = dev(f1c.detach()).requires_grad_(), dev(f2c.detach()).requires_grad_()
+        cv = ops.corr(f1, f2, d)
+        what = 'corr B%d C%d H%d W%d d%d' % (B, C, H, W, d)
+        close(cv, cv_ref, rtol=1e-5, atol=2e-6, what=what)
+        cv.backward(dev(gout))
+        close(f1.grad, f1c.grad, rtol=1e-4, atol=1e-5, what=what)
+        close(f2.grad, f2c.grad, rtol=1e-4, atol=1e-5, what=what)
+        # warp (+mask) on the same geometry
+        ac = bool(trial & 1)
+        Cw = min(C, 8)
+        xw = rnd(4000 + trial, (B, Cw, H, W), uniform=True)
+        fl = rnd(5000 + trial, (B, 2, H, W), float(rng.choice([0.5, 3.0, 12.0])))
+        y_ref = R.warp_flow(xw, fl, True, ac)
+        m_ref = R.warp_mask(xw.shape, fl, ac).numpy()
+        y, m = ops.warp_flow_masked(xw.cuda(), fl.cuda(), align_corners=ac)
+        assert np.array_equal(m.cpu().numpy(), m_ref), 'mask ' + what
+        close(y, y_ref, rtol=1e-5, atol=1e-6, what='warp ' + what)
