@@ -11,7 +11,7 @@ import collections
 import csv
 import sys
 
-MARK = 'corr_fwd_ring_kernel'
+MARK = 'corr_fwd_ring_kernel<4, 2, 9>'     # launched exactly once per step (level 2)
 
 
 def main():
