@@ -116,8 +116,6 @@ def main():
         from unopticalflow_amd.tuning import enable_miopen_tuning
         enable_miopen_tuning()                    # shipped find-db for exactly these conv shapes (tuning.py)
     model = get_model('flow')(cfg).to(dev)
-    if os.environ.get('UNFLOW_CHANNELS_LAST', '0') == '1':
-        model = model.to(memory_format=torch.channels_last)
     trainer = FlowTrainer(cfg, model, distributed=(world > 1), use_graph=bool(args.graph))
     if args.graph:
         args.no_kernel_timing = True
@@ -172,12 +170,13 @@ def main():
             if nl:
                 traffic = None        # HBM bytes/launch from the PMC passes (profiles/, collected separately)
                 pmc = os.path.join(ROOT, 'profiles', 'r1_corr_fwd_ring_pmc.json')
-                if os.path.exists(pmc):
+                if os.path.exists(pmc) and (fh, fw, args.batch) == (H, W, B_PER_GPU):
                     traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
                 gbs = nbytes / (ms * 1e-3) / 1e9
                 roof = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                        'kernel': 'corr_fwd_ring_kernel<R=4,CC=2> (cost volume fwd, level 2, [2B=16,32,64,208])',
+                        'kernel': 'corr_fwd_ring_kernel<4,2,9> (cost volume forward, pyramid level 2, [2B=%d,32,%d,%d])'
+                                  % (2 * args.batch, fh // 4, fw // 4),
                         'launches': nl, 'avg_us': round(ms * 1e3 / nl, 2),
                         'algorithmic_bytes_per_launch': int(nbytes / nl)}
         base = None
