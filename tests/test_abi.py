@@ -91,7 +91,7 @@ def test_dma_ring_kernels_do_not_spill():
         if 'ring_kernel' in n or 'gs_kernel' in n:
             assert s == 0, (n, s)
             checked += 1
-    assert checked >= 4
+    assert checked >= 3      # ring<9 rows>, ring<3 rows>, group-split backward
 
 
 def test_c_program_links_against_the_abi(tmp_path):

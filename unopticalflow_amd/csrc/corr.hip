@@ -5,13 +5,18 @@
 //
 //   cv[b, i*DD+j, y, x] = (1/C) sum_c f1[b,c,y,x] * f2[b,c,y+i-R,x+j-R]     DD = 2R+1
 //
-// Layout: NCHW fp32, x contiguous.  A 256-thread workgroup owns a TW x 8 pixel tile of one
-// sample; the f2 halo tile of CC channels is staged in LDS with coalesced row reads, f1 goes
-// straight to registers (no reuse across lanes), every lane keeps PX pixels x DG x DD
-// displacement accumulators in VGPRs and walks the LDS rows (ds_read_b64 when PX == 2).
+// Layout: NCHW fp32, x contiguous.  Kernel families (chosen per shape by pick_variant(), measured):
+//   * tile kernels  corr_fwd_kernel / corr_bwd_kernel<R,PX,DG,CC>: a 256-thread workgroup owns a
+//     (32*PX) x 8 pixel tile; CC channels of the f2 halo tile (and of f1) are staged in LDS through
+//     registers; a lane keeps PX pixels x DG x DD accumulators (forward) or upstream-gradient values
+//     (backward) in VGPRs and walks the LDS rows.  Any W; radii 1, 2, 4, 8.
+//   * ring kernels  corr_fwd_ring_kernel<R,CC,DG>, corr_bwd_gs_kernel<R,CC>: same arithmetic, but the
+//     channels stream through an LDS ring filled by global_load_lds_dwordx4 (LDS-DMA) several stages
+//     ahead, with hand-counted s_waitcnt vmcnt / lgkmcnt and an XCD-aware tile order.  W % 4 == 0.
+//   * generic kernels: one lane per output element (tiny maps with many channels; any radius).
 // The backward is the same gather twice: gf1 = sum_ij g[ij] * f2(shifted), and
-// gf2 = sum_ij g[ij](shifted back) * f1(shifted back), written as a gather -- no atomics
-// (except when the displacement rows are split over workgroups, R > 4).
+// gf2 = sum_ij g[ij](shifted back) * f1(shifted back), written as a gather -- no float atomics
+// (except in the tile kernel when the displacement rows are split over workgroups, R > 4).
 #include "common.h"
 #include <stdlib.h>
 
@@ -290,147 +295,10 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_kernel(const float* __restric
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Large-map forward: 4 pixels per lane, displacement rows in NG passes, LDS-DMA double buffer.
-//
-// The level-2/3 maps of a 832x256 batch fit on the chip in a single round of workgroups, so
-// load / compute / store phases of all workgroups line up unless a workgroup overlaps them
-// itself.  Here a 256-thread workgroup owns a 64x16 pixel tile and walks the DD displacement
-// rows in NG passes of DG rows: a pass keeps DG*DD*4 accumulators per lane (108 for d=4), streams
-// the channels through a 2-deep LDS ring filled by global_load_lds_dwordx4 (no staging
-// registers; out-of-image slots read a zero line), and its 27 output planes are stored with
-// dwordx4 while the next pass is already computing.  Lanes read their 4+2R f2 floats as three
-// aligned ds_read_b128 (16 lanes = one 256-byte row: conflict-free) for 36 FMAs: VALU-bound,
-// not LDS-bound.  Re-staging f2 per pass comes from L2 / Infinity Cache, not HBM.
-// Requires W % 4 == 0 (16-byte rows).
-// ---------------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(16))) float kZeroLine[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) float kZeroLine[4] = {0.f, 0.f, 0.f, 0.f};    // source of out-of-image DMA slots
 
 typedef __attribute__((address_space(1))) const void* gas_ptr;
 typedef __attribute__((address_space(3))) void* lds_ptr;
-
-template <int R, int DG, int CC>
-struct Px4Cfg {
-    static constexpr int DD = 2 * R + 1;
-    static constexpr int NG = (DD + DG - 1) / DG;
-    static constexpr int TW = 64, TYB = 16;
-    static constexpr int LW = TW + 2 * R;              // floats; 2R % 4 == 0 required
-    static constexpr int LH = TYB + DG - 1;
-    static constexpr int S2 = LH * LW / 4;             // float4 slots of the f2 halo tile
-    static constexpr int S1 = TYB * TW / 4;            // float4 slots of the f1 tile
-    static constexpr int SC = S2 + S1;                 // per channel
-    static constexpr int SLOTS = ((CC * SC + 255) / 256) * 256;   // per ring stage, whole wave-instructions
-    static constexpr int ITER = SLOTS / 256;
-};
-
-template <int R, int DG, int CC>
-__device__ __forceinline__ void px4_stage(float* stage, const float* __restrict__ f1,
-                                          const float* __restrict__ f2, int b, int C, int H, int W,
-                                          int c0, int y0, int x0, int i0) {
-    using K = Px4Cfg<R, DG, CC>;
-    const int wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int it = 0; it < K::ITER; ++it) {
-        const int s = it * 256 + threadIdx.x;
-        const int c = s / K::SC;
-        int r = s - c * K::SC;
-        const float* src;
-        int gy, gx;
-        if (r < K::S2) {
-            const int ly = r / (K::LW / 4);
-            gy = y0 - R + i0 + ly;
-            gx = x0 - R + (r - ly * (K::LW / 4)) * 4;
-            src = f2;
-        } else {
-            r -= K::S2;
-            const int ly = r / (K::TW / 4);
-            gy = y0 + ly;
-            gx = x0 + (r - ly * (K::TW / 4)) * 4;
-            src = f1;
-        }
-        const int gc = c0 + c;
-        const bool in = (c < CC) && (gc < C) && (gy >= 0) && (gy < H) && (gx >= 0) && (gx < W);
-        const float* g = in ? src + ((size_t)(b * C + gc) * H + gy) * W + gx : kZeroLine;
-        // wave-uniform LDS base; lane l lands at base + 16*l
-        __builtin_amdgcn_global_load_lds((gas_ptr)g, (lds_ptr)(stage + (it * 256 + wave * 64) * 4), 16, 0, 0);
-    }
-}
-
-template <int R, int DG, int CC>
-__global__ __launch_bounds__(256, 2) void corr_fwd_px4_kernel(const float* __restrict__ f1,
-                                                              const float* __restrict__ f2,
-                                                              float* __restrict__ cv, int C, int H, int W,
-                                                              float inv_c) {
-    using K = Px4Cfg<R, DG, CC>;
-    constexpr int DD = K::DD, LW = K::LW, NG = K::NG;
-    __shared__ __attribute__((aligned(16))) float ring[2][K::SLOTS * 4];
-
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int b = blockIdx.z;
-    const int x0 = blockIdx.x * K::TW, y0 = blockIdx.y * K::TYB;
-    const int px = x0 + tx * 4, py = y0 + ty;
-    const int nchunk = (C + CC - 1) / CC;
-    const size_t plane = (size_t)H * W;
-
-    for (int g = 0; g < NG; ++g) {
-        const int i0 = g * DG;
-        float acc[DG][DD][4];
-#pragma unroll
-        for (int i = 0; i < DG; ++i)
-#pragma unroll
-            for (int j = 0; j < DD; ++j)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) acc[i][j][p] = 0.f;
-
-        px4_stage<R, DG, CC>(ring[0], f1, f2, b, C, H, W, 0, y0, x0, i0);
-        __syncthreads();                                   // drains the DMA (vmcnt(0)) + barrier
-        for (int k = 0; k < nchunk; ++k) {
-            if (k + 1 < nchunk) px4_stage<R, DG, CC>(ring[(k + 1) & 1], f1, f2, b, C, H, W, (k + 1) * CC, y0, x0, i0);
-            const float* st = ring[k & 1];
-#pragma unroll
-            for (int c = 0; c < CC; ++c) {
-                const float* t2 = st + c * K::SC * 4;
-                const float4 a4 = *reinterpret_cast<const float4*>(t2 + K::S2 * 4 + ty * K::TW + tx * 4);
-                const float a[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                for (int i = 0; i < DG; ++i) {
-                    const float4* rp = reinterpret_cast<const float4*>(t2 + (ty + i) * LW + tx * 4);
-                    float row[4 + 2 * R];
-#pragma unroll
-                    for (int q = 0; q < (4 + 2 * R) / 4; ++q) {
-                        const float4 v = rp[q];
-                        row[4 * q] = v.x; row[4 * q + 1] = v.y; row[4 * q + 2] = v.z; row[4 * q + 3] = v.w;
-                    }
-#pragma unroll
-                    for (int j = 0; j < DD; ++j)
-#pragma unroll
-                        for (int p = 0; p < 4; ++p) acc[i][j][p] = fmaf(a[p], row[j + p], acc[i][j][p]);
-                    __builtin_amdgcn_sched_barrier(0);      // keep one row of reads in flight, not all
-                }
-            }
-            __syncthreads();
-        }
-        if (py < H && px < W) {
-            float* out = cv + ((size_t)b * DD * DD) * plane + (size_t)py * W + px;
-#pragma unroll
-            for (int i = 0; i < DG; ++i) {
-                if (i0 + i >= DD) break;
-#pragma unroll
-                for (int j = 0; j < DD; ++j)
-                    *reinterpret_cast<float4*>(out + (size_t)((i0 + i) * DD + j) * plane) =
-                        make_float4(acc[i][j][0] * inv_c, acc[i][j][1] * inv_c, acc[i][j][2] * inv_c, acc[i][j][3] * inv_c);
-            }
-        }
-    }
-}
-
-template <int R, int DG, int CC>
-int launch_fwd_px4(const float* f1, const float* f2, float* cv, int B, int C, int H, int W, hipStream_t s) {
-    using K = Px4Cfg<R, DG, CC>;
-    dim3 grid(ceil_div(W, K::TW), ceil_div(H, K::TYB), B);
-    hipLaunchKernelGGL((corr_fwd_px4_kernel<R, DG, CC>), grid, dim3(256), 0, s, f1, f2, cv, C, H, W, 1.0f / C);
-    return unflow_launch_status();
-}
 
 // Hand-issued LDS reads with hand-counted waits.  hipcc tracks its own ds_reads with lgkmcnt(0)
 // whenever a register buffer is re-used, which exposes the full LDS latency every few rows at two
@@ -946,13 +814,12 @@ int launch_bwd(const float* f1, const float* f2, const float* g, float* gf1, flo
 
 }  // namespace
 
-// Tuning knob (diagnostic): UNFLOW_CORR_VARIANT=1..9 forces a d=4 forward code path
+// Tuning knob (diagnostic): UNFLOW_CORR_VARIANT forces a d=4 forward code path
 //   1: 64x8 tiles, 2 px/lane, all 81 displacements per lane, register-staged LDS tiles
 //   2: 32x8 tiles, 1 px/lane, all 81 displacements per lane
 //   3: 32x8 tiles, 1 px/lane, displacement rows split over 3 workgroups
 //   4: one lane per output element, direct (cached) global reads    (tiny maps, many channels)
-//   5, 6: 4 px/lane, displacement passes, 2-deep LDS-DMA ring (experimental)
-//   7, 8, 9: LDS-DMA ring kernel with 9 / 5 / 3 displacement rows per workgroup
+//   7, 9: LDS-DMA ring kernel with 9 / 3 displacement rows per workgroup
 static int forced_variant() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("UNFLOW_CORR_VARIANT"); v = e ? atoi(e) : 0; }
@@ -992,11 +859,7 @@ extern "C" int unflow_corr_fwd(const float* f1, const float* f2, float* cv, int 
                 if (variant == 1) return launch_fwd<4, 2, 9, 8>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 2) return launch_fwd<4, 1, 9, 8>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 3) return launch_fwd<4, 1, 3, 8>(f1, f2, cv, B, C, H, W, s);
-                if (variant == 5 && (W & 3) == 0) return launch_fwd_px4<4, 3, 2>(f1, f2, cv, B, C, H, W, s);
-                if (variant == 6 && (W & 3) == 0) return launch_fwd_px4<4, 3, 4>(f1, f2, cv, B, C, H, W, s);
-                if (variant == 5 || variant == 6) return launch_fwd<4, 2, 9, 8>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 7 && (W & 3) == 0) return launch_fwd_ring<4, 2, 9>(f1, f2, cv, B, C, H, W, s);
-                if (variant == 8 && (W & 3) == 0) return launch_fwd_ring<4, 2, 5>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 9 && (W & 3) == 0) return launch_fwd_ring<4, 2, 3>(f1, f2, cv, B, C, H, W, s);
                 if (variant >= 7) return launch_fwd<4, 2, 9, 8>(f1, f2, cv, B, C, H, W, s);
                 break;
@@ -1021,7 +884,7 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 // group-split ring kernel: measured best for mid-size maps (levels 3, 4); level 2 stays on the tile kernel
                 if ((W & 3) == 0 && (forced_bwd() == 1 || (forced_bwd() == 0 && variant == 9)))
                     return launch_bwd_gs<4, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                if (variant == 1 || variant == 7 || variant == 8) return launch_bwd<4, 2, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                if (variant == 1 || variant == 7) return launch_bwd<4, 2, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (variant == 2 || variant == 3 || (variant == 9 && (long)B * H * W >= 32768))
                     return launch_bwd<4, 1, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 break;
