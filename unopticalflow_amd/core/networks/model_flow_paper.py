@@ -146,8 +146,9 @@ class Model_flow(nn.Module):
             frames = torch.cat((imgl, img, imgr), 0)
         with self._autocast():
             feats = self.fpyramid(frames)                                    # [3B, ...] per level
-            feat_c2 = [torch.cat((f[B:2 * B], f[B:2 * B]), 0) for f in feats]
-            feat_lr = [torch.cat((f[:B], f[2 * B:]), 0) for f in feats]
+            # the decoder never reads pyramid level 1 (pwc_tf.py:108-179 uses c12..c16 / c22..c26): no copy for it
+            feat_c2 = [None] + [torch.cat((f[B:2 * B], f[B:2 * B]), 0) for f in feats[1:]]
+            feat_lr = [None] + [torch.cat((f[:B], f[2 * B:]), 0) for f in feats[1:]]
             flows = self.pwc_model(feat_c2, feat_lr, [img_h, img_w])         # [2B, 2, h, w] per scale
         flows = [f.float() for f in flows]
         return [f[:B] for f in flows], [f[B:] for f in flows]            # bwd (centre->left), fwd
