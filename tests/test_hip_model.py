@@ -85,7 +85,7 @@ def test_module_128_golden(golden, ac):
         np.testing.assert_allclose(loss.item(), g['loss_step%d%s' % (it, tag)], rtol=1e-4 if it == 0 else 2e-3)
         if it in (0, 2):
             pa = np.array([p.detach().double().abs().sum().item() for p in model.parameters()])
-            np.testing.assert_allclose(pa, g['param_abs_step%d%s' % (it + 1, tag)], rtol=2e-4)
+            np.testing.assert_allclose(pa, g['param_abs_step%d%s' % (it + 1, tag)], rtol=5e-4)   # |Adam update| <= lr per element
 
 
 def test_kitti_256x832_golden(golden):
