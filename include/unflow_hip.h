@@ -127,6 +127,17 @@ int unflow_bias_leaky_bwd(const float* y, const float* gout, float* gin, float* 
 int unflow_img_pyramid(const float* img, float* half, float* quarter, int planes, int H, int W,
                        void* stream);
 
+/* ---- input stage: KITTI_Prepared.__getitem__ after the PNG decode, core/dataset/kitti_prepared.py:63-90,145-148 ----
+ * src: B decoded stacked triplets, uint8, 3 interleaved channels, back to back in one device buffer;
+ * offsets[b]: first byte of image b; dims[2b], dims[2b+1]: its rows (three frames of int(rows/3) rows)
+ * and columns; flip[b] != 0: horizontal flip (cv2.flip(img, 1)), NULL = none.  dst [B,3,3H,W] fp32 =
+ * each frame resized to HxW with OpenCV's 8-bit INTER_LINEAR fixed-point arithmetic, / 255.0.
+ * swap_rb != 0 writes source channel c to plane 2-c (RGB-decoded PNG -> the BGR planes cv2.imread gives).
+ * W multiple of 4.  offsets, dims, flip are device pointers. */
+int unflow_prepare_triplets(const uint8_t* src, const long long* offsets, const int* dims,
+                            const uint8_t* flip, float* dst, int B, int H, int W, int swap_rb,
+                            void* stream);
+
 /* ---- host helper of the evaluation path (KITTI 16-bit flow PNGs, core/evaluation/flowlib.py:107-127) ----
  * rows: height x (1 + stride) host bytes (filter byte + filtered scanline per row), decoded in place.
  * Runs on the CPU; no GPU work. */

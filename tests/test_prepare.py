@@ -1,0 +1,107 @@
+"""Input stage: decoded stacked triplet -> [3,3H,W] float, kitti_prepared.py:63-90,145-148.
+
+cv2 is not installed here (parity of the resize is unpinned, see oracle/prepare_cpu.py); the CPU tests
+check the restatement's structural properties, the GPU tests check the HIP kernel bit-for-bit against it.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.prepare_cpu import cv2_resize_linear_u8, prepare_triplet
+
+KITTI_SIZES = [(375, 1242), (370, 1224), (374, 1238), (376, 1241)]
+
+
+def _float_bilinear(img, W, H):
+    t = torch.from_numpy(img.astype(np.float64)).permute(2, 0, 1)[None]
+    return F.interpolate(t, size=(H, W), mode='bilinear', align_corners=False)[0].permute(1, 2, 0).numpy()
+
+
+@pytest.mark.parametrize('h,w,H,W', [(375, 1242, 256, 832), (436, 1024, 448, 1024), (90, 300, 256, 832), (31, 57, 64, 64)])
+def test_resize_within_one_grey_level_of_float_bilinear(h, w, H, W):
+    img = np.random.default_rng(h + w).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    out = cv2_resize_linear_u8(img, W, H)
+    assert out.shape == (H, W, 3) and out.dtype == np.uint8
+    assert np.abs(out.astype(np.float64) - _float_bilinear(img, W, H)).max() < 1.0
+
+
+def test_resize_identities():
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (128, 192, 3), dtype=np.uint8)
+    assert (cv2_resize_linear_u8(img, 192, 128) == img).all()                       # same size: copy
+    a = img.astype(np.int64)
+    box = (a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2   # OpenCV's 2x fast-area path
+    assert (cv2_resize_linear_u8(img, 96, 64) == box).all()
+    flat = np.full((50, 70, 3), 201, np.uint8)                                       # constants survive the fixed point
+    assert (cv2_resize_linear_u8(flat, 832, 256) == 201).all()
+
+
+def test_prepare_triplet_layout_and_flip():
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (3 * 100 + 2, 160, 3), dtype=np.uint8)                # 2 leftover rows are ignored
+    out = prepare_triplet(img, (64, 128), False)
+    assert out.shape == (3, 192, 128) and out.dtype == np.float32
+    for k in range(3):
+        frame = cv2_resize_linear_u8(img[k * 100:(k + 1) * 100], 128, 64)
+        np.testing.assert_array_equal(out[:, k * 64:(k + 1) * 64], (frame / 255.0).transpose(2, 0, 1).astype(np.float32))
+    np.testing.assert_array_equal(prepare_triplet(img, (64, 128), True), out[:, :, ::-1])
+
+
+# ----------------------------------------------------------------------------------------------------------
+gpu = pytest.mark.gpu
+
+
+@gpu
+@pytest.mark.parametrize('img_hw', [(256, 832), (64, 128)])
+def test_prepare_triplets_kernel_bit_exact(img_hw):
+    from unopticalflow_amd import ops
+    rng = np.random.default_rng(11)
+    sizes = KITTI_SIZES + [(img_hw[0], img_hw[1]), (2 * img_hw[0], 2 * img_hw[1]), (40, 50), (img_hw[0] + 1, 3 * img_hw[1] + 7)]
+    images = [rng.integers(0, 256, (3 * h + (i % 3), w, 3), dtype=np.uint8) for i, (h, w) in enumerate(sizes)]
+    flips = [bool(i & 1) for i in range(len(images))]
+    out = ops.prepare_triplets(images, img_hw, flips, 'cuda:0', src_is_rgb=False)
+    torch.cuda.synchronize()
+    assert out.shape == (len(images), 3, 3 * img_hw[0], img_hw[1])
+    for i, im in enumerate(images):
+        np.testing.assert_array_equal(out[i].cpu().numpy(), prepare_triplet(im, img_hw, flips[i]), err_msg='image %d' % i)
+    rgb = ops.prepare_triplets(images[:2], img_hw, None, 'cuda:0', src_is_rgb=True)   # RGB-decoded PNG -> BGR planes
+    np.testing.assert_array_equal(rgb[1].cpu().numpy(), prepare_triplet(images[1][:, :, ::-1], img_hw, False))
+
+
+@gpu
+def test_prepare_triplets_rejects_bad_input():
+    from unopticalflow_amd import ops
+    with pytest.raises(ValueError):
+        ops.prepare_triplets([np.zeros((30, 40, 3), np.float32)], (64, 128), None, 'cuda:0')
+    with pytest.raises(ValueError):
+        ops.prepare_triplets([np.zeros((30, 40, 3), np.uint8)], (64, 130), None, 'cuda:0')
+    with pytest.raises(ValueError):
+        ops.prepare_triplets([np.zeros((30, 40, 3), np.uint8)], (64, 128), None, 'cpu')
+
+
+@gpu
+def test_device_loader_matches_oracle(tmp_path):
+    """train.txt + stacked PNGs -> DeviceTripletLoader batches == oracle on the decoded files (same flip draws)."""
+    from unopticalflow_amd.data import DecodedTriplets, DeviceTripletLoader
+    from unopticalflow_amd.evaluation import read_png, write_png
+    rng = np.random.default_rng(2)
+    names = []
+    for i, (h, w) in enumerate(KITTI_SIZES + [(100, 320)]):
+        os.makedirs(tmp_path / 'seq', exist_ok=True)
+        write_png(str(tmp_path / 'seq' / ('%d.png' % i)), rng.integers(0, 256, (3 * h, w, 3), dtype=np.uint8))
+        names.append('seq/%d.png seq/%d_cam.txt' % (i, i))
+    (tmp_path / 'train.txt').write_text('\n'.join(names) + '\n')
+    ds = DecodedTriplets(str(tmp_path), img_hw=(64, 128))
+    loader = DeviceTripletLoader(ds, 2, 'cuda:0', (64, 128), num_workers=0, shuffle=False)
+    np.random.seed(123)
+    got = [b.cpu().numpy() for b in loader]
+    assert [g.shape[0] for g in got] == [2, 2, 1]
+    np.random.seed(123)
+    for i in range(5):
+        img = read_png(str(tmp_path / 'seq' / ('%d.png' % i)))
+        flip = bool(np.random.rand() > 0.5)
+        want = prepare_triplet(np.ascontiguousarray(img[:, :, ::-1]), (64, 128), flip)   # file order RGB -> BGR
+        np.testing.assert_array_equal(got[i // 2][i % 2], want)

@@ -90,7 +90,34 @@ def losses(B=8):
                 nm, s, B, h, w, tf, bytes_f / tf / 1e3, tb, bytes_b / tb / 1e3), flush=True)
 
 
+def prepare(B=8):
+    """Input stage: B decoded KITTI triplets (uint8, 1242x375 x 3 frames) -> [B,3,768,832] fp32."""
+    import ctypes
+    import numpy as np
+    for (h, w), (H, W) in (((375, 1242), (256, 832)), ((436, 1024), (448, 1024))):
+        n_src = 3 * h * w * 3
+        pad = (n_src + 15) // 16 * 16
+        src = torch.randint(0, 256, (B * pad,), dtype=torch.uint8, device='cuda')
+        offs = torch.tensor([i * pad for i in range(B)], dtype=torch.int64, device='cuda')
+        dims = torch.tensor([[3 * h, w]] * B, dtype=torch.int32, device='cuda')
+        out = torch.empty(B, 3, 3 * H, W, device='cuda')
+        lib = _lib.load()
+        P = ctypes.c_void_p
+        st = P(torch.cuda.current_stream().cuda_stream)
+        t = timeit(lambda: lib.unflow_prepare_triplets(P(src.data_ptr()), P(offs.data_ptr()), P(dims.data_ptr()), P(0),
+                                                       P(out.data_ptr()), B, H, W, 1, st))
+        nbytes = B * n_src + out.numel() * 4
+        print('prepare     [%d x %dx%dx3 u8] -> [%d,3,%d,%d] f32  %7.1f us (%6.0f GB/s algorithmic)' % (
+            B, 3 * h, w, B, 3 * H, W, t, nbytes / t / 1e3), flush=True)
+        imgs = [np.random.randint(0, 256, (3 * h, w, 3), dtype=np.uint8) for _ in range(B)]
+        t0 = time.perf_counter()
+        for _ in range(10):
+            ops.prepare_triplets(imgs, (H, W), None, 'cuda:0')
+        torch.cuda.synchronize()
+        print('  host-inclusive (pack + pinned H2D + kernel): %.2f ms per batch of %d' % ((time.perf_counter() - t0) * 100, B), flush=True)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['corr', 'warp', 'losses']
+    which = sys.argv[1:] or ['corr', 'warp', 'losses', 'prepare']
     for w_ in which:
         globals()[w_]()

@@ -4,8 +4,10 @@
 ``PreparedTriplets`` reads the stacked-triplet PNGs + train.txt that the reference's
 ``KITTI_RAW.prepare_data_mp`` / ``SINTEL_RAW.prepare_data_mp`` write (kitti_prepared.py:10-42,133-153)
 with PIL instead of cv2 (resize to img_hw, random horizontal flip, /255, channel order BGR so the
-published checkpoints see what they were trained on).  Image decoding stays on the CPU: it is an
-I/O stage outside the kernel scope.
+published checkpoints see what they were trained on), everything on the CPU like the reference.
+``DecodedTriplets`` + ``DeviceTripletLoader`` are the MI355X input stage:
+the workers only decode the PNG; resize / flip / scaling / layout run on the GPU in
+``unflow_prepare_triplets`` with OpenCV's 8-bit arithmetic, on a side stream one batch ahead of the step.
 """
 import os
 
@@ -59,3 +61,93 @@ class PreparedTriplets(torch.utils.data.Dataset):
             arr = arr[:, ::-1]
         arr = np.ascontiguousarray(arr.transpose(2, 0, 1)).astype(np.float32) / 255.0
         return torch.from_numpy(arr)
+
+
+class DecodedTriplets(torch.utils.data.Dataset):
+    """Same file list, sampling and flip draw as ``PreparedTriplets`` / kitti_prepared.py:38-42,80-84, but
+    ``__getitem__`` stops after the decode: (uint8 [rows, w, 3] in file (RGB) order, flip flag)."""
+
+    def __init__(self, data_dir, num_scales=3, img_hw=(256, 832), num_iterations=None):
+        self.data_dir, self.num_scales, self.img_hw, self.num_iterations = data_dir, num_scales, img_hw, num_iterations
+        with open(os.path.join(data_dir, 'train.txt')) as f:
+            self.files = [os.path.join(data_dir, ln.split()[0]) for ln in f if ln.strip()]
+        print('A total of {} image pairs found'.format(len(self.files)))
+
+    def count(self):
+        return len(self.files)
+
+    def __len__(self):
+        return self.count() if self.num_iterations is None else self.num_iterations
+
+    def rand_num(self, idx):
+        np.random.seed(idx)
+        return np.random.randint(self.count())
+
+    def __getitem__(self, idx):
+        from .evaluation import read_png
+        if self.num_iterations is not None:
+            idx = self.rand_num(idx)
+        img = read_png(self.files[idx])
+        if img.dtype != np.uint8:
+            raise ValueError('%s: expected an 8-bit PNG' % self.files[idx])
+        if img.ndim == 2:
+            img = np.repeat(img[:, :, None], 3, 2)
+        flip = bool(np.random.rand() > 0.5)
+        return torch.from_numpy(np.ascontiguousarray(img[:, :, :3])), flip
+
+
+def _collate_decoded(samples):
+    return [s[0] for s in samples], [s[1] for s in samples]
+
+
+class DeviceTripletLoader:
+    """Iterates ``[B,3,3H,W]`` device batches built by ``ops.prepare_triplets`` from a ``DecodedTriplets``.
+
+    The upload + kernel of batch i+1 are enqueued on a side stream while the caller trains on batch i; the
+    consumer stream waits on the batch's event, so there is no host synchronisation in the loop.  Two
+    pinned staging buffers alternate; a buffer is rewritten only after the copy that read it has finished.
+    """
+
+    def __init__(self, dataset, batch_size, device, img_hw, num_workers=4, sampler=None, shuffle=True):
+        self.loader = torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=(shuffle and sampler is None),
+                                                  sampler=sampler, num_workers=num_workers, drop_last=False,
+                                                  collate_fn=_collate_decoded)
+        self.device, self.img_hw = torch.device(device), img_hw
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.staging = [None, None]
+        self.copied = [None, None]
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _enqueue(self, images, flips, slot):
+        from . import ops
+        need = sum((im.numel() + 15) // 16 * 16 for im in images) + 64 * len(images) + 64
+        if self.copied[slot] is not None:
+            self.copied[slot].synchronize()                           # the copy that last read this buffer
+        if self.staging[slot] is None or self.staging[slot].numel() < need:
+            self.staging[slot] = torch.empty(need * 5 // 4, dtype=torch.uint8).pin_memory()
+        with torch.cuda.stream(self.stream):
+            batch = ops.prepare_triplets(images, self.img_hw, flips, self.device, True, self.staging[slot])
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
+        self.copied[slot] = ready
+        return batch, ready
+
+    def __iter__(self):
+        pending, slot = None, 0
+        for images, flips in self.loader:
+            nxt = self._enqueue(images, flips, slot)
+            slot ^= 1
+            if pending is not None:
+                yield self._hand_over(pending)
+            pending = nxt
+        if pending is not None:
+            yield self._hand_over(pending)
+
+    def _hand_over(self, item):
+        batch, ready = item
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ready)
+        batch.record_stream(cur)
+        return batch

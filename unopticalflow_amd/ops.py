@@ -451,3 +451,48 @@ def img_pyramid(img):
         _call('unflow_img_pyramid', _ptr(img), _ptr(half), _ptr(quarter), N * C, H, W, _stream(),
               nbytes=N * C * H * W * 4 * 21 // 16, shape=(N, C, H, W))
     return half, quarter
+
+
+def prepare_triplets(images, img_hw, flips=None, device=None, src_is_rgb=True, staging=None):
+    """Decoded stacked triplets -> the train step's input ``[B,3,3H,W]`` fp32 on the device.
+
+    ``images``: list of uint8 host arrays / CPU tensors ``[rows, w, 3]`` (sizes may differ: KITTI drives have
+    different resolutions).  Device side of ``KITTI_Prepared.__getitem__`` (kitti_prepared.py:63-90,145-148):
+    frame split, cv2-compatible 8-bit bilinear resize to ``img_hw``, optional horizontal flip, /255.
+    One pinned staging buffer, one async copy, one kernel on the current stream.  A caller that passes its
+    own ``staging`` (pinned uint8) must not rewrite it before this call's copy has run (see data.py).
+    """
+    dev = torch.device(device if device is not None else ('cuda', torch.cuda.current_device()))
+    if dev.type != 'cuda':
+        raise ValueError('prepare_triplets runs on an MI355X; got device %s' % dev)
+    H, W = int(img_hw[0]), int(img_hw[1])
+    if W % 4:
+        raise ValueError('img_hw[1] must be a multiple of 4, got %d' % W)
+    B = len(images)
+    imgs = [torch.as_tensor(im) for im in images]
+    for im in imgs:
+        if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3 or im.shape[0] < 3:
+            raise ValueError('expected uint8 [rows>=3, w, 3] images, got %s %s' % (im.dtype, tuple(im.shape)))
+    sizes = [im.numel() for im in imgs]
+    head = 16 * B + 8 * B + ((B + 15) // 16) * 16                    # offsets (i64) | dims (2 x i32) | flips (u8, padded)
+    offs, pos = [], head
+    for n in sizes:
+        offs.append(pos)
+        pos += (n + 15) // 16 * 16
+    if staging is None or staging.numel() < pos:
+        staging = torch.empty(pos, dtype=torch.uint8).pin_memory()
+    host = staging[:pos]
+    host[:8 * B].view(torch.int64).copy_(torch.tensor(offs, dtype=torch.int64))
+    host[8 * B:16 * B].view(torch.int32).copy_(torch.tensor([[im.shape[0], im.shape[1]] for im in imgs], dtype=torch.int32).view(-1))
+    fl = torch.zeros(B, dtype=torch.uint8) if flips is None else torch.as_tensor(flips).to(torch.uint8)
+    host[16 * B:16 * B + B].copy_(fl)
+    for im, o, n in zip(imgs, offs, sizes):
+        host[o:o + n].copy_(im.contiguous().view(-1))
+    buf = host.to(dev, non_blocking=True)
+    out = torch.empty((B, 3, 3 * H, W), dtype=torch.float32, device=dev)
+    base = buf.data_ptr()
+    with torch.cuda.device(dev):
+        _call('unflow_prepare_triplets', ctypes.c_void_p(base), ctypes.c_void_p(base), ctypes.c_void_p(base + 8 * B),
+              ctypes.c_void_p(base + 16 * B), _ptr(out), B, H, W,
+              1 if src_is_rgb else 0, _stream(), nbytes=sum(sizes) + out.numel() * 4, shape=(B, 3, 3 * H, W))
+    return out

@@ -20,7 +20,7 @@ import torch
 import yaml
 
 from .core.networks import get_model
-from .data import PreparedTriplets, SyntheticTriplets
+from .data import DecodedTriplets, DeviceTripletLoader, PreparedTriplets, SyntheticTriplets
 from .parallel import init_distributed
 from .trainer import FlowTrainer
 
@@ -62,11 +62,15 @@ def train(cfg):
         if not os.path.exists(os.path.join(data_dir, 'train.txt')):
             raise FileNotFoundError('no prepared triplets under {} (raw-dataset preparation is outside this '
                                     'package: run the reference\'s prepare_data_mp once, or use --synthetic)'.format(data_dir))
-        ds = PreparedTriplets(data_dir, cfg.num_scales, cfg.img_hw, (cfg.num_iterations - cfg.iter_start) * per_rank)
+        n_items = (cfg.num_iterations - cfg.iter_start) * per_rank
+        ds = (PreparedTriplets if cfg.host_input else DecodedTriplets)(data_dir, cfg.num_scales, cfg.img_hw, n_items)
         sampler = torch.utils.data.distributed.DistributedSampler(ds, world, rank, shuffle=True) if world > 1 else None
-        loader = torch.utils.data.DataLoader(ds, batch_size=per_rank, shuffle=(sampler is None), sampler=sampler,
-                                             num_workers=cfg.num_workers, drop_last=False, pin_memory=True)
-        batches = (b.to(dev, non_blocking=True) for b in loader)
+        if cfg.host_input:                                             # the reference's all-CPU pipeline (PIL resize)
+            loader = torch.utils.data.DataLoader(ds, batch_size=per_rank, shuffle=(sampler is None), sampler=sampler,
+                                                 num_workers=cfg.num_workers, drop_last=False, pin_memory=True)
+            batches = (b.to(dev, non_blocking=True) for b in loader)
+        else:                                                          # decode on the CPU, the rest on the GPU
+            batches = DeviceTripletLoader(ds, per_rank, dev, cfg.img_hw, cfg.num_workers, sampler)
 
     if rank == 0:
         print('starting iteration: {}.'.format(cfg.iter_start))
@@ -116,6 +120,7 @@ def main(argv=None):
     ap.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'bf16'], help='conv-stack precision.')
     ap.add_argument('--miopen_find', type=int, default=1, help='1: use the shipped MIOpen find-db + benchmark mode.')
     ap.add_argument('--graph', type=int, default=0, help='1: replay the train step as a hipGraph.')
+    ap.add_argument('--host_input', type=int, default=0, help='1: resize/flip/scale on the CPU workers (PIL) instead of the GPU.')
     args = ap.parse_args(argv)
     if args.config_file is None:
         raise ValueError('config file needed. -c --config_file.')
