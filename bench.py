@@ -31,6 +31,7 @@ import torch                                                     # noqa: E402
 import torch.distributed as dist                                 # noqa: E402
 
 H, W, B_PER_GPU = 256, 832, 8
+MFMA_PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0}   # dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
@@ -80,6 +81,14 @@ def cpu_baseline(sample_b):
     for _ in range(n):
         R.train_step(model, opt, x, weights)
     dt = time.perf_counter() - t0
+    # single-thread figure: one timed step of one triplet after one untimed step
+    torch.set_num_threads(1)
+    x1 = x[:1].contiguous()
+    R.train_step(model, opt, x1, weights)
+    t1 = time.perf_counter()
+    R.train_step(model, opt, x1, weights)
+    dt1 = time.perf_counter() - t1
+    torch.set_num_threads(cores)
     cpu = 'unknown CPU'
     try:
         for ln in open('/proc/cpuinfo'):
@@ -89,9 +98,9 @@ def cpu_baseline(sample_b):
     except OSError:
         pass
     return {'value': round(2 * sample_b * n / dt, 4), 'unit': 'pairs/s', 'cores': torch.get_num_threads(),
-            'kind': 'port',
+            'kind': 'port', 'value_1thread': round(2 / dt1, 4),
             'sample': '%d timed train steps (+1 untimed) of %d synthetic 832x256 triplets (%.1f s), fp32, torch CPU '
-                      'oracle on %s' % (n, sample_b, dt, cpu)}
+                      'oracle on %s; value_1thread: 1 timed step of 1 triplet on one thread (%.1f s)' % (n, sample_b, dt, cpu, dt1)}
 
 
 def main():
@@ -148,6 +157,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
 
+    # dense-contraction FLOPs of one step (forward + data-gradient + weight-gradient of every convolution),
+    # counted by hooks over one extra untimed step; SURVEY 8d: 1.945 TFLOP at 832x256, B=8
+    conv_flops = [0.0]
+
+    def count(mod, inp, out):
+        c = mod[0] if isinstance(mod, torch.nn.Sequential) else mod
+        out = out[0] if isinstance(out, tuple) else out      # ConvLeaky(consumers=2) returns two handles
+        f = 2.0 * out.numel() * c.in_channels * c.kernel_size[0] * c.kernel_size[1]
+        conv_flops[0] += f * (3.0 if inp[0].requires_grad else 2.0)
+    from unopticalflow_amd.core.networks.structures.net_utils import ConvLeaky
+    hooks = [m.register_forward_hook(count) for m in model.modules()
+             if isinstance(m, ConvLeaky) or (isinstance(m, torch.nn.Conv2d) and m.bias is not None and m.out_channels == 2)]
+    if not args.graph:
+        trainer.step(inputs)
+        torch.cuda.synchronize()
+    for h_ in hooks:
+        h_.remove()
+
     survey = None
     if rank == 0 and world == 1 and not args.no_kernel_timing:
         # per-entry-point timings of the hand-written kernels: 3 extra (untimed) steps with a HIP-event pair
@@ -193,7 +220,15 @@ def main():
                                                                             (1 if args.precision == 'fp32' else 2) if (fh, fw) == (H, W) else 3),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                        'triplets_per_s': round(pairs / 2 / dt, 2)},
-            'roofline': roof, 'cpu_baseline': base, 'kernel_survey': survey,
+            'roofline': roof, 'cpu_baseline': base,
+            # whole-step lower bound on the conv stacks' MFMA utilisation: conv FLOPs / (entire step time);
+            # profiles/ holds the per-kernel split (convolutions alone: see DESIGN.md section 4)
+            'conv_stack': None if not conv_flops[0] else {
+                'bound': 'mfma', 'flops_per_step': conv_flops[0],
+                'achieved_lower_bound': round(conv_flops[0] / (dt / args.steps) / 1e12, 1),
+                'peak': MFMA_PEAK_TFLOPS[args.precision], 'unit': 'TFLOP/s',
+                'frac_lower_bound': round(conv_flops[0] / (dt / args.steps) / 1e12 / MFMA_PEAK_TFLOPS[args.precision], 4)},
+            'kernel_survey': survey,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

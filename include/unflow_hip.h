@@ -121,6 +121,15 @@ int unflow_bias_leaky_partials(int N, int C, int H, int W);
 int unflow_bias_leaky_bwd(const float* y, const float* gout, float* gin, float* gbias, float* partials,
                           int N, int C, int H, int W, float slope, void* stream);
 
+/* The same with the gradients of up to two consumers of the activation added on the fly
+ * (gin = (gout + gout2) * ...; gout2 may be NULL), each possibly a channel slice of a wider NCHW tensor
+ * -- what autograd hands out for a torch.cat operand (pwc_tf.py:113-117: every decoder activation feeds
+ * the next conv and a cat): sample stride in elements (>= C*H*W), the (C,H,W) block of a sample dense.
+ * Replaces the separate gradient-accumulation pass and the .contiguous() copy of a sliced gradient. */
+int unflow_bias_leaky_bwd2(const float* y, const float* gout, long long gout_stride, const float* gout2,
+                           long long gout2_stride, float* gin, float* gbias, float* partials,
+                           int N, int C, int H, int W, float slope, void* stream);
+
 /* ---- image pyramid: Model_flow.generate_img_pyramid scales 1 and 2, model_flow_paper.py:54-60 ----
  * img [planes,H,W] (planes = B*C, any leading layout) -> half [planes,H/2,W/2] (2x2 box means) and
  * quarter [planes,H/4,W/4] (4x4 box means of img).  H, W multiples of 4. */

@@ -313,6 +313,34 @@ def test_bias_leaky_relu_vs_torch(ops, shape):
     close(bg.grad, bc.grad, rtol=1e-4, atol=1e-4 * bc.grad.abs().max().item())
 
 
+@pytest.mark.parametrize('shape', [(4, 32, 16, 52), (2, 5, 7, 9), (1, 3, 5, 6), (3, 8, 4, 4)])
+def test_bias_leaky_two_consumers(ops, shape):
+    """Decoder wiring (pwc_tf.py:113-118): the activation feeds a conv-like consumer and a torch.cat; the two
+    gradients (one dense, one a channel slice of the cat's gradient) are added inside the backward kernel."""
+    N, C, H, W = shape
+    y0, bias, other = rnd(67, shape), rnd(68, (C,), 0.3), rnd(69, (N, 3, H, W))
+    wa, wb = rnd(70, shape), rnd(71, (N, C + 3, H, W))
+
+    def graph(act_a, act_b, oth):
+        return (act_a * wa.to(act_a.device)).sum() + (torch.cat((oth, act_b), 1) * wb.to(act_a.device)).sum()
+    yc, bc = y0.clone().requires_grad_(), bias.clone().requires_grad_()
+    ref = torch.nn.functional.leaky_relu(yc + bc.view(1, C, 1, 1), 0.1)
+    graph(ref, ref, other).backward()
+    yg, bg = y0.cuda().requires_grad_(), bias.cuda().requires_grad_()
+    a, b = ops.bias_leaky_relu_(yg * 1.0, bg, 0.1, consumers=2)
+    assert a.data_ptr() == b.data_ptr() and torch.equal(a.cpu(), ref.detach())
+    graph(a, b, other.cuda()).backward()
+    close(yg.grad, yc.grad, rtol=1e-6, atol=1e-6)
+    close(bg.grad, bc.grad, rtol=1e-4, atol=1e-4 * bc.grad.abs().max().item())
+    # one handle unused (pyramid level 1 in training), and both gradients slices of cats
+    yg2, bg2 = y0.cuda().requires_grad_(), bias.cuda().requires_grad_()
+    a, b = ops.bias_leaky_relu_(yg2 * 1.0, bg2, 0.1, consumers=2)
+    (torch.cat((other.cuda(), b), 1) * wb.cuda()).sum().backward()
+    yc2 = y0.clone().requires_grad_()
+    (torch.cat((other, torch.nn.functional.leaky_relu(yc2 + bias.view(1, C, 1, 1), 0.1)), 1) * wb).sum().backward()
+    close(yg2.grad, yc2.grad, rtol=1e-6, atol=1e-6)
+
+
 def test_conv_block_matches_reference_block(ops):
     from unopticalflow_amd import conv as conv_hip
     torch.manual_seed(0)

@@ -147,11 +147,13 @@ class Model_flow(nn.Module):
         with self._autocast():
             feats = self.fpyramid(frames)                                    # [3B, ...] per level
             # the decoder never reads pyramid level 1 (pwc_tf.py:108-179 uses c12..c16 / c22..c26): no copy for it
-            feat_c2 = [None] + [torch.cat((f[B:2 * B], f[B:2 * B]), 0) for f in feats[1:]]
-            feat_lr = [None] + [torch.cat((f[:B], f[2 * B:]), 0) for f in feats[1:]]
+            # split (not slices): its backward is one cat, a slice's is a zero-fill + copy + add of the whole 3B map
+            parts = [f.split(B) for f in feats[1:]]                          # (left, centre, right)
+            feat_c2 = [None] + [torch.cat((c, c), 0) for _, c, _ in parts]
+            feat_lr = [None] + [torch.cat((l, r), 0) for l, _, r in parts]
             flows = self.pwc_model(feat_c2, feat_lr, [img_h, img_w])         # [2B, 2, h, w] per scale
-        flows = [f.float() for f in flows]
-        return [f[:B] for f in flows], [f[B:] for f in flows]            # bwd (centre->left), fwd
+        halves = [f.float().split(B) for f in flows]
+        return [h[0] for h in halves], [h[1] for h in halves]            # bwd (centre->left), fwd
 
     def forward(self, inputs, output_flow=False, use_flow_loss=True, is_second_phase=False):
         images = inputs

@@ -18,8 +18,12 @@ class FeaturePyramid(nn.Module):
             cin = cout
 
     def forward(self, img):
-        outs, t = [], img
+        outs, t, last = [], img, len(_CHANNELS) - 1
         for lvl in range(len(_CHANNELS)):
-            t = getattr(self, 'conv%d' % (2 * lvl + 2))(getattr(self, 'conv%d' % (2 * lvl + 1))(t))
-            outs.append(t)
+            t = getattr(self, 'conv%d' % (2 * lvl + 1))(t)
+            if lvl < last:      # two consumers (the next level and the caller): one handle each, see ConvLeaky
+                t, out = getattr(self, 'conv%d' % (2 * lvl + 2))(t, 2)
+            else:
+                t = out = getattr(self, 'conv%d' % (2 * lvl + 2))(t)
+            outs.append(out)
         return tuple(outs)

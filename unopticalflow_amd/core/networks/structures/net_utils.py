@@ -3,6 +3,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .... import ops
+import os
+_AB_OFF = os.environ.get('UNFLOW_AB_OFF') == '1'
 
 
 class ConvLeaky(nn.Sequential):
@@ -11,12 +13,18 @@ class ConvLeaky(nn.Sequential):
     contraction bias-free on MFMA (PyTorch-ROCm / MIOpen) and applies bias + LeakyReLU in one in-place
     HIP pass (csrc/elementwise.hip); the backward of that pass also produces the bias gradient."""
 
-    def forward(self, x):
+    def forward(self, x, consumers=1):
+        """``consumers=2``: returns (y, y) -- two handles of the same activation, one per consumer, so the two
+        gradients meet inside the epilogue's backward kernel (ops.bias_leaky_relu_)."""
         c = self[0]
         y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
         if y.dtype != torch.float32:       # bf16 autocast run (cfg.precision == 'bf16'): unfused torch epilogue
-            return F.leaky_relu(y + c.bias.to(y.dtype).view(1, -1, 1, 1), self[1].negative_slope)
-        return ops.bias_leaky_relu_(y, c.bias, self[1].negative_slope)
+            y = F.leaky_relu(y + c.bias.to(y.dtype).view(1, -1, 1, 1), self[1].negative_slope)
+            return (y, y) if consumers == 2 else y
+        if consumers == 2 and _AB_OFF:
+            y = ops.bias_leaky_relu_(y, c.bias, self[1].negative_slope)
+            return y, y
+        return ops.bias_leaky_relu_(y, c.bias, self[1].negative_slope, consumers)
 
 
 def conv(in_planes, out_planes, kernel_size=3, stride=1, padding=1, dilation=1):

@@ -46,13 +46,19 @@ class PWC_tf(nn.Module):
         return ops.corr(input1.float(), input2.float(), d)
 
     def _decoder(self, lvl, x):
+        """reference pwc_tf.py:113-118 (and the same six lines per level).  Every activation feeds two
+        consumers; it is taken as two handles (ConvLeaky(consumers=2)) so the gradients are summed inside
+        the epilogue's backward kernel."""
         c = [getattr(self, 'conv%d_%d' % (lvl, k)) for k in range(5)]
-        x0 = c[0](x)
-        x1 = c[1](x0)
-        x2 = c[2](torch.cat((x0, x1), 1))
-        x3 = c[3](torch.cat((x1, x2), 1))
-        x4 = c[4](torch.cat((x2, x3), 1))
-        return getattr(self, 'predict_flow%d' % lvl)(torch.cat((x3, x4), 1)).float(), x4
+        x0, x0b = c[0](x, 2)
+        x1, x1b = c[1](x0, 2)
+        x2, x2b = c[2](torch.cat((x0b, x1), 1), 2)
+        x3, x3b = c[3](torch.cat((x1b, x2), 1), 2)
+        if lvl == 2:                                  # x4 of level 2 also feeds the context network
+            x4, x4b = c[4](torch.cat((x2b, x3), 1), 2)
+        else:
+            x4 = x4b = c[4](torch.cat((x2b, x3), 1))
+        return getattr(self, 'predict_flow%d' % lvl)(torch.cat((x3b, x4), 1)).float(), x4b
 
     def forward(self, feature_list_1, feature_list_2, img_hw):
         f1 = dict(zip(range(1, 7), feature_list_1))

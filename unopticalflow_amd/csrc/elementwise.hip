@@ -41,14 +41,21 @@ __global__ __launch_bounds__(256) void bias_leaky_fwd_kernel(float* __restrict__
     }
 }
 
-// gin = gout * (y > 0 ? 1 : slope)   (y is the activation OUTPUT; LeakyReLU keeps the sign)
+// gin = (gout [+ gout2]) * (y > 0 ? 1 : slope)   (y is the activation OUTPUT; LeakyReLU keeps the sign)
 // partials[(c * N + n) * nchunk + chunk] = sum of gin over the workgroup's elements
+// gout / gout2 may be channel slices of a wider NCHW tensor (the views autograd hands out for a
+// torch.cat operand): their sample stride is passed in elements, the (C,H,W) block of a sample is dense.
+// TWO: the activation had two consumers; adding their gradients here replaces a separate add pass.
+template <bool TWO>
 __global__ __launch_bounds__(256) void bias_leaky_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gout,
-                                                             float* __restrict__ gin, float* __restrict__ partials,
-                                                             int C, int HW, float slope) {
+                                                             long long gstride, const float* __restrict__ gout2,
+                                                             long long gstride2, float* __restrict__ gin,
+                                                             float* __restrict__ partials, int C, int HW, float slope) {
     __shared__ float red[4];
     const int c = blockIdx.y, n = blockIdx.z, N = gridDim.z;
     const size_t base = ((size_t)n * C + c) * HW;
+    const float* ga = gout + (size_t)n * gstride + (size_t)c * HW;
+    const float* gb = TWO ? gout2 + (size_t)n * gstride2 + (size_t)c * HW : nullptr;
     const int e0 = blockIdx.x * EW_TILE;
     float acc[1] = {0.f};
     if ((HW & 3) == 0) {
@@ -57,7 +64,11 @@ __global__ __launch_bounds__(256) void bias_leaky_bwd_kernel(const float* __rest
             const int e = e0 + (k * 256 + threadIdx.x) * 4;
             if (e < HW) {
                 const float4 v = *reinterpret_cast<const float4*>(y + base + e);
-                float4 g = *reinterpret_cast<const float4*>(gout + base + e);
+                float4 g = *reinterpret_cast<const float4*>(ga + e);
+                if (TWO) {
+                    const float4 h = *reinterpret_cast<const float4*>(gb + e);
+                    g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w;
+                }
                 g.x = v.x > 0.f ? g.x : g.x * slope; g.y = v.y > 0.f ? g.y : g.y * slope;
                 g.z = v.z > 0.f ? g.z : g.z * slope; g.w = v.w > 0.f ? g.w : g.w * slope;
                 *reinterpret_cast<float4*>(gin + base + e) = g;
@@ -66,7 +77,8 @@ __global__ __launch_bounds__(256) void bias_leaky_bwd_kernel(const float* __rest
         }
     } else {
         for (int e = e0 + threadIdx.x; e < min(e0 + EW_TILE, HW); e += 256) {
-            float g = gout[base + e];
+            float g = ga[e];
+            if (TWO) g += gb[e];
             g = y[base + e] > 0.f ? g : g * slope;
             gin[base + e] = g;
             acc[0] += g;
@@ -126,14 +138,29 @@ extern "C" int unflow_bias_leaky_partials(int N, int C, int H, int W) {
     return N * C * ceil_div(H * W, EW_TILE);
 }
 
-extern "C" int unflow_bias_leaky_bwd(const float* y, const float* gout, float* gin, float* gbias, float* partials,
-                                     int N, int C, int H, int W, float slope, void* stream) {
+extern "C" int unflow_bias_leaky_bwd2(const float* y, const float* gout, long long gout_stride, const float* gout2,
+                                      long long gout2_stride, float* gin, float* gbias, float* partials,
+                                      int N, int C, int H, int W, float slope, void* stream) {
     UNFLOW_REQUIRE(y && gout && gin && gbias && partials && N > 0 && C > 0 && H > 0 && W > 0 && N <= 65535 && C <= 65535);
     const int HW = H * W, nchunk = ceil_div(HW, EW_TILE);
+    UNFLOW_REQUIRE(gout_stride >= (long long)C * HW && (!gout2 || gout2_stride >= (long long)C * HW));
+    if ((HW & 3) == 0)      // the 16-byte path needs every sample block on a 16-byte boundary
+        UNFLOW_REQUIRE((gout_stride & 3) == 0 && ((size_t)gout & 15) == 0 &&
+                       (!gout2 || ((gout2_stride & 3) == 0 && ((size_t)gout2 & 15) == 0)));
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bias_leaky_bwd_kernel, dim3(nchunk, C, N), dim3(256), 0, s, y, gout, gin, partials, C, HW, slope);
+    if (gout2)
+        hipLaunchKernelGGL(bias_leaky_bwd_kernel<true>, dim3(nchunk, C, N), dim3(256), 0, s, y, gout, gout_stride, gout2,
+                           gout2_stride, gin, partials, C, HW, slope);
+    else
+        hipLaunchKernelGGL(bias_leaky_bwd_kernel<false>, dim3(nchunk, C, N), dim3(256), 0, s, y, gout, gout_stride, gout2,
+                           gout2_stride, gin, partials, C, HW, slope);
     hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3(C), dim3(256), 0, s, partials, N * nchunk, gbias);
     return unflow_launch_status();
+}
+
+extern "C" int unflow_bias_leaky_bwd(const float* y, const float* gout, float* gin, float* gbias, float* partials,
+                                     int N, int C, int H, int W, float slope, void* stream) {
+    return unflow_bias_leaky_bwd2(y, gout, (long long)C * H * W, nullptr, 0, gin, gbias, partials, N, C, H, W, slope, stream);
 }
 
 extern "C" int unflow_img_pyramid(const float* img, float* half, float* quarter, int planes, int H, int W,

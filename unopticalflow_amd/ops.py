@@ -401,39 +401,87 @@ def consis_loss(fwd_flow, bwd_flow, w_fwd):
 # ------------------------------------------------------------------------------------------
 # conv() epilogue and image pyramid
 # ------------------------------------------------------------------------------------------
+def _sample_strided(g, shape):
+    """(tensor, sample stride in elements) for a gradient whose per-sample (C,H,W) block is dense -- a
+    contiguous tensor or a channel slice of a wider NCHW one (a torch.cat operand's gradient); anything
+    else is made contiguous first."""
+    N, C, H, W = shape
+    st = g.stride()
+    dense = (st[3] == 1 or W == 1) and (st[2] == W or H == 1) and (st[1] == H * W or C == 1)
+    if not dense or (N > 1 and st[0] < C * H * W) or ((H * W) % 4 == 0 and (st[0] % 4 or g.data_ptr() % 16)):
+        g = g.contiguous()
+        st = g.stride()
+    return g, (st[0] if N > 1 else C * H * W)
+
+
+def _bias_leaky_backward(ctx, ga, gb):
+    (y,) = ctx.saved_tensors
+    N, C, H, W = y.shape
+    if ga is None:
+        ga, gb = gb, None
+    if ga is None:
+        return None, None, None
+    ga, sa = _sample_strided(ga, y.shape)
+    sb = 0
+    if gb is not None:
+        gb, sb = _sample_strided(gb, y.shape)
+    gin = torch.empty_like(y)
+    gbias = torch.empty(C, dtype=torch.float32, device=y.device)
+    npart = _lib.load().unflow_bias_leaky_partials(N, C, H, W)
+    part = torch.empty(npart, dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+        _call('unflow_bias_leaky_bwd2', _ptr(y), _ptr(ga), sa, _ptr(gb), sb, _ptr(gin), _ptr(gbias), _ptr(part),
+              N, C, H, W, ctypes.c_float(ctx.slope), _stream(),
+              nbytes=(12 if gb is None else 16) * N * C * H * W, shape=(N, C, H, W))
+    return gin, gbias, None
+
+
+def _bias_leaky_forward(ctx, y, bias, slope):
+    _dev(y, bias)
+    if not y.is_contiguous():
+        raise RuntimeError('bias_leaky_relu_ works in place on a contiguous NCHW convolution output')
+    N, C, H, W = y.shape
+    with torch.cuda.device(y.device):
+        _call('unflow_bias_leaky_fwd', _ptr(y), _ptr(bias), N, C, H, W, ctypes.c_float(slope), _stream(),
+              nbytes=8 * N * C * H * W, shape=(N, C, H, W))
+    ctx.mark_dirty(y)
+    ctx.save_for_backward(y)
+    ctx.slope = slope
+    ctx.set_materialize_grads(False)
+
+
 class _BiasLeaky(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, bias, slope):
-        _dev(y, bias)
-        if not y.is_contiguous():
-            raise RuntimeError('bias_leaky_relu_ works in place on a contiguous NCHW convolution output')
-        N, C, H, W = y.shape
-        with torch.cuda.device(y.device):
-            _call('unflow_bias_leaky_fwd', _ptr(y), _ptr(bias), N, C, H, W, ctypes.c_float(slope), _stream(),
-                  nbytes=8 * N * C * H * W, shape=(N, C, H, W))
-        ctx.mark_dirty(y)
-        ctx.save_for_backward(y)
-        ctx.slope = slope
+        _bias_leaky_forward(ctx, y, bias, slope)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        (y,) = ctx.saved_tensors
-        N, C, H, W = y.shape
-        g = g.contiguous()
-        gin = torch.empty_like(g)
-        gbias = torch.empty(C, dtype=torch.float32, device=y.device)
-        npart = _lib.load().unflow_bias_leaky_partials(N, C, H, W)
-        part = torch.empty(npart, dtype=torch.float32, device=y.device)
-        with torch.cuda.device(y.device):
-            _call('unflow_bias_leaky_bwd', _ptr(y), _ptr(g), _ptr(gin), _ptr(gbias), _ptr(part), N, C, H, W,
-                  ctypes.c_float(ctx.slope), _stream(), nbytes=12 * N * C * H * W, shape=(N, C, H, W))
-        return gin, gbias, None
+        return _bias_leaky_backward(ctx, g, None)
 
 
-def bias_leaky_relu_(y, bias, negative_slope=0.1):
+class _BiasLeakyTwo(torch.autograd.Function):
+    """The same activation handed out twice (the second output aliases the first): autograd then delivers
+    the gradients of its two consumers separately and the backward kernel adds them while it reads them."""
+
+    @staticmethod
+    def forward(ctx, y, bias, slope):
+        _bias_leaky_forward(ctx, y, bias, slope)
+        return y, y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        return _bias_leaky_backward(ctx, ga, gb)
+
+
+def bias_leaky_relu_(y, bias, negative_slope=0.1, consumers=1):
     """In-place ``leaky_relu(y + bias[None,:,None,None])`` on a bias-free conv output: the epilogue of the
-    reference's conv() block (net_utils.py:7-11) in one pass; its backward also reduces the bias gradient."""
+    reference's conv() block (net_utils.py:7-11) in one pass; its backward also reduces the bias gradient.
+    ``consumers=2`` returns the activation twice (one handle per consumer) so that the backward pass adds the
+    two incoming gradients inside the kernel instead of in a separate pass."""
+    if consumers == 2:
+        return _BiasLeakyTwo.apply(y, bias, float(negative_slope))
     return _BiasLeaky.apply(y, bias, float(negative_slope))
 
 
