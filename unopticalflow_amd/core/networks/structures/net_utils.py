@@ -3,8 +3,6 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .... import ops
-import os
-_AB_OFF = os.environ.get('UNFLOW_AB_OFF') == '1'
 
 
 class ConvLeaky(nn.Sequential):
@@ -21,9 +19,6 @@ class ConvLeaky(nn.Sequential):
         if y.dtype != torch.float32:       # bf16 autocast run (cfg.precision == 'bf16'): unfused torch epilogue
             y = F.leaky_relu(y + c.bias.to(y.dtype).view(1, -1, 1, 1), self[1].negative_slope)
             return (y, y) if consumers == 2 else y
-        if consumers == 2 and _AB_OFF:
-            y = ops.bias_leaky_relu_(y, c.bias, self[1].negative_slope)
-            return y, y
         return ops.bias_leaky_relu_(y, c.bias, self[1].negative_slope, consumers)
 
 
