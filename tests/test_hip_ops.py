@@ -103,6 +103,22 @@ def test_corr_large_map_paths(ops, B, C, h, w):
     close(f2.grad, f2c.grad, rtol=1e-5, atol=5e-6)
 
 
+@pytest.mark.parametrize('B,C,h,w', [(16, 32, 64, 208), (5, 7, 100, 268), (3, 2, 40, 72), (12, 64, 32, 104), (16, 96, 16, 52)])
+def test_corr_d8_large_map_paths(ops, B, C, h, w):
+    """d=8 (BASELINE config 5) at the batch the step uses (2B=16): the LDS-DMA ring forward with 17 displacement
+    rows split over workgroups (4 or 3 rows each, the last group partial), ragged tiles, odd channel counts."""
+    f1c, f2c = rnd(17, (B, C, h, w)).requires_grad_(), rnd(18, (B, C, h, w)).requires_grad_()
+    cv_ref = R.corr_naive(f1c, f2c, 8)
+    gout = rnd(19, tuple(cv_ref.shape))
+    cv_ref.backward(gout)
+    f1, f2 = dev(f1c.detach()).requires_grad_(), dev(f2c.detach()).requires_grad_()
+    cv = ops.corr(f1, f2, 8)
+    close(cv, cv_ref, rtol=1e-5, atol=2e-6)
+    cv.backward(dev(gout))
+    close(f1.grad, f1c.grad, rtol=1e-4, atol=1e-5)
+    close(f2.grad, f2c.grad, rtol=1e-4, atol=1e-5)
+
+
 def test_corr_shape_mismatch_asserts(ops):
     with pytest.raises(AssertionError):                       # pwc_tf.py:99
         ops.corr(torch.zeros(1, 2, 4, 4, device='cuda'), torch.zeros(1, 2, 4, 5, device='cuda'))

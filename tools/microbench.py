@@ -25,21 +25,27 @@ def timeit(fn, n=20, warm=3):
     return e0.elapsed_time(e1) / n * 1e3   # us
 
 
-def corr(B=16):
+def corr8(B=16):
+    """BASELINE config 5: d=8 on every pyramid level."""
+    corr(B, 8)
+
+
+def corr(B=16, d=4):
+    D2 = (2 * d + 1) ** 2
     for name, (C, h, w) in LEVELS.items():
         f1 = torch.randn(B, C, h, w, device='cuda')
         f2 = torch.randn(B, C, h, w, device='cuda')
-        g = torch.randn(B, 81, h, w, device='cuda')
-        cv = torch.empty(B, 81, h, w, device='cuda')
+        g = torch.randn(B, D2, h, w, device='cuda')
+        cv = torch.empty(B, D2, h, w, device='cuda')
         gf1, gf2 = torch.empty_like(f1), torch.empty_like(f2)
         lib = _lib.load()
         P = ops._ptr
-        fb = 4 * B * h * w * (2 * C + 81)
-        bb = 4 * B * h * w * (4 * C + 81)
-        tf = timeit(lambda: lib.unflow_corr_fwd(P(f1), P(f2), P(cv), B, C, h, w, 4, ops._stream()))
-        tb = timeit(lambda: lib.unflow_corr_bwd(P(f1), P(f2), P(g), P(gf1), P(gf2), B, C, h, w, 4, ops._stream()))
-        print('corr %s [%d,%d,%d,%d] variant=%s  fwd %7.1f us (%6.0f GB/s)   bwd %7.1f us (%6.0f GB/s)' % (
-            name, B, C, h, w, os.environ.get('UNFLOW_CORR_VARIANT', 'auto'), tf, fb / tf / 1e3, tb, bb / tb / 1e3), flush=True)
+        fb = 4 * B * h * w * (2 * C + D2)
+        bb = 4 * B * h * w * (4 * C + D2)
+        tf = timeit(lambda: lib.unflow_corr_fwd(P(f1), P(f2), P(cv), B, C, h, w, d, ops._stream()))
+        tb = timeit(lambda: lib.unflow_corr_bwd(P(f1), P(f2), P(g), P(gf1), P(gf2), B, C, h, w, d, ops._stream()))
+        print('corr d=%d %s [%d,%d,%d,%d] variant=%s  fwd %7.1f us (%6.0f GB/s)   bwd %7.1f us (%6.0f GB/s)' % (
+            d, name, B, C, h, w, os.environ.get('UNFLOW_CORR_VARIANT', 'auto'), tf, fb / tf / 1e3, tb, bb / tb / 1e3), flush=True)
 
 
 def warp(B=16):

@@ -19,6 +19,7 @@
 // (except in the tile kernel when the displacement rows are split over workgroups, R > 4).
 #include "common.h"
 #include <stdlib.h>
+#include <utility>
 
 namespace {
 
@@ -322,17 +323,15 @@ __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :
 // One row-step of the forward pipeline: ST = c * DG + i  (channel-in-stage, displacement row of the group).
 template <int ST, int STEPS, int PF, int DG, int DD, int NCOL, int CH_BYTES, int ROW_BYTES>
 struct FwdStep {
+    template <int Q, int... Ks>
+    static __device__ __forceinline__ void load_cols(v2f (&row)[PF + 1][NCOL], unsigned addr,
+                                                     std::integer_sequence<int, Ks...>) {
+        constexpr int off = (Q / DG) * CH_BYTES + (Q % DG) * ROW_BYTES;
+        ((row[Q % (PF + 1)][Ks] = lds_read_b64<off + 8 * Ks>(addr)), ...);      // 2 px + 2R halo floats = NCOL float2 columns
+    }
     template <int Q>
     static __device__ __forceinline__ void load(v2f (&row)[PF + 1][NCOL], unsigned addr) {
-        if constexpr (Q < STEPS) {
-            constexpr int off = (Q / DG) * CH_BYTES + (Q % DG) * ROW_BYTES;
-            row[Q % (PF + 1)][0] = lds_read_b64<off>(addr);
-            row[Q % (PF + 1)][1] = lds_read_b64<off + 8>(addr);
-            row[Q % (PF + 1)][2] = lds_read_b64<off + 16>(addr);
-            row[Q % (PF + 1)][3] = lds_read_b64<off + 24>(addr);
-            row[Q % (PF + 1)][4] = lds_read_b64<off + 32>(addr);
-            static_assert(NCOL == 5, "2 px + 2*4 halo floats = 5 float2 columns");
-        }
+        if constexpr (Q < STEPS) load_cols<Q>(row, addr, std::make_integer_sequence<int, NCOL>{});
     }
     template <int CC>
     static __device__ __forceinline__ void run(float (&acc)[DG][DD][2], v2f (&row)[PF + 1][NCOL],
@@ -449,7 +448,8 @@ __global__ __launch_bounds__(256, (RingCfg<R, CC, DG>::WAVES)) void corr_fwd_rin
         if (dbg & 2) continue;
         // CC*DG row-steps per stage as one software pipeline (FwdStep): reads of step s+PF are in
         // flight behind the FMAs of step s.
-        constexpr int PF = 2, STEPS = CC * DG, NCOL = NROW / 2;
+        constexpr int NCOL = NROW / 2, STEPS = CC * DG;
+        constexpr int PF = (2 * NCOL <= 15) ? 2 : 1;         // lgkmcnt is a 4-bit counter: <= 15 row reads in flight
         const unsigned abase = rows_addr + (unsigned)sbase * 4u;
         v2f a[CC];
 #pragma unroll
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256, (RingCfg<R, CC, DG>::WAVES)) void corr_fwd_rin
         v2f row[PF + 1][NCOL];
         using Step0 = FwdStep<0, STEPS, PF, DG, DD, NCOL, K::SC * 16, LW * 4>;
         Step0::template load<0>(row, abase);
-        Step0::template load<1>(row, abase);
+        if constexpr (PF > 1) Step0::template load<1>(row, abase);
         Step0::template run<CC>(acc, row, a, abase);
     }
     vm_wait<0>();                                            // drain the zero-line tail loads
@@ -508,35 +508,39 @@ int launch_fwd_ring(const float* f1, const float* f2, float* cv, int B, int C, i
 // produces a partial dot product per channel; pairs 1 and 2 hand theirs to pair 0 through a
 // double-buffered LDS slab one stage later (no extra barrier), pair 0 adds them in a fixed order
 // and issues the 8-byte stores.  ~100 VGPRs -> 4-5 waves per SIMD, so LDS latency, DMA latency and
-// stores overlap across waves.  F streams through the same 4-slot global_load_lds ring as the
-// forward kernel.  Requires W % 4 == 0 and DD == 9 (R == 4).
+// stores overlap across waves.  F streams through the same global_load_lds ring as the forward kernel.
+// R = 8: six wave pairs (768 threads), the last one with two live rows.  Requires W % 4 == 0.
 // ---------------------------------------------------------------------------------------------
 template <int R, int CC>
 struct BwdGsCfg {
-    static constexpr int DD = 2 * R + 1, DG = 3, NGRP = 3;
-    static constexpr int TW = 64, TYB = 4, NS = 3, THREADS = 128 * NGRP;       // 3 slots (44 KB, 3 workgroups per CU) measured
+    static constexpr int DD = 2 * R + 1, DG = 3, NGRP = (DD + DG - 1) / DG;    // R=4: 3 wave pairs; R=8: 6 (the last one has 2 live rows)
+    static constexpr int TW = 64, TYB = 4, NS = 3, THREADS = 128 * NGRP;       // 3 slots (44 KB, 3 workgroups per CU at R=4) measured
                                                                                // best: 6 slots (80 KB) halves the residency
-    static constexpr int LW = TW + 2 * R, LH = TYB + 2 * R;
+    static constexpr int LW = TW + 2 * R, LH = TYB + DG * NGRP - 1;            // = TYB + 2R when DD % 3 == 0; else one spare row
     static constexpr int SC = LH * LW / 4;                                      // float4 slots per channel
     static constexpr int ITER = (CC * SC + THREADS - 1) / THREADS;
     static constexpr int STAGE = ITER * THREADS * 4;                            // floats per ring slot
-    static constexpr int RED = 2 * CC * 128 * 2;                                // floats per hand-off buffer (pairs 1, 2)
+    static constexpr int RED = (NGRP - 1) * CC * 128 * 2;                       // floats per hand-off buffer (pairs 1 .. NGRP-1)
 };
+
+// Hand-off slab of the group-split backward: entry e = (pair - 1) * CC + c, 128 lanes x 8 bytes each.
+template <int N, int... Es>
+__device__ __forceinline__ void slab_read(v2f (&q)[N], unsigned addr, std::integer_sequence<int, Es...>) {
+    ((q[Es] = lds_read_b64<Es * 128 * 8>(addr)), ...);
+}
 
 // One row-step of the backward pipeline: ST = c * 3 + i.
 template <int ST, int STEPS, int PF, int DD, int NCOL, int CH_BYTES, int ROW_BYTES>
 struct GsStep {
+    template <int Q, int... Ks>
+    static __device__ __forceinline__ void load_cols(v2f (&row)[PF + 1][NCOL], unsigned addr,
+                                                     std::integer_sequence<int, Ks...>) {
+        constexpr int off = (Q / 3) * CH_BYTES + (Q % 3) * ROW_BYTES;
+        ((row[Q % (PF + 1)][Ks] = lds_read_b64<off + 8 * Ks>(addr)), ...);
+    }
     template <int Q>
     static __device__ __forceinline__ void load(v2f (&row)[PF + 1][NCOL], unsigned addr) {
-        if constexpr (Q < STEPS) {
-            constexpr int off = (Q / 3) * CH_BYTES + (Q % 3) * ROW_BYTES;
-            row[Q % (PF + 1)][0] = lds_read_b64<off>(addr);
-            row[Q % (PF + 1)][1] = lds_read_b64<off + 8>(addr);
-            row[Q % (PF + 1)][2] = lds_read_b64<off + 16>(addr);
-            row[Q % (PF + 1)][3] = lds_read_b64<off + 24>(addr);
-            row[Q % (PF + 1)][4] = lds_read_b64<off + 32>(addr);
-            static_assert(NCOL == 5, "2 px + 2*4 halo floats = 5 float2 columns");
-        }
+        if constexpr (Q < STEPS) load_cols<Q>(row, addr, std::make_integer_sequence<int, NCOL>{});
     }
     template <int CC>
     static __device__ __forceinline__ void run(const float (&wr)[3][DD][2], float (&acc)[CC][2][2],
@@ -560,7 +564,7 @@ struct GsStep {
 };
 
 template <int R, int CC>
-__global__ __launch_bounds__(384) void corr_bwd_gs_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+__global__ __launch_bounds__((BwdGsCfg<R, CC>::THREADS)) void corr_bwd_gs_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                          const float* __restrict__ g, float* __restrict__ gf1,
                                                          float* __restrict__ gf2, int C, int H, int W,
                                                          int tiles_x, int tiles_y, float inv_c) {
@@ -598,12 +602,12 @@ __global__ __launch_bounds__(384) void corr_bwd_gs_kernel(const float* __restric
             for (int j = 0; j < DD; ++j)
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    const int i = grp * 3 + ii;
+                    const int i = min(grp * 3 + ii, DD - 1);      // rows past DD (last pair when DD % 3 != 0) are zeroed below
                     // branch-free: clamp the gather position, load unconditionally, zero afterwards, so the
                     // 54 loads of a lane go out back to back instead of as 54 exec-masked blocks
                     const int sy = mode ? py + i - R : py, sx = mode ? px + p + j - R : px + p;
                     const int pl = mode ? (2 * R - i) * DD + (2 * R - j) : i * DD + j;
-                    const bool ok = (py < H) && (px + p < W) && sy >= 0 && sy < H && sx >= 0 && sx < W;
+                    const bool ok = (grp * 3 + ii < DD) && (py < H) && (px + p < W) && sy >= 0 && sy < H && sx >= 0 && sx < W;
                     const int cy = min(max(sy, 0), H - 1), cx = min(max(sx, 0), W - 1);
                     float v = gb[(size_t)pl * plane + (size_t)cy * W + cx];
                     v = ok ? v : 0.f;
@@ -650,21 +654,18 @@ __global__ __launch_bounds__(384) void corr_bwd_gs_kernel(const float* __restric
     const unsigned red_addr = (unsigned)(size_t)(lds_cfloat*)(red + l * 2);
     auto finish = [&](int st, const float (&mine)[CC][2]) {
         const unsigned ra = red_addr + (unsigned)((st & 1) * K::RED) * 4u;
-        v2f q1[CC], q2[CC];
-#pragma unroll
-        for (int c = 0; c < CC; ++c) {
-            if (c == 0) { q1[c] = lds_read_b64<0>(ra); q2[c] = lds_read_b64<CC * 128 * 8>(ra); }
-            else { q1[c] = lds_read_b64<128 * 8>(ra); q2[c] = lds_read_b64<CC * 128 * 8 + 128 * 8>(ra); }
-        }
-        static_assert(CC <= 2, "slab reads are spelled out for CC <= 2");
+        v2f q[(K::NGRP - 1) * CC];                       // partial (pair g+1, channel c) at q[g * CC + c]
+        slab_read(q, ra, std::make_integer_sequence<int, (K::NGRP - 1) * CC>{});
         lds_wait<0>();
 #pragma unroll
         for (int c = 0; c < CC; ++c) {
-            const v2f p1 = q1[c], p2 = q2[c];
+            float sx = mine[c][0], sy = mine[c][1];
+#pragma unroll
+            for (int gq = 0; gq < K::NGRP - 1; ++gq) { sx += q[gq * CC + c].x; sy += q[gq * CC + c].y; }   // fixed order
             const int gc = st * CC + c;
             // exactly one store instruction per channel per wave (lanes masked by EXEC): the vmcnt counts below rely on it
             if (live && gc < C)
-                *reinterpret_cast<float2*>(op + (size_t)gc * plane) = make_float2((mine[c][0] + p1.x) + p2.x, (mine[c][1] + p1.y) + p2.y);
+                *reinterpret_cast<float2*>(op + (size_t)gc * plane) = make_float2(sx, sy);
         }
     };
 
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(384) void corr_bwd_gs_kernel(const float* __restric
         if (grp == 0 && k > 0) finish(k - 1, keep);
         issue(k + K::NS - 1);
 
-        constexpr int PF = 2, STEPS = CC * 3;
+        constexpr int PF = (2 * NCOL <= 15) ? 2 : 1, STEPS = CC * 3;      // lgkmcnt: <= 15 row reads in flight
         const unsigned abase = rows_addr + (unsigned)((k % K::NS) * K::STAGE) * 4u;
         float acc[CC][2][2];
 #pragma unroll
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(384) void corr_bwd_gs_kernel(const float* __restric
         v2f row[PF + 1][NCOL];
         using Step0 = GsStep<0, STEPS, PF, DD, NCOL, K::SC * 16, LW * 4>;
         Step0::template load<0>(row, abase);
-        Step0::template load<1>(row, abase);
+        if constexpr (PF > 1) Step0::template load<1>(row, abase);
         Step0::template run<CC>(wr, acc, row, abase);
 
         if (grp == 0) {
@@ -839,6 +840,8 @@ static int pick_variant(int B, int C, int H, int W) {
     //   level 2 [16,32,64,208]: ring, all 81 displacements per workgroup (7)   37 us
     //   level 3 [16,64,32,104], level 4 [16,96,16,52]: ring, 3 displacement rows per workgroup (9)  29 / 30 us
     //   levels 5, 6: one lane per output element (4)   14 / 11 us
+    // d=8 (tools/microbench.py corr8): ring with 3 of the 17 rows per workgroup 125 / 52 / 46 us at levels 2 / 3 / 4
+    // (tile kernel 234 / 128 / 85), one lane per element 29 / 15 us at levels 5 / 6 (tile kernel 158 / 226)
     const long px = (long)B * H * W;
     const bool dma_ok = ((W & 3) == 0);
     if (W >= 96 && px >= 131072) return dma_ok ? 7 : 1;
@@ -863,7 +866,10 @@ extern "C" int unflow_corr_fwd(const float* f1, const float* f2, float* cv, int 
                 if (variant == 9 && (W & 3) == 0) return launch_fwd_ring<4, 2, 3>(f1, f2, cv, B, C, H, W, s);
                 if (variant >= 7) return launch_fwd<4, 2, 9, 8>(f1, f2, cv, B, C, H, W, s);
                 break;
-        case 8: return launch_fwd<8, 1, 6, 8>(f1, f2, cv, B, C, H, W, s);
+        case 8: variant = pick_variant(B, C, H, W);
+                if ((variant == 7 || variant == 9) && (W & 3) == 0) return launch_fwd_ring<8, 2, 3>(f1, f2, cv, B, C, H, W, s);
+                if (variant == 4 || (variant == 3 && (long)B * H * W < 8192)) break;
+                return launch_fwd<8, 1, 6, 8>(f1, f2, cv, B, C, H, W, s);
         default: break;
     }
     const size_t n = (size_t)B * (2 * d + 1) * (2 * d + 1) * H * W;
@@ -888,7 +894,11 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 if (variant == 2 || variant == 3 || (variant == 9 && (long)B * H * W >= 32768))
                     return launch_bwd<4, 1, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 break;
-        case 8: return launch_bwd<8, 1, 6, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+        case 8: variant = pick_variant(B, C, H, W);
+                if (variant == 4 || (long)B * H * W < 8192) break;      // small maps: one lane per element (117 / 57 us at levels 5 / 6, tile kernel 283 / 378)
+                // (corr_bwd_gs_kernel<8,1> needs 768 threads at <= 170 VGPRs and spills 14 of them; scratch traffic
+                //  would break its counted vmcnt waits, so d=8 keeps the tile kernel for large maps)
+                return launch_bwd<8, 1, 6, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
         default: break;
     }
     const size_t n = (size_t)B * C * H * W;
