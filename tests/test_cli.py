@@ -1,0 +1,75 @@
+"""The reference's command lines (train.py:166-226, test.py:205-255) end to end on the GPU: a prepared-triplet
+directory (stacked PNGs + train.txt, what kitti_prepared.py reads) -> train.py -> checkpoints -> resume -> test.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+YAML = """cfg_name: 'default'
+dataset: 'kitti_depth'
+img_hw: [64, 128]
+num_scales: 3
+num_iterations: 6
+w_ssim: 0.85
+w_flow_smooth: 10.0
+w_flow_consis: 0.01
+h_flow_consist_alpha: 3.0
+h_flow_consist_beta: 0.05
+prepared_base_dir: '%s'
+gt_2012_dir: './none'
+gt_2015_dir: './none'
+"""
+
+
+def _dataset(root):
+    from unopticalflow_amd.evaluation import write_png
+    rng = np.random.default_rng(0)
+    os.makedirs(os.path.join(root, 'data_s1', 'seq'))
+    names = []
+    for i, (h, w) in enumerate([(75, 248), (74, 244), (80, 260), (75, 248), (90, 300), (64, 128)]):
+        base = rng.integers(0, 256, (h + 8, w + 8, 3), dtype=np.uint8)
+        frames = [base[4 + dy:4 + dy + h, 4 + dx:4 + dx + w] for dy, dx in ((0, -3), (0, 0), (1, 3))]   # shifted views
+        write_png(os.path.join(root, 'data_s1', 'seq', '%d.png' % i), np.concatenate(frames, 0))
+        names.append('seq/%d.png seq/%d_cam.txt' % (i, i))
+    with open(os.path.join(root, 'data_s1', 'train.txt'), 'w') as f:
+        f.write('\n'.join(names) + '\n')
+
+
+@pytest.mark.parametrize('host_input', [0, 1])
+def test_train_resume_and_test_cli(tmp_path, host_input, capsys):
+    from unopticalflow_amd import train as train_cli, test as test_cli
+    root = str(tmp_path)
+    _dataset(root)
+    cfg = os.path.join(root, 'cfg.yaml')
+    with open(cfg, 'w') as f:
+        f.write(YAML % root)
+    common = ['-c', cfg, '--gpu', '0', '--mode', 'flow', '--model_dir', os.path.join(root, 'models'), '--batch_size', '2',
+              '--num_workers', '0', '--log_interval', '1', '--save_interval', '3', '--miopen_find', '0',
+              '--host_input', str(host_input)]
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        trainer = train_cli.main(common)
+        out = capsys.readouterr().out
+        assert 'iter: 5, loss_pixel:' in out and 'pairs/s' in out            # Visualizer.print_loss line + rate
+        mdir = os.path.join(root, 'models', 'flow')
+        for name in ('iter_2.pth', 'iter_5.pth', 'last.pth', 'config.pkl', 'cfg.yaml'):
+            assert os.path.exists(os.path.join(mdir, name)), name
+        ck = torch.load(os.path.join(mdir, 'last.pth'), map_location='cpu')
+        assert set(ck) == {'iteration', 'model_state_dict', 'optimizer_state_dict'} and ck['iteration'] == 5
+        assert len(ck['model_state_dict']) == 98 and 'pwc_model.dc_conv7.bias' in ck['model_state_dict']
+        for k, v in trainer.model.state_dict().items():
+            assert torch.equal(v.cpu(), ck['model_state_dict'][k]), k
+        # resume from iter_2 and run to the end again (train.py:42-46)
+        trainer2 = train_cli.main(common + ['--resume', '--iter_start', '2'])
+        assert 'iter: 5, loss_pixel:' in capsys.readouterr().out
+        assert all(torch.isfinite(p).all() for p in trainer2.model.parameters())
+        # test.py on the saved checkpoint (synthetic task: no dataset needed)
+        res = test_cli.main(['-c', cfg, '--gpu', '0', '--mode', 'flow', '--task', 'synthetic_flow',
+                             '--pretrained_model', os.path.join(mdir, 'last.pth')])
+        assert res is not None
+    finally:
+        os.chdir(cwd)
