@@ -130,6 +130,15 @@ int unflow_bias_leaky_bwd2(const float* y, const float* gout, long long gout_str
                            long long gout2_stride, float* gin, float* gbias, float* partials,
                            int N, int C, int H, int W, float slope, void* stream);
 
+/* bf16 activations (the bf16 conv-stack option: torch.autocast around the reference's conv() blocks): y, gout,
+ * gout2, gin are bf16 (raw uint16_t), bias / gbias / partials fp32; arithmetic in fp32, one round-to-nearest-even
+ * per element; gbias sums the rounded gin values.  Same scratch size (unflow_bias_leaky_partials). */
+int unflow_bias_leaky_fwd_bf16(uint16_t* y, const float* bias, int N, int C, int H, int W, float slope,
+                               void* stream);
+int unflow_bias_leaky_bwd2_bf16(const uint16_t* y, const uint16_t* gout, long long gout_stride,
+                                const uint16_t* gout2, long long gout2_stride, uint16_t* gin, float* gbias,
+                                float* partials, int N, int C, int H, int W, float slope, void* stream);
+
 /* ---- image pyramid: Model_flow.generate_img_pyramid scales 1 and 2, model_flow_paper.py:54-60 ----
  * img [planes,H,W] (planes = B*C, any leading layout) -> half [planes,H/2,W/2] (2x2 box means) and
  * quarter [planes,H/4,W/4] (4x4 box means of img).  H, W multiples of 4. */

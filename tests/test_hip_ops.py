@@ -357,6 +357,29 @@ def test_bias_leaky_two_consumers(ops, shape):
     close(yg2.grad, yc2.grad, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize('shape', [(16, 128, 64, 208), (2, 5, 7, 9), (3, 8, 4, 4), (2, 16, 8, 26)])
+def test_bias_leaky_bf16(ops, shape):
+    """bf16 conv-stack option: same epilogue on bf16 activations -- fp32 arithmetic, one rounding per element."""
+    N, C, H, W = shape
+    y0 = rnd(72, shape).to(torch.bfloat16)
+    bias = rnd(73, (C,), 0.3)
+    ga, gcat = rnd(74, shape).to(torch.bfloat16), rnd(75, (N, C + 3, H, W)).to(torch.bfloat16)
+    act = torch.nn.functional.leaky_relu(y0.float() + bias.view(1, C, 1, 1), 0.1)
+    ref_out = act.to(torch.bfloat16)
+    gsum = ga.float() + gcat[:, 3:].float()
+    ref_gin = (gsum * torch.where(ref_out.float() > 0, 1.0, 0.1)).to(torch.bfloat16)
+    yg, bg = y0.cuda().requires_grad_(), bias.cuda().requires_grad_()
+    a, b = ops.bias_leaky_relu_(yg * 1.0, bg, 0.1, consumers=2)
+    assert a.dtype == torch.bfloat16 and torch.equal(a.cpu(), ref_out)
+    torch.autograd.backward([a, b], [ga.cuda(), gcat.cuda()[:, 3:]])       # second gradient: a channel slice (cat operand)
+    assert yg.grad.dtype == torch.bfloat16 and torch.equal(yg.grad.cpu(), ref_gin)
+    assert bg.grad.dtype == torch.float32
+    want = ref_gin.float().sum((0, 2, 3))
+    close(bg.grad, want, rtol=1e-4, atol=1e-4 * want.abs().max().item())
+    one = ops.bias_leaky_relu_(y0.cuda().clone(), bias.cuda(), 0.1)            # single-consumer entry, no grad
+    assert torch.equal(one.cpu(), ref_out)
+
+
 def test_conv_block_matches_reference_block(ops):
     from unopticalflow_amd import conv as conv_hip
     torch.manual_seed(0)

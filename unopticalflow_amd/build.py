@@ -12,7 +12,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libunflow_hip.so')
-SOURCES = ('corr.hip', 'warp.hip', 'ssim.hip', 'photo.hip', 'elementwise.hip', 'prepare.hip', 'png_host.cpp')
+SOURCES = ('corr.hip', 'warp.hip', 'ssim.hip', 'photo.hip', 'elementwise.hip', 'elementwise_bf16.hip', 'prepare.hip', 'png_host.cpp')
 # -ffp-contract=off: mask / SSIM arithmetic must follow the reference op by op; the kernels call
 # fmaf() explicitly where a fused multiply-add is wanted.
 FLAGS = ('-O3', '--offload-arch=gfx950', '-fPIC', '-shared', '-std=c++17', '-ffp-contract=off',

@@ -9,16 +9,14 @@ class ConvLeaky(nn.Sequential):
     """The reference's conv() block, Sequential(Conv2d(bias=True), LeakyReLU(0.1)): same children, same
     ``<name>.0.weight`` / ``<name>.0.bias`` state-dict keys.  On a HIP tensor the forward runs the
     contraction bias-free on MFMA (PyTorch-ROCm / MIOpen) and applies bias + LeakyReLU in one in-place
-    HIP pass (csrc/elementwise.hip); the backward of that pass also produces the bias gradient."""
+    HIP pass (csrc/elementwise.hip, elementwise_bf16.hip); the backward of that pass also produces the bias gradient."""
 
     def forward(self, x, consumers=1):
         """``consumers=2``: returns (y, y) -- two handles of the same activation, one per consumer, so the two
         gradients meet inside the epilogue's backward kernel (ops.bias_leaky_relu_)."""
         c = self[0]
         y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
-        if y.dtype != torch.float32:       # bf16 autocast run (cfg.precision == 'bf16'): unfused torch epilogue
-            y = F.leaky_relu(y + c.bias.to(y.dtype).view(1, -1, 1, 1), self[1].negative_slope)
-            return (y, y) if consumers == 2 else y
+        # fp32, or bf16 under the autocast of cfg.precision == 'bf16' (bias stays fp32): the same fused epilogue
         return ops.bias_leaky_relu_(y, c.bias, self[1].negative_slope, consumers)
 
 

@@ -408,7 +408,8 @@ def _sample_strided(g, shape):
     N, C, H, W = shape
     st = g.stride()
     dense = (st[3] == 1 or W == 1) and (st[2] == W or H == 1) and (st[1] == H * W or C == 1)
-    if not dense or (N > 1 and st[0] < C * H * W) or ((H * W) % 4 == 0 and (st[0] % 4 or g.data_ptr() % 16)):
+    vec = 16 // g.element_size()                      # elements per 16-byte lane access
+    if not dense or (N > 1 and st[0] < C * H * W) or ((H * W) % vec == 0 and (st[0] % vec or g.data_ptr() % 16)):
         g = g.contiguous()
         st = g.stride()
     return g, (st[0] if N > 1 else C * H * W)
@@ -421,6 +422,9 @@ def _bias_leaky_backward(ctx, ga, gb):
         ga, gb = gb, None
     if ga is None:
         return None, None, None
+    half = y.dtype == torch.bfloat16
+    if ga.dtype != y.dtype or (gb is not None and gb.dtype != y.dtype):
+        raise TypeError('gradient dtype %s does not match the activation (%s)' % (ga.dtype, y.dtype))
     ga, sa = _sample_strided(ga, y.shape)
     sb = 0
     if gb is not None:
@@ -430,20 +434,23 @@ def _bias_leaky_backward(ctx, ga, gb):
     npart = _lib.load().unflow_bias_leaky_partials(N, C, H, W)
     part = torch.empty(npart, dtype=torch.float32, device=y.device)
     with torch.cuda.device(y.device):
-        _call('unflow_bias_leaky_bwd2', _ptr(y), _ptr(ga), sa, _ptr(gb), sb, _ptr(gin), _ptr(gbias), _ptr(part),
-              N, C, H, W, ctypes.c_float(ctx.slope), _stream(),
-              nbytes=(12 if gb is None else 16) * N * C * H * W, shape=(N, C, H, W))
+        _call('unflow_bias_leaky_bwd2_bf16' if half else 'unflow_bias_leaky_bwd2', _ptr(y), _ptr(ga), sa, _ptr(gb), sb,
+              _ptr(gin), _ptr(gbias), _ptr(part), N, C, H, W, ctypes.c_float(ctx.slope), _stream(),
+              nbytes=(3 if gb is None else 4) * y.element_size() * N * C * H * W, shape=(N, C, H, W))
     return gin, gbias, None
 
 
 def _bias_leaky_forward(ctx, y, bias, slope):
-    _dev(y, bias)
+    half = y.dtype == torch.bfloat16                  # bf16 conv-stack option: bf16 activation, fp32 bias
+    _dev(None if half else y, bias)
+    if half and (not y.is_cuda or y.device != bias.device):
+        raise RuntimeError('bias_leaky_relu_: activation and bias must be on the same HIP device')
     if not y.is_contiguous():
         raise RuntimeError('bias_leaky_relu_ works in place on a contiguous NCHW convolution output')
     N, C, H, W = y.shape
     with torch.cuda.device(y.device):
-        _call('unflow_bias_leaky_fwd', _ptr(y), _ptr(bias), N, C, H, W, ctypes.c_float(slope), _stream(),
-              nbytes=8 * N * C * H * W, shape=(N, C, H, W))
+        _call('unflow_bias_leaky_fwd_bf16' if half else 'unflow_bias_leaky_fwd', _ptr(y), _ptr(bias), N, C, H, W,
+              ctypes.c_float(slope), _stream(), nbytes=2 * y.element_size() * N * C * H * W, shape=(N, C, H, W))
     ctx.mark_dirty(y)
     ctx.save_for_backward(y)
     ctx.slope = slope
