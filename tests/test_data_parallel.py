@@ -45,8 +45,16 @@ def _worker(rank, world, port, steps, out_path):
     trainer = FlowTrainer(cfg, model, distributed=True, fused_adam=False)
     x = R.synthetic_triplets(2 * world, H, W, seed=5, structured=True)
     mine = shard_batch(x, rank, world)
+    early = []
     for _ in range(steps):
-        loss, _ = trainer.step(mine)
+        trainer.grads.zero()
+        loss_pack = trainer.model(mine)                     # the step of FlowTrainer.step, opened up to look at
+        trainer.total_loss(loss_pack).backward()            # how many pieces left during backward
+        early.append(trainer.grads.launched_early)
+        trainer.grads.all_reduce_mean()
+        trainer.optimizer.step()
+        loss = trainer.total_loss(loss_pack).detach()
+    assert trainer.grads.overlap and early == [trainer.grads.chunks] * steps, early   # all pieces sent by the hooks
     trainer.grads.check_views()
     if rank == 0:
         torch.save({'grad': trainer.grads.flat.clone(), 'params': [p.detach().clone() for p in model.parameters()],
@@ -90,6 +98,18 @@ def test_flat_gradients_alias_and_zero():
     model.zero_grad(set_to_none=True)
     with pytest.raises(RuntimeError):
         fg.check_views()
+
+
+def test_flat_gradient_pieces_cover_buffer():
+    cfg, model = _make()
+    fg = FlatGradients(model.parameters(), chunks=4)
+    assert fg.chunks == 4 and fg.pieces[0][0] == 0 and fg.pieces[-1][1] == fg.numel
+    assert all(a[1] == b[0] for a, b in zip(fg.pieces[:-1], fg.pieces[1:]))
+    assert sum(n for _, _, n in fg.pieces) == 98
+    sizes = [b - a for a, b, _ in fg.pieces]
+    assert max(sizes) < 0.45 * fg.numel                        # roughly balanced
+    many = FlatGradients(model.parameters(), chunks=1000)      # more pieces than parameters: still a partition
+    assert 4 < many.chunks <= 98 and many.pieces[-1][1] == many.numel and sum(n for _, _, n in many.pieces) == 98
 
 
 def test_shard_batch_requires_divisible():

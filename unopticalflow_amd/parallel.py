@@ -6,8 +6,11 @@ value that is batch-meaned (train.py:147-150), so averaging the per-rank gradien
 per-rank batches reproduces DataParallel's global-batch mean exactly.
 
 All 98 parameter gradients live in ONE flat fp32 buffer (5,134,324 elements = 20.5 MB): backward
-accumulates straight into views of it, and a step needs one (chunked, async) all-reduce over xGMI
-instead of 98 small ones; ``zero_grad`` is one memset.
+accumulates straight into views of it, and a step needs a few large all-reduces over xGMI instead of 98
+small ones; ``zero_grad`` is one memset.  The buffer is cut into ``chunks`` pieces on parameter
+boundaries; a piece is handed to RCCL (async, on RCCL's own stream) the moment backward has produced
+its last gradient, so all but the final piece (the first pyramid layers, 2 % of the bytes) travel
+while backward is still computing.
 """
 import os
 
@@ -34,28 +37,78 @@ def init_distributed(backend=None):
 class FlatGradients:
     """Owns a flat gradient buffer for ``params`` and averages it across ranks.
 
-    chunks: the buffer is reduced in ``chunks`` async pieces so the ring starts on the first bytes
-    while later ones are still being queued; xGMI is point-to-point, so a 20 MB payload is already
-    per-link bound (~0.25 ms on a ring) -- there is nothing to gain from finer buckets.
+    chunks: number of pieces of roughly equal size (cut on parameter boundaries).  xGMI is point-to-point,
+    so a 5 MB piece is already per-link bound on a ring; finer buckets only add launch latency.
+    overlap: launch each piece from a post-accumulate-grad hook while backward is still running
+    (``all_reduce_mean`` then only launches what is left and waits).  Without it everything is launched
+    after backward (used when the step is replayed as a hipGraph: collectives stay outside the graph).
     """
 
-    def __init__(self, params, chunks=4, group=None):
+    def __init__(self, params, chunks=4, group=None, overlap=False):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError('no trainable parameters')
         dev, dtype = self.params[0].device, self.params[0].dtype
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(self.numel, device=dev, dtype=dtype)
-        off = 0
+        off, offsets = 0, []
         for p in self.params:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
+            offsets.append(off)
             off += n
-        self.chunks = max(1, int(chunks))
         self.group = group
+        # piece boundaries on parameter boundaries, ~numel/chunks elements each
+        chunks = max(1, min(int(chunks), len(self.params)))
+        target, bounds, acc = self.numel / chunks, [0], 0
+        for i, p in enumerate(self.params):
+            acc += p.numel()
+            if acc >= target * len(bounds) and len(bounds) < chunks and i + 1 < len(self.params):
+                bounds.append(i + 1)
+        bounds.append(len(self.params))
+        self.pieces = []                                  # (first element, one past the last, number of params)
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            end = offsets[b] if b < len(self.params) else self.numel
+            self.pieces.append((offsets[a], end, b - a))
+        self.chunks = len(self.pieces)
+        self._piece_of = {}
+        for k, (a, b) in enumerate(zip(bounds[:-1], bounds[1:])):
+            for p in self.params[a:b]:
+                self._piece_of[id(p)] = k
+        self._left = [n for _, _, n in self.pieces]
+        self._works = [None] * self.chunks
+        self.launched_early = 0                           # pieces sent from a hook during the last backward
+        self.overlap = False
+        self._hooks = []
+        if overlap:
+            self.enable_overlap()
+
+    # ---- collective plumbing
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _launch(self, k):
+        a, b, _ = self.pieces[k]
+        self._works[k] = dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def enable_overlap(self):
+        if self.overlap:
+            return
+        self.overlap = True
+
+        def hook(p):
+            k = self._piece_of[id(p)]
+            self._left[k] -= 1
+            if self._left[k] == 0 and self._works[k] is None and self._active():
+                self._launch(k)                           # every gradient of piece k is final: send it now
+                self.launched_early += 1
+        self._hooks = [p.register_post_accumulate_grad_hook(hook) for p in self.params]
 
     def zero(self):
         self.flat.zero_()
+        self._left = [n for _, _, n in self.pieces]
+        self._works = [None] * self.chunks
+        self.launched_early = 0
 
     def check_views(self):
         """Guard against something (e.g. ``zero_grad(set_to_none=True)``) having detached a view."""
@@ -68,20 +121,17 @@ class FlatGradients:
             off += p.numel()
 
     def all_reduce_mean(self):
-        """Average the flat gradient over all ranks (no-op for a single process)."""
-        if not (dist.is_available() and dist.is_initialized()):
+        """Average the flat gradient over all ranks (no-op for a single process).  Pieces already sent by the
+        hooks are only waited for; the rest is launched here."""
+        if not self._active():
             return
         world = dist.get_world_size(self.group)
-        if world == 1:
-            return
-        works = []
-        n = self.numel
-        step = (n + self.chunks - 1) // self.chunks
-        for s in range(0, n, step):
-            works.append(dist.all_reduce(self.flat[s:s + step], op=dist.ReduceOp.SUM, group=self.group,
-                                         async_op=True))
-        for w in works:
+        for k in range(self.chunks):
+            if self._works[k] is None:
+                self._launch(k)
+        for w in self._works:
             w.wait()
+        self._works = [None] * self.chunks
         self.flat.mul_(1.0 / world)
 
 

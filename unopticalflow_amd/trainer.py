@@ -21,7 +21,9 @@ class FlowTrainer:
         params = [p for p in model.parameters() if p.requires_grad]      # train.py:39
         if distributed:
             broadcast_parameters(model)
-        self.grads = FlatGradients(params, chunks=allreduce_chunks)
+        # gradients leave for RCCL piece by piece during backward, except under hipGraph replay (collectives stay
+        # outside the captured graph)
+        self.grads = FlatGradients(params, chunks=allreduce_chunks, overlap=(distributed and not use_graph))
         self.distributed = distributed
         kw = {}
         if fused_adam is None:
