@@ -164,3 +164,63 @@ def test_bf16_conv_stacks_close_to_fp32_oracle():
     for k in ('loss_pixel', 'loss_ssim', 'loss_flow_consis'):
         close(pack[k], pr[k], rtol=5e-2, what=k)          # 8-bit mantissa through 5 coarse-to-fine levels
     close(pack['loss_flow_smooth'], pr['loss_flow_smooth'], rtol=0.5, what='smooth')   # 2nd differences of a bf16-rounded flow
+
+
+# ------------------------------------------------------------------------------------ two ranks on one GPU
+def _gpu_rank(rank, world, port, out_path):
+    import os
+    import torch.distributed as dist
+    os.environ.update(RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from unopticalflow_amd import get_model
+    from unopticalflow_amd.parallel import init_distributed, shard_batch
+    from unopticalflow_amd.trainer import FlowTrainer
+    init_distributed('gloo')                                  # RCCL refuses two ranks on one device; gloo moves HIP tensors
+    torch.cuda.set_device(0)
+    cfg = R.default_cfg()
+    torch.manual_seed(7 + rank)                               # rank 0's weights must win the broadcast
+    model = get_model('flow')(cfg).cuda()
+    if rank == 0:
+        model.load_state_dict(R.seeded_state_dict(R.Model_flow(cfg), 1234, 0.25))
+    trainer = FlowTrainer(cfg, model, distributed=True)
+    x = R.synthetic_triplets(2 * world, 64, 128, seed=5, structured=True).cuda()
+    first = None
+    for _ in range(2):
+        trainer.grads.zero()
+        pack = model(shard_batch(x, rank, world))
+        trainer.total_loss(pack).backward()
+        early = trainer.grads.launched_early
+        trainer.grads.all_reduce_mean()
+        if first is None:
+            first = trainer.grads.flat.cpu()
+        trainer.optimizer.step()
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({'grad': first, 'early': early, 'chunks': trainer.grads.chunks,
+                    'params': [p.detach().cpu() for p in model.parameters()]}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
+    """SURVEY 8e with the HIP model: 2 processes x 2 triplets (gradient pieces all-reduced from the backward hooks)
+    == 1 process x 4 triplets, gradients and parameters after two Adam steps."""
+    import socket
+    import torch.multiprocessing as mp
+    from unopticalflow_amd import get_model
+    from unopticalflow_amd.trainer import FlowTrainer
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / 'rank0.pt')
+    mp.start_processes(_gpu_rank, args=(2, port, out), nprocs=2, join=True, start_method='spawn')
+    got = torch.load(out)
+    assert got['early'] == got['chunks']
+    cfg = R.default_cfg()
+    model = get_model('flow')(cfg).cuda()
+    model.load_state_dict(R.seeded_state_dict(R.Model_flow(cfg), 1234, 0.25))
+    trainer = FlowTrainer(cfg, model, distributed=False)
+    x = R.synthetic_triplets(4, 64, 128, seed=5, structured=True).cuda()
+    trainer.step(x)
+    g_ref = trainer.grads.flat.cpu()                          # gradients of the first step (same weights on both sides)
+    trainer.step(x)
+    np.testing.assert_allclose(got['grad'].numpy(), g_ref.numpy(), rtol=2e-3, atol=2e-4 * g_ref.abs().max().item())
+    for a, b in zip(got['params'], model.parameters()):
+        np.testing.assert_allclose(a.numpy(), b.detach().cpu().numpy(), rtol=1e-3, atol=2.5e-4)   # 2 Adam steps: |update| <= 2e-4
