@@ -123,6 +123,42 @@ def prepare(B=8):
         print('  host-inclusive (pack + pinned H2D + kernel): %.2f ms per batch of %d' % ((time.perf_counter() - t0) * 100, B), flush=True)
 
 
+def loader(n_files=64, workers=8, B=8):
+    """Input stage end to end: stacked KITTI-sized PNG triplets on disk -> DeviceTripletLoader batches
+    (PNG inflate + unfilter on `workers` CPU processes, everything else in unflow_prepare_triplets)."""
+    import tempfile
+    import numpy as np
+    from unopticalflow_amd.data import DecodedTriplets, DeviceTripletLoader, PreparedTriplets
+    from unopticalflow_amd.evaluation import write_png
+    root = tempfile.mkdtemp(prefix='unflow_loader_')
+    os.makedirs(os.path.join(root, 'seq'))
+    rng = np.random.default_rng(0)
+    yy, xx = np.mgrid[0:1125, 0:1242]
+    names = []
+    for i in range(n_files):            # smooth texture + noise: compresses roughly like a photograph (~1.7x)
+        img = np.stack([127 + 90 * np.sin(xx / (17.0 + c + i % 5) + i) * np.cos(yy / (23.0 + c)) for c in range(3)], -1)
+        img = np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+        write_png(os.path.join(root, 'seq', '%d.png' % i), img)
+        names.append('seq/%d.png seq/%d_cam.txt' % (i, i))
+    open(os.path.join(root, 'train.txt'), 'w').write('\n'.join(names) + '\n')
+    size = sum(os.path.getsize(os.path.join(root, 'seq', f)) for f in os.listdir(os.path.join(root, 'seq'))) / n_files / 1e6
+    for kind in ('device', 'host'):
+        if kind == 'device':
+            it = DeviceTripletLoader(DecodedTriplets(root, img_hw=(256, 832), num_iterations=40 * B), B, 'cuda:0', (256, 832), workers)
+        else:
+            ds = PreparedTriplets(root, img_hw=(256, 832), num_iterations=40 * B)
+            dl = torch.utils.data.DataLoader(ds, batch_size=B, num_workers=workers, pin_memory=True)
+            it = (b.cuda(non_blocking=True) for b in dl)
+        n, t0 = 0, None
+        for b in it:
+            if t0 is None:              # first batch pays the worker start-up
+                torch.cuda.synchronize(); t0 = time.perf_counter(); continue
+            n += b.shape[0]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print('loader %-6s %d workers, %.1f MB PNGs: %.0f triplets/s (%.0f pairs/s)' % (kind, workers, size, n / dt, 2 * n / dt), flush=True)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['corr', 'warp', 'losses', 'prepare']
     for w_ in which:
