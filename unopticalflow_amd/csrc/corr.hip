@@ -609,9 +609,16 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC>::THREADS)) void corr_bwd_gs_kernel
                     const int pl = mode ? (2 * R - i) * DD + (2 * R - j) : i * DD + j;
                     const bool ok = (grp * 3 + ii < DD) && (py < H) && (px + p < W) && sy >= 0 && sy < H && sx >= 0 && sx < W;
                     const int cy = min(max(sy, 0), H - 1), cx = min(max(sx, 0), W - 1);
-                    float v = gb[(size_t)pl * plane + (size_t)cy * W + cx];
-                    v = ok ? v : 0.f;
-                    wr[ii][j][p] = v * inv_c;
+                    if constexpr (R <= 4) {
+                        float v = gb[(size_t)pl * plane + (size_t)cy * W + cx];
+                        v = ok ? v : 0.f;
+                        wr[ii][j][p] = v * inv_c;
+                    } else {
+                        // 102 gathers per lane: keeping 102 validity masks alive until the loads return overflows the
+                        // SGPR file (masks spill to VGPR lanes, values to scratch); fold validity into the address
+                        const float* src = ok ? gb + ((size_t)pl * plane + (size_t)cy * W + cx) : kZeroLine;
+                        wr[ii][j][p] = *src * inv_c;
+                    }
                 }
     }
 
@@ -700,14 +707,16 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC>::THREADS)) void corr_bwd_gs_kernel
         if (grp == 0 && k > 0) finish(k - 1, keep);
         issue(k + K::NS - 1);
 
-        constexpr int PF = (2 * NCOL <= 15) ? 2 : 1, STEPS = CC * 3;      // lgkmcnt: <= 15 row reads in flight
+        // row reads in flight ahead of their FMAs: 2 row-steps at R=4, 1 at R=8 (lgkmcnt allows <= 15 reads, and 768
+        // threads must fit 170 VGPRs each)
+        constexpr int PF = (2 * NCOL <= 15) ? 2 : 1, STEPS = CC * 3;
         const unsigned abase = rows_addr + (unsigned)((k % K::NS) * K::STAGE) * 4u;
         float acc[CC][2][2];
 #pragma unroll
         for (int c = 0; c < CC; ++c) { acc[c][0][0] = 0.f; acc[c][0][1] = 0.f; acc[c][1][0] = 0.f; acc[c][1][1] = 0.f; }
         v2f row[PF + 1][NCOL];
         using Step0 = GsStep<0, STEPS, PF, DD, NCOL, K::SC * 16, LW * 4>;
-        Step0::template load<0>(row, abase);
+        if constexpr (PF > 0) Step0::template load<0>(row, abase);
         if constexpr (PF > 1) Step0::template load<1>(row, abase);
         Step0::template run<CC>(wr, acc, row, abase);
 
@@ -896,8 +905,7 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 break;
         case 8: variant = pick_variant(B, C, H, W);
                 if (variant == 4 || (long)B * H * W < 8192) break;      // small maps: one lane per element (117 / 57 us at levels 5 / 6, tile kernel 283 / 378)
-                // (corr_bwd_gs_kernel<8,1> needs 768 threads at <= 170 VGPRs and spills 14 of them; scratch traffic
-                //  would break its counted vmcnt waits, so d=8 keeps the tile kernel for large maps)
+                if ((variant == 7 || variant == 9) && (W & 3) == 0) return launch_bwd_gs<8, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 return launch_bwd<8, 1, 6, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
         default: break;
     }
