@@ -175,7 +175,7 @@ def main():
     for h_ in hooks:
         h_.remove()
 
-    survey = None
+    survey = corr_warp = None
     if rank == 0 and world == 1 and not args.no_kernel_timing:
         # per-entry-point timings of the hand-written kernels: 3 extra (untimed) steps with a HIP-event pair
         # around every C call; kept out of the timed region so `value` is not perturbed
@@ -184,7 +184,15 @@ def main():
             trainer.step(inputs)
         torch.cuda.synchronize()
         rows = ops.kernel_timer.end_survey()
+        # every cost-volume and warp launch of the step (all pyramid levels, forward and backward) as one figure
+        cw = [r for r in rows if r['entry'] in ('unflow_corr_fwd', 'unflow_corr_bwd', 'unflow_warp_fwd', 'unflow_warp_bwd')]
+        cw_us, cw_bytes = sum(r['total_us'] for r in cw) / 3.0, sum(r['total_bytes'] for r in cw) / 3.0
+        corr_warp = {'bound': 'hbm', 'algorithmic_bytes_per_step': int(cw_bytes), 'us_per_step': round(cw_us, 1),
+                     'achieved': round(cw_bytes / cw_us / 1e3, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': round(cw_bytes / cw_us / 1e3 / HBM_PEAK_GBS, 4),
+                     'launches_per_step': sum(r['launches'] for r in cw) / 3.0} if cw_us > 0 else None
         for r in rows:
+            r.pop('total_us'); r.pop('total_bytes')
             if r['algorithmic_GBps'] is not None:
                 r['frac_of_hbm_peak'] = round(r['algorithmic_GBps'] / HBM_PEAK_GBS, 3)
             r['launches_per_step'] = r.pop('launches') / 3.0
@@ -228,7 +236,7 @@ def main():
                 'achieved_lower_bound': round(conv_flops[0] / (dt / args.steps) / 1e12, 1),
                 'peak': MFMA_PEAK_TFLOPS[args.precision], 'unit': 'TFLOP/s',
                 'frac_lower_bound': round(conv_flops[0] / (dt / args.steps) / 1e12 / MFMA_PEAK_TFLOPS[args.precision], 4)},
-            'kernel_survey': survey,
+            'corr_warp_all_levels': corr_warp, 'kernel_survey': survey,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

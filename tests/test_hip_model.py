@@ -223,4 +223,5 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     trainer.step(x)
     np.testing.assert_allclose(got['grad'].numpy(), g_ref.numpy(), rtol=2e-3, atol=2e-4 * g_ref.abs().max().item())
     for a, b in zip(got['params'], model.parameters()):
-        np.testing.assert_allclose(a.numpy(), b.detach().cpu().numpy(), rtol=1e-3, atol=2.5e-4)   # 2 Adam steps: |update| <= 2e-4
+        np.testing.assert_allclose(a.numpy(), b.detach().cpu().numpy(), rtol=1e-3, atol=4.5e-4)   # 2 Adam steps of <= lr = 1e-4 each;
+        # a gradient that is numerically zero takes either sign, so two runs can differ by 4 * lr there

@@ -83,7 +83,7 @@ class _KernelTimer:
             ms = sum(a.elapsed_time(b) for a, b, _ in v)
             nb = sum(n for _, _, n in v)
             rows.append({'entry': name, 'shape': list(shape) if shape else None, 'launches': len(v),
-                         'avg_us': round(ms * 1e3 / len(v), 2),
+                         'avg_us': round(ms * 1e3 / len(v), 2), 'total_us': ms * 1e3, 'total_bytes': nb,
                          'algorithmic_GBps': round(nb / (ms * 1e-3) / 1e9, 1) if ms > 0 and nb else None})
         rows.sort(key=lambda r: -r['avg_us'] * r['launches'])
         return rows
