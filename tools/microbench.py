@@ -1,5 +1,7 @@
 """Time individual HIP operators on the pyramid-level shapes of the 832x256, B=8 step (2B=16 for
-corr / feature warp).  GPU only.  python tools/microbench.py [op ...]"""
+corr / feature warp).  GPU only.  python tools/microbench.py [op ...]
+Backward figures go through torch.autograd.grad, i.e. they include ~40-60 us of host-side autograd dispatch when
+the kernel itself is shorter than that (the small loss kernels); bench.py's kernel_survey has the in-step times."""
 import os
 import sys
 import time
@@ -48,21 +50,32 @@ def corr(B=16, d=4):
             d, name, B, C, h, w, os.environ.get('UNFLOW_CORR_VARIANT', 'auto'), tf, fb / tf / 1e3, tb, bb / tb / 1e3), flush=True)
 
 
+def _smooth_flow(B, h, w):
+    """What a flow network produces: a translation plus low-frequency variation (neighbouring pixels land on
+    neighbouring source pixels).  The backward scatter merges adjacent taps in-wave; i.i.d. noise defeats that."""
+    yy, xx = torch.meshgrid(torch.arange(h, device='cuda', dtype=torch.float32),
+                            torch.arange(w, device='cuda', dtype=torch.float32), indexing='ij')
+    u = 2.3 + 1.5 * torch.sin(xx / 37.0) * torch.cos(yy / 23.0)
+    v = -1.1 + 0.8 * torch.cos(xx / 29.0 + yy / 41.0)
+    return torch.stack((u, v), 0)[None].repeat(B, 1, 1, 1).contiguous()
+
+
 def warp(B=16):
     for name, (C, h, w) in list(LEVELS.items())[:4]:
         x = torch.randn(B, C, h, w, device='cuda', requires_grad=True)
-        fl = (torch.randn(B, 2, h, w, device='cuda') * 2).requires_grad_()
         g = torch.randn(B, C, h, w, device='cuda')
-        tf = timeit(lambda: ops.warp_flow(x.detach(), fl.detach()))
-        y = ops.warp_flow(x, fl)
-        tb = timeit(lambda: torch.autograd.grad(y, (x, fl), g, retain_graph=True))
         fb, bb = 4 * B * h * w * (2 * C + 2), 4 * B * h * w * (3 * C + 4)
-        print('warp %s [%d,%d,%d,%d] fwd %7.1f us (%6.0f GB/s)   bwd %7.1f us (%6.0f GB/s)' % (
-            name, B, C, h, w, tf, fb / tf / 1e3, tb, bb / tb / 1e3), flush=True)
+        for kind, fl0 in (('smooth flow', _smooth_flow(B, h, w)), ('noise flow ', torch.randn(B, 2, h, w, device='cuda') * 2)):
+            fl = fl0.requires_grad_()
+            tf = timeit(lambda: ops.warp_flow(x.detach(), fl.detach()))
+            y = ops.warp_flow(x, fl)
+            tb = timeit(lambda: torch.autograd.grad(y, (x, fl), g, retain_graph=True))
+            print('warp %s [%d,%d,%d,%d] %s fwd %7.1f us (%6.0f GB/s)   bwd %7.1f us (%6.0f GB/s)' % (
+                name, B, C, h, w, kind, tf, fb / tf / 1e3, tb, bb / tb / 1e3), flush=True)
     for s in range(3):
         h, w = 256 >> s, 832 >> s
         x = torch.rand(8, 3, h, w, device='cuda')
-        fl = (torch.randn(8, 2, h, w, device='cuda') * 2).requires_grad_()
+        fl = _smooth_flow(8, h, w).requires_grad_()
         g = torch.randn(8, 3, h, w, device='cuda')
         tf = timeit(lambda: ops.warp_flow_masked(x, fl.detach()))
         y, _ = ops.warp_flow_masked(x, fl)
@@ -116,9 +129,12 @@ def prepare(B=8):
         print('prepare     [%d x %dx%dx3 u8] -> [%d,3,%d,%d] f32  %7.1f us (%6.0f GB/s algorithmic)' % (
             B, 3 * h, w, B, 3 * H, W, t, nbytes / t / 1e3), flush=True)
         imgs = [np.random.randint(0, 256, (3 * h, w, 3), dtype=np.uint8) for _ in range(B)]
+        staging = torch.empty(B * pad + 4096, dtype=torch.uint8).pin_memory()
+        ops.prepare_triplets(imgs, (H, W), None, 'cuda:0', True, staging)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(10):
-            ops.prepare_triplets(imgs, (H, W), None, 'cuda:0')
+            ops.prepare_triplets(imgs, (H, W), None, 'cuda:0', True, staging)
         torch.cuda.synchronize()
         print('  host-inclusive (pack + pinned H2D + kernel): %.2f ms per batch of %d' % ((time.perf_counter() - t0) * 100, B), flush=True)
 
