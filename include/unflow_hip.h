@@ -9,8 +9,9 @@
  * wraps them in torch.autograd.Function under the reference's own names.
  *
  * Conventions
- *   - every tensor is a dense fp32 NCHW device buffer (masks: uint8), caller-allocated;
- *     kernels never allocate, free or synchronise;
+ *   - every tensor is a dense fp32 NCHW device buffer (masks: uint8; the *_bf16 epilogue entries
+ *     and unflow_prepare_triplets state their own element types), caller-allocated; kernels never
+ *     allocate, free or synchronise;
  *   - `stream` is a hipStream_t (NULL = the default stream); work is only enqueued;
  *   - the return value is the hipError_t of the launch (0 = hipSuccess),
  *     UNFLOW_EINVAL (-22) for a bad argument (NULL pointer, non-positive size, d < 0);
