@@ -190,7 +190,10 @@ def main():
         corr_warp = {'bound': 'hbm', 'algorithmic_bytes_per_step': int(cw_bytes), 'us_per_step': round(cw_us, 1),
                      'achieved': round(cw_bytes / cw_us / 1e3, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': round(cw_bytes / cw_us / 1e3 / HBM_PEAK_GBS, 4),
-                     'launches_per_step': sum(r['launches'] for r in cw) / 3.0} if cw_us > 0 else None
+                     'launches_per_step': sum(r['launches'] for r in cw) / 3.0,
+                     'per_level': [{'entry': r['entry'], 'shape': r['shape'], 'avg_us': r['avg_us'],
+                                    'launches_per_step': r['launches'] / 3.0, 'algorithmic_GBps': r['algorithmic_GBps']}
+                                   for r in cw]} if cw_us > 0 else None
         for r in rows:
             r.pop('total_us'); r.pop('total_bytes')
             if r['algorithmic_GBps'] is not None:

@@ -119,6 +119,22 @@ def test_corr_d8_large_map_paths(ops, B, C, h, w):
     close(f2.grad, f2c.grad, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize('B,C,h,w', [(16, 128, 8, 26), (16, 196, 4, 13), (3, 5, 7, 11), (1, 2, 30, 34), (2, 1, 3, 3), (4, 128, 14, 32)])
+def test_corr_small_map_backward(ops, B, C, h, w):
+    """Levels 5 / 6 (832x256 and 1024x448) and ragged tiny maps: the whole-map backward kernel (a lane owns a pixel
+    and its 81 upstream gradients; channel chunks over workgroups; odd channel counts, several pixel blocks)."""
+    f1c, f2c = rnd(20, (B, C, h, w)).requires_grad_(), rnd(21, (B, C, h, w)).requires_grad_()
+    cv_ref = R.corr_naive(f1c, f2c, 4)
+    gout = rnd(22, tuple(cv_ref.shape))
+    cv_ref.backward(gout)
+    f1, f2 = dev(f1c.detach()).requires_grad_(), dev(f2c.detach()).requires_grad_()
+    cv = ops.corr(f1, f2, 4)
+    close(cv, cv_ref, rtol=1e-5, atol=2e-6)
+    cv.backward(dev(gout))
+    close(f1.grad, f1c.grad, rtol=1e-5, atol=5e-6)
+    close(f2.grad, f2c.grad, rtol=1e-5, atol=5e-6)
+
+
 def test_corr_shape_mismatch_asserts(ops):
     with pytest.raises(AssertionError):                       # pwc_tf.py:99
         ops.corr(torch.zeros(1, 2, 4, 4, device='cuda'), torch.zeros(1, 2, 4, 5, device='cuda'))

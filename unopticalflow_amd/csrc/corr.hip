@@ -751,6 +751,97 @@ int launch_bwd_gs(const float* f1, const float* f2, const float* g, float* gf1, 
     return unflow_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small-map backward (pyramid levels 5, 6: 8x26 and 4x13 pixels, 128-196 channels).  Too few pixels
+// for the tile kernels (16 samples x 1 tile), and the per-element kernel re-reads 2*DD*DD gradient
+// values per output.  Here a lane owns one pixel of the WHOLE map and keeps its DD*DD upstream
+// gradients in registers (mode 1: gathered at the displaced positions, planes flipped); a workgroup =
+// PXL pixels x CSUB channel phases of one (sample, channel chunk, mode); the chunk's F planes sit
+// zero-padded in LDS, so the DD*DD taps of a lane are stride-1 LDS reads and need no bounds checks.
+// grid (pixel blocks, channel chunks, 2*B).
+// ---------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256, 3) void corr_bwd_small_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                             const float* __restrict__ g, float* __restrict__ gf1,
+                                                             float* __restrict__ gf2, int C, int H, int W, int pxl,
+                                                             int cch, float inv_c) {
+    constexpr int DD = 2 * R + 1;
+    extern __shared__ float planes[];                  // cch x (H+2R) x (W+2R), zero padded
+    const int mode = blockIdx.z & 1, b = blockIdx.z >> 1;
+    const float* __restrict__ F = mode ? f1 : f2;
+    float* __restrict__ out = mode ? gf2 : gf1;
+    const int PH = H + 2 * R, PW = W + 2 * R, plane = H * W, pplane = PH * PW;
+    const int csub = 256 / pxl;                        // channel phases per workgroup
+    const int lp = threadIdx.x % pxl, cs = threadIdx.x / pxl;
+    const int q = blockIdx.x * pxl + lp;               // this lane's pixel
+    const bool live = q < plane;
+    const int y = live ? q / W : 0, x = live ? q - y * W : 0;
+    const int c0 = blockIdx.y * cch;
+
+    float wr[DD][DD];
+    const float* gb = g + (size_t)b * DD * DD * plane;
+#pragma unroll
+    for (int i = 0; i < DD; ++i)
+#pragma unroll
+        for (int j = 0; j < DD; ++j) {
+            const int sy = mode ? y + i - R : y, sx = mode ? x + j - R : x;
+            const int pl = mode ? (2 * R - i) * DD + (2 * R - j) : i * DD + j;
+            const bool ok = live && sy >= 0 && sy < H && sx >= 0 && sx < W;
+            const float* src = ok ? gb + (size_t)pl * plane + sy * W + sx : kZeroLine;   // validity folded into the address
+            wr[i][j] = *src * inv_c;
+        }
+
+    // stage the chunk's planes (zero padded); F[c][yy][xx] lands at planes[c][yy+R][xx+R]
+    const int nch = min(cch, C - c0);
+#pragma unroll 4
+    for (int e = threadIdx.x; e < cch * pplane; e += 256) {
+        const int c = e / pplane, r = e - c * pplane;
+        const int yy = r / PW - R, xx = r - (r / PW) * PW - R;
+        float v = 0.f;
+        if (c < nch && yy >= 0 && yy < H && xx >= 0 && xx < W) v = F[((size_t)(b * C + c0 + c)) * plane + yy * W + xx];
+        planes[e] = v;
+    }
+    __syncthreads();
+    if (!live) return;
+    for (int c = cs; c < nch; c += csub) {
+        const float* p = planes + c * pplane + y * PW + x;       // tap (i, j) at p[i * PW + j]
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < DD; ++i) {
+#pragma unroll
+            for (int j = 0; j < DD; ++j) {
+                if ((i * DD + j) & 1) a1 = fmaf(wr[i][j], p[i * PW + j], a1);
+                else a0 = fmaf(wr[i][j], p[i * PW + j], a0);
+            }
+            __builtin_amdgcn_sched_barrier(0);           // one tap row in flight at a time: the DD*DD gradients own the registers
+        }
+        out[((size_t)(b * C + c0 + c)) * plane + q] = a0 + a1;
+    }
+}
+
+// 0 = not applicable (map too large / LDS would not fit a useful chunk)
+template <int R>
+int launch_bwd_small(const float* f1, const float* f2, const float* g, float* gf1, float* gf2,
+                     int B, int C, int H, int W, hipStream_t s, bool* launched) {
+    *launched = false;
+    const int plane = H * W, pplane = (H + 2 * R) * (W + 2 * R);
+    if (plane > 1024 || B > 32767) return 0;
+    int pxl = 32;
+    while (pxl < plane && pxl < 256) pxl <<= 1;
+    const int csub = 256 / pxl;
+    // few channels per workgroup: these maps are tiny, so the launch wants many short workgroups (the per-lane
+    // gradient gather is repeated per chunk, out of L2) rather than a long serial channel loop
+    // aim at ~1024 workgroups (4 per CU): levels 5 / 6 of the 832x256 step get 4 / 8 channels per workgroup
+    int cch = ceil_div(ceil_div(C * 2 * B * ceil_div(plane, pxl), 1024), csub) * csub;
+    if ((size_t)cch * pplane * sizeof(float) > 40 * 1024) cch = (int)(40 * 1024 / sizeof(float) / pplane) / csub * csub;
+    if (cch < csub || cch < 1) return 0;
+    dim3 grid(ceil_div(plane, pxl), ceil_div(C, cch), 2 * B);
+    hipLaunchKernelGGL((corr_bwd_small_kernel<R>), grid, dim3(256), (size_t)cch * pplane * sizeof(float), s,
+                       f1, f2, g, gf1, gf2, C, H, W, pxl, cch, 1.0f / C);
+    *launched = true;
+    return unflow_launch_status();
+}
+
 // ---- any-radius fallback (one thread per output element, direct global reads) ----
 __global__ void corr_fwd_generic(const float* __restrict__ f1, const float* __restrict__ f2,
                                  float* __restrict__ cv, int B, int C, int H, int W, int R, float inv_c) {
@@ -902,6 +993,11 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 if (variant == 1 || variant == 7) return launch_bwd<4, 2, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (variant == 2 || variant == 3 || (variant == 9 && (long)B * H * W >= 32768))
                     return launch_bwd<4, 1, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                if (forced_bwd() != 2) {                 // small maps (levels 5, 6): whole-map kernel; UNFLOW_CORR_BWD=2: per-element
+                    bool launched = false;
+                    const int rc = launch_bwd_small<4>(f1, f2, gcv, gf1, gf2, B, C, H, W, s, &launched);
+                    if (launched) return rc;
+                }
                 break;
         case 8: variant = pick_variant(B, C, H, W);
                 if (variant == 4 || (long)B * H * W < 8192) break;      // small maps: one lane per element (117 / 57 us at levels 5 / 6, tile kernel 283 / 378)
