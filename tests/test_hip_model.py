@@ -47,7 +47,8 @@ def test_module_128_golden(golden, ac):
     with torch.no_grad():
         feats = model.fpyramid(img)
         close(feats[4], g['feat5' + tag], rtol=1e-4, atol=1e-5); close(feats[5], g['feat6' + tag], rtol=1e-4, atol=1e-5)
-        fb, ff = model._flows(imgl, img, imgr)
+        stacked = model._flows(imgl, img, imgr)              # per scale [2B,2,h,w] = (centre->left | centre->right)
+        fb, ff = [f[:B] for f in stacked], [f[B:] for f in stacked]
         for s in range(4):
             st = 1 if s >= 1 else 8
             scale = np.abs(g['flow_fwd%d%s' % (s, tag)]).max()

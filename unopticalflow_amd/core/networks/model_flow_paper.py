@@ -140,20 +140,21 @@ class Model_flow(nn.Module):
         return torch.autocast('cuda', dtype=torch.bfloat16, enabled=(self.precision == 'bf16'))
 
     def _flows(self, imgl, img, imgr, frames=None):
-        """Both directed flow pyramids with one 3B pyramid pass and one 2B decoder pass."""
+        """Both directed flow pyramids with one 3B pyramid pass and one 2B decoder pass.  ``frames`` is the
+        [3B,3,H,W] batch ordered (left, right, centre), so the decoder's second inputs (left | right) are a view of
+        the pyramid output; returns per scale the stacked flows [2B,2,h,w] = (centre->left | centre->right)."""
         B, _, img_h, img_w = img.shape
         if frames is None:
-            frames = torch.cat((imgl, img, imgr), 0)
+            frames = torch.cat((imgl, imgr, img), 0)
         with self._autocast():
             feats = self.fpyramid(frames)                                    # [3B, ...] per level
-            # the decoder never reads pyramid level 1 (pwc_tf.py:108-179 uses c12..c16 / c22..c26): no copy for it
+            # the decoder never reads pyramid level 1 (pwc_tf.py:108-179 uses c12..c16 / c22..c26): nothing built for it.
             # split (not slices): its backward is one cat, a slice's is a zero-fill + copy + add of the whole 3B map
-            parts = [f.split(B) for f in feats[1:]]                          # (left, centre, right)
-            feat_c2 = [None] + [torch.cat((c, c), 0) for _, c, _ in parts]
-            feat_lr = [None] + [torch.cat((l, r), 0) for l, _, r in parts]
+            parts = [f.split((2 * B, B)) for f in feats[1:]]                 # (left | right), centre
+            feat_lr = [None] + [lr for lr, _ in parts]
+            feat_c2 = [None] + [torch.cat((c, c), 0) for _, c in parts]
             flows = self.pwc_model(feat_c2, feat_lr, [img_h, img_w])         # [2B, 2, h, w] per scale
-        halves = [f.float().split(B) for f in flows]
-        return [h[0] for h in halves], [h[1] for h in halves]            # bwd (centre->left), fwd
+        return [f.float() for f in flows]
 
     def forward(self, inputs, output_flow=False, use_flow_loss=True, is_second_phase=False):
         images = inputs
@@ -162,25 +163,30 @@ class Model_flow(nn.Module):
         imgl, img, imgr = images[:, :, :img_h, :], images[:, :, img_h:2 * img_h, :], images[:, :, 2 * img_h:3 * img_h, :]
 
         B = images.shape[0]
-        # the three frames as one contiguous [3B,3,H,W] batch (left, centre, right): feeds the 3B
-        # pyramid pass and, through one HIP pooling kernel, all three image pyramids
-        frames = images[:, :, :3 * img_h].reshape(B, 3, 3, img_h, img_w).permute(2, 0, 1, 3, 4).reshape(3 * B, 3, img_h, img_w)
-        optical_flows_bwd, optical_flows_fwd = self._flows(imgl, img, imgr, frames)
+        # the three frames as one contiguous [3B,3,H,W] batch (left, right, centre): feeds the 3B pyramid pass and,
+        # through one HIP pooling kernel, all three image pyramids; (left | right) stay adjacent so both warp
+        # directions of a scale run as ONE 2B launch
+        frames = images[:, :, :3 * img_h].reshape(B, 3, 3, img_h, img_w).permute(2, 0, 1, 3, 4)[[0, 2, 1]] \
+            .reshape(3 * B, 3, img_h, img_w)
+        flows_lr = self._flows(imgl, img, imgr, frames)
+        halves = [f.split(B) for f in flows_lr]
+        optical_flows_bwd, optical_flows_fwd = [h[0] for h in halves], [h[1] for h in halves]   # centre->left, centre->right
 
         loss_pack = {}
         n = self.num_scales          # the reference also builds the unused 4th level
         if n <= 3 and img_h % 4 == 0 and img_w % 4 == 0:
             scales = (frames.detach(),) + ops.img_pyramid(frames)
-            imgl_pyramid = [t[:B] for t in scales[:n]]
-            img_pyramid = [t[B:2 * B] for t in scales[:n]]
-            imgr_pyramid = [t[2 * B:] for t in scales[:n]]
+            imglr_pyramid = [t[:2 * B] for t in scales[:n]]
+            img_pyramid = [t[2 * B:] for t in scales[:n]]
         else:
-            imgl_pyramid = self.generate_img_pyramid(imgl, n)
+            pl, pr = self.generate_img_pyramid(imgl, n), self.generate_img_pyramid(imgr, n)
+            imglr_pyramid = [torch.cat((a, b), 0) for a, b in zip(pl, pr)]
             img_pyramid = self.generate_img_pyramid(img, n)
-            imgr_pyramid = self.generate_img_pyramid(imgr, n)
 
-        img_warped_pyramid_from_l = self.warp_flow_pyramid(imgl_pyramid, optical_flows_bwd)
-        img_warped_pyramid_from_r = self.warp_flow_pyramid(imgr_pyramid, optical_flows_fwd)
+        # warp_flow_pyramid(imgl, flows_bwd) and (imgr, flows_fwd) (reference :221-222) as one 2B call per scale
+        warped = [w.split(B) for w in self.warp_flow_pyramid(imglr_pyramid, flows_lr)]
+        img_warped_pyramid_from_l = [w[0] for w in warped]
+        img_warped_pyramid_from_r = [w[1] for w in warped]
 
         diff_bwd, diff_fwd, weight_bwd, weight_fwd = self.compute_diff_weight(
             img_warped_pyramid_from_l, img_pyramid, img_warped_pyramid_from_r)
