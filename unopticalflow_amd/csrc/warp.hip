@@ -181,7 +181,7 @@ extern "C" int unflow_warp_fwd(const float* src, const float* flow, float* out, 
     if (C <= 4) {
         if (mask) hipLaunchKernelGGL((warp_fwd_kernel<1, true>), grid, dim3(64, 1), 0, s, src, flow, out, mask, C, H, W, ac);
         else      hipLaunchKernelGGL((warp_fwd_kernel<1, false>), grid, dim3(64, 1), 0, s, src, flow, out, mask, C, H, W, ac);
-    } else if ((long)grid.x * H * B < 1024 && C >= 64) {      // small maps: more channel phases per workgroup
+    } else if ((long)grid.x * H * B < 4096 && C >= 64) {      // small maps: more channel phases per workgroup
         if (mask) hipLaunchKernelGGL((warp_fwd_kernel<16, true>), grid, dim3(64, 16), 0, s, src, flow, out, mask, C, H, W, ac);
         else      hipLaunchKernelGGL((warp_fwd_kernel<16, false>), grid, dim3(64, 16), 0, s, src, flow, out, mask, C, H, W, ac);
     } else {
@@ -205,7 +205,7 @@ extern "C" int unflow_warp_bwd(const float* src, const float* flow, const float*
 #define LAUNCH(NY, M, G) hipLaunchKernelGGL((warp_bwd_kernel<NY, M, G>), grid, dim3(64, NY), 0, s, src, flow, gout, mask, gsrc, gflow, C, H, W, ac)
     // few pixels, many channels (pyramid levels 4-6): 16 channel phases per workgroup instead of 4 -- the launch
     // has too few pixel rows to fill the chip, and the per-wave channel loop is a serial chain of atomics
-    const bool small_map = (long)grid.x * H * B < 1024 && C >= 64;
+    const bool small_map = (long)grid.x * H * B < 4096 && C >= 64;
     if (C <= 4) {
         if (mask) { if (gsrc) LAUNCH(1, true, true); else LAUNCH(1, true, false); }
         else      { if (gsrc) LAUNCH(1, false, true); else LAUNCH(1, false, false); }
