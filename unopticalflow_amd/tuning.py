@@ -10,9 +10,13 @@ solver -> measured ms per conv config, produced by ``tools/gpu_find.sh``), and p
 
 sets MIOPEN_USER_DB_PATH (unless the user already did) and ``torch.backends.cudnn.benchmark``.
 Configs that are not in the shipped db (other resolutions / batch sizes) make MIOpen run its find
-once (minutes on first use) and append to the db.
+once (minutes on first use) and append to the db.  With several ranks per node every process works on a
+private copy of the shipped files (removed at exit), so no two processes ever append to the same file.
 """
+import atexit
 import os
+import shutil
+import tempfile
 
 import torch
 
@@ -20,6 +24,21 @@ DB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'miopen_db')
 
 
 def enable_miopen_tuning(benchmark=True):
-    os.environ.setdefault('MIOPEN_USER_DB_PATH', DB_DIR)
+    if 'MIOPEN_USER_DB_PATH' not in os.environ:
+        path = DB_DIR
+        if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+            path = tempfile.mkdtemp(prefix='unflow_miopen_rank%s_' % os.environ.get('RANK', '0'))
+            for name in os.listdir(DB_DIR):
+                shutil.copy(os.path.join(DB_DIR, name), path)
+            atexit.register(shutil.rmtree, path, ignore_errors=True)
+        os.environ['MIOPEN_USER_DB_PATH'] = path
+    # The db files are keyed by architecture + CU count ("gfx950100" = gfx950, 0x100 CUs).  On a device the shipped db
+    # does not cover (another partition mode / SKU) benchmark mode would start an exhaustive find of ~140 configs
+    # (>10 min): stay on MIOpen's immediate-mode heuristics there (~5 % slower) unless the user insists.
+    if benchmark and torch.cuda.is_available() and os.environ.get('UNFLOW_MIOPEN_FORCE_FIND') != '1':
+        prop = torch.cuda.get_device_properties(torch.cuda.current_device())
+        key = '%s%x' % (prop.gcnArchName.split(':')[0], prop.multi_processor_count)
+        if not any(n.startswith(key) for n in os.listdir(os.environ['MIOPEN_USER_DB_PATH'])):
+            benchmark = False
     torch.backends.cudnn.benchmark = bool(benchmark)
     return os.environ['MIOPEN_USER_DB_PATH']
