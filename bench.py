@@ -111,9 +111,15 @@ def main():
     import types
 
     _lib.load()                                   # no HIP library -> fail loudly, never fall back
-    rank, local_rank, world = init_distributed('nccl')
+    # one rank per GPU over RCCL.  UNFLOW_BENCH_ONE_GPU=1 is a rehearsal mode for boxes with a single GPU: every rank
+    # shares device 0 and the collectives go through gloo (RCCL refuses two ranks on one device) -- it exercises the
+    # multi-rank plumbing, its numbers mean nothing.
+    one_gpu = os.environ.get('UNFLOW_BENCH_ONE_GPU') == '1'
+    rank, local_rank, world = init_distributed('gloo' if one_gpu else 'nccl')
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
