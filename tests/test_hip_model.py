@@ -226,3 +226,28 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     for a, b in zip(got['params'], model.parameters()):
         np.testing.assert_allclose(a.numpy(), b.detach().cpu().numpy(), rtol=1e-3, atol=4.5e-4)   # 2 Adam steps of <= lr = 1e-4 each;
         # a gradient that is numerically zero takes either sign, so two runs can differ by 4 * lr there
+
+
+def test_hipgraph_replay_matches_eager():
+    """trainer.FlowTrainer(use_graph=True): the whole step (forward, losses, backward, Adam) captured once and
+    replayed -- nothing in the step may allocate index tensors or synchronise.  Same losses as the eager trainer."""
+    from unopticalflow_amd import get_model
+    from unopticalflow_amd.trainer import FlowTrainer
+    cfg = R.default_cfg()
+    sd = R.seeded_state_dict(R.Model_flow(cfg), 1234, 0.25)
+    xs = [R.synthetic_triplets(2, 64, 128, seed=s, structured=True).cuda() for s in (1, 2, 3)]
+    out = {}
+    for mode in (False, True):
+        model = get_model('flow')(cfg).cuda()
+        model.load_state_dict(sd)
+        tr = FlowTrainer(cfg, model, use_graph=mode)
+        if mode:                       # the graph is built from the first batch after 3 warm-up steps on it: rewind
+            tr._build_graph(xs[0])
+            model.load_state_dict(sd)
+            for st in tr.optimizer.state.values():      # the graph holds these very tensors: reset them in place
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        out[mode] = [float(tr.step(x)[0]) for x in xs]
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-4)
+    np.testing.assert_allclose(out[True], out[False], rtol=5e-3)        # later steps: after (re-started) Adam updates

@@ -166,8 +166,9 @@ class Model_flow(nn.Module):
         # the three frames as one contiguous [3B,3,H,W] batch (left, right, centre): feeds the 3B pyramid pass and,
         # through one HIP pooling kernel, all three image pyramids; (left | right) stay adjacent so both warp
         # directions of a scale run as ONE 2B launch
-        frames = images[:, :, :3 * img_h].reshape(B, 3, 3, img_h, img_w).permute(2, 0, 1, 3, 4)[[0, 2, 1]] \
-            .reshape(3 * B, 3, img_h, img_w)
+        # (no index tensors here: the step must stay capturable as a hipGraph)
+        v = images[:, :, :3 * img_h].reshape(B, 3, 3, img_h, img_w)
+        frames = torch.cat((v[:, :, 0], v[:, :, 2], v[:, :, 1]), 0)
         flows_lr = self._flows(imgl, img, imgr, frames)
         halves = [f.split(B) for f in flows_lr]
         optical_flows_bwd, optical_flows_fwd = [h[0] for h in halves], [h[1] for h in halves]   # centre->left, centre->right

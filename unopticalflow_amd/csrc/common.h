@@ -12,6 +12,26 @@ static inline int unflow_launch_status() { return (int)hipGetLastError(); }
 
 __host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Zero-fill as a kernel launch (not hipMemsetAsync): every piece of work of an entry point is then an ordinary
+// kernel node when the caller captures the stream into a hipGraph.  n floats, p 4-byte aligned.
+__global__ static void unflow_zero_kernel(float* __restrict__ p, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if ((((size_t)p) & 15) == 0) {
+        float4* p4 = reinterpret_cast<float4*>(p);
+        const size_t n4 = n >> 2;
+        for (size_t k = i; k < n4; k += stride) p4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (size_t k = (n4 << 2) + i; k < n; k += stride) p[k] = 0.f;
+    } else {
+        for (size_t k = i; k < n; k += stride) p[k] = 0.f;
+    }
+}
+static inline void unflow_zero_async(float* p, size_t n, hipStream_t s) {
+    const size_t want = (n / 4 + 255) / 256;
+    const int blocks = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+    hipLaunchKernelGGL(unflow_zero_kernel, dim3(blocks), dim3(256), 0, s, p, n);
+}
+
 // 64-lane butterfly sum (DPP/ds_swizzle shuffles, no LDS).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -901,12 +901,9 @@ int launch_bwd(const float* f1, const float* f2, const float* g, float* gf1, flo
                int B, int C, int H, int W, hipStream_t s) {
     using K = CorrCfg<R, PX, DG, CC>;
     dim3 grid(ceil_div(W, K::TW), ceil_div(H, TY), B * K::NG);
-    if (K::NG > 1) {
-        const size_t bytes = (size_t)B * C * H * W * sizeof(float);
-        hipError_t e = hipMemsetAsync(gf1, 0, bytes, s);
-        if (e != hipSuccess) return (int)e;
-        e = hipMemsetAsync(gf2, 0, bytes, s);
-        if (e != hipSuccess) return (int)e;
+    if (K::NG > 1) {                                      // row groups add their partial gradients atomically
+        unflow_zero_async(gf1, (size_t)B * C * H * W, s);
+        unflow_zero_async(gf2, (size_t)B * C * H * W, s);
     }
     hipLaunchKernelGGL((corr_bwd_kernel<R, PX, DG, CC, 0>), grid, dim3(256), 0, s, f2, g, gf1, C, H, W, 1.0f / C);
     hipLaunchKernelGGL((corr_bwd_kernel<R, PX, DG, CC, 1>), grid, dim3(256), 0, s, f1, g, gf2, C, H, W, 1.0f / C);

@@ -196,10 +196,7 @@ extern "C" int unflow_warp_bwd(const float* src, const float* flow, const float*
                                void* stream) {
     UNFLOW_REQUIRE(src && flow && gout && gflow && B > 0 && C > 0 && H > 0 && W > 0);
     hipStream_t s = (hipStream_t)stream;
-    if (gsrc) {
-        hipError_t e = hipMemsetAsync(gsrc, 0, (size_t)B * C * H * W * sizeof(float), s);
-        if (e != hipSuccess) return (int)e;
-    }
+    if (gsrc) unflow_zero_async(gsrc, (size_t)B * C * H * W, s);
     dim3 grid(ceil_div(W, 64), H, B);
     const int ac = align_corners ? 1 : 0;
 #define LAUNCH(NY, M, G) hipLaunchKernelGGL((warp_bwd_kernel<NY, M, G>), grid, dim3(64, NY), 0, s, src, flow, gout, mask, gsrc, gflow, C, H, W, ac)
