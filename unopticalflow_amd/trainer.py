@@ -88,8 +88,8 @@ class FlowTrainer:
     def step(self, inputs):
         """One optimisation step on this rank's shard.  Returns (loss, loss_pack) (detached)."""
         self.model.train()
-        if self.use_graph:
-            return self._graph_step(inputs)
+        if self.use_graph and (self._graph is None or inputs.shape == self._static_in.shape):
+            return self._graph_step(inputs)          # (a ragged last batch of an epoch falls through to the eager step)
         self.grads.zero()
         loss_pack = self.model(inputs)
         loss = self.total_loss(loss_pack)
