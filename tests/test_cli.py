@@ -67,6 +67,11 @@ def test_train_resume_and_test_cli(tmp_path, host_input, capsys):
         trainer2 = train_cli.main(common + ['--resume', '--iter_start', '2'])
         assert 'iter: 5, loss_pixel:' in capsys.readouterr().out
         assert all(torch.isfinite(p).all() for p in trainer2.model.parameters())
+        # --flow_pretrained_model (train.py:47-61): weights only, fresh optimizer, DataParallel-prefixed keys accepted
+        ck['model_state_dict'] = {'module.' + k: v for k, v in ck['model_state_dict'].items()}
+        torch.save(ck, os.path.join(root, 'published.pth'))
+        trainer3 = train_cli.main(common + ['--flow_pretrained_model', os.path.join(root, 'published.pth'), '--num_iterations', '2'])
+        assert 'Load Flow Pretrained Model' in capsys.readouterr().out and trainer3.iteration == 2
         # test.py on the saved checkpoint (synthetic task: no dataset needed)
         res = test_cli.main(['-c', cfg, '--gpu', '0', '--mode', 'flow', '--task', 'synthetic_flow',
                              '--pretrained_model', os.path.join(mdir, 'last.pth')])
