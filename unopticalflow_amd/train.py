@@ -44,7 +44,7 @@ def train(cfg):
         enable_miopen_tuning()
         if rank == 0 and tuple(cfg.img_hw) not in ((256, 832), (448, 1024)):
             print('MIOpen find mode: the shipped find-db covers 832x256 (bs 8/GPU) and 1024x448 (bs 4/GPU); other shapes are '
-                  'measured once during the first iterations (several minutes) -- pass --miopen_find 0 to skip that.', flush=True)
+                  'measured once during the first iterations (20+ minutes for a full-size shape) -- pass --miopen_find 0 to skip that.', flush=True)
     model = get_model(cfg.mode)(cfg).to(dev)
     trainer = FlowTrainer(cfg, model, distributed=(world > 1), use_graph=bool(getattr(cfg, 'graph', 0)))
     if cfg.resume:                                                     # train.py:42-46

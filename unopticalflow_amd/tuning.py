@@ -10,7 +10,7 @@ solver -> measured ms per conv config, produced by ``tools/gpu_find.sh``), and p
 
 sets MIOPEN_USER_DB_PATH (unless the user already did) and ``torch.backends.cudnn.benchmark``.
 Configs that are not in the shipped db (other resolutions / batch sizes) make MIOpen run its find
-once (minutes on first use) and append to the db.  With several ranks per node every process works on a
+once (20+ minutes on first use for a full-size resolution: ~140 conv configs) and append to the db.  With several ranks per node every process works on a
 private copy of the shipped files (removed at exit), so no two processes ever append to the same file.
 """
 import atexit
