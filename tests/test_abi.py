@@ -107,3 +107,25 @@ def test_c_program_links_against_the_abi(tmp_path):
                         '-Wl,-rpath,' + os.path.join(ROOT, 'unopticalflow_amd'), '-o', exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert os.path.exists(exe)
+
+
+def test_miopen_tuning_paths(monkeypatch):
+    """tuning.enable_miopen_tuning: in-tree find-db for a single process, a private copy per rank otherwise (no two
+    processes append to the same file); a user-provided MIOPEN_USER_DB_PATH is left alone."""
+    import torch
+    from unopticalflow_amd import tuning
+    saved = torch.backends.cudnn.benchmark
+    try:
+        monkeypatch.delenv('MIOPEN_USER_DB_PATH', raising=False)
+        monkeypatch.delenv('WORLD_SIZE', raising=False)
+        assert tuning.enable_miopen_tuning() == tuning.DB_DIR and torch.backends.cudnn.benchmark
+        shipped = sorted(os.listdir(tuning.DB_DIR))
+        assert any(n.endswith('.ufdb.txt') for n in shipped) and any(n.endswith('.udb.txt') for n in shipped)
+        monkeypatch.delenv('MIOPEN_USER_DB_PATH', raising=False)
+        monkeypatch.setenv('WORLD_SIZE', '8'); monkeypatch.setenv('RANK', '3')
+        private = tuning.enable_miopen_tuning()
+        assert private != tuning.DB_DIR and 'rank3' in private and sorted(os.listdir(private)) == shipped
+        monkeypatch.setenv('MIOPEN_USER_DB_PATH', '/some/where')
+        assert tuning.enable_miopen_tuning(benchmark=False) == '/some/where' and not torch.backends.cudnn.benchmark
+    finally:
+        torch.backends.cudnn.benchmark = saved
