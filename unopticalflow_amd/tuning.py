@@ -24,7 +24,8 @@ DB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'miopen_db')
 
 
 def enable_miopen_tuning(benchmark=True):
-    if 'MIOPEN_USER_DB_PATH' not in os.environ:
+    ours = 'MIOPEN_USER_DB_PATH' not in os.environ          # a user-provided db path is the user's business
+    if ours:
         path = DB_DIR
         if int(os.environ.get('WORLD_SIZE', '1')) > 1:
             path = tempfile.mkdtemp(prefix='unflow_miopen_rank%s_' % os.environ.get('RANK', '0'))
@@ -35,7 +36,7 @@ def enable_miopen_tuning(benchmark=True):
     # The db files are keyed by architecture + CU count ("gfx950100" = gfx950, 0x100 CUs).  On a device the shipped db
     # does not cover (another partition mode / SKU) benchmark mode would start an exhaustive find of ~140 configs
     # (>10 min): stay on MIOpen's immediate-mode heuristics there (~5 % slower) unless the user insists.
-    if benchmark and torch.cuda.is_available() and os.environ.get('UNFLOW_MIOPEN_FORCE_FIND') != '1':
+    if ours and benchmark and torch.cuda.is_available() and os.environ.get('UNFLOW_MIOPEN_FORCE_FIND') != '1':
         prop = torch.cuda.get_device_properties(torch.cuda.current_device())
         key = '%s%x' % (prop.gcnArchName.split(':')[0], prop.multi_processor_count)
         if not any(n.startswith(key) for n in os.listdir(os.environ['MIOPEN_USER_DB_PATH'])):
