@@ -11,11 +11,19 @@ synthetic KITTI-sized triplets [8,3,768,832] fp32 already resident in HBM (BASEL
 832x256, bs=8 per GPU, fp32; weak scaling: the per-GPU batch is fixed).  pairs/s = 2 * triplets/s.
 
 The single JSON line also carries
-  roofline:     the dominant hand-written kernel (cost-volume forward, wide-tile variant used
-                at pyramid levels 2 and 3): algorithmic bytes 4*B*n*(2C+81) per launch over its
-                mean launch duration, HIP events on the launch stream inside the timed steps;
+  roofline:     the dominant hand-written kernel (cost-volume forward at pyramid level 2, the LDS-DMA
+                ring kernel): algorithmic bytes 4*B*n*(2C+81) per launch over its mean launch duration,
+                HIP events on the launch stream inside the timed steps; traffic = HBM bytes per launch
+                from the PMC passes committed under profiles/;
   cpu_baseline: the CPU oracle (oracle/ref_cpu.py, the restatement of the reference's op graph,
-                kind "port") timed on the host cores of this box on a bounded sample.
+                kind "port") timed on the host cores of this box on a bounded sample (all cores the
+                cgroup allows, plus a one-thread figure);
+  conv_stack:   convolution FLOPs of the step / whole step time / dense MFMA peak of the dtype: a lower
+                bound on the conv stacks' MFMA utilisation;
+  corr_warp_all_levels, kernel_survey (N = 1 only, 3 extra untimed steps with HIP events around every C
+                entry point): all cost-volume + warp launches as one HBM-roofline figure with a per-level
+                table, and the 14 heaviest entry points.
+UNFLOW_BENCH_ONE_GPU=1 is a rehearsal mode for a single-GPU box (all ranks on device 0, gloo).
 """
 import argparse
 import json
