@@ -110,21 +110,33 @@ def test_c_program_links_against_the_abi(tmp_path):
 
 
 def test_miopen_tuning_paths(monkeypatch):
-    """tuning.enable_miopen_tuning: in-tree find-db for a single process, a private copy per rank otherwise (no two
-    processes append to the same file); a user-provided MIOPEN_USER_DB_PATH is left alone."""
+    """tuning.enable_miopen_tuning: every process gets a private copy of the shipped find-db (the package directory is
+    never written); find mode only when the shipped files are named for this device AND this MIOpen build; a
+    user-provided MIOPEN_USER_DB_PATH is left alone."""
     import torch
     from unopticalflow_amd import tuning
     saved = torch.backends.cudnn.benchmark
     try:
-        monkeypatch.delenv('MIOPEN_USER_DB_PATH', raising=False)
-        monkeypatch.delenv('WORLD_SIZE', raising=False)
-        assert tuning.enable_miopen_tuning() == tuning.DB_DIR and torch.backends.cudnn.benchmark
         shipped = sorted(os.listdir(tuning.DB_DIR))
         assert any(n.endswith('.ufdb.txt') for n in shipped) and any(n.endswith('.udb.txt') for n in shipped)
         monkeypatch.delenv('MIOPEN_USER_DB_PATH', raising=False)
-        monkeypatch.setenv('WORLD_SIZE', '8'); monkeypatch.setenv('RANK', '3')
+        monkeypatch.delenv('UNFLOW_MIOPEN_FORCE_FIND', raising=False)
         private = tuning.enable_miopen_tuning()
-        assert private != tuning.DB_DIR and 'rank3' in private and sorted(os.listdir(private)) == shipped
+        assert private != tuning.DB_DIR and os.path.dirname(private) != os.path.dirname(tuning.DB_DIR)
+        assert sorted(os.listdir(private)) == shipped
+        assert not torch.backends.cudnn.benchmark          # no GPU here: the device key cannot match
+        monkeypatch.delenv('MIOPEN_USER_DB_PATH', raising=False)
+        other = tuning.enable_miopen_tuning()
+        assert other != private                             # one copy per call / process, never shared
+        # the name check: device key + MIOpen build tag must both match a shipped file
+        dev_key, tag = shipped[0].split('.HIP.')[0], 'HIP.' + shipped[0].split('.HIP.')[1].rsplit('.', 2)[0]
+        assert tuning.shipped_db_matches(dev_key, tag)
+        assert not tuning.shipped_db_matches(dev_key, tag + 'x')             # another MIOpen build
+        assert not tuning.shipped_db_matches(dev_key, 'HIP.3_5_1_5b515cf1bc')
+        assert not tuning.shipped_db_matches('gfx95080', tag)                # another partition mode
+        assert not tuning.shipped_db_matches(None, tag) and not tuning.shipped_db_matches(dev_key, None)
+        t = tuning.loaded_miopen_db_tag()                   # torch's own libMIOpen is mapped in this process
+        assert t is None or t.startswith('HIP.')
         monkeypatch.setenv('MIOPEN_USER_DB_PATH', '/some/where')
         assert tuning.enable_miopen_tuning(benchmark=False) == '/some/where' and not torch.backends.cudnn.benchmark
     finally:

@@ -11,6 +11,12 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unopticalflow_amd import ops, _lib   # noqa: E402
 
+if os.environ.get('UNFLOW_MICROBENCH_TUNING') == '1':
+    # the tuning build (python -m unopticalflow_amd.build --tuning): same kernels + the environment-driven variant
+    # switches the sweeps below flip; the shipped library has none
+    from unopticalflow_amd import build as _build
+    _lib.LIB_PATH = _build.LIB_TUNING
+
 LEVELS = {'L2': (32, 64, 208), 'L3': (64, 32, 104), 'L4': (96, 16, 52), 'L5': (128, 8, 26), 'L6': (196, 4, 13)}
 
 
@@ -83,6 +89,111 @@ def warp(B=16):
         fb, bb = 8 * h * w * 33, 4 * 8 * h * w * 10
         print('imgwarp s%d [8,3,%d,%d] fwd %7.1f us (%6.0f GB/s)   bwd %7.1f us (%6.0f GB/s)' % (
             s, h, w, tf, fb / tf / 1e3, tb, bb / tb / 1e3), flush=True)
+
+
+def _sweep(envs, fn):
+    """Run fn() under each environment override (tuning library only); restores the environment."""
+    for env in envs:
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update({k: str(v) for k, v in env.items()})
+        try:
+            fn(' '.join('%s=%s' % (k.replace('UNFLOW_', ''), v) for k, v in env.items()) or 'default')
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+
+def warp_c(B=16):
+    """Feature warp through the C ABI (no autograd dispatch in the timings), tile-shape sweep on the tuning library."""
+    lib = _lib.load()
+    P = ops._ptr
+    envs = [{}]
+    if os.environ.get('UNFLOW_MICROBENCH_TUNING') == '1':
+        envs = [{'UNFLOW_WARP_TILES': 0}] + [{'UNFLOW_WARP_TH': th, 'UNFLOW_WARP_WGS': n} for th in (8, 16) for n in (256, 1024, 4096)]
+    for name, (C, h, w) in list(LEVELS.items())[:4]:
+        x = torch.randn(B, C, h, w, device='cuda')
+        g = torch.randn(B, C, h, w, device='cuda')
+        out, gsrc = torch.empty_like(x), torch.empty_like(x)
+        fb, bb = 4 * B * h * w * (2 * C + 2), 4 * B * h * w * (3 * C + 4)
+        for kind, fl in (('smooth', _smooth_flow(B, h, w)), ('noise', torch.randn(B, 2, h, w, device='cuda') * 2)):
+            gfl = torch.empty_like(fl)
+
+            def run(tag):
+                tf = timeit(lambda: lib.unflow_warp_fwd(P(x), P(fl), P(out), None, B, C, h, w, 0, ops._stream()))
+                tb = timeit(lambda: lib.unflow_warp_bwd(P(x), P(fl), P(g), None, P(gsrc), P(gfl), B, C, h, w, 0, ops._stream()))
+                print('warp_c %s [%d,%d,%d,%d] %-6s %-28s fwd %7.1f us (%6.0f GB/s)   bwd %7.1f us (%6.0f GB/s)' % (
+                    name, B, C, h, w, kind, tag, tf, fb / tf / 1e3, tb, bb / tb / 1e3), flush=True)
+            _sweep(envs, run)
+
+
+def corr_bwd_sweep(B=16):
+    """d=4 backward variants (tuning library): tile kernel, group-split ring kernel at 64x4 / 64x8 tiles."""
+    lib = _lib.load()
+    P = ops._ptr
+    envs = [{}] + [{'UNFLOW_CORR_BWD': v, 'UNFLOW_CORR_GROUPS': g_} for v in (6, 1, 3, 4, 5) for g_ in (1, 2, 4)]
+    for name, (C, h, w) in list(LEVELS.items())[:3]:
+        f1 = torch.randn(B, C, h, w, device='cuda')
+        f2 = torch.randn(B, C, h, w, device='cuda')
+        g = torch.randn(B, 81, h, w, device='cuda')
+        gf1, gf2 = torch.empty_like(f1), torch.empty_like(f2)
+        bb = 4 * B * h * w * (4 * C + 81)
+        ref = {}
+
+        def run(tag):
+            gf1.zero_(); gf2.zero_()
+            tb = timeit(lambda: lib.unflow_corr_bwd(P(f1), P(f2), P(g), P(gf1), P(gf2), B, C, h, w, 4, ops._stream()))
+            if not ref:
+                ref['a'], ref['b'] = gf1.clone(), gf2.clone()
+            err = max((gf1 - ref['a']).abs().max().item(), (gf2 - ref['b']).abs().max().item())
+            print('corr_bwd %s [%d,%d,%d,%d] %-34s %7.1f us (%6.0f GB/s)  max|diff vs default| %.2e' % (
+                name, B, C, h, w, tag, tb, bb / tb / 1e3, err), flush=True)
+        _sweep(envs, run)
+
+
+def ablate(B=16):
+    """Phase ablations at level 2 (tuning library; results are wrong by construction, only the times matter)."""
+    lib = _lib.load()
+    P = ops._ptr
+    C, h, w = LEVELS['L2']
+    x = torch.randn(B, C, h, w, device='cuda'); g = torch.randn(B, C, h, w, device='cuda')
+    gsrc = torch.empty_like(x); fl = _smooth_flow(B, h, w); gfl = torch.empty_like(fl)
+    for th in (8, 16):
+        for dbg in (0, 1, 2, 4, 3):
+            os.environ.update({'UNFLOW_WARP_TH': str(th), 'UNFLOW_WARP_DEBUG': str(dbg)})
+            tb = timeit(lambda: lib.unflow_warp_bwd(P(x), P(fl), P(g), None, P(gsrc), P(gfl), B, C, h, w, 0, ops._stream()))
+            print('warp_bwd L2 TH=%d dbg=%d (1 no LDS adds, 2 no flush, 4 no global atomics): %7.1f us' % (th, dbg, tb), flush=True)
+    os.environ.pop('UNFLOW_WARP_DEBUG'); os.environ.pop('UNFLOW_WARP_TH')
+    tz = timeit(lambda: gsrc.zero_())
+    print('zero-fill of gsrc alone: %.1f us' % tz, flush=True)
+    f1 = torch.randn(B, C, h, w, device='cuda'); f2 = torch.randn(B, C, h, w, device='cuda')
+    gc = torch.randn(B, 81, h, w, device='cuda'); gf1, gf2 = torch.empty_like(f1), torch.empty_like(f2)
+    for fb in (3, 4):
+        for dbg in (0, 8):
+            os.environ.update({'UNFLOW_CORR_BWD': str(fb), 'UNFLOW_CORR_DEBUG': str(dbg)})
+            tb = timeit(lambda: lib.unflow_corr_bwd(P(f1), P(f2), P(gc), P(gf1), P(gf2), B, C, h, w, 4, ops._stream()))
+            print('corr_bwd L2 variant %d dbg=%d (8: no upstream-gradient gather): %7.1f us' % (fb, dbg, tb), flush=True)
+    os.environ.pop('UNFLOW_CORR_BWD'); os.environ.pop('UNFLOW_CORR_DEBUG')
+
+
+def pmc_l2(B=16):
+    """The level-2 launches of corr / feature warp, a few times each: target of the PMC passes (tools/gpu_pmc.sh)."""
+    lib = _lib.load()
+    P = ops._ptr
+    for lvl in ('L2', 'L3'):
+        C, h, w = LEVELS[lvl]
+        f1 = torch.randn(B, C, h, w, device='cuda'); f2 = torch.randn(B, C, h, w, device='cuda')
+        gc = torch.randn(B, 81, h, w, device='cuda'); cv = torch.empty_like(gc)
+        gf1, gf2 = torch.empty_like(f1), torch.empty_like(f2)
+        fl = _smooth_flow(B, h, w); gfl = torch.empty_like(fl)
+        for _ in range(3):
+            lib.unflow_corr_fwd(P(f1), P(f2), P(cv), B, C, h, w, 4, ops._stream())
+            lib.unflow_corr_bwd(P(f1), P(f2), P(gc), P(gf1), P(gf2), B, C, h, w, 4, ops._stream())
+            lib.unflow_warp_fwd(P(f1), P(fl), P(gf1), None, B, C, h, w, 0, ops._stream())
+            lib.unflow_warp_bwd(P(f1), P(fl), P(f2), None, P(gf1), P(gfl), B, C, h, w, 0, ops._stream())
+        torch.cuda.synchronize()
 
 
 def losses(B=8):

@@ -376,6 +376,14 @@ struct RingCfg {
     static constexpr int WAVES = (DG * DD * 2 <= 96) ? 3 : 2;                   // occupancy the registers allow
 };
 
+// Phase-ablation switches of the ring kernel (loads / compute / stores only) exist in tuning builds
+// (-DUNFLOW_TUNING, tools/) alone: the shipped library has no environment-dependent behaviour.
+#ifdef UNFLOW_TUNING
+#define RING_DBG(bit) (dbg & (bit))
+#else
+#define RING_DBG(bit) 0
+#endif
+
 template <int R, int CC, int DG>
 __global__ __launch_bounds__(256, (RingCfg<R, CC, DG>::WAVES)) void corr_fwd_ring_kernel(
     const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ cv, int C, int H, int W,
@@ -437,15 +445,15 @@ __global__ __launch_bounds__(256, (RingCfg<R, CC, DG>::WAVES)) void corr_fwd_rin
     const unsigned own_addr = (unsigned)(size_t)(lds_cfloat*)(ring + K::S2 * 4 + ty * K::TW + tx * 2);
 
 #pragma unroll
-    for (int st = 0; st < K::NS - 1; ++st) if (!(dbg & 4)) issue(st);       // stages beyond nchunk read the zero line
+    for (int st = 0; st < K::NS - 1; ++st) if (!RING_DBG(4)) issue(st);       // stages beyond nchunk read the zero line
 
     for (int k = 0; k < nchunk; ++k) {
         // all but the newest (NS-2) stages have landed -> stage k is complete for this wave ...
         vm_wait<K::ITER * (K::NS - 2)>();
         __builtin_amdgcn_s_barrier();                        // ... and for every wave; slot (k-1) is free
-        if (!(dbg & 4)) issue(k + K::NS - 1);
+        if (!RING_DBG(4)) issue(k + K::NS - 1);
         const int sbase = (k & (K::NS - 1)) * K::STAGE;
-        if (dbg & 2) continue;
+        if (RING_DBG(2)) continue;
         // CC*DG row-steps per stage as one software pipeline (FwdStep): reads of step s+PF are in
         // flight behind the FMAs of step s.
         constexpr int NCOL = NROW / 2, STEPS = CC * DG;
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(256, (RingCfg<R, CC, DG>::WAVES)) void corr_fwd_rin
 
     if (py >= H || px >= W) return;
     float* out = cv + ((size_t)b * DD * DD) * plane + (size_t)py * W + px;
-    if (dbg & 1) {      // timing experiment: keep the accumulators alive, store one plane
+    if (RING_DBG(1)) {      // timing experiment: keep the accumulators alive, store one plane
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < DG; ++i)
@@ -491,8 +499,12 @@ template <int R, int CC, int DG>
 int launch_fwd_ring(const float* f1, const float* f2, float* cv, int B, int C, int H, int W, hipStream_t s) {
     using K = RingCfg<R, CC, DG>;
     const int tx = ceil_div(W, K::TW), ty = ceil_div(H, K::TYB);
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("UNFLOW_CORR_DEBUG"); dbg = e ? atoi(e) : 0; }   // timing experiments only
+#ifdef UNFLOW_TUNING
+    const char* e = getenv("UNFLOW_CORR_DEBUG");               // timing experiments only
+    const int dbg = e ? atoi(e) : 0;
+#else
+    const int dbg = 0;
+#endif
     hipLaunchKernelGGL((corr_fwd_ring_kernel<R, CC, DG>), dim3(tx * ty * B, K::NG), dim3(256), 0, s, f1, f2, cv, C, H, W,
                        tx, ty, 1.0f / C, dbg);
     return unflow_launch_status();
@@ -511,22 +523,30 @@ int launch_fwd_ring(const float* f1, const float* f2, float* cv, int B, int C, i
 // stores overlap across waves.  F streams through the same global_load_lds ring as the forward kernel.
 // R = 8: six wave pairs (768 threads), the last one with two live rows.  Requires W % 4 == 0.
 // ---------------------------------------------------------------------------------------------
-template <int R, int CC>
+template <int R, int CC, int TYB_ = 4>
 struct BwdGsCfg {
-    static constexpr int DD = 2 * R + 1, DG = 3, NGRP = (DD + DG - 1) / DG;    // R=4: 3 wave pairs; R=8: 6 (the last one has 2 live rows)
-    static constexpr int TW = 64, TYB = 4, NS = 3, THREADS = 128 * NGRP;       // 3 slots (44 KB, 3 workgroups per CU at R=4) measured
-                                                                               // best: 6 slots (80 KB) halves the residency
+    static constexpr int DD = 2 * R + 1, DG = 3, NGRP = (DD + DG - 1) / DG;    // R=4: 3 wave groups; R=8: 6 (the last one has 2 live rows)
+    static constexpr int TW = 64, TYB = TYB_, GL = 32 * TYB;                   // GL lanes (2 px each) per wave group
+    static constexpr int NS = 3, THREADS = GL * NGRP;                          // 3 slots measured best: 6 slots halve the residency
     static constexpr int LW = TW + 2 * R, LH = TYB + DG * NGRP - 1;            // = TYB + 2R when DD % 3 == 0; else one spare row
     static constexpr int SC = LH * LW / 4;                                      // float4 slots per channel
     static constexpr int ITER = (CC * SC + THREADS - 1) / THREADS;
     static constexpr int STAGE = ITER * THREADS * 4;                            // floats per ring slot
-    static constexpr int RED = (NGRP - 1) * CC * 128 * 2;                       // floats per hand-off buffer (pairs 1 .. NGRP-1)
+    static constexpr int RED = (NGRP - 1) * CC * GL * 2;                        // floats per hand-off buffer (groups 1 .. NGRP-1)
 };
 
-// Hand-off slab of the group-split backward: entry e = (pair - 1) * CC + c, 128 lanes x 8 bytes each.
-template <int N, int... Es>
+// Hand-off slab of the group-split backward: entry e = (group - 1) * CC + c, GL lanes x 8 bytes each.
+template <int GL, int N, int... Es>
 __device__ __forceinline__ void slab_read(v2f (&q)[N], unsigned addr, std::integer_sequence<int, Es...>) {
-    ((q[Es] = lds_read_b64<Es * 128 * 8>(addr)), ...);
+    ((q[Es] = lds_read_b64<Es * GL * 8>(addr)), ...);
+}
+template <int OFF>
+__device__ __forceinline__ void lds_write_b64(unsigned addr, v2f v) {
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int GL, int CC, int... Cs>
+__device__ __forceinline__ void slab_write(unsigned addr, const v2f (&v)[CC], std::integer_sequence<int, Cs...>) {
+    (lds_write_b64<Cs * GL * 8>(addr, v[Cs]), ...);
 }
 
 // One row-step of the backward pipeline: ST = c * 3 + i.
@@ -563,27 +583,32 @@ struct GsStep {
     }
 };
 
-template <int R, int CC>
-__global__ __launch_bounds__((BwdGsCfg<R, CC>::THREADS)) void corr_bwd_gs_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+template <int R, int CC, int TYB>
+__global__ __launch_bounds__((BwdGsCfg<R, CC, TYB>::THREADS)) void corr_bwd_gs_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                          const float* __restrict__ g, float* __restrict__ gf1,
-                                                         float* __restrict__ gf2, int C, int H, int W,
-                                                         int tiles_x, int tiles_y, float inv_c) {
-    using K = BwdGsCfg<R, CC>;
-    constexpr int DD = K::DD, LW = K::LW, NROW = 2 + 2 * R, NCOL = NROW / 2;
+                                                         float* __restrict__ gf2, int Ctot, int cpg, int H, int W,
+                                                         int tiles_x, int tiles_y, float inv_c, int dbg) {
+    using K = BwdGsCfg<R, CC, TYB>;
+    constexpr int DD = K::DD, LW = K::LW, NROW = 2 + 2 * R, NCOL = NROW / 2, GL = K::GL;
     static_assert(K::NS >= 3 && K::NS <= 6, "ring depth (the counted vmcnt waits cover NS-2 <= 4 store groups)");
     __shared__ __attribute__((aligned(16))) float lds[K::NS * K::STAGE + 2 * K::RED];
     float* ring = lds;
     float* red = lds + K::NS * K::STAGE;
 
-    const int mode = blockIdx.y;
+    // work item = (tile, gradient): the two gradients of a tile are neighbours in the XCD-local order, so the
+    // upstream-gradient planes both of them read are fetched from HBM once and served from that XCD's L2 the second time
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int mode = t & 1; t >>= 1;
     const float* __restrict__ F = mode ? f1 : f2;
     float* __restrict__ out = mode ? gf2 : gf1;
-    int t = xcd_remap(blockIdx.x, gridDim.x);
     const int bx = t % tiles_x; t /= tiles_x;
     const int by = t % tiles_y;
     const int b = t / tiles_y;
-    const int l = threadIdx.x & 127, wave = threadIdx.x >> 6;
-    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);     // wave-uniform: branches on it are scalar
+    // blockIdx.y: channel group [c_begin, c_begin + C) of the Ctot channels (small maps: more, shorter workgroups)
+    const int c_begin = blockIdx.y * cpg;
+    const int C = min(cpg, Ctot - c_begin);
+    const int l = threadIdx.x % GL, wave = threadIdx.x >> 6;
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x / GL);     // wave-uniform: branches on it are scalar
     const int tx = l & 31, ty = l >> 5;
     const int x0 = bx * K::TW, y0 = by * K::TYB;
     const int px = x0 + tx * 2, py = y0 + ty;
@@ -610,6 +635,7 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC>::THREADS)) void corr_bwd_gs_kernel
                     const bool ok = (grp * 3 + ii < DD) && (py < H) && (px + p < W) && sy >= 0 && sy < H && sx >= 0 && sx < W;
                     const int cy = min(max(sy, 0), H - 1), cx = min(max(sx, 0), W - 1);
                     if constexpr (R <= 4) {
+                        if (RING_DBG(8)) { wr[ii][j][p] = (float)(ii + j + p) * inv_c; continue; }      // ablation: no gather
                         float v = gb[(size_t)pl * plane + (size_t)cy * W + cx];
                         v = ok ? v : 0.f;
                         wr[ii][j][p] = v * inv_c;
@@ -622,7 +648,7 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC>::THREADS)) void corr_bwd_gs_kernel
                 }
     }
 
-    const float* baseF = F + (size_t)b * C * plane;
+    const float* baseF = F + ((size_t)b * Ctot + c_begin) * plane;
     // per-lane DMA slot descriptors, computed once: plane offset of the slot's 16 bytes (or -1 outside the
     // image / in the padding) and its channel within the stage.  (Recomputing them per stage cost ~70 %
     // extra VALU instructions; with ~100 VGPRs there is room to keep them.)
@@ -653,7 +679,7 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC>::THREADS)) void corr_bwd_gs_kernel
 
     // rows of this pair start 3*grp below the tile's first halo row
     const unsigned rows_addr = (unsigned)(size_t)(lds_cfloat*)(ring + (ty + 3 * grp) * LW + tx * 2);
-    float* op = out + ((size_t)b * C * H + py) * W + px;
+    float* op = out + (((size_t)b * Ctot + c_begin) * H + py) * W + px;
 
     // pair 0: add the partials pairs 1 and 2 left for stage `st` and store its CC channels
     // (the slab is read and written with hand-issued ds ops: compiler-visible LDS accesses next to an
@@ -662,7 +688,7 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC>::THREADS)) void corr_bwd_gs_kernel
     auto finish = [&](int st, const float (&mine)[CC][2]) {
         const unsigned ra = red_addr + (unsigned)((st & 1) * K::RED) * 4u;
         v2f q[(K::NGRP - 1) * CC];                       // partial (pair g+1, channel c) at q[g * CC + c]
-        slab_read(q, ra, std::make_integer_sequence<int, (K::NGRP - 1) * CC>{});
+        slab_read<GL>(q, ra, std::make_integer_sequence<int, (K::NGRP - 1) * CC>{});
         lds_wait<0>();
 #pragma unroll
         for (int c = 0; c < CC; ++c) {
@@ -724,15 +750,14 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC>::THREADS)) void corr_bwd_gs_kernel
 #pragma unroll
             for (int c = 0; c < CC; ++c) { keep[c][0] = acc[c][0][0] + acc[c][1][0]; keep[c][1] = acc[c][0][1] + acc[c][1][1]; }
         } else {
-            const unsigned wa = red_addr + (unsigned)((k & 1) * K::RED + (grp - 1) * CC * 128 * 2) * 4u;
+            const unsigned wa = red_addr + (unsigned)((k & 1) * K::RED + (grp - 1) * CC * GL * 2) * 4u;
+            v2f pv[CC];
 #pragma unroll
             for (int c = 0; c < CC; ++c) {
-                v2f v;
-                v.x = acc[c][0][0] + acc[c][1][0];
-                v.y = acc[c][0][1] + acc[c][1][1];
-                if (c == 0) asm volatile("ds_write_b64 %0, %1" ::"v"(wa), "v"(v) : "memory");
-                else asm volatile("ds_write_b64 %0, %1 offset:1024" ::"v"(wa), "v"(v) : "memory");
+                pv[c].x = acc[c][0][0] + acc[c][1][0];
+                pv[c].y = acc[c][0][1] + acc[c][1][1];
             }
+            slab_write<GL, CC>(wa, pv, std::make_integer_sequence<int, CC>{});
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slab written before the next barrier
         }
     }
@@ -741,13 +766,21 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC>::THREADS)) void corr_bwd_gs_kernel
     if (grp == 0) finish(nchunk - 1, keep);
 }
 
-template <int R, int CC>
+template <int R, int CC, int TYB>
 int launch_bwd_gs(const float* f1, const float* f2, const float* g, float* gf1, float* gf2,
-                  int B, int C, int H, int W, hipStream_t s) {
-    using K = BwdGsCfg<R, CC>;
+                  int B, int C, int H, int W, int groups, hipStream_t s) {
+    using K = BwdGsCfg<R, CC, TYB>;
     const int tx = ceil_div(W, K::TW), ty = ceil_div(H, K::TYB);
-    hipLaunchKernelGGL((corr_bwd_gs_kernel<R, CC>), dim3(tx * ty * B, 2), dim3(K::THREADS), 0, s, f1, f2, g, gf1, gf2,
-                       C, H, W, tx, ty, 1.0f / C);
+    groups = groups < 1 ? 1 : groups;
+    const int cpg = ceil_div(ceil_div(C, groups), CC) * CC;      // whole ring stages per channel group
+#ifdef UNFLOW_TUNING
+    const char* e = getenv("UNFLOW_CORR_DEBUG");
+    const int dbg = e ? atoi(e) : 0;
+#else
+    const int dbg = 0;
+#endif
+    hipLaunchKernelGGL((corr_bwd_gs_kernel<R, CC, TYB>), dim3(tx * ty * B * 2, ceil_div(C, cpg)), dim3(K::THREADS), 0, s,
+                       f1, f2, g, gf1, gf2, C, cpg, H, W, tx, ty, 1.0f / C, dbg);
     return unflow_launch_status();
 }
 
@@ -912,23 +945,25 @@ int launch_bwd(const float* f1, const float* f2, const float* g, float* gf1, flo
 
 }  // namespace
 
-// Tuning knob (diagnostic): UNFLOW_CORR_VARIANT forces a d=4 forward code path
+// Tuning knobs (tools/ builds with -DUNFLOW_TUNING only; the shipped library never reads the environment):
+// UNFLOW_CORR_VARIANT forces a d=4 forward code path
 //   1: 64x8 tiles, 2 px/lane, all 81 displacements per lane, register-staged LDS tiles
 //   2: 32x8 tiles, 1 px/lane, all 81 displacements per lane
 //   3: 32x8 tiles, 1 px/lane, displacement rows split over 3 workgroups
 //   4: one lane per output element, direct (cached) global reads    (tiny maps, many channels)
 //   7, 9: LDS-DMA ring kernel with 9 / 3 displacement rows per workgroup
-static int forced_variant() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("UNFLOW_CORR_VARIANT"); v = e ? atoi(e) : 0; }
-    return v;
-}
-
-static int forced_bwd() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("UNFLOW_CORR_BWD"); v = e ? atoi(e) : 0; }
-    return v;
-}
+// UNFLOW_CORR_BWD forces a d=4 backward path (1, 3, 4, 5: group-split ring kernel with 64x4 / 64x8 tiles and 2 / 4
+// channels per stage; 2: per element; 6: tile kernel), UNFLOW_CORR_GROUPS its number of channel groups.
+#ifdef UNFLOW_TUNING
+static int env_int(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
+static int forced_variant() { return env_int("UNFLOW_CORR_VARIANT"); }      // re-read per call: one process sweeps them
+static int forced_bwd() { return env_int("UNFLOW_CORR_BWD"); }
+static int forced_groups() { return env_int("UNFLOW_CORR_GROUPS"); }
+#else
+static inline int forced_variant() { return 0; }
+static inline int forced_bwd() { return 0; }
+static inline int forced_groups() { return 0; }
+#endif
 
 static int pick_variant(int B, int C, int H, int W) {
     const int f = forced_variant();
@@ -952,6 +987,7 @@ extern "C" int unflow_corr_fwd(const float* f1, const float* f2, float* cv, int 
     UNFLOW_REQUIRE(f1 && f2 && cv && B > 0 && C > 0 && H > 0 && W > 0 && d >= 0);
     hipStream_t s = (hipStream_t)stream;
     int variant = 4;
+    const bool ring_ok = (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0);     // LDS-DMA moves aligned 16-byte pieces
     switch (d) {
         case 1: return launch_fwd<1, 2, 3, 8>(f1, f2, cv, B, C, H, W, s);
         case 2: return launch_fwd<2, 2, 5, 8>(f1, f2, cv, B, C, H, W, s);
@@ -959,12 +995,12 @@ extern "C" int unflow_corr_fwd(const float* f1, const float* f2, float* cv, int 
                 if (variant == 1) return launch_fwd<4, 2, 9, 8>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 2) return launch_fwd<4, 1, 9, 8>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 3) return launch_fwd<4, 1, 3, 8>(f1, f2, cv, B, C, H, W, s);
-                if (variant == 7 && (W & 3) == 0) return launch_fwd_ring<4, 2, 9>(f1, f2, cv, B, C, H, W, s);
-                if (variant == 9 && (W & 3) == 0) return launch_fwd_ring<4, 2, 3>(f1, f2, cv, B, C, H, W, s);
+                if (variant == 7 && ring_ok) return launch_fwd_ring<4, 2, 9>(f1, f2, cv, B, C, H, W, s);
+                if (variant == 9 && ring_ok) return launch_fwd_ring<4, 2, 3>(f1, f2, cv, B, C, H, W, s);
                 if (variant >= 7) return launch_fwd<4, 2, 9, 8>(f1, f2, cv, B, C, H, W, s);
                 break;
         case 8: variant = pick_variant(B, C, H, W);
-                if ((variant == 7 || variant == 9) && (W & 3) == 0) return launch_fwd_ring<8, 2, 3>(f1, f2, cv, B, C, H, W, s);
+                if ((variant == 7 || variant == 9) && ring_ok) return launch_fwd_ring<8, 2, 3>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 4 || (variant == 3 && (long)B * H * W < 8192)) break;
                 return launch_fwd<8, 1, 6, 8>(f1, f2, cv, B, C, H, W, s);
         default: break;
@@ -983,22 +1019,36 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
     switch (d) {
         case 1: return launch_bwd<1, 2, 3, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
         case 2: return launch_bwd<2, 2, 5, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-        case 4: variant = pick_variant(B, C, H, W);
-                // group-split ring kernel: measured best for mid-size maps (levels 3, 4); level 2 stays on the tile kernel
-                if ((W & 3) == 0 && (forced_bwd() == 1 || (forced_bwd() == 0 && variant == 9)))
-                    return launch_bwd_gs<4, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                if (variant == 1 || variant == 7) return launch_bwd<4, 2, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+        case 4: {
+                variant = pick_variant(B, C, H, W);
+                const bool ring_ok = (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0);   // LDS-DMA moves aligned 16-byte pieces
+                const int fb = forced_bwd();
+                // work items (64x8 tile, gradient) of the group-split ring kernel; smaller maps split the channels over
+                // workgroups until every CU has one (measured: level 3 = 256 items, 1 group: 35 us; level 4 = 64 items,
+                // 4 groups: 20 us; more groups than that only repeat the upstream-gradient gather)
+                const int items = ceil_div(W, 64) * ceil_div(H, 8) * B * 2;
+                int groups = forced_groups() ? forced_groups() : (items >= 256 ? 1 : 256 / items);
+                if (ring_ok && fb == 1) return launch_bwd_gs<4, 2, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, groups, s);
+                if (ring_ok && fb == 3) return launch_bwd_gs<4, 2, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, groups, s);
+                if (ring_ok && fb == 5) return launch_bwd_gs<4, 4, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, groups, s);
+                // group-split ring kernel, 64x8 tiles, 4 channels per stage: levels 2-4 (83 / 35 / 20 us; the tile kernel
+                // with all 81 gradients per lane takes 107 us at level 2)
+                if (ring_ok && (fb == 4 || (fb == 0 && (variant == 7 || variant == 9))))
+                    return launch_bwd_gs<4, 4, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, groups, s);
+                if (fb == 6 || variant == 1 || variant == 7) return launch_bwd<4, 2, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (variant == 2 || variant == 3 || (variant == 9 && (long)B * H * W >= 32768))
                     return launch_bwd<4, 1, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                if (forced_bwd() != 2) {                 // small maps (levels 5, 6): whole-map kernel; UNFLOW_CORR_BWD=2: per-element
+                if (fb != 2) {                           // small maps (levels 5, 6): whole-map kernel; UNFLOW_CORR_BWD=2: per-element
                     bool launched = false;
                     const int rc = launch_bwd_small<4>(f1, f2, gcv, gf1, gf2, B, C, H, W, s, &launched);
                     if (launched) return rc;
                 }
                 break;
+        }
         case 8: variant = pick_variant(B, C, H, W);
                 if (variant == 4 || (long)B * H * W < 8192) break;      // small maps: one lane per element (117 / 57 us at levels 5 / 6, tile kernel 283 / 378)
-                if ((variant == 7 || variant == 9) && (W & 3) == 0) return launch_bwd_gs<8, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                if ((variant == 7 || variant == 9) && (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0))
+                    return launch_bwd_gs<8, 1, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, 1, s);
                 return launch_bwd<8, 1, 6, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
         default: break;
     }

@@ -25,6 +25,8 @@ struct Taps {
     float nw, ne, sw, se;      // weights with out-of-range taps zeroed
     float w, e, n, s;          // raw fractional weights (for the flow gradient)
     int o_nw, o_ne, o_sw, o_se;  // element offsets inside one HxW plane (clamped, always valid)
+    int xc0, xc1, yc0, yc1;      // the clamped tap coordinates those offsets were built from
+    int x0, y0;                  // position of the nw tap before clamping to the image (itself limited to [-2, size+1])
     bool v_nw, v_ne, v_sw, v_se;
     bool mask;
 };
@@ -63,6 +65,8 @@ __device__ __forceinline__ Taps make_taps(float u, float v, int x, int y, int H,
     const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y1, 0), H - 1);
     t.o_nw = yc0 * W + xc0; t.o_ne = yc0 * W + xc1;
     t.o_sw = yc1 * W + xc0; t.o_se = yc1 * W + xc1;
+    t.xc0 = xc0; t.xc1 = xc1; t.yc0 = yc0; t.yc1 = yc1;
+    t.x0 = x0; t.y0 = y0;
     const float m = __fadd_rn(__fadd_rn(__fadd_rn(t.nw, t.ne), t.sw), t.se);
     t.mask = (m >= 0.9999f);
     return t;
@@ -170,14 +174,449 @@ __global__ void warp_bwd_kernel(const float* __restrict__ src, const float* __re
     gflow[((size_t)b * 2 + 1) * plane + pix] = (giy * my) / dy * 2.0f;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Feature-map warp through LDS tiles (pyramid levels: many channels, smooth flow).
+//
+// A 256-thread workgroup owns a TW x TH tile of destination pixels (PPT pixels per thread, lanes along
+// x) and a group of channels.  The taps of its pixels are computed once; their bounding box in the
+// source map is the tile's SOURCE WINDOW.  When the window fits the LDS budget (WXS x WY floats per
+// channel: the tile plus its flow range) the channels stream through LDS CC at a time:
+//   forward : window rows are loaded coalesced (one dword per lane) into LDS, the four taps of a pixel
+//             are LDS reads, outputs are coalesced stores;
+//   backward: the same window feeds the flow gradient; the source gradient is accumulated into a second
+//             LDS window (ds_add_f32) and flushed once per chunk with row-contiguous float atomics --
+//             every source element is added ~1.2x (tile interior once, halo twice) instead of 4x by
+//             scattered per-tap atomics (the op runs at the chip's float-atomic rate, not at HBM rate).
+// A tile whose flow spreads its taps over more than the window falls back to per-tap global gathers /
+// atomics for that tile only (noise flows, motion boundaries): always correct, decided per workgroup.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBig = 0x3fffffff;
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+template <int PPT>
+struct TileCtx {
+    Taps t[PPT];
+    bool live[PPT];            // the pixel exists (inside the tile and the image)
+    int pix[PPT];              // y * W + x (0 for dead slots)
+    int wx0, wy0, ww, wh;      // source window, workgroup-uniform; ww == 0: no tap of the tile lies inside the image
+};
+
+template <int PPT>
+__device__ __forceinline__ void tile_setup(TileCtx<PPT>& k, const float* __restrict__ flow_b, int H, int W, int ac,
+                                           int x0t, int y0t, int TW, int TH, int* s_box) {
+    const int plane = H * W;
+    int bx0 = kBig, bx1 = -1, by0 = kBig, by1 = -1;
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        const int idx = q * 256 + (int)threadIdx.x;
+        const int ly = idx / TW, lx = idx - ly * TW;
+        const int x = x0t + lx, y = y0t + ly;
+        const bool live = ly < TH && x < W && y < H;
+        const int xs = live ? x : 0, ys = live ? y : 0;
+        const int pix = ys * W + xs;
+        const float u = live ? flow_b[pix] : 0.f;
+        const float v = live ? flow_b[plane + pix] : 0.f;
+        k.t[q] = make_taps(u, v, xs, ys, H, W, ac);
+        k.live[q] = live;
+        k.pix[q] = pix;
+        if (live && (k.t[q].v_nw || k.t[q].v_ne || k.t[q].v_sw || k.t[q].v_se)) {
+            bx0 = min(bx0, k.t[q].xc0); bx1 = max(bx1, k.t[q].xc1);
+            by0 = min(by0, k.t[q].yc0); by1 = max(by1, k.t[q].yc1);
+        }
+    }
+    bx0 = wave_min_i(bx0); by0 = wave_min_i(by0); bx1 = wave_max_i(bx1); by1 = wave_max_i(by1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_box[wave * 4 + 0] = bx0; s_box[wave * 4 + 1] = by0; s_box[wave * 4 + 2] = bx1; s_box[wave * 4 + 3] = by1; }
+    __syncthreads();
+    bx0 = min(min(s_box[0], s_box[4]), min(s_box[8], s_box[12]));
+    by0 = min(min(s_box[1], s_box[5]), min(s_box[9], s_box[13]));
+    bx1 = max(max(s_box[2], s_box[6]), max(s_box[10], s_box[14]));
+    by1 = max(max(s_box[3], s_box[7]), max(s_box[11], s_box[15]));
+    k.wx0 = bx0; k.wy0 = by0;
+    k.ww = bx1 >= bx0 ? bx1 - bx0 + 1 : 0;
+    k.wh = by1 >= by0 ? by1 - by0 + 1 : 0;
+}
+
+typedef __attribute__((address_space(1))) const void* wgas_ptr;
+typedef __attribute__((address_space(3))) void* wlds_ptr;
+
+// The source window in LDS: rows [wy0, wy0+wh) x [wxa, wxa+rs) of a channel plane, packed with row stride `rs`
+// (runtime: the window is as wide as this tile's flow makes it), channel stride WIN floats.
+//   vec (W % 4 == 0, 16-byte aligned source): wxa = wx0 rounded down to 4, rs a multiple of 4; the window is moved by
+//       global_load_lds_dwordx4 (LDS-DMA: no staging registers, every piece of a chunk in flight at once); piece p of a
+//       channel = float4 slots [64p, 64p+64) of the packed window, whose plane offsets are computed once per workgroup;
+//   otherwise: dword loads through registers, one row per wave-instruction.
+template <int WIN>
+struct Window {
+    static constexpr int MAXP = (WIN / 4 + 63) / 64;
+    int wxa, wy0, rs, wh, per_ch;
+    bool vec;
+    int goff[MAXP];            // plane offset of this lane's float4 slot in piece p, -1 beyond the window
+};
+
+template <int WIN, int PPT>
+__device__ __forceinline__ bool window_setup(Window<WIN>& w, const TileCtx<PPT>& k, int W, bool vec_ok) {
+    w.vec = vec_ok;
+    w.wxa = vec_ok ? (k.wx0 & ~3) : k.wx0;
+    w.wy0 = k.wy0;
+    const int wwa = k.wx0 - w.wxa + k.ww;
+    w.rs = vec_ok ? ((wwa + 3) & ~3) : wwa;
+    w.wh = k.wh;
+    if (k.ww == 0 || w.rs * w.wh > WIN) return false;
+    const int ww4 = w.rs >> 2, slots = ww4 * w.wh;
+    w.per_ch = (slots + 63) >> 6;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int p = 0; p < Window<WIN>::MAXP; ++p) {
+        const int sl = p * 64 + lane;
+        const int r = vec_ok ? sl / ww4 : 0, c4 = sl - r * ww4;
+        w.goff[p] = (vec_ok && sl < slots) ? (w.wy0 + r) * W + w.wxa + c4 * 4 : -1;
+    }
+    return true;
+}
+
+// Issue the staging of `nc` channel planes (wave v moves channels v, v+4, ...).  The caller waits (vmcnt(0)) and
+// barriers before the first read.
+template <int WIN, int CC>
+__device__ __forceinline__ void window_stage(float* __restrict__ dst, const Window<WIN>& w, const float* __restrict__ planes,
+                                             int plane, int W, int nc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (w.vec) {
+#pragma unroll
+        for (int cc = 0; cc < (CC + 3) / 4; ++cc) {
+            const int c = wave + 4 * cc;
+            if (c < nc) {
+                const float* g = planes + (size_t)c * plane;
+#pragma unroll
+                for (int p = 0; p < Window<WIN>::MAXP; ++p)
+                    if (p < w.per_ch && w.goff[p] >= 0)
+                        __builtin_amdgcn_global_load_lds((wgas_ptr)(g + w.goff[p]), (wlds_ptr)(dst + c * WIN + p * 256), 16, 0, 0);
+            }
+        }
+    } else {
+        const int rows = nc * w.wh;
+        for (int r = wave; r < rows; r += 4) {
+            const int c = r / w.wh, ry = r - c * w.wh;
+            const float* g = planes + (size_t)c * plane + (size_t)(w.wy0 + ry) * W + w.wxa;
+            float* d = dst + c * WIN + ry * w.rs;
+            for (int x = lane; x < w.rs; x += 64) d[x] = g[x];
+        }
+    }
+}
+
+__device__ __forceinline__ void stage_fence() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA pieces have landed ...
+    __syncthreads();                                      // ... and everyone else's
+}
+
+// LDS offsets of a pixel's four taps inside the packed window (0 for pixels that sample nothing)
+template <int WIN, int PPT>
+__device__ __forceinline__ void tap_offsets(const Window<WIN>& w, const TileCtx<PPT>& k, int (&l_nw)[PPT], int (&l_ne)[PPT],
+                                            int (&l_sw)[PPT], int (&l_se)[PPT]) {
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        const Taps& tp = k.t[q];
+        const bool any = k.live[q] && (tp.v_nw || tp.v_ne || tp.v_sw || tp.v_se);
+        const int ya = any ? (tp.yc0 - w.wy0) * w.rs : 0, yb = any ? (tp.yc1 - w.wy0) * w.rs : 0;
+        const int xa = any ? tp.xc0 - w.wxa : 0, xb = any ? tp.xc1 - w.wxa : 0;
+        l_nw[q] = ya + xa; l_ne[q] = ya + xb; l_sw[q] = yb + xa; l_se[q] = yb + xb;
+    }
+}
+
+template <int PPT, int WIN, int CC>
+__global__ __launch_bounds__(256) void warp_fwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow,
+                                                            float* __restrict__ out, int C, int H, int W, int ac,
+                                                            int TW, int TH, int tiles_x, int tiles_y, int cpg, int vec_ok) {
+    __shared__ __attribute__((aligned(16))) float s_src[CC * WIN];
+    __shared__ int s_box[16];
+    int t = blockIdx.x;
+    const int bx = t % tiles_x; t /= tiles_x;
+    const int by = t % tiles_y;
+    const int b = t / tiles_y;
+    const int c_begin = blockIdx.y * cpg, c_end = min(C, c_begin + cpg);
+    const int plane = H * W;
+    TileCtx<PPT> k;
+    tile_setup<PPT>(k, flow + (size_t)b * 2 * plane, H, W, ac, bx * TW, by * TH, TW, TH, s_box);
+    const float* sp = src + (size_t)b * C * plane;
+    float* op = out + (size_t)b * C * plane;
+    Window<WIN> w;
+    if (!window_setup<WIN, PPT>(w, k, W, vec_ok != 0)) {
+        // nothing sampled (all zeros) or the flow spreads the taps beyond the LDS window: per-tap global gathers
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            if (!k.live[q]) continue;
+            const Taps& tp = k.t[q];
+#pragma unroll 4
+            for (int c = c_begin; c < c_end; ++c) {
+                const float* p = sp + (size_t)c * plane;
+                float r = p[tp.o_nw] * tp.nw;
+                r = fmaf(p[tp.o_ne], tp.ne, r);
+                r = fmaf(p[tp.o_sw], tp.sw, r);
+                r = fmaf(p[tp.o_se], tp.se, r);
+                op[(size_t)c * plane + k.pix[q]] = r;
+            }
+        }
+        return;
+    }
+    int l_nw[PPT], l_ne[PPT], l_sw[PPT], l_se[PPT];
+    tap_offsets<WIN, PPT>(w, k, l_nw, l_ne, l_sw, l_se);
+    for (int c0 = c_begin; c0 < c_end; c0 += CC) {
+        const int nc = min(CC, c_end - c0);
+        window_stage<WIN, CC>(s_src, w, sp + (size_t)c0 * plane, plane, W, nc);
+        stage_fence();
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const Taps& tp = k.t[q];
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                if (c < nc) {
+                    const float* win = s_src + c * WIN;
+                    // same accumulation order as ATen: nw, ne, sw, se
+                    float r = win[l_nw[q]] * tp.nw;
+                    r = fmaf(win[l_ne[q]], tp.ne, r);
+                    r = fmaf(win[l_sw[q]], tp.sw, r);
+                    r = fmaf(win[l_se[q]], tp.se, r);
+                    if (k.live[q]) op[(size_t)(c0 + c) * plane + k.pix[q]] = r;
+                }
+            }
+        }
+        __syncthreads();                                      // the window may be overwritten
+    }
+}
+
+// Phase ablations (tuning builds only): 1 no LDS accumulation, 2 no flush, 4 flush without the global atomics.
+#ifdef UNFLOW_TUNING
+#define WARP_DBG(bit) (dbg & (bit))
+#else
+#define WARP_DBG(bit) 0
+#endif
+
+// SPLIT: the channels of a tile are spread over gridDim.y workgroups; their flow-gradient partials are
+// added atomically into a zeroed gflow (otherwise gflow is written once, reproducibly).
+template <int PPT, int WIN, int CC, bool SPLIT>
+__global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow,
+                                                            const float* __restrict__ gout, float* __restrict__ gsrc,
+                                                            float* __restrict__ gflow, int C, int H, int W, int ac,
+                                                            int TW, int TH, int tiles_x, int tiles_y, int cpg, int vec_ok, int dbg) {
+    __shared__ __attribute__((aligned(16))) float s_src[CC * WIN];
+    __shared__ __attribute__((aligned(16))) float s_acc[CC * WIN];
+    __shared__ int s_box[16];
+    int t = blockIdx.x;
+    const int bx = t % tiles_x; t /= tiles_x;
+    const int by = t % tiles_y;
+    const int b = t / tiles_y;
+    const int c_begin = blockIdx.y * cpg, c_end = min(C, c_begin + cpg);
+    const int plane = H * W;
+    TileCtx<PPT> k;
+    tile_setup<PPT>(k, flow + (size_t)b * 2 * plane, H, W, ac, bx * TW, by * TH, TW, TH, s_box);
+    const float* sp = src + (size_t)b * C * plane;
+    const float* gp = gout + (size_t)b * C * plane;
+    float* dp = gsrc ? gsrc + (size_t)b * C * plane : nullptr;
+    float gix[PPT], giy[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) { gix[q] = 0.f; giy[q] = 0.f; }
+
+    Window<WIN> w;
+    const bool fits = window_setup<WIN, PPT>(w, k, W, vec_ok != 0);
+    if (k.ww == 0) {
+        // no tap inside the image: both gradients are zero
+    } else if (!fits) {
+        // taps spread beyond the LDS window: per-tap global gathers and atomics for this tile
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            if (!k.live[q]) continue;
+            const Taps& tp = k.t[q];
+#pragma unroll 2
+            for (int c = c_begin; c < c_end; ++c) {
+                const float* p = sp + (size_t)c * plane;
+                const float g = gp[(size_t)c * plane + k.pix[q]];
+                const float a = tp.v_nw ? p[tp.o_nw] : 0.f, bq = tp.v_ne ? p[tp.o_ne] : 0.f;
+                const float cq = tp.v_sw ? p[tp.o_sw] : 0.f, dq = tp.v_se ? p[tp.o_se] : 0.f;
+                gix[q] += g * ((bq - a) * tp.s + (dq - cq) * tp.n);
+                giy[q] += g * ((cq - a) * tp.e + (dq - bq) * tp.w);
+                if (dp) {
+                    float* d = dp + (size_t)c * plane;
+                    if (tp.v_nw) atomicAdd(d + tp.o_nw, g * tp.nw);
+                    if (tp.v_ne) atomicAdd(d + tp.o_ne, g * tp.ne);
+                    if (tp.v_sw) atomicAdd(d + tp.o_sw, g * tp.sw);
+                    if (tp.v_se) atomicAdd(d + tp.o_se, g * tp.se);
+                }
+            }
+        }
+    } else {
+        int l_nw[PPT], l_ne[PPT], l_sw[PPT], l_se[PPT];
+        tap_offsets<WIN, PPT>(w, k, l_nw, l_ne, l_sw, l_se);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int used = w.rs * w.wh;                         // floats of a channel's window actually in use
+        // Are the nw-tap positions of the tile's pixels pairwise different (the flow does not fold or compress by a
+        // whole pixel inside the tile)?  Then each of the four tap kinds touches every accumulator cell at most once,
+        // and the taps can be added with plain LDS read-add-write, one kind at a time (ds_add_f32 runs ~20x slower
+        // than a read + write pair).  Every pixel posts its id at its position; whoever reads back another id collided.
+        bool inj = true;
+        if (dp) {
+            int* marker = reinterpret_cast<int*>(s_acc);      // (wh + 1) x (rs + 1) cells, position (x0 + 1, y0 + 1) relative to the window
+            const int mrs = w.rs + 1;
+            int cell[PPT];
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                const Taps& tp = k.t[q];
+                const bool any = k.live[q] && (tp.v_nw || tp.v_ne || tp.v_sw || tp.v_se);
+                cell[q] = any ? (tp.y0 + 1 - w.wy0) * mrs + (tp.x0 + 1 - w.wxa) : -1;
+                if (cell[q] >= 0) marker[cell[q]] = q * 256 + (int)threadIdx.x;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < PPT; ++q)
+                if (cell[q] >= 0 && marker[cell[q]] != q * 256 + (int)threadIdx.x) inj = false;
+            inj = __syncthreads_and(inj ? 1 : 0) != 0;
+            for (int c = 0; c < CC; ++c)
+                for (int i = threadIdx.x; i < used; i += 256) s_acc[c * WIN + i] = 0.f;
+            if ((w.wh + 1) * mrs > used)                      // the marker grid is one row and one column larger than a window
+                for (int i = used + threadIdx.x; i < (w.wh + 1) * mrs; i += 256) s_acc[i] = 0.f;
+        }
+        for (int c0 = c_begin; c0 < c_end; c0 += CC) {
+            const int nc = min(CC, c_end - c0);
+            window_stage<WIN, CC>(s_src, w, sp + (size_t)c0 * plane, plane, W, nc);
+            float g[PPT][CC];                                 // upstream gradients of the chunk: in flight with the window pieces
+#pragma unroll
+            for (int q = 0; q < PPT; ++q)
+#pragma unroll
+                for (int c = 0; c < CC; ++c)
+                    g[q][c] = (k.live[q] && c < nc) ? gp[(size_t)(c0 + c) * plane + k.pix[q]] : 0.f;
+            stage_fence();                                    // window staged, accumulator zero
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                const Taps& tp = k.t[q];
+#pragma unroll
+                for (int c = 0; c < CC; ++c) {
+                    if (c < nc) {
+                        const float* win = s_src + c * WIN;
+                        const float gv = g[q][c];
+                        const float a = tp.v_nw ? win[l_nw[q]] : 0.f, bq = tp.v_ne ? win[l_ne[q]] : 0.f;
+                        const float cq = tp.v_sw ? win[l_sw[q]] : 0.f, dq = tp.v_se ? win[l_se[q]] : 0.f;
+                        gix[q] += gv * ((bq - a) * tp.s + (dq - cq) * tp.n);
+                        giy[q] += gv * ((cq - a) * tp.e + (dq - bq) * tp.w);
+                        if (dp && k.live[q] && !inj && !WARP_DBG(1)) {
+                            float* acc = s_acc + c * WIN;
+                            if (tp.v_nw) atomicAdd(acc + l_nw[q], gv * tp.nw);
+                            if (tp.v_ne) atomicAdd(acc + l_ne[q], gv * tp.ne);
+                            if (tp.v_sw) atomicAdd(acc + l_sw[q], gv * tp.sw);
+                            if (tp.v_se) atomicAdd(acc + l_se[q], gv * tp.se);
+                        }
+                    }
+                }
+            }
+            if (dp && inj && !WARP_DBG(1)) {
+                // one tap kind at a time: within a kind all cells are distinct, so plain read-add-write is race free
+#define TAP_PHASE(VALID, OFF, WGT)                                                                   \
+                _Pragma("unroll") for (int q = 0; q < PPT; ++q) {                                    \
+                    const Taps& tp = k.t[q];                                                         \
+                    if (k.live[q] && tp.VALID) {                                                     \
+                        _Pragma("unroll") for (int c = 0; c < CC; ++c)                               \
+                            if (c < nc) s_acc[c * WIN + OFF[q]] += g[q][c] * tp.WGT;                 \
+                    }                                                                                \
+                }
+                TAP_PHASE(v_nw, l_nw, nw)
+                __syncthreads();
+                TAP_PHASE(v_ne, l_ne, ne)
+                __syncthreads();
+                TAP_PHASE(v_sw, l_sw, sw)
+                __syncthreads();
+                TAP_PHASE(v_se, l_se, se)
+#undef TAP_PHASE
+            }
+            __syncthreads();                                  // every tap of the chunk is in the LDS accumulator
+            if (dp && !WARP_DBG(2)) {
+                // flush: one window row per wave-instruction (row-contiguous float atomics), re-zero behind it
+                const int rows = nc * w.wh;
+                for (int r = wave; r < rows; r += 4) {
+                    const int c = r / w.wh, ry = r - c * w.wh;
+                    float* d = dp + (size_t)(c0 + c) * plane + (size_t)(w.wy0 + ry) * W + w.wxa;
+                    float* a = s_acc + c * WIN + ry * w.rs;
+                    for (int x = lane; x < w.rs; x += 64) {
+                        const float v = a[x];
+                        if (v != 0.f) { if (!WARP_DBG(4)) atomicAdd(d + x, v); a[x] = 0.f; }
+                    }
+                }
+            }
+            // (the next chunk's staging writes s_src only; its fence orders the next taps against this flush)
+        }
+    }
+    const float mx = ac ? (float)(W - 1) * 0.5f : (float)W * 0.5f;
+    const float my = ac ? (float)(H - 1) * 0.5f : (float)H * 0.5f;
+    const float dx = (float)(W > 1 ? W - 1 : 1), dy = (float)(H > 1 ? H - 1 : 1);
+    float* gf = gflow + (size_t)b * 2 * plane;
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        if (!k.live[q]) continue;
+        const float vx = (gix[q] * mx) / dx * 2.0f, vy = (giy[q] * my) / dy * 2.0f;
+        if (SPLIT) { atomicAdd(gf + k.pix[q], vx); atomicAdd(gf + plane + k.pix[q], vy); }
+        else { gf[k.pix[q]] = vx; gf[plane + k.pix[q]] = vy; }
+    }
+}
+
+// Tile geometry for an H x W map with C channels: tiles as wide as the map allows up to 64 (52 for the 13 * 2^k wide
+// KITTI levels: no dead lanes), channel groups so that the launch has >= ~1024 workgroups.
+struct TilePlan { int TW, TH, tiles_x, tiles_y, groups, cpg; };
+inline TilePlan plan_tiles(int B, int C, int H, int W, int TH, int CC, int want_wgs) {
+    TilePlan p;
+    p.tiles_x = ceil_div(W, 64);
+    p.TW = ceil_div(ceil_div(W, p.tiles_x), 4) * 4;
+    p.tiles_x = ceil_div(W, p.TW);
+    p.TH = TH;
+    p.tiles_y = ceil_div(H, TH);
+    const int tiles = p.tiles_x * p.tiles_y * B;
+    int groups = ceil_div(want_wgs, tiles);
+    const int max_groups = ceil_div(C, CC);
+    if (groups > max_groups) groups = max_groups;
+    if (groups < 1) groups = 1;
+    p.cpg = ceil_div(ceil_div(C, groups), CC) * CC;
+    p.groups = ceil_div(C, p.cpg);
+    return p;
+}
+
 }  // namespace
+
+// Feature maps (no mask, >= 8 channels) go through the LDS-tile kernels.
+static bool use_tiles(const uint8_t* mask, int C, int W) { return mask == nullptr && C >= 8 && W >= 8; }
+
+// Tuning builds (tools/, -DUNFLOW_TUNING) may override the tile height / workgroup target; the shipped library
+// never reads the environment.
+#ifdef UNFLOW_TUNING
+#include <stdlib.h>
+static int wenv(const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; }
+#else
+static inline int wenv(const char*, int dflt) { return dflt; }
+#endif
 
 extern "C" int unflow_warp_fwd(const float* src, const float* flow, float* out, uint8_t* mask,
                                int B, int C, int H, int W, int align_corners, void* stream) {
     UNFLOW_REQUIRE(src && flow && out && B > 0 && C > 0 && H > 0 && W > 0);
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(ceil_div(W, 64), H, B);
     const int ac = align_corners ? 1 : 0;
+    if (use_tiles(mask, C, W) && wenv("UNFLOW_WARP_TILES", 1)) {
+        const int th = wenv("UNFLOW_WARP_TH", H >= 12 ? 16 : 8);
+        const TilePlan p = plan_tiles(B, C, H, W, th, 8, wenv("UNFLOW_WARP_WGS", 1024));
+        dim3 grid(p.tiles_x * p.tiles_y * B, p.groups);
+        const int vec_ok = ((W & 3) == 0 && (((size_t)src) & 15) == 0) ? 1 : 0;
+#define LAUNCH_T(PPT, WIN) hipLaunchKernelGGL((warp_fwd_tile_kernel<PPT, WIN, 8>), grid, dim3(256), 0, s, src, flow, out, \
+                                              C, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y, p.cpg, vec_ok)
+        if (p.TH == 16) LAUNCH_T(4, 1600); else LAUNCH_T(2, 1024);
+#undef LAUNCH_T
+        return unflow_launch_status();
+    }
+    dim3 grid(ceil_div(W, 64), H, B);
     if (C <= 4) {
         if (mask) hipLaunchKernelGGL((warp_fwd_kernel<1, true>), grid, dim3(64, 1), 0, s, src, flow, out, mask, C, H, W, ac);
         else      hipLaunchKernelGGL((warp_fwd_kernel<1, false>), grid, dim3(64, 1), 0, s, src, flow, out, mask, C, H, W, ac);
@@ -197,8 +636,22 @@ extern "C" int unflow_warp_bwd(const float* src, const float* flow, const float*
     UNFLOW_REQUIRE(src && flow && gout && gflow && B > 0 && C > 0 && H > 0 && W > 0);
     hipStream_t s = (hipStream_t)stream;
     if (gsrc) unflow_zero_async(gsrc, (size_t)B * C * H * W, s);
-    dim3 grid(ceil_div(W, 64), H, B);
     const int ac = align_corners ? 1 : 0;
+    if (use_tiles(mask, C, W) && wenv("UNFLOW_WARP_TILES", 1)) {
+        const int th = wenv("UNFLOW_WARP_TH", H >= 12 ? 16 : 8);
+        const TilePlan p = plan_tiles(B, C, H, W, th, 4, wenv("UNFLOW_WARP_WGS", 1024));
+        dim3 tgrid(p.tiles_x * p.tiles_y * B, p.groups);
+        const int vec_ok = ((W & 3) == 0 && (((size_t)src) & 15) == 0) ? 1 : 0;
+        if (p.groups > 1) unflow_zero_async(gflow, (size_t)B * 2 * H * W, s);     // channel groups add their partials
+#define LAUNCH_T(PPT, WIN, SPLIT) hipLaunchKernelGGL((warp_bwd_tile_kernel<PPT, WIN, 4, SPLIT>), tgrid, dim3(256), 0, s, src, flow, \
+                                                     gout, gsrc, gflow, C, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y, p.cpg, vec_ok, wenv("UNFLOW_WARP_DEBUG", 0))
+#define LAUNCH_S(PPT, WIN) do { if (p.groups > 1) LAUNCH_T(PPT, WIN, true); else LAUNCH_T(PPT, WIN, false); } while (0)
+        if (p.TH == 16) LAUNCH_S(4, 1600); else LAUNCH_S(2, 1024);
+#undef LAUNCH_S
+#undef LAUNCH_T
+        return unflow_launch_status();
+    }
+    dim3 grid(ceil_div(W, 64), H, B);
 #define LAUNCH(NY, M, G) hipLaunchKernelGGL((warp_bwd_kernel<NY, M, G>), grid, dim3(64, NY), 0, s, src, flow, gout, mask, gsrc, gflow, C, H, W, ac)
     // few pixels, many channels (pyramid levels 4-6): 16 channel phases per workgroup instead of 4 -- the launch
     // has too few pixel rows to fill the chip, and the per-wave channel loop is a serial chain of atomics
