@@ -112,7 +112,7 @@ def warp_c(B=16):
     P = ops._ptr
     envs = [{}]
     if os.environ.get('UNFLOW_MICROBENCH_TUNING') == '1':
-        envs = [{'UNFLOW_WARP_TILES': 0}] + [{'UNFLOW_WARP_TH': th, 'UNFLOW_WARP_WGS': n} for th in (8, 16) for n in (256, 1024, 4096)]
+        envs = [{'UNFLOW_WARP_TILES': 0}] + [{'UNFLOW_WARP_TH': th, 'UNFLOW_WARP_WGS': n} for th in (8,) for n in (256, 512, 1024, 2048)]
     for name, (C, h, w) in list(LEVELS.items())[:4]:
         x = torch.randn(B, C, h, w, device='cuda')
         g = torch.randn(B, C, h, w, device='cuda')

@@ -273,7 +273,7 @@ __device__ __forceinline__ bool window_setup(Window<WIN>& w, const TileCtx<PPT>&
     const int wwa = k.wx0 - w.wxa + k.ww;
     w.rs = vec_ok ? ((wwa + 3) & ~3) : wwa;
     w.wh = k.wh;
-    if (k.ww == 0 || w.rs * w.wh > WIN) return false;
+    if (k.ww == 0 || w.rs * w.wh > WIN || w.rs > 128) return false;      // (rows are moved / flushed as two 64-lane pieces)
     const int ww4 = w.rs >> 2, slots = ww4 * w.wh;
     w.per_ch = (slots + 63) >> 6;
     const int lane = threadIdx.x & 63;
@@ -288,7 +288,7 @@ __device__ __forceinline__ bool window_setup(Window<WIN>& w, const TileCtx<PPT>&
 
 // Issue the staging of `nc` channel planes (wave v moves channels v, v+4, ...).  The caller waits (vmcnt(0)) and
 // barriers before the first read.
-template <int WIN, int CC>
+template <int STRIDE, int WIN, int CC>
 __device__ __forceinline__ void window_stage(float* __restrict__ dst, const Window<WIN>& w, const float* __restrict__ planes,
                                              int plane, int W, int nc) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -301,7 +301,7 @@ __device__ __forceinline__ void window_stage(float* __restrict__ dst, const Wind
 #pragma unroll
                 for (int p = 0; p < Window<WIN>::MAXP; ++p)
                     if (p < w.per_ch && w.goff[p] >= 0)
-                        __builtin_amdgcn_global_load_lds((wgas_ptr)(g + w.goff[p]), (wlds_ptr)(dst + c * WIN + p * 256), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds((wgas_ptr)(g + w.goff[p]), (wlds_ptr)(dst + c * STRIDE + p * 256), 16, 0, 0);
             }
         }
     } else {
@@ -309,7 +309,7 @@ __device__ __forceinline__ void window_stage(float* __restrict__ dst, const Wind
         for (int r = wave; r < rows; r += 4) {
             const int c = r / w.wh, ry = r - c * w.wh;
             const float* g = planes + (size_t)c * plane + (size_t)(w.wy0 + ry) * W + w.wxa;
-            float* d = dst + c * WIN + ry * w.rs;
+            float* d = dst + c * STRIDE + ry * w.rs;
             for (int x = lane; x < w.rs; x += 64) d[x] = g[x];
         }
     }
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void warp_fwd_tile_kernel(const float* __restr
     tap_offsets<WIN, PPT>(w, k, l_nw, l_ne, l_sw, l_se);
     for (int c0 = c_begin; c0 < c_end; c0 += CC) {
         const int nc = min(CC, c_end - c0);
-        window_stage<WIN, CC>(s_src, w, sp + (size_t)c0 * plane, plane, W, nc);
+        window_stage<WIN, WIN, CC>(s_src, w, sp + (size_t)c0 * plane, plane, W, nc);
         stage_fence();
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
@@ -405,12 +405,16 @@ __global__ __launch_bounds__(256) void warp_fwd_tile_kernel(const float* __restr
 // SPLIT: the channels of a tile are spread over gridDim.y workgroups; their flow-gradient partials are
 // added atomically into a zeroed gflow (otherwise gflow is written once, reproducibly).
 template <int PPT, int WIN, int CC, bool SPLIT>
-__global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PPT == 4 ? 3 : 4))) void warp_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow,
                                                             const float* __restrict__ gout, float* __restrict__ gsrc,
                                                             float* __restrict__ gflow, int C, int H, int W, int ac,
                                                             int TW, int TH, int tiles_x, int tiles_y, int cpg, int vec_ok, int dbg) {
-    __shared__ __attribute__((aligned(16))) float s_src[CC * WIN];
-    __shared__ __attribute__((aligned(16))) float s_acc[CC * WIN];
+    // Per channel: WIN floats of window + one private cell per thread.  A tap that does not exist (outside the image,
+    // dead lane) is pointed at its thread's private cell: the source copy reads 0 there, the accumulator copy absorbs
+    // the (zero) contribution -- so the inner loops carry no validity branches at all.
+    constexpr int WINP = WIN + 256;
+    __shared__ __attribute__((aligned(16))) float s_src[CC * WINP];
+    __shared__ __attribute__((aligned(16))) float s_acc[CC * WINP];
     __shared__ int s_box[16];
     int t = blockIdx.x;
     const int bx = t % tiles_x; t /= tiles_x;
@@ -455,16 +459,31 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const float* __restr
             }
         }
     } else {
-        int l_nw[PPT], l_ne[PPT], l_sw[PPT], l_se[PPT];
-        tap_offsets<WIN, PPT>(w, k, l_nw, l_ne, l_sw, l_se);
+        int o_nw[PPT], o_ne[PPT], o_sw[PPT], o_se[PPT];
+        {
+            int l_nw[PPT], l_ne[PPT], l_sw[PPT], l_se[PPT];
+            tap_offsets<WIN, PPT>(w, k, l_nw, l_ne, l_sw, l_se);
+            const int mine = WIN + (int)threadIdx.x;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                const Taps& tp = k.t[q];
+                o_nw[q] = (k.live[q] && tp.v_nw) ? l_nw[q] : mine;
+                o_ne[q] = (k.live[q] && tp.v_ne) ? l_ne[q] : mine;
+                o_sw[q] = (k.live[q] && tp.v_sw) ? l_sw[q] : mine;
+                o_se[q] = (k.live[q] && tp.v_se) ? l_se[q] : mine;
+            }
+        }
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int used = w.rs * w.wh;                         // floats of a channel's window actually in use
-        // Are the nw-tap positions of the tile's pixels pairwise different (the flow does not fold or compress by a
-        // whole pixel inside the tile)?  Then each of the four tap kinds touches every accumulator cell at most once,
-        // and the taps can be added with plain LDS read-add-write, one kind at a time (ds_add_f32 runs ~20x slower
-        // than a read + write pair).  Every pixel posts its id at its position; whoever reads back another id collided.
-        bool inj = true;
-        if (dp) {
+        // ds_add_f32 runs ~20x slower than an LDS read + write pair, so the taps are added with PLAIN read-add-write
+        // wherever that is race free: every pixel posts its id at the (unclamped) position of its nw tap; the pixel
+        // that reads its own id back is the cell's "solo" owner.  Solo pixels have pairwise different positions, so
+        // within one tap kind (nw / ne / sw / se) they touch pairwise different accumulator cells: four plain passes
+        // separated by barriers.  The others (where the flow compresses, two pixels floor to the same position: a few
+        // per cent of a smooth flow) add theirs with LDS atomics in a fifth pass.
+        bool solo[PPT];
+        bool any_dup = false;
+        {
             int* marker = reinterpret_cast<int*>(s_acc);      // (wh + 1) x (rs + 1) cells, position (x0 + 1, y0 + 1) relative to the window
             const int mrs = w.rs + 1;
             int cell[PPT];
@@ -477,17 +496,17 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const float* __restr
             }
             __syncthreads();
 #pragma unroll
-            for (int q = 0; q < PPT; ++q)
-                if (cell[q] >= 0 && marker[cell[q]] != q * 256 + (int)threadIdx.x) inj = false;
-            inj = __syncthreads_and(inj ? 1 : 0) != 0;
-            for (int c = 0; c < CC; ++c)
-                for (int i = threadIdx.x; i < used; i += 256) s_acc[c * WIN + i] = 0.f;
-            if ((w.wh + 1) * mrs > used)                      // the marker grid is one row and one column larger than a window
-                for (int i = used + threadIdx.x; i < (w.wh + 1) * mrs; i += 256) s_acc[i] = 0.f;
+            for (int q = 0; q < PPT; ++q) {
+                solo[q] = cell[q] < 0 || marker[cell[q]] == q * 256 + (int)threadIdx.x;
+                any_dup = any_dup || !solo[q];
+            }
+            any_dup = __syncthreads_or(any_dup ? 1 : 0) != 0;
         }
+        for (int i = threadIdx.x; i < CC * WINP; i += 256) { s_acc[i] = 0.f; s_src[i] = 0.f; }
+        __syncthreads();                                      // (the staging below must not be overtaken by this fill)
         for (int c0 = c_begin; c0 < c_end; c0 += CC) {
             const int nc = min(CC, c_end - c0);
-            window_stage<WIN, CC>(s_src, w, sp + (size_t)c0 * plane, plane, W, nc);
+            window_stage<WINP, WIN, CC>(s_src, w, sp + (size_t)c0 * plane, plane, W, nc);
             float g[PPT][CC];                                 // upstream gradients of the chunk: in flight with the window pieces
 #pragma unroll
             for (int q = 0; q < PPT; ++q)
@@ -495,58 +514,79 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const float* __restr
                 for (int c = 0; c < CC; ++c)
                     g[q][c] = (k.live[q] && c < nc) ? gp[(size_t)(c0 + c) * plane + k.pix[q]] : 0.f;
             stage_fence();                                    // window staged, accumulator zero
+            // channels beyond nc hold an older chunk's (finite) values and g == 0: they add nothing
 #pragma unroll
             for (int q = 0; q < PPT; ++q) {
                 const Taps& tp = k.t[q];
 #pragma unroll
                 for (int c = 0; c < CC; ++c) {
-                    if (c < nc) {
-                        const float* win = s_src + c * WIN;
-                        const float gv = g[q][c];
-                        const float a = tp.v_nw ? win[l_nw[q]] : 0.f, bq = tp.v_ne ? win[l_ne[q]] : 0.f;
-                        const float cq = tp.v_sw ? win[l_sw[q]] : 0.f, dq = tp.v_se ? win[l_se[q]] : 0.f;
-                        gix[q] += gv * ((bq - a) * tp.s + (dq - cq) * tp.n);
-                        giy[q] += gv * ((cq - a) * tp.e + (dq - bq) * tp.w);
-                        if (dp && k.live[q] && !inj && !WARP_DBG(1)) {
-                            float* acc = s_acc + c * WIN;
-                            if (tp.v_nw) atomicAdd(acc + l_nw[q], gv * tp.nw);
-                            if (tp.v_ne) atomicAdd(acc + l_ne[q], gv * tp.ne);
-                            if (tp.v_sw) atomicAdd(acc + l_sw[q], gv * tp.sw);
-                            if (tp.v_se) atomicAdd(acc + l_se[q], gv * tp.se);
+                    const float* win = s_src + c * WINP;
+                    const float gv = g[q][c];
+                    const float a = win[o_nw[q]], bq = win[o_ne[q]], cq = win[o_sw[q]], dq = win[o_se[q]];
+                    gix[q] += gv * ((bq - a) * tp.s + (dq - cq) * tp.n);
+                    giy[q] += gv * ((cq - a) * tp.e + (dq - bq) * tp.w);
+                }
+                __builtin_amdgcn_sched_barrier(0);            // one pixel's taps in flight at a time (registers)
+            }
+            if (dp && !WARP_DBG(1)) {
+                const int mine = WIN + (int)threadIdx.x;
+                // one tap kind at a time: within a kind the solo pixels' cells are distinct, so plain read-add-write is race free
+#define TAP_PHASE(OFF, WGT)                                                                          \
+                _Pragma("unroll") for (int q = 0; q < PPT; ++q) {                                    \
+                    const int o = solo[q] ? OFF[q] : mine;                                           \
+                    _Pragma("unroll") for (int c = 0; c < CC; ++c)                                   \
+                        s_acc[c * WINP + o] += g[q][c] * k.t[q].WGT;                                 \
+                    __builtin_amdgcn_sched_barrier(0);                                               \
+                }
+                TAP_PHASE(o_nw, nw)
+                __syncthreads();
+                TAP_PHASE(o_ne, ne)
+                __syncthreads();
+                TAP_PHASE(o_sw, sw)
+                __syncthreads();
+                TAP_PHASE(o_se, se)
+#undef TAP_PHASE
+                if (any_dup) {
+                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < PPT; ++q) {
+                        if (!solo[q]) {
+#pragma unroll
+                            for (int c = 0; c < CC; ++c) {
+                                float* acc = s_acc + c * WINP;
+                                atomicAdd(acc + o_nw[q], g[q][c] * k.t[q].nw);
+                                atomicAdd(acc + o_ne[q], g[q][c] * k.t[q].ne);
+                                atomicAdd(acc + o_sw[q], g[q][c] * k.t[q].sw);
+                                atomicAdd(acc + o_se[q], g[q][c] * k.t[q].se);
+                            }
                         }
                     }
                 }
             }
-            if (dp && inj && !WARP_DBG(1)) {
-                // one tap kind at a time: within a kind all cells are distinct, so plain read-add-write is race free
-#define TAP_PHASE(VALID, OFF, WGT)                                                                   \
-                _Pragma("unroll") for (int q = 0; q < PPT; ++q) {                                    \
-                    const Taps& tp = k.t[q];                                                         \
-                    if (k.live[q] && tp.VALID) {                                                     \
-                        _Pragma("unroll") for (int c = 0; c < CC; ++c)                               \
-                            if (c < nc) s_acc[c * WIN + OFF[q]] += g[q][c] * tp.WGT;                 \
-                    }                                                                                \
-                }
-                TAP_PHASE(v_nw, l_nw, nw)
-                __syncthreads();
-                TAP_PHASE(v_ne, l_ne, ne)
-                __syncthreads();
-                TAP_PHASE(v_sw, l_sw, sw)
-                __syncthreads();
-                TAP_PHASE(v_se, l_se, se)
-#undef TAP_PHASE
-            }
             __syncthreads();                                  // every tap of the chunk is in the LDS accumulator
             if (dp && !WARP_DBG(2)) {
-                // flush: one window row per wave-instruction (row-contiguous float atomics), re-zero behind it
-                const int rows = nc * w.wh;
-                for (int r = wave; r < rows; r += 4) {
-                    const int c = r / w.wh, ry = r - c * w.wh;
-                    float* d = dp + (size_t)(c0 + c) * plane + (size_t)(w.wy0 + ry) * W + w.wxa;
-                    float* a = s_acc + c * WIN + ry * w.rs;
-                    for (int x = lane; x < w.rs; x += 64) {
-                        const float v = a[x];
-                        if (v != 0.f) { if (!WARP_DBG(4)) atomicAdd(d + x, v); a[x] = 0.f; }
+                // flush: one window row per wave-instruction (row-contiguous float atomics), re-zero behind it; wave v owns
+                // channels v, v+4, ..., four rows in flight per wave
+#pragma unroll
+                for (int cc = 0; cc < (CC + 3) / 4; ++cc) {
+                    const int c = wave + 4 * cc;
+                    if (c < nc) {
+                        float* d = dp + (size_t)(c0 + c) * plane + (size_t)w.wy0 * W + w.wxa;
+                        float* a = s_acc + c * WINP;
+                        for (int ry = 0; ry < w.wh; ry += 4) {
+                            float v[4], v2[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const bool row = ry + u < w.wh;
+                                v[u] = (row && lane < w.rs) ? a[(ry + u) * w.rs + lane] : 0.f;
+                                v2[u] = (row && lane + 64 < w.rs) ? a[(ry + u) * w.rs + lane + 64] : 0.f;
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                if (v[u] != 0.f) { if (!WARP_DBG(4)) atomicAdd(d + (size_t)(ry + u) * W + lane, v[u]); a[(ry + u) * w.rs + lane] = 0.f; }
+                                if (v2[u] != 0.f) { if (!WARP_DBG(4)) atomicAdd(d + (size_t)(ry + u) * W + lane + 64, v2[u]); a[(ry + u) * w.rs + lane + 64] = 0.f; }
+                            }
+                        }
                     }
                 }
             }
@@ -589,7 +629,8 @@ inline TilePlan plan_tiles(int B, int C, int H, int W, int TH, int CC, int want_
 }  // namespace
 
 // Feature maps (no mask, >= 8 channels) go through the LDS-tile kernels.
-static bool use_tiles(const uint8_t* mask, int C, int W) { return mask == nullptr && C >= 8 && W >= 8; }
+// Feature maps (no mask, >= 8 channels, >= 512 pixels: pyramid levels 2-4) go through the LDS-tile kernels.
+static bool use_tiles(const uint8_t* mask, int C, int H, int W) { return mask == nullptr && C >= 8 && W >= 8 && H * W >= 512; }
 
 // Tuning builds (tools/, -DUNFLOW_TUNING) may override the tile height / workgroup target; the shipped library
 // never reads the environment.
@@ -605,8 +646,8 @@ extern "C" int unflow_warp_fwd(const float* src, const float* flow, float* out, 
     UNFLOW_REQUIRE(src && flow && out && B > 0 && C > 0 && H > 0 && W > 0);
     hipStream_t s = (hipStream_t)stream;
     const int ac = align_corners ? 1 : 0;
-    if (use_tiles(mask, C, W) && wenv("UNFLOW_WARP_TILES", 1)) {
-        const int th = wenv("UNFLOW_WARP_TH", H >= 12 ? 16 : 8);
+    if (use_tiles(mask, C, H, W) && wenv("UNFLOW_WARP_TILES", 1)) {
+        const int th = wenv("UNFLOW_WARP_TH", 8);              // measured: 64x8 tiles, ~1024 workgroups (levels 2-4: 17 / 9 / 7.5 us)
         const TilePlan p = plan_tiles(B, C, H, W, th, 8, wenv("UNFLOW_WARP_WGS", 1024));
         dim3 grid(p.tiles_x * p.tiles_y * B, p.groups);
         const int vec_ok = ((W & 3) == 0 && (((size_t)src) & 15) == 0) ? 1 : 0;
@@ -637,9 +678,9 @@ extern "C" int unflow_warp_bwd(const float* src, const float* flow, const float*
     hipStream_t s = (hipStream_t)stream;
     if (gsrc) unflow_zero_async(gsrc, (size_t)B * C * H * W, s);
     const int ac = align_corners ? 1 : 0;
-    if (use_tiles(mask, C, W) && wenv("UNFLOW_WARP_TILES", 1)) {
-        const int th = wenv("UNFLOW_WARP_TH", H >= 12 ? 16 : 8);
-        const TilePlan p = plan_tiles(B, C, H, W, th, 4, wenv("UNFLOW_WARP_WGS", 1024));
+    if (use_tiles(mask, C, H, W) && wenv("UNFLOW_WARP_TILES", 1)) {
+        const int th = wenv("UNFLOW_WARP_TH", 8);              // 2 px per lane: 152 VGPRs (3 workgroups per CU); 4 px needs 256
+        const TilePlan p = plan_tiles(B, C, H, W, th, 4, wenv("UNFLOW_WARP_WGS", 512));   // level 2: 512 tiles, all channels in one workgroup
         dim3 tgrid(p.tiles_x * p.tiles_y * B, p.groups);
         const int vec_ok = ((W & 3) == 0 && (((size_t)src) & 15) == 0) ? 1 : 0;
         if (p.groups > 1) unflow_zero_async(gflow, (size_t)B * 2 * H * W, s);     // channel groups add their partials
