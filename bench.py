@@ -11,18 +11,23 @@ synthetic KITTI-sized triplets [8,3,768,832] fp32 already resident in HBM (BASEL
 832x256, bs=8 per GPU, fp32; weak scaling: the per-GPU batch is fixed).  pairs/s = 2 * triplets/s.
 
 The single JSON line also carries
-  roofline:     the dominant hand-written kernel (cost-volume forward at pyramid level 2, the LDS-DMA
-                ring kernel): algorithmic bytes 4*B*n*(2C+81) per launch over its mean launch duration,
-                HIP events on the launch stream inside the timed steps; traffic = HBM bytes per launch
-                from the PMC passes committed under profiles/;
+  roofline:     HIP events around EVERY cost-volume / warp entry point inside the timed steps (on the launch stream).
+                The object describes the (entry point, shape) with the LARGEST time per step -- the kernel that weighs most,
+                not the one that looks best: algorithmic bytes per launch (SURVEY 8d formulas) / mean launch duration
+                against the 8 TB/s HBM peak.  `traffic` = HBM bytes per launch from the PMC passes committed under
+                profiles/ -- only when that file was measured on the very kernel sources of this build (sha256 of
+                csrc/*.hip recorded next to it), else null.  `aggregate` = all cost-volume + warp launches of a step as
+                one figure (north_star: "achieved HBM GB/s for corr/warp") with the per-level table; `best` = the entry
+                with the highest fraction, for reference;
   cpu_baseline: the CPU oracle (oracle/ref_cpu.py, the restatement of the reference's op graph,
                 kind "port") timed on the host cores of this box on a bounded sample (all cores the
                 cgroup allows, plus a one-thread figure);
   conv_stack:   convolution FLOPs of the step / whole step time / dense MFMA peak of the dtype: a lower
                 bound on the conv stacks' MFMA utilisation;
-  corr_warp_all_levels, kernel_survey (N = 1 only, 3 extra untimed steps with HIP events around every C
-                entry point): all cost-volume + warp launches as one HBM-roofline figure with a per-level
-                table, and the 14 heaviest entry points.
+  kernel_survey (N = 1 only, 3 extra untimed steps with HIP events around every C entry point): the 14 heaviest
+                entry points (losses and conv epilogues included).
+--force-ddp runs the N = 1 step through the data-parallel path on RCCL with a one-rank communicator (hooks, async
+all-reduce on RCCL's stream, waits): a rehearsal of what every rank of an 8-GPU job executes.
 UNFLOW_BENCH_ONE_GPU=1 is a rehearsal mode for a single-GPU box (all ranks on device 0, gloo).
 """
 import argparse
@@ -46,8 +51,8 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=B_PER_GPU, help='triplets per GPU (8 = BASELINE config)')
     ap.add_argument('--hw', type=int, nargs=2, default=[H, W], metavar=('H', 'W'),
                     help='frame size (default 256 832 = the BASELINE metric; 448 1024 = config 4, not in the shipped find-db)')
@@ -56,6 +61,7 @@ def parse():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'], help='conv-stack precision (bf16: BASELINE config 3; the headline metric is fp32)')
     ap.add_argument('--graph', type=int, default=0, help='1: replay the step as a hipGraph (kernel timing events are then off)')
+    ap.add_argument('--force-ddp', action='store_true', help='N = 1 only: run the step through the RCCL data-parallel path with a one-rank communicator')
     return ap.parse_args()
 
 
@@ -111,6 +117,34 @@ def cpu_baseline(sample_b):
                       'oracle on %s; value_1thread: 1 timed step of 1 triplet on one thread (%.1f s)' % (n, sample_b, dt, cpu, dt1)}
 
 
+def sources_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from, in name order."""
+    import hashlib
+    d = os.path.join(ROOT, 'unopticalflow_amd', 'csrc')
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith(('.hip', '.h', '.cpp')):
+            h.update(name.encode()); h.update(open(os.path.join(d, name), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(entry, shape, path=None):
+    """HBM bytes per launch of (entry point, shape) from the rocprofv3 PMC passes under profiles/ (FETCH_SIZE x2 per the
+    gfx950 wide-load correction + WRITE_SIZE, tools/pmc_traffic.py) -- but only if that file was measured on exactly the
+    kernel sources of this build; a stale file gives (None, reason)."""
+    path = path or os.path.join(ROOT, 'profiles', 'r2_pmc_traffic.json')
+    if not os.path.exists(path):
+        return None, 'no PMC file'
+    d = json.load(open(path))
+    if d.get('sources_sha16') != sources_sha16():
+        return None, 'PMC file %s was measured on other kernel sources (%s != %s)' % (os.path.basename(path), d.get('sources_sha16'), sources_sha16())
+    key = '%s %s' % (entry, list(shape) if shape else None)
+    v = d.get('entries', {}).get(key)
+    if v is None:
+        return None, 'no PMC entry for %s' % key
+    return int(v['hbm_bytes_per_launch']), 'profiles/%s (sources %s)' % (os.path.basename(path), d['sources_sha16'])
+
+
 def main():
     args = parse()
     from unopticalflow_amd import get_model, _lib, ops
@@ -123,7 +157,8 @@ def main():
     # shares device 0 and the collectives go through gloo (RCCL refuses two ranks on one device) -- it exercises the
     # multi-rank plumbing, its numbers mean nothing.
     one_gpu = os.environ.get('UNFLOW_BENCH_ONE_GPU') == '1'
-    rank, local_rank, world = init_distributed('gloo' if one_gpu else 'nccl')
+    rank, local_rank, world = init_distributed('gloo' if one_gpu else 'nccl', device_index=0 if one_gpu else None,
+                                               force=args.force_ddp)
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
     if one_gpu:
@@ -139,7 +174,8 @@ def main():
         from unopticalflow_amd.tuning import enable_miopen_tuning
         enable_miopen_tuning()                    # shipped find-db for exactly these conv shapes (tuning.py)
     model = get_model('flow')(cfg).to(dev)
-    trainer = FlowTrainer(cfg, model, distributed=(world > 1), use_graph=bool(args.graph))
+    trainer = FlowTrainer(cfg, model, distributed=(world > 1 or args.force_ddp), use_graph=bool(args.graph),
+                          single_rank_collectives=args.force_ddp)
     if args.graph:
         args.no_kernel_timing = True
     gen = torch.Generator(device=dev)
@@ -148,14 +184,15 @@ def main():
     inputs = torch.rand((args.batch, 3, 3 * fh, fw), generator=gen, device=dev, dtype=torch.float32)
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         trainer.step(inputs)
+    CW = ('unflow_corr_fwd', 'unflow_corr_bwd', 'unflow_warp_fwd', 'unflow_warp_bwd', 'unflow_warp_corr_fwd', 'unflow_warp_corr_bwd')
     if not args.no_kernel_timing:
-        ops.kernel_timer.enable('unflow_corr_fwd', min_width=200)
+        ops.kernel_timer.enable(CW)                # every cost-volume / warp launch of the timed steps, on its own stream
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -163,6 +200,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ops.kernel_timer.disable()
+    timed_rows = ops.kernel_timer.rows() if not args.no_kernel_timing else []      # (device is synchronised: barrier())
     if not torch.isfinite(loss):
         raise SystemExit('non-finite loss in the timed region')
 
@@ -189,25 +227,16 @@ def main():
     for h_ in hooks:
         h_.remove()
 
-    survey = corr_warp = None
+    survey = None
     if rank == 0 and world == 1 and not args.no_kernel_timing:
-        # per-entry-point timings of the hand-written kernels: 3 extra (untimed) steps with a HIP-event pair
-        # around every C call; kept out of the timed region so `value` is not perturbed
-        ops.kernel_timer.start_survey()
+        # per-entry-point timings of ALL hand-written kernels: 3 extra (untimed) steps with a HIP-event pair
+        # around every C call
+        ops.kernel_timer.enable(True)
         for _ in range(3):
             trainer.step(inputs)
         torch.cuda.synchronize()
-        rows = ops.kernel_timer.end_survey()
-        # every cost-volume and warp launch of the step (all pyramid levels, forward and backward) as one figure
-        cw = [r for r in rows if r['entry'] in ('unflow_corr_fwd', 'unflow_corr_bwd', 'unflow_warp_fwd', 'unflow_warp_bwd')]
-        cw_us, cw_bytes = sum(r['total_us'] for r in cw) / 3.0, sum(r['total_bytes'] for r in cw) / 3.0
-        corr_warp = {'bound': 'hbm', 'algorithmic_bytes_per_step': int(cw_bytes), 'us_per_step': round(cw_us, 1),
-                     'achieved': round(cw_bytes / cw_us / 1e3, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': round(cw_bytes / cw_us / 1e3 / HBM_PEAK_GBS, 4),
-                     'launches_per_step': sum(r['launches'] for r in cw) / 3.0,
-                     'per_level': [{'entry': r['entry'], 'shape': r['shape'], 'avg_us': r['avg_us'],
-                                    'launches_per_step': r['launches'] / 3.0, 'algorithmic_GBps': r['algorithmic_GBps']}
-                                   for r in cw]} if cw_us > 0 else None
+        ops.kernel_timer.disable()
+        rows = ops.kernel_timer.rows()
         for r in rows:
             r.pop('total_us'); r.pop('total_bytes')
             if r['algorithmic_GBps'] is not None:
@@ -217,20 +246,30 @@ def main():
 
     if rank == 0:
         roof = None
-        if not args.no_kernel_timing:
-            nl, ms, nbytes = ops.kernel_timer.summary()
-            if nl:
-                traffic = None        # HBM bytes/launch from the PMC passes (profiles/, collected separately)
-                pmc = os.path.join(ROOT, 'profiles', 'r1_corr_fwd_ring_pmc.json')
-                if os.path.exists(pmc) and (fh, fw, args.batch) == (H, W, B_PER_GPU):
-                    traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
-                gbs = nbytes / (ms * 1e-3) / 1e9
-                roof = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                        'kernel': 'corr_fwd_ring_kernel<4,2,9> (cost volume forward, pyramid level 2, [2B=%d,32,%d,%d])'
-                                  % (2 * args.batch, fh // 4, fw // 4),
-                        'launches': nl, 'avg_us': round(ms * 1e3 / nl, 2),
-                        'algorithmic_bytes_per_launch': int(nbytes / nl)}
+        if timed_rows:
+            K = float(args.steps)
+
+            def entry(r):
+                return {'entry': r['entry'], 'shape': r['shape'], 'avg_us': r['avg_us'], 'launches_per_step': r['launches'] / K,
+                        'us_per_step': round(r['total_us'] / K, 2), 'algorithmic_bytes_per_launch': int(r['total_bytes'] / r['launches']),
+                        'algorithmic_GBps': r['algorithmic_GBps'], 'frac': round((r['algorithmic_GBps'] or 0.0) / HBM_PEAK_GBS, 4)}
+            top = timed_rows[0]                      # rows() sorts by total time: the heaviest (entry point, shape)
+            best = max(timed_rows, key=lambda r: r['algorithmic_GBps'] or 0.0)
+            tot_us, tot_b = sum(r['total_us'] for r in timed_rows) / K, sum(r['total_bytes'] for r in timed_rows) / K
+            traffic, traffic_note = measured_traffic(top['entry'], top['shape'])
+            gbs = top['algorithmic_GBps'] or 0.0
+            roof = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
+                    'traffic': traffic, 'traffic_source': traffic_note,
+                    'kernel': '%s %s: the cost-volume / warp entry point with the largest time per step' % (top['entry'], top['shape']),
+                    'launches': top['launches'], 'avg_us': top['avg_us'],
+                    'algorithmic_bytes_per_launch': int(top['total_bytes'] / top['launches']),
+                    'aggregate': {'what': 'every cost-volume and warp launch of a step (all pyramid levels, forward and backward)',
+                                  'algorithmic_bytes_per_step': int(tot_b), 'us_per_step': round(tot_us, 1),
+                                  'achieved': round(tot_b / tot_us / 1e3, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                  'frac': round(tot_b / tot_us / 1e3 / HBM_PEAK_GBS, 4),
+                                  'launches_per_step': sum(r['launches'] for r in timed_rows) / K,
+                                  'per_level': [entry(r) for r in timed_rows]},
+                    'best': entry(best)}
         base = None
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_baseline(args.cpu_sample)
@@ -253,10 +292,10 @@ def main():
                 'achieved_lower_bound': round(conv_flops[0] / (dt / args.steps) / 1e12, 1),
                 'peak': MFMA_PEAK_TFLOPS[args.precision], 'unit': 'TFLOP/s',
                 'frac_lower_bound': round(conv_flops[0] / (dt / args.steps) / 1e12 / MFMA_PEAK_TFLOPS[args.precision], 4)},
-            'corr_warp_all_levels': corr_warp, 'kernel_survey': survey,
+            'kernel_survey': survey,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

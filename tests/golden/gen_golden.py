@@ -178,7 +178,10 @@ def param_stats(model):
         np.array([p.detach().double().abs().sum().item() for p in model.parameters()])
 
 
-def gen_module(name, B, H, W, steps, full_flows):
+FULL_GRADS = ('fpyramid.conv1.0.weight', 'pwc_model.conv2_0.0.weight', 'pwc_model.dc_conv7.weight')
+
+
+def gen_module(name, B, H, W, steps, full_flows, mask_flow_scales=(), full_grads=False):
     out = {'B': B, 'H': H, 'W': W, 'flow_gain': FLOW_GAIN}
     cfg = R.default_cfg()
     weights = R.generate_loss_weights_dict(cfg)
@@ -204,6 +207,10 @@ def gen_module(name, B, H, W, steps, full_flows):
                         st = 1 if (full_flows and s >= 1) else max(1, 8 >> s)
                         out['flow_%s%d%s' % (nm, s, tag)] = npy(fl[:, :, ::st, ::st])
                         out['flow_%s%d_sum%s' % (nm, s, tag)] = fl.double().sum().item()
+                        if s in mask_flow_scales and (ac == 0 or full_flows):
+                            # the exact flow the mask fixtures below were warped with: lets the GPU test demand
+                            # bit-equal masks at model scale (no conv rounding in between)
+                            out['flowfull_%s%d%s' % (nm, s, tag)] = npy(fl)
                 pyr_l, pyr_r = model.generate_img_pyramid(imgl, 4), model.generate_img_pyramid(imgr, 4)
                 for s in range(4):
                     for nm, pyr, fl in (('bwd', pyr_l, fb), ('fwd', pyr_r, ff)):
@@ -224,6 +231,10 @@ def gen_module(name, B, H, W, steps, full_flows):
                     out['grad_sum' + tag], out['grad_abs' + tag] = gs, ga
                     out['grad_norm' + tag] = float(np.sqrt(sum((p.grad.double() ** 2).sum().item()
                                                                for p in model.parameters())))
+                    if full_grads and ac == 0:
+                        for n, p in model.named_parameters():
+                            if n in FULL_GRADS:
+                                out['gradfull_' + n + tag] = npy(p.grad)
                 opt.step()
                 if it in (0, 2):
                     ps, pa = param_stats(model)
@@ -238,5 +249,5 @@ if __name__ == '__main__':
     gen_corr()
     gen_warp()
     gen_losses()
-    gen_module('g2_module_128.npz', 2, 128, 128, steps=3, full_flows=True)
-    gen_module('g3_kitti_256x832.npz', 1, 256, 832, steps=1, full_flows=False)
+    gen_module('g2_module_128.npz', 2, 128, 128, steps=3, full_flows=True, mask_flow_scales=(0, 1, 2, 3), full_grads=True)
+    gen_module('g3_kitti_256x832.npz', 1, 256, 832, steps=1, full_flows=False, mask_flow_scales=(1, 2, 3))

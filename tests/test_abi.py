@@ -94,6 +94,22 @@ def test_dma_ring_kernels_do_not_spill():
     assert checked >= 3      # ring<9 rows>, ring<3 rows>, group-split backward
 
 
+def test_host_library_has_no_hip_dependency():
+    """libunflow_host.so (PNG unfilter for the DataLoader workers) must load without the HIP runtime."""
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build()
+    from unopticalflow_amd import _lib
+    lib = _lib.load_host()
+    assert hasattr(lib, 'unflow_png_unfilter')
+    needed = subprocess.run(['readelf', '-d', _lib.HOST_LIB_PATH], capture_output=True, text=True).stdout
+    assert 'amdhip' not in needed and 'hsa-runtime' not in needed, needed
+    import numpy as np
+    rows = np.array([[0, 1, 2, 3], [2, 5, 5, 5]], np.uint8)          # filter 0 (none), filter 2 (up)
+    assert lib.unflow_png_unfilter(ctypes.c_void_p(rows.ctypes.data), 2, 3, 1) == 0
+    assert rows[1, 1:].tolist() == [6, 7, 8]
+
+
 def test_c_program_links_against_the_abi(tmp_path):
     """tools/capi_bench.cpp uses include/unflow_hip.h from plain C++ (no torch, no Python): it must compile and
     link against the in-tree library (it is only run on the GPU box)."""

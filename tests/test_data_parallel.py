@@ -138,3 +138,60 @@ def test_checkpoint_roundtrip_and_module_prefix(tmp_path):
     l1, _ = tr.step(x)
     l2, _ = tr2.step(x)
     assert torch.allclose(l1, l2, rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------ train.py plumbing (CPU)
+@pytest.mark.parametrize('world,batch,iters,start', [(1, 8, 50, 0), (4, 8, 50, 0), (8, 64, 25, 5), (2, 6, 7, 0)])
+def test_every_rank_gets_all_scheduled_iterations(tmp_path, world, batch, iters, start):
+    """train.py sizes the dataset with the GLOBAL batch (reference train.py:110); DistributedSampler then hands each
+    rank 1/world of it, so every rank's loader must yield exactly num_iterations - iter_start batches (sizing it with
+    the per-rank batch silently ran 1/world of the schedule)."""
+    import types
+    from unopticalflow_amd.train import training_items
+    from unopticalflow_amd.data import DecodedTriplets
+    (tmp_path / 'train.txt').write_text(''.join('seq/%d.png seq/%d_cam.txt\n' % (i, i) for i in range(11)))
+    cfg = types.SimpleNamespace(batch_size=batch, num_iterations=iters, iter_start=start)
+    n_items, per_rank = training_items(cfg, world)
+    assert per_rank * world == batch and n_items == (iters - start) * batch
+    ds = DecodedTriplets(str(tmp_path), 3, (64, 128), n_items)
+    for rank in range(world):
+        sampler = torch.utils.data.distributed.DistributedSampler(ds, world, rank, shuffle=True) if world > 1 else None
+        loader = torch.utils.data.DataLoader(ds, batch_size=per_rank, sampler=sampler, drop_last=False, collate_fn=lambda s: s)
+        assert len(loader) == iters - start, (rank, len(loader))
+    with pytest.raises(ValueError):
+        training_items(types.SimpleNamespace(batch_size=6, num_iterations=4, iter_start=0), 4)
+
+
+def test_gpu_flag_selects_devices():
+    """--gpu is the device list (reference train.py:198: CUDA_VISIBLE_DEVICES = args.gpu): rank r drives its r-th id."""
+    from unopticalflow_amd.train import gpu_ids
+    assert gpu_ids('0') == [0] and gpu_ids('3') == [3] and gpu_ids('4,5,6,7') == [4, 5, 6, 7] and gpu_ids(2) == [2]
+    with pytest.raises(ValueError):
+        gpu_ids('')
+
+
+def test_single_rank_group_runs_the_collectives():
+    """A process group of ONE rank (what the RCCL rehearsal on a single-GPU box uses): with single_rank_collectives the
+    hooks launch every piece during backward and all_reduce_mean leaves the gradient unchanged (sum over 1 rank / 1)."""
+    os.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    r, lr, w = init_distributed('gloo', force=True)
+    try:
+        assert (r, w) == (0, 1) and dist.is_initialized() and dist.get_world_size() == 1
+        torch.set_num_threads(2)
+        cfg, model = _make()
+        tr = FlowTrainer(cfg, model, distributed=True, fused_adam=False, single_rank_collectives=True)
+        x = R.synthetic_triplets(1, H, W, seed=5, structured=True)
+        tr.grads.zero()
+        tr.total_loss(tr.model(x)).backward()
+        assert tr.grads.launched_early == tr.grads.chunks
+        before = tr.grads.flat.clone()
+        tr.grads.all_reduce_mean()
+        assert torch.equal(before, tr.grads.flat)
+        # without the flag a one-rank group stays silent (no collectives for a plain single-process run)
+        cfg2, model2 = _make()
+        tr2 = FlowTrainer(cfg2, model2, distributed=True, fused_adam=False)
+        tr2.grads.zero()
+        tr2.total_loss(tr2.model(x)).backward()
+        assert tr2.grads.launched_early == 0
+    finally:
+        dist.destroy_process_group()

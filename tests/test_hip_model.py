@@ -77,9 +77,17 @@ def test_module_128_golden(golden, ac):
                 close(pack[k], g[k + tag], rtol=1e-4, what=k)
             close(loss, g['total' + tag], rtol=1e-4)
             gn = float(np.sqrt(sum((p.grad.double() ** 2).sum().item() for p in model.parameters())))
-            np.testing.assert_allclose(gn, float(g['grad_norm' + tag]), rtol=2e-3)
+            np.testing.assert_allclose(gn, float(g['grad_norm' + tag]), rtol=5e-4)
             ga = np.array([p.grad.double().abs().sum().item() for p in model.parameters()])
-            np.testing.assert_allclose(ga, g['grad_abs' + tag], rtol=2e-2)
+            np.testing.assert_allclose(ga, g['grad_abs' + tag], rtol=2e-2)      # per-tensor L1: small tensors near zero dominate the ratio
+            if ac == 0:
+                # full gradient tensors of the first pyramid layer (end of the whole backward chain), the widest level-2
+                # decoder layer (fed by cost volume + warp) and the last context layer: every element within 1e-3 of the
+                # tensor's largest gradient
+                named = dict(model.named_parameters())
+                for name in ('fpyramid.conv1.0.weight', 'pwc_model.conv2_0.0.weight', 'pwc_model.dc_conv7.weight'):
+                    ref_g = g['gradfull_' + name + tag]
+                    close(named[name].grad, ref_g, rtol=0, atol=1e-3 * np.abs(ref_g).max(), what='grad ' + name)
         opt.step()
         # step 0 is pure forward parity (1e-4); later steps follow Adam updates, whose sign-normalised
         # steps amplify conv-rounding differences between MIOpen solvers and MKL-DNN (observed 4e-4)
@@ -87,6 +95,28 @@ def test_module_128_golden(golden, ac):
         if it in (0, 2):
             pa = np.array([p.detach().double().abs().sum().item() for p in model.parameters()])
             np.testing.assert_allclose(pa, g['param_abs_step%d%s' % (it + 1, tag)], rtol=5e-4)   # |Adam update| <= lr per element
+
+
+@pytest.mark.parametrize('fixture,scales,acs', [('g2_module_128.npz', (0, 1, 2, 3), (0, 1)), ('g3_kitti_256x832.npz', (1, 2, 3), (0,))])
+def test_model_scale_masks_bit_exact(golden, fixture, scales, acs):
+    """Bit-exact binary masks at model scale (north_star): the reference's OWN flows (fixture ``flowfull_*``: what its
+    pwc_model produced, i.e. what its warp_flow saw) go through the HIP warp; the uint8 masks must equal the
+    reference's bit for bit at every pyramid scale, both directions -- no conv rounding in between, no mismatch
+    allowance.  (test_module_128_golden compares end-to-end masks, where a flow that differs in the last bits may
+    legitimately flip a pixel sitting on the 0.9999 threshold.)"""
+    from unopticalflow_amd import ops
+    g = golden(fixture)
+    for ac in acs:
+        tag = '_ac%d' % ac
+        for s in scales:
+            for nm in ('fwd', 'bwd'):
+                fl = torch.from_numpy(g['flowfull_%s%d%s' % (nm, s, tag)]).cuda()
+                ones = torch.ones((fl.shape[0], 1) + tuple(fl.shape[2:]), device='cuda')
+                out, m = ops.warp_flow_masked(ones, fl, align_corners=bool(ac))
+                ref_bits = np.unpackbits(g['mask_%s%d%s' % (nm, s, tag)])[: m.numel()].reshape(m.shape)
+                assert np.array_equal(m.cpu().numpy(), ref_bits), (fixture, nm, s, ac, int((m.cpu().numpy() != ref_bits).sum()))
+                o = out.cpu().numpy()                                  # warp(ones) * mask: 0 where masked, >= 0.9999 elsewhere
+                assert np.array_equal(o != 0, ref_bits != 0) and (o[ref_bits != 0] >= 0.9999).all()
 
 
 def test_kitti_256x832_golden(golden):
@@ -167,6 +197,34 @@ def test_bf16_conv_stacks_close_to_fp32_oracle():
     close(pack['loss_flow_smooth'], pr['loss_flow_smooth'], rtol=0.5, what='smooth')   # 2nd differences of a bf16-rounded flow
 
 
+def test_bf16_step_at_kitti_size():
+    """BASELINE config 3 at its real shape: one bf16 train step at 832x256, B=8 (the per-GPU batch of the 8-GPU job).
+    No bf16 reference exists; the fp32 HIP model on the same weights is the yardstick: photometric / SSIM / consistency
+    losses within 3 % per sample (8-bit mantissa through 5 coarse-to-fine levels), smoothness (second differences of a
+    bf16-rounded flow) within a factor 2, every gradient finite and the gradient norm within 25 %."""
+    from unopticalflow_amd import get_model
+    from unopticalflow_amd.trainer import FlowTrainer
+    x = R.synthetic_triplets(8, 256, 832, seed=3, structured=True).cuda()
+    packs, norms = {}, {}
+    for prec in ('fp32', 'bf16'):
+        cfg = R.default_cfg(precision=prec)
+        model = get_model('flow')(cfg).cuda()
+        model.load_state_dict(R.seeded_state_dict(model, 1234, 0.25))
+        tr = FlowTrainer(cfg, model)
+        tr.grads.zero()
+        pack = model(x)
+        tr.total_loss(pack).backward()
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+        norms[prec] = float(tr.grads.flat.double().norm())
+        packs[prec] = {k: v.detach().float().cpu() for k, v in pack.items()}
+        tr.optimizer.step()
+        assert all(torch.isfinite(p).all() for p in model.parameters())
+    for k in ('loss_pixel', 'loss_ssim', 'loss_flow_consis'):
+        close(packs['bf16'][k], packs['fp32'][k], rtol=3e-2, what=k)
+    close(packs['bf16']['loss_flow_smooth'], packs['fp32']['loss_flow_smooth'], rtol=1.0, what='smooth')
+    assert abs(norms['bf16'] - norms['fp32']) <= 0.25 * norms['fp32'], norms
+
+
 # ------------------------------------------------------------------------------------ two ranks on one GPU
 def _gpu_rank(rank, world, port, out_path):
     import os
@@ -226,6 +284,62 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     for a, b in zip(got['params'], model.parameters()):
         np.testing.assert_allclose(a.numpy(), b.detach().cpu().numpy(), rtol=1e-3, atol=4.5e-4)   # 2 Adam steps of <= lr = 1e-4 each;
         # a gradient that is numerically zero takes either sign, so two runs can differ by 4 * lr there
+
+
+def _rccl_single_rank(port, out_path):
+    import os
+    import torch.distributed as dist
+    os.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    from unopticalflow_amd import get_model
+    from unopticalflow_amd.parallel import init_distributed
+    from unopticalflow_amd.trainer import FlowTrainer
+    init_distributed('nccl', device_index=0, force=True)      # RCCL, one rank: the real backend on the real stream
+    assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1
+    cfg = R.default_cfg()
+    sd = R.seeded_state_dict(R.Model_flow(cfg), 1234, 0.25)
+    x = R.synthetic_triplets(2, 64, 128, seed=5, structured=True).cuda()
+    res = {}
+    for name, kw in (('ddp', dict(distributed=True, single_rank_collectives=True)), ('plain', dict(distributed=False))):
+        model = get_model('flow')(cfg).cuda()
+        model.load_state_dict(sd)
+        tr = FlowTrainer(cfg, model, **kw)
+        losses, early = [], []
+        for _ in range(3):
+            tr.grads.zero()
+            pack = model(x)
+            loss = tr.total_loss(pack)
+            loss.backward()
+            early.append(tr.grads.launched_early)
+            tr.grads.all_reduce_mean()
+            tr.optimizer.step()
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        res[name] = {'losses': losses, 'early': early, 'chunks': tr.grads.chunks, 'grad': tr.grads.flat.cpu(),
+                     'params': [p.detach().cpu() for p in model.parameters()]}
+    torch.save(res, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_path_with_one_rank_matches_plain_step(tmp_path):
+    """The data-parallel step on the REAL backend: RCCL accepts a communicator of one rank, so a single-GPU box can run
+    broadcast_parameters, the post-accumulate-grad hooks, the async all_reduce on RCCL's stream, the waits and the 1/world
+    scale exactly as an 8-GPU job does.  Three Adam steps must match the non-distributed trainer (the sum over one rank
+    is the identity; gsrc atomics make the last bits run-dependent, hence the tolerances)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / 'rccl1.pt')
+    mp.start_processes(_rccl_single_rank, args=(port, out), nprocs=1, join=True, start_method='spawn')
+    res = torch.load(out)
+    assert res['ddp']['early'] == [res['ddp']['chunks']] * 3          # every piece left from a hook during backward
+    assert res['plain']['early'] == [0] * 3
+    np.testing.assert_allclose(res['ddp']['losses'], res['plain']['losses'], rtol=2e-4)
+    g = res['plain']['grad']
+    np.testing.assert_allclose(res['ddp']['grad'].numpy(), g.numpy(), rtol=2e-3, atol=2e-4 * g.abs().max().item())
+    for a, b in zip(res['ddp']['params'], res['plain']['params']):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-3, atol=6.5e-4)     # 3 Adam steps of <= lr = 1e-4 each (see above)
 
 
 def test_hipgraph_replay_matches_eager():

@@ -196,6 +196,27 @@ def pmc_l2(B=16):
         torch.cuda.synchronize()
 
 
+def corr_fwd_sweep(B=16):
+    """d=4 forward variants (tuning library) at levels 2-4."""
+    lib = _lib.load()
+    P = ops._ptr
+    envs = [{}] + [{'UNFLOW_CORR_VARIANT': v} for v in (7, 9, 10, 11, 1, 3)]
+    for name, (C, h, w) in list(LEVELS.items())[:3]:
+        f1 = torch.randn(B, C, h, w, device='cuda'); f2 = torch.randn(B, C, h, w, device='cuda')
+        cv = torch.empty(B, 81, h, w, device='cuda')
+        fb = 4 * B * h * w * (2 * C + 81)
+        ref = {}
+
+        def run(tag):
+            cv.zero_()
+            tf = timeit(lambda: lib.unflow_corr_fwd(P(f1), P(f2), P(cv), B, C, h, w, 4, ops._stream()))
+            if not ref:
+                ref['a'] = cv.clone()
+            print('corr_fwd %s [%d,%d,%d,%d] %-24s %7.1f us (%6.0f GB/s)  max|diff vs default| %.2e' % (
+                name, B, C, h, w, tag, tf, fb / tf / 1e3, (cv - ref['a']).abs().max().item()), flush=True)
+        _sweep(envs, run)
+
+
 def losses(B=8):
     for s in range(3):
         h, w = 256 >> s, 832 >> s

@@ -78,6 +78,29 @@ def load():
     return lib
 
 
+HOST_LIB_PATH = os.path.join(PKG, 'libunflow_host.so')
+_host = None
+
+
+def load_host():
+    """libunflow_host.so: the host-only helpers (PNG unfilter) built WITHOUT any HIP dependency.  DataLoader workers
+    are forked after the parent initialised the GPU; loading the HIP fat-binary library there would run its
+    registration constructors against forked HIP runtime state, which is unsupported -- this library is plain C++."""
+    global _host
+    if _host is not None:
+        return _host
+    if not os.path.exists(HOST_LIB_PATH):
+        raise UnflowLibraryError('libunflow_host.so is not built (%s). Run `python -m unopticalflow_amd.build`.' % HOST_LIB_PATH)
+    try:
+        lib = ctypes.CDLL(HOST_LIB_PATH)
+    except OSError as e:
+        raise UnflowLibraryError('cannot load %s: %s' % (HOST_LIB_PATH, e))
+    lib.unflow_png_unfilter.argtypes = SIGNATURES['unflow_png_unfilter']
+    lib.unflow_png_unfilter.restype = ctypes.c_int
+    _host = lib
+    return lib
+
+
 def check(status, name):
     if status != 0:
         raise RuntimeError('%s failed with status %d%s' % (

@@ -320,6 +320,12 @@ __device__ __forceinline__ void lds_wait() {
 template <int N>
 __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// the lane's own f1 pixels of the stage's CC channels (channel stride CH_BYTES)
+template <int CH_BYTES, int CC, int... Cs>
+__device__ __forceinline__ void own_reads(v2f (&a)[CC], unsigned addr, std::integer_sequence<int, Cs...>) {
+    ((a[Cs] = lds_read_b64<Cs * CH_BYTES>(addr)), ...);
+}
+
 // One row-step of the forward pipeline: ST = c * DG + i  (channel-in-stage, displacement row of the group).
 template <int ST, int STEPS, int PF, int DG, int DD, int NCOL, int CH_BYTES, int ROW_BYTES>
 struct FwdStep {
@@ -460,12 +466,8 @@ __global__ __launch_bounds__(256, (RingCfg<R, CC, DG>::WAVES)) void corr_fwd_rin
         constexpr int PF = (2 * NCOL <= 15) ? 2 : 1;         // lgkmcnt is a 4-bit counter: <= 15 row reads in flight
         const unsigned abase = rows_addr + (unsigned)sbase * 4u;
         v2f a[CC];
-#pragma unroll
-        for (int c = 0; c < CC; ++c) {
-            if (c == 0) a[c] = lds_read_b64<0>(own_addr + (unsigned)sbase * 4u);
-            else a[c] = lds_read_b64<K::SC * 16>(own_addr + (unsigned)sbase * 4u);
-        }
-        static_assert(CC <= 2, "a[] reads are spelled out for CC <= 2");
+        own_reads<K::SC * 16>(a, own_addr + (unsigned)sbase * 4u, std::make_integer_sequence<int, CC>{});
+        static_assert(CC * K::SC * 16 + 64 * 1024 > 0 && CC <= 8, "ds offsets are 16-bit: CC * SC * 16 must stay below 64 KiB");
         v2f row[PF + 1][NCOL];
         using Step0 = FwdStep<0, STEPS, PF, DG, DD, NCOL, K::SC * 16, LW * 4>;
         Step0::template load<0>(row, abase);
@@ -997,6 +999,8 @@ extern "C" int unflow_corr_fwd(const float* f1, const float* f2, float* cv, int 
                 if (variant == 3) return launch_fwd<4, 1, 3, 8>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 7 && ring_ok) return launch_fwd_ring<4, 2, 9>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 9 && ring_ok) return launch_fwd_ring<4, 2, 3>(f1, f2, cv, B, C, H, W, s);
+                if (variant == 10 && ring_ok) return launch_fwd_ring<4, 4, 3>(f1, f2, cv, B, C, H, W, s);
+                if (variant == 11 && ring_ok) return launch_fwd_ring<4, 8, 3>(f1, f2, cv, B, C, H, W, s);
                 if (variant >= 7) return launch_fwd<4, 2, 9, 8>(f1, f2, cv, B, C, H, W, s);
                 break;
         case 8: variant = pick_variant(B, C, H, W);

@@ -46,9 +46,9 @@ def read_png(path):
     bpp = ch * depth // 8
     stride = W * bpp
     raw = np.frombuffer(zlib.decompress(b''.join(idat)), np.uint8).reshape(H, stride + 1).copy()
-    from . import _lib                                   # sequential byte filters: native helper (csrc/png_host.cpp)
-    import ctypes
-    _lib.check(_lib.load().unflow_png_unfilter(ctypes.c_void_p(raw.ctypes.data), H, stride, bpp), 'unflow_png_unfilter')
+    from . import _lib                                   # sequential byte filters: native helper (csrc/png_host.cpp),
+    import ctypes                                        # from the HIP-free host library (safe in forked loader workers)
+    _lib.check(_lib.load_host().unflow_png_unfilter(ctypes.c_void_p(raw.ctypes.data), H, stride, bpp), 'unflow_png_unfilter')
     out = raw[:, 1:]
     if depth == 16:
         arr = out.reshape(H, W, ch, 2)

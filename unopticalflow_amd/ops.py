@@ -45,39 +45,45 @@ def _dev(*tensors):
 
 def _call(name, *args, nbytes=0, shape=None):
     """Call one C entry point.  ``nbytes`` = algorithmic HBM bytes of the launch (include/unflow_hip.h,
-    DESIGN.md section 3); only used when bench.py's kernel survey is on."""
+    DESIGN.md section 3); only used when bench.py's kernel timing is on."""
     lib = _lib.load()
-    if kernel_timer.survey:
+    if kernel_timer.names is not None and (kernel_timer.names is True or name in kernel_timer.names):
         ev0 = kernel_timer.start()
         _lib.check(getattr(lib, name)(*args), name)
-        kernel_timer.stop_survey(name, shape, ev0, nbytes)
+        kernel_timer.stop(name, shape, ev0, nbytes)
         return
     _lib.check(getattr(lib, name)(*args), name)
 
 
 class _KernelTimer:
-    """HIP-event timing of one C entry point on the stream it is launched on (bench.py's roofline
-    leg).  Disabled by default: no events, no overhead."""
+    """HIP-event timing of C entry points on the stream they are launched on (bench.py's roofline legs).
+    Disabled by default: no events, no overhead.  ``enable(names)`` times every call of the named entry points
+    (``True``: all of them) until ``disable()``; ``rows()`` groups the launches by (entry point, shape)."""
 
     def __init__(self):
-        self.name = None
-        self.min_width = 0
-        self.pairs = []
-        self.bytes = 0
-        self.survey = False
+        self.names = None
         self.table = {}
 
-    def start_survey(self):
-        self.survey, self.table = True, {}
+    def enable(self, names=True):
+        self.names = names if names is True else frozenset(names)
+        self.table = {}
 
-    def stop_survey(self, name, shape, ev0, nbytes):
+    def disable(self):
+        self.names = None
+
+    def start(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()                       # torch's current stream == the stream handed to the kernel
+        return ev
+
+    def stop(self, name, shape, ev0, nbytes):
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
         self.table.setdefault((name, shape), []).append((ev0, ev1, nbytes))
 
-    def end_survey(self):
-        """-> list of dicts (entry point, shape, launches, mean us, algorithmic GB/s); call after a synchronize."""
-        self.survey = False
+    def rows(self):
+        """-> list of dicts (entry point, shape, launches, mean us, total us, algorithmic bytes, GB/s), heaviest first;
+        call after a device synchronize."""
         rows = []
         for (name, shape), v in self.table.items():
             ms = sum(a.elapsed_time(b) for a, b, _ in v)
@@ -85,33 +91,8 @@ class _KernelTimer:
             rows.append({'entry': name, 'shape': list(shape) if shape else None, 'launches': len(v),
                          'avg_us': round(ms * 1e3 / len(v), 2), 'total_us': ms * 1e3, 'total_bytes': nb,
                          'algorithmic_GBps': round(nb / (ms * 1e-3) / 1e9, 1) if ms > 0 and nb else None})
-        rows.sort(key=lambda r: -r['avg_us'] * r['launches'])
+        rows.sort(key=lambda r: -r['total_us'])
         return rows
-
-    def enable(self, name, min_width=0):
-        self.name, self.min_width, self.pairs, self.bytes = name, min_width, [], 0
-
-    def disable(self):
-        self.name = None
-
-    def wants(self, name, width):
-        return self.name == name and width >= self.min_width
-
-    def start(self):
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()                       # torch's current stream == the stream handed to the kernel
-        return ev
-
-    def stop(self, ev0, nbytes):
-        ev1 = torch.cuda.Event(enable_timing=True)
-        ev1.record()
-        self.pairs.append((ev0, ev1))
-        self.bytes += nbytes
-
-    def summary(self):
-        """(launches, total ms, total algorithmic bytes); call after a device synchronize."""
-        ms = sum(a.elapsed_time(b) for a, b in self.pairs)
-        return len(self.pairs), ms, self.bytes
 
 
 kernel_timer = _KernelTimer()
@@ -133,12 +114,8 @@ class _Corr(torch.autograd.Function):
         B, C, H, W = f1.shape
         cv = torch.empty((B, (2 * d + 1) ** 2, H, W), dtype=f1.dtype, device=f1.device)
         with torch.cuda.device(f1.device):
-            timed = kernel_timer.wants('unflow_corr_fwd', W)
-            ev = kernel_timer.start() if timed else None
-            _call('unflow_corr_fwd', _ptr(f1), _ptr(f2), _ptr(cv), B, C, H, W, d, _stream(),
-                  nbytes=4 * B * H * W * (2 * C + (2 * d + 1) ** 2), shape=(B, C, H, W))
-            if timed:                     # algorithmic bytes: read f1, f2 once, write cv once
-                kernel_timer.stop(ev, 4 * B * H * W * (2 * C + (2 * d + 1) ** 2))
+            _call('unflow_corr_fwd', _ptr(f1), _ptr(f2), _ptr(cv), B, C, H, W, d, _stream(),      # algorithmic bytes: read
+                  nbytes=4 * B * H * W * (2 * C + (2 * d + 1) ** 2), shape=(B, C, H, W))          # f1, f2 once, write cv once
         ctx.save_for_backward(f1, f2)
         ctx.d = d
         return cv

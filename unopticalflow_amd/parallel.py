@@ -18,19 +18,28 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend=None):
-    """Initialise torch.distributed from the torchrun environment.  Returns (rank, local_rank, world)."""
+def init_distributed(backend=None, device_index=None, force=False):
+    """Initialise torch.distributed from the torchrun environment.  Returns (rank, local_rank, world).
+
+    ``device_index``: the GPU this rank drives (default: LOCAL_RANK); it is made current and handed to
+    ``init_process_group(device_id=...)`` so RCCL binds its communicator to that device up front instead of guessing
+    at the first collective.  ``force``: create the process group even for a single process (world size 1) -- RCCL
+    accepts that, and it lets one GPU rehearse the whole hook -> async all-reduce -> wait path.
+    """
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'     # 'nccl' is RCCL on ROCm
+        kw = {}
         if backend == 'nccl':
-            torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            idx = local_rank if device_index is None else int(device_index)
+            torch.cuda.set_device(idx)
+            kw['device_id'] = torch.device('cuda', idx)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
 
 
@@ -44,7 +53,8 @@ class FlatGradients:
     after backward (used when the step is replayed as a hipGraph: collectives stay outside the graph).
     """
 
-    def __init__(self, params, chunks=4, group=None, overlap=False):
+    def __init__(self, params, chunks=4, group=None, overlap=False, single_rank_collectives=False):
+        self.single_rank_collectives = bool(single_rank_collectives)
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError('no trainable parameters')
@@ -85,7 +95,11 @@ class FlatGradients:
 
     # ---- collective plumbing
     def _active(self):
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        """Collectives run when a process group exists and has more than one rank -- or exactly one rank when the
+        owner asked for it (``single_rank_collectives``: the RCCL rehearsal on a one-GPU box)."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size(self.group) > 1 or self.single_rank_collectives
 
     def _launch(self, k):
         a, b, _ = self.pieces[k]
@@ -135,9 +149,9 @@ class FlatGradients:
         self.flat.mul_(1.0 / world)
 
 
-def broadcast_parameters(module, src=0, group=None):
+def broadcast_parameters(module, src=0, group=None, single_rank=False):
     """Rank ``src``'s weights to everyone (DataParallel's per-step replicate, done once)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not single_rank):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=group)

@@ -27,8 +27,9 @@ def epe(flow, gt):
 
 def _predict(cfg, model, dataset):
     flows = []
+    dev = next(model.parameters()).device
     for idx in range(len(dataset)):
-        img = dataset[idx][None].cuda()
+        img = dataset[idx][None].to(dev)
         img_h = int(img.shape[2] / 2)
         with torch.no_grad():
             flow = model.inference_flow(img[:, :, :img_h, :], img[:, :, img_h:, :])
@@ -100,9 +101,17 @@ def main(argv=None):
         setattr(cfg_new, k, v)
     if args.mode != 'flow':
         raise ValueError('only --mode flow is covered by this package')
-    model = Model_flow(cfg_new).cuda()
+    # --gpu selects the device like the reference's CUDA_VISIBLE_DEVICES=args.gpu (test.py:213); the first id is used
+    gpu = int(str(args.gpu).split(',')[0])
+    if not torch.cuda.is_available():
+        raise RuntimeError('unopticalflow_amd.test needs an MI355X; there is no CPU path')
+    if gpu >= torch.cuda.device_count():
+        raise ValueError('--gpu {}: this process sees {} device(s)'.format(gpu, torch.cuda.device_count()))
+    dev = torch.device('cuda', gpu)
+    torch.cuda.set_device(dev)
+    model = Model_flow(cfg_new).to(dev)
     if args.pretrained_model:
-        weights = torch.load(args.pretrained_model, map_location='cuda')
+        weights = torch.load(args.pretrained_model, map_location=dev)
         sd = {k[len('module.'):] if k.startswith('module.') else k: v for k, v in weights['model_state_dict'].items()}
         model.load_state_dict(sd)
     model.eval()

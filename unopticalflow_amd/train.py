@@ -32,12 +32,78 @@ def print_loss(loss_pack, iter_=None, extra=''):
           .format(v['loss_pixel'], v['loss_ssim'], v['loss_flow_smooth'], v['loss_flow_consis'], iter_) + extra, flush=True)
 
 
+def gpu_ids(gpu_arg):
+    """``--gpu 4,5,6,7`` -> [4, 5, 6, 7] (reference train.py:198 sets CUDA_VISIBLE_DEVICES from the same flag).  With
+    one process per GPU, rank r drives the r-th id of the list (relative to whatever HIP_VISIBLE_DEVICES already allows)."""
+    ids = [int(x) for x in str(gpu_arg).split(',') if x.strip() != '']
+    if not ids:
+        raise ValueError('--gpu needs at least one device id')
+    return ids
+
+
+def training_items(cfg, world):
+    """Number of dataset items and the per-rank batch so that EVERY rank's loader yields exactly
+    ``num_iterations - iter_start`` batches: the dataset is sized with the GLOBAL batch (reference train.py:110:
+    ``(num_iterations - iter_start) * batch_size``), and DistributedSampler hands each rank 1/world of it."""
+    per_rank = cfg.batch_size // world
+    if per_rank * world != cfg.batch_size:
+        raise ValueError('batch size {} is not divisible by {} ranks'.format(cfg.batch_size, world))
+    return (cfg.num_iterations - cfg.iter_start) * per_rank * world, per_rank
+
+
+def evaluate_during_training(cfg, model, iter_):
+    """Periodic KITTI evaluation of the reference loop (train.py:157-162: test_kitti_2012 / test_kitti_2015 every
+    ``--test_interval`` iterations unless ``--no_test``), results appended to ``log.pkl``.  Runs only when the ground-truth
+    directories of the yaml exist (they do not on a synthetic run); otherwise it says so once and is skipped."""
+    from . import test as test_cli
+    dirs = [(name, getattr(cfg, key, None)) for name, key in (('kitti_2012', 'gt_2012_dir'), ('kitti_2015', 'gt_2015_dir'))]
+    dirs = [(n, d) for n, d in dirs if d and os.path.isdir(d)]
+    if not dirs:
+        if not getattr(cfg, '_warned_no_gt', False):
+            print('evaluation skipped: no ground-truth directory (gt_2012_dir / gt_2015_dir) on this machine; '
+                  'pass --no_test to silence this', flush=True)
+            cfg._warned_no_gt = True
+        return None
+    from . import evaluation as ev
+    cache = cfg.__dict__.setdefault('_gt_cache', {})                 # ground truth is read once (train.py:113-117)
+    was_training = model.training
+    model.eval()
+    results = {}
+    try:
+        with torch.no_grad():
+            for name, d in dirs:
+                if name not in cache:
+                    gt_flows, noc_masks = ev.load_gt_flow_kitti(d, name)
+                    cache[name] = (gt_flows, noc_masks, ev.load_gt_mask(d) if name == 'kitti_2015' else None)
+                gt_flows, noc_masks, gt_masks = cache[name]
+                if name == 'kitti_2012':
+                    results[name] = test_cli.test_kitti_2012(cfg, model, gt_flows, noc_masks)
+                else:
+                    results[name] = test_cli.test_kitti_2015(cfg, model, gt_flows, noc_masks, gt_masks)
+    finally:
+        model.train(was_training)
+    log = []
+    if os.path.exists(cfg.log_dump_dir):
+        with open(cfg.log_dump_dir, 'rb') as f:
+            log = pickle.load(f)
+    log.append({'iteration': iter_, **results})
+    with open(cfg.log_dump_dir, 'wb') as f:
+        pickle.dump(log, f)
+    return results
+
+
 def train(cfg):
-    rank, local_rank, world = init_distributed('nccl')
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    ids = gpu_ids(getattr(cfg, 'gpu', '0'))
+    if local >= len(ids):
+        raise ValueError('LOCAL_RANK {} but --gpu lists only {} device(s)'.format(local, len(ids)))
     if not torch.cuda.is_available():
         raise RuntimeError('unopticalflow_amd.train needs an MI355X; there is no CPU path')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    if ids[local] >= torch.cuda.device_count():
+        raise ValueError('--gpu {}: this process sees {} device(s)'.format(ids[local], torch.cuda.device_count()))
+    rank, local_rank, world = init_distributed('nccl', device_index=ids[local])
+    torch.cuda.set_device(ids[local])
+    dev = torch.device('cuda', ids[local])
 
     if getattr(cfg, 'miopen_find', 1):
         from .tuning import enable_miopen_tuning
@@ -57,7 +123,7 @@ def train(cfg):
         print(missing); print(unexpected)
         print('Load Flow Pretrained Model from ' + cfg.flow_pretrained_model)
 
-    per_rank = cfg.batch_size // world
+    n_items, per_rank = training_items(cfg, world)
     if cfg.synthetic:
         batches = SyntheticTriplets(per_rank, cfg.img_hw, dev, seed=rank)
     else:
@@ -65,7 +131,6 @@ def train(cfg):
         if not os.path.exists(os.path.join(data_dir, 'train.txt')):
             raise FileNotFoundError('no prepared triplets under {} (raw-dataset preparation is outside this '
                                     'package: run the reference\'s prepare_data_mp once, or use --synthetic)'.format(data_dir))
-        n_items = (cfg.num_iterations - cfg.iter_start) * per_rank
         ds = (PreparedTriplets if cfg.host_input else DecodedTriplets)(data_dir, cfg.num_scales, cfg.img_hw, n_items)
         sampler = torch.utils.data.distributed.DistributedSampler(ds, world, rank, shuffle=True) if world > 1 else None
         if cfg.host_input:                                             # the reference's all-CPU pipeline (PIL resize)
@@ -90,6 +155,8 @@ def train(cfg):
             rate = n_last * cfg.batch_size / dt
             print_loss(loss_pack, iter_=iter_, extra=', samples/s: {:.1f}, pairs/s: {:.1f}'.format(rate, 2 * rate))
             t_last, n_last = time.perf_counter(), 0
+        if rank == 0 and not cfg.no_test and (iter_ + 1) % cfg.test_interval == 0:     # train.py:157-162
+            evaluate_during_training(cfg, model, iter_)
         if rank == 0 and (iter_ + 1) % cfg.save_interval == 0:         # train.py:153-155
             trainer.iteration = iter_
             trainer.save(os.path.join(cfg.model_dir, 'iter_{}.pth'.format(iter_)))

@@ -14,16 +14,18 @@ from .parallel import FlatGradients, broadcast_parameters
 
 
 class FlowTrainer:
-    def __init__(self, cfg, model, distributed=False, allreduce_chunks=4, fused_adam=None, use_graph=False):
+    def __init__(self, cfg, model, distributed=False, allreduce_chunks=4, fused_adam=None, use_graph=False,
+                 single_rank_collectives=False):
         self.cfg = cfg
         self.model = model
         self.loss_weights = generate_loss_weights_dict(cfg)
         params = [p for p in model.parameters() if p.requires_grad]      # train.py:39
         if distributed:
-            broadcast_parameters(model)
+            broadcast_parameters(model, single_rank=single_rank_collectives)
         # gradients leave for RCCL piece by piece during backward, except under hipGraph replay (collectives stay
         # outside the captured graph)
-        self.grads = FlatGradients(params, chunks=allreduce_chunks, overlap=(distributed and not use_graph))
+        self.grads = FlatGradients(params, chunks=allreduce_chunks, overlap=(distributed and not use_graph),
+                                   single_rank_collectives=(distributed and single_rank_collectives))
         self.distributed = distributed
         kw = {}
         if fused_adam is None:
