@@ -61,6 +61,7 @@ def parse():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'], help='conv-stack precision (bf16: BASELINE config 3; the headline metric is fp32)')
     ap.add_argument('--graph', type=int, default=0, help='1: replay the step as a hipGraph (kernel timing events are then off)')
+    ap.add_argument('--fused', type=int, default=0, help='1: warp + cost volume of each decoder level as one kernel (cfg.fused_warp_corr)')
     ap.add_argument('--force-ddp', action='store_true', help='N = 1 only: run the step through the RCCL data-parallel path with a one-rank communicator')
     return ap.parse_args()
 
@@ -168,7 +169,7 @@ def main():
 
     cfg = types.SimpleNamespace(mode='flow', dataset='kitti_depth', num_scales=3, h_flow_consist_alpha=3.0,
                                 h_flow_consist_beta=0.05, w_ssim=0.85, w_flow_smooth=10.0, w_flow_consis=0.01,
-                                lr=1e-4, align_corners=False, precision=args.precision)
+                                lr=1e-4, align_corners=False, precision=args.precision, fused_warp_corr=bool(args.fused))
     torch.manual_seed(1234)                       # same random init on every rank
     if os.environ.get('UNFLOW_MIOPEN_FIND', '1') == '1':
         from unopticalflow_amd.tuning import enable_miopen_tuning

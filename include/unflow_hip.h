@@ -63,6 +63,22 @@ int unflow_warp_bwd(const float* src, const float* flow, const float* gout, cons
                     float* gsrc, float* gflow,
                     int B, int C, int H, int W, int align_corners, void* stream);
 
+/* ---- fused warp + cost volume: one decoder level of PWC_tf.forward, pwc_tf.py:121-122 (134-135, 146-147, 159-160) ----
+ *   feat2_warped = self.warp(f2, flow);  cv = self.corr(f1, feat2_warped)
+ * in one kernel: the warped map only ever exists as LDS tiles.  f1, f2: [B,C,H,W]; flow: [B,2,H,W] (the x2-upsampled
+ * flow of the level above); cv: [B,(2d+1)^2,H,W].  Same numerics as unflow_warp_fwd followed by unflow_corr_fwd.
+ * unflow_warp_corr_supported() tells whether a shape is covered (d = 4, W a multiple of 4, 16-byte aligned inputs);
+ * otherwise the entry returns UNFLOW_EINVAL and the caller runs the two separate entry points. */
+int unflow_warp_corr_supported(int C, int H, int W, int d);
+int unflow_warp_corr_fwd(const float* f1, const float* f2, const float* flow, float* cv,
+                         int B, int C, int H, int W, int d, int align_corners, void* stream);
+/* autograd of the above without anything saved by the forward pass: the warped map is recomputed.  gcv
+ * [B,(2d+1)^2,H,W] -> gf1 [B,C,H,W], gf2 [B,C,H,W] (zeroed, then scatter-added; may be NULL), gflow [B,2,H,W].
+ * scratch: 2*B*C*H*W floats (warped map | gradient w.r.t. it), caller-owned.  Any shape unflow_corr_bwd accepts. */
+int unflow_warp_corr_bwd(const float* f1, const float* f2, const float* flow, const float* gcv,
+                         float* gf1, float* gf2, float* gflow, float* scratch,
+                         int B, int C, int H, int W, int d, int align_corners, void* stream);
+
 /* ---- occlusion weights: Model_flow.compute_diff_weight, model_flow_paper.py:101-134 ----
  * img, from_l, from_r: [B,3,H,W].  diff_*: mean_c|img-from_*| [B,1,H,W]; w_*: soft occlusion
  * weight * validity [B,1,H,W]; valid_* (may be NULL): uint8 1 - prod_c[from_* == 0]. */

@@ -119,6 +119,33 @@ def test_model_scale_masks_bit_exact(golden, fixture, scales, acs):
                 assert np.array_equal(o != 0, ref_bits != 0) and (o[ref_bits != 0] >= 0.9999).all()
 
 
+def test_fused_warp_corr_model_matches_golden(golden):
+    """cfg.fused_warp_corr: every decoder level's warp + cost volume as one kernel (N3; pwc_tf.py:121-122 ...).  Same G2
+    fixture, same bars as the two-kernel path: losses 1e-4 rel, flows 1e-4 of the largest flow; the gradient norm of
+    the first step within 5e-4."""
+    from unopticalflow_amd import get_model, generate_loss_weights_dict
+    g = golden('g2_module_128.npz')
+    cfg = R.default_cfg(fused_warp_corr=True)
+    model = get_model('flow')(cfg).cuda()
+    assert model.pwc_model.fused_warp_corr
+    model.load_state_dict(R.seeded_state_dict(model, 1234, float(g['flow_gain'])))
+    weights = generate_loss_weights_dict(cfg)
+    B, H, W = int(g['B']), int(g['H']), int(g['W'])
+    x = R.synthetic_triplets(B, H, W, seed=0, structured=True).cuda()
+    with torch.no_grad():
+        stacked = model._flows(x[:, :, :H], x[:, :, H:2 * H], x[:, :, 2 * H:])
+        for s_ in (1, 2, 3):
+            ref = g['flow_fwd%d_ac0' % s_]
+            close(stacked[s_][B:], ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+    pack = model(x)
+    loss = sum(weights[k] * pack[k].mean() for k in pack)
+    loss.backward()
+    for k in pack:
+        close(pack[k], g[k + '_ac0'], rtol=1e-4, what=k)
+    gn = float(np.sqrt(sum((p.grad.double() ** 2).sum().item() for p in model.parameters())))
+    np.testing.assert_allclose(gn, float(g['grad_norm_ac0']), rtol=5e-4)
+
+
 def test_kitti_256x832_golden(golden):
     """832x256 (KITTI size), B=1: loss pack and inference flow against the reference fixture."""
     g = golden('g3_kitti_256x832.npz')

@@ -261,6 +261,41 @@ def test_warp_feature_tiles_vs_oracle(ops, kind, C, h, w):
         close(f2.grad, fc.grad, rtol=1e-4, atol=2e-5 * scale, what='gflow only %s' % kind)
 
 
+@pytest.mark.parametrize('kind', ['smooth', 'mixed', 'edge', 'outside', 'noise'])
+@pytest.mark.parametrize('C,h,w', [(32, 64, 208), (64, 32, 104), (96, 16, 52), (128, 8, 26), (196, 4, 12), (5, 23, 72), (3, 70, 260)])
+def test_warp_corr_fused_vs_oracle(ops, kind, C, h, w):
+    """Fused warp + cost volume (pwc_tf.py:121-122) at the pyramid-level shapes and ragged ones, forward and backward,
+    against the oracle's  corr_naive(f1, warp_flow(f2, flow))  for both grid_sample generations."""
+    B = 3
+    for ac in (False, True):
+        f1c, f2c = rnd(31 + C, (B, C, h, w)).requires_grad_(), rnd(32 + C, (B, C, h, w)).requires_grad_()
+        fc = _structured_flow(B, h, w, kind, seed=h + w + C).requires_grad_()
+        cvr = R.corr_naive(f1c, R.warp_flow(f2c, fc, False, ac), 4)
+        g = rnd(33 + C, tuple(cvr.shape))
+        cvr.backward(g)
+        f1, f2, f = dev(f1c.detach()).requires_grad_(), dev(f2c.detach()).requires_grad_(), dev(fc.detach()).requires_grad_()
+        assert ops.warp_corr_supported(f1, 4) == (w % 4 == 0)         # (W = 26: served by the two separate operators)
+        cv = ops.warp_corr(f1, f2, f, 4, align_corners=ac)
+        close(cv, cvr, rtol=1e-5, atol=2e-6, what='fused cv %s' % kind)
+        cv.backward(dev(g))
+        amax = max(f1c.grad.abs().max().item(), f2c.grad.abs().max().item(), 1e-6)
+        close(f1.grad, f1c.grad, rtol=1e-4, atol=max(5e-6, 2e-6 * amax), what='fused gf1 %s' % kind)
+        close(f2.grad, f2c.grad, rtol=1e-4, atol=max(2e-5, 2e-6 * amax), what='fused gf2 %s' % kind)
+        scale = max(fc.grad.abs().max().item(), 1e-6)
+        close(f.grad, fc.grad, rtol=1e-4, atol=2e-5 * scale, what='fused gflow %s' % kind)
+
+
+def test_warp_corr_unsupported_shapes_fall_back(ops):
+    """W % 4 != 0 and d != 4 are served by the separate operators behind the same call."""
+    for (C, h, w, d) in ((6, 9, 13, 4), (4, 12, 40, 2)):
+        f1c, f2c, fc = rnd(1, (2, C, h, w)), rnd(2, (2, C, h, w)), rnd(3, (2, 2, h, w), 1.5)
+        cvr = R.corr_naive(f1c, R.warp_flow(f2c, fc), d)
+        cv = ops.warp_corr(dev(f1c), dev(f2c), dev(fc), d)
+        close(cv, cvr, rtol=1e-5, atol=2e-6)
+    with pytest.raises(ValueError):
+        ops.warp_corr(dev(rnd(1, (1, 4, 8, 8))), dev(rnd(2, (1, 4, 8, 8))), dev(rnd(3, (1, 2, 8, 9))))
+
+
 def test_warp_shape_mismatch_raises(ops):
     with pytest.raises(ValueError):                           # net_utils.py:35-36
         ops.warp_flow(torch.zeros(1, 3, 8, 8, device='cuda'), torch.zeros(1, 2, 8, 9, device='cuda'))

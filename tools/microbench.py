@@ -217,6 +217,26 @@ def corr_fwd_sweep(B=16):
         _sweep(envs, run)
 
 
+def fused(B=16):
+    """Fused warp + cost volume forward against the two separate launches (C ABI)."""
+    lib = _lib.load()
+    P = ops._ptr
+    for name, (C, h, w) in list(LEVELS.items())[:4]:
+        f1 = torch.randn(B, C, h, w, device='cuda'); f2 = torch.randn(B, C, h, w, device='cuda')
+        cv = torch.empty(B, 81, h, w, device='cuda'); wp = torch.empty_like(f2)
+        for kind, fl in (('smooth', _smooth_flow(B, h, w)), ('noise', torch.randn(B, 2, h, w, device='cuda') * 2)):
+            tfu = timeit(lambda: lib.unflow_warp_corr_fwd(P(f1), P(f2), P(fl), P(cv), B, C, h, w, 4, 0, ops._stream()))
+            a = cv.clone()
+
+            def two():
+                lib.unflow_warp_fwd(P(f2), P(fl), P(wp), None, B, C, h, w, 0, ops._stream())
+                lib.unflow_corr_fwd(P(f1), P(wp), P(cv), B, C, h, w, 4, ops._stream())
+            tsep = timeit(two)
+            nb = 4 * B * h * w * (4 * C + 2 + 81)
+            print('fused %s [%d,%d,%d,%d] %-6s fused %7.1f us (%6.0f GB/s)   separate %7.1f us   max|diff| %.2e' % (
+                name, B, C, h, w, kind, tfu, nb / tfu / 1e3, tsep, (a - cv).abs().max().item()), flush=True)
+
+
 def losses(B=8):
     for s in range(3):
         h, w = 256 >> s, 832 >> s

@@ -21,6 +21,9 @@ SIGNATURES = {
     'unflow_corr_bwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'unflow_warp_fwd': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'unflow_warp_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'unflow_warp_corr_supported': [_I, _I, _I, _I],
+    'unflow_warp_corr_fwd': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    'unflow_warp_corr_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'unflow_occ_weight_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     'unflow_absdiff_bwd': [_P, _P, _P, _P, _I, _I, _I, _P],
     'unflow_masked_mean_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _P],
@@ -43,7 +46,7 @@ SIGNATURES = {
     'unflow_png_unfilter': [_P, _I, _I, _I],
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 

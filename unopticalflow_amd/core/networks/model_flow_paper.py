@@ -31,7 +31,7 @@ class Model_flow(nn.Module):
         if self.precision not in ('fp32', 'bf16'):
             raise ValueError('precision must be fp32 or bf16, got {}'.format(self.precision))
         self.fpyramid = FeaturePyramid()
-        self.pwc_model = PWC_tf(align_corners=self.align_corners)
+        self.pwc_model = PWC_tf(align_corners=self.align_corners, fused_warp_corr=bool(getattr(cfg, 'fused_warp_corr', False)))
         if cfg.mode == 'depth' or cfg.mode == 'flowposenet':
             # Stage 2 training
             for param in self.fpyramid.parameters():

@@ -17,9 +17,14 @@ class PWC_tf(nn.Module):
     reference checkpoint.
     """
 
-    def __init__(self, md=4, align_corners=False):
+    def __init__(self, md=4, align_corners=False, fused_warp_corr=False):
         super(PWC_tf, self).__init__()
         self.corr = self.corr_naive
+        # True: warp + cost volume of a level as ONE kernel (ops.warp_corr; the warped features never reach HBM).
+        # Measured on MI355X (profiles/r2_fused_warp_corr.txt): at parity with the two separate kernels at level 2 and
+        # slower below it -- the cost-volume kernel is LDS/VALU-bound, so the warp stage adds to the bound resource --
+        # hence off by default.
+        self.fused_warp_corr = bool(fused_warp_corr)
         self.leakyRELU = nn.LeakyReLU(0.1)
         self.align_corners = align_corners
         nd = (2 * md + 1) ** 2
@@ -67,7 +72,10 @@ class PWC_tf(nn.Module):
         level_flow = {}
         for lvl in (5, 4, 3, 2):
             up = F.interpolate(flow, scale_factor=2.0, mode='bilinear') * 2.0
-            cv = self.corr(f1[lvl], self.warp(f2[lvl], up))
+            if self.fused_warp_corr and self.corr == self.corr_naive:      # (a user-supplied self.corr keeps the two-op path)
+                cv = ops.warp_corr(f1[lvl].float(), f2[lvl].float(), up.float(), 4, self.align_corners)
+            else:
+                cv = self.corr(f1[lvl], self.warp(f2[lvl], up))
             flow, x4 = self._decoder(lvl, torch.cat((cv, f1[lvl], up), 1))
             flow = flow + up
             level_flow[lvl] = flow

@@ -293,7 +293,7 @@ inline int flat_blocks(size_t n) {
 
 int unflow_ssim_blocks(int H, int W);   // ssim.hip
 
-extern "C" int unflow_abi_version(void) { return 1; }
+extern "C" int unflow_abi_version(void) { return 2; }   // 2: + unflow_warp_corr_*
 
 extern "C" int unflow_partials_per_sample(int H, int W) {
     if (H <= 0 || W <= 0) return UNFLOW_EINVAL;

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 
-__all__ = ['corr', 'warp_flow', 'warp_flow_masked', 'occ_weight', 'masked_mean', 'ssim_loss',
+__all__ = ['corr', 'warp_flow', 'warp_flow_masked', 'warp_corr', 'occ_weight', 'masked_mean', 'ssim_loss',
            'ssim_map', 'smooth2_loss', 'consis_loss', 'bias_leaky_relu_', 'img_pyramid']
 
 
@@ -192,6 +192,59 @@ def warp_flow_masked(x, flow, align_corners=False):
     """warp_flow(..., use_mask=True) that also returns the binary uint8 mask of net_utils.py:47-51."""
     _check_flow_shape(x, flow)
     return _Warp.apply(x, flow, True, bool(align_corners))
+
+
+# ------------------------------------------------------------------------------------------
+# fused warp + cost volume
+# ------------------------------------------------------------------------------------------
+class _WarpCorr(torch.autograd.Function):
+    """cv = corr(f1, warp(f2, flow)) with the warped map living only in LDS (csrc/warp_corr.hip).  Nothing but the
+    inputs is saved for the backward pass, which recomputes what it needs."""
+
+    @staticmethod
+    def forward(ctx, f1, f2, flow, d, align_corners):
+        _dev(f1, f2, flow)
+        f1, f2, flow = f1.contiguous(), f2.contiguous(), flow.contiguous()
+        B, C, H, W = f1.shape
+        cv = torch.empty((B, (2 * d + 1) ** 2, H, W), dtype=f1.dtype, device=f1.device)
+        with torch.cuda.device(f1.device):
+            # algorithmic bytes: those of the two ops it replaces (SURVEY 8d): warp 4*n*(2C+2) + corr 4*n*(2C+D^2)
+            _call('unflow_warp_corr_fwd', _ptr(f1), _ptr(f2), _ptr(flow), _ptr(cv), B, C, H, W, d, int(align_corners),
+                  _stream(), nbytes=4 * B * H * W * (4 * C + 2 + (2 * d + 1) ** 2), shape=(B, C, H, W))
+        ctx.save_for_backward(f1, f2, flow)
+        ctx.d, ctx.ac = d, int(align_corners)
+        return cv
+
+    @staticmethod
+    def backward(ctx, g):
+        f1, f2, flow = ctx.saved_tensors
+        B, C, H, W = f1.shape
+        g = g.contiguous()
+        gf1 = torch.empty_like(f1)
+        gf2 = torch.empty_like(f2) if ctx.needs_input_grad[1] else None
+        gflow = torch.empty_like(flow)
+        scratch = torch.empty((2,) + tuple(f2.shape), dtype=f2.dtype, device=f2.device)     # warped map | its gradient: dies here
+        D2 = (2 * ctx.d + 1) ** 2
+        with torch.cuda.device(f1.device):
+            _call('unflow_warp_corr_bwd', _ptr(f1), _ptr(f2), _ptr(flow), _ptr(g), _ptr(gf1), _ptr(gf2), _ptr(gflow),
+                  _ptr(scratch), B, C, H, W, ctx.d, ctx.ac, _stream(),
+                  nbytes=4 * B * H * W * ((4 * C + D2) + (3 * C + 4)), shape=(B, C, H, W))
+        return gf1, gf2, (gflow if ctx.needs_input_grad[2] else None), None, None
+
+
+def warp_corr_supported(f1, d):
+    B, C, H, W = f1.shape
+    return bool(_lib.load().unflow_warp_corr_supported(C, H, W, int(d)))
+
+
+def warp_corr(input1, input2, flow, d=4, align_corners=False):
+    """One decoder level's `corr(feat1, warp(feat2, flow))` (pwc_tf.py:121-122 and the three level blocks below it) as ONE
+    kernel; shapes the fused kernel does not cover run the two separate operators."""
+    assert (input1.shape == input2.shape)            # pwc_tf.py:99
+    _check_flow_shape(input2, flow)
+    if not warp_corr_supported(input1, d):
+        return corr(input1, warp_flow(input2, flow, use_mask=False, align_corners=align_corners), d)
+    return _WarpCorr.apply(input1, input2, flow, int(d), bool(align_corners))
 
 
 # ------------------------------------------------------------------------------------------
