@@ -200,7 +200,7 @@ def corr_fwd_sweep(B=16):
     """d=4 forward variants (tuning library) at levels 2-4."""
     lib = _lib.load()
     P = ops._ptr
-    envs = [{}] + [{'UNFLOW_CORR_VARIANT': v} for v in (7, 9, 10, 11, 1, 3)]
+    envs = [{}] + [{'UNFLOW_CORR_VARIANT': v} for v in (7, 9, 10, 12, 13)]
     for name, (C, h, w) in list(LEVELS.items())[:3]:
         f1 = torch.randn(B, C, h, w, device='cuda'); f2 = torch.randn(B, C, h, w, device='cuda')
         cv = torch.empty(B, 81, h, w, device='cuda')

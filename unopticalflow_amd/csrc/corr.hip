@@ -439,6 +439,157 @@ int launch_fwd_ring(const float* f1, const float* f2, float* cv, int B, int C, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// Mid-size maps (pyramid levels 3, 4), forward: the ring kernel above with the CHANNELS split over PH phases inside
+// one workgroup.  A 64x8 tile times 3 displacement rows is a workgroup of the plain ring kernel; level 4 has only 96
+// of them, each grinding through all channels on four waves (one wave per SIMD issues an FMA every 4 cycles): 31 us
+// for 4 MB.  Here a workgroup has PH x 4 waves; phase p streams its own C/PH channels through its own LDS ring and
+// accumulates its own partial cost volume; the partials meet in phase 0 through LDS (fixed order, no atomics).
+// Requires W % 4 == 0.
+// ---------------------------------------------------------------------------------------------
+template <int R, int CC, int DG, int PH>
+struct RingPCfg {
+    static constexpr int DD = 2 * R + 1;
+    static constexpr int NG = (DD + DG - 1) / DG;
+    static constexpr int TW = 64, TYB = 8, NS = 3;
+    static constexpr int LW = TW + 2 * R, LH = TYB + DG - 1;
+    static constexpr int S2 = LH * LW / 4, S1 = TYB * TW / 4, SC = S2 + S1;
+    static constexpr int ITER = (CC * SC + 255) / 256;
+    static constexpr int STAGE = ITER * 256 * 4;
+    static constexpr int RING = NS * STAGE;                                     // floats per phase
+    static constexpr int THREADS = 256 * PH;
+    static_assert(DG * DD * 2 * 256 <= PH * RING, "the partial sums of one phase must fit the (then idle) rings");
+};
+
+template <int R, int CC, int DG, int PH>
+__global__ __launch_bounds__((RingPCfg<R, CC, DG, PH>::THREADS)) void corr_fwd_ringp_kernel(
+    const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ cv, int C, int H, int W,
+    int tiles_x, int tiles_y, float inv_c) {
+    using K = RingPCfg<R, CC, DG, PH>;
+    constexpr int DD = K::DD, LW = K::LW, NROW = 2 + 2 * R;
+    __shared__ __attribute__((aligned(16))) float lds[PH * K::RING];
+
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = t % tiles_x; t /= tiles_x;
+    const int by = t % tiles_y;
+    const int b = t / tiles_y;
+    const int i0 = blockIdx.y * DG;
+    const int phase = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);      // wave-uniform
+    const int tid = threadIdx.x & 255;
+    const int tx = tid & 31, ty = tid >> 5, wave = tid >> 6;
+    const int x0 = bx * K::TW, y0 = by * K::TYB;
+    const int px = x0 + tx * 2, py = y0 + ty;
+    const size_t plane = (size_t)H * W;
+    // this phase's channels [cb, cb + cn): whole stages per phase, the same number of stages in every phase
+    const int cpp = ceil_div(ceil_div(C, PH), CC) * CC;
+    const int nchunk = cpp / CC;
+    const int cb = phase * cpp;
+    const int cn = max(0, min(cpp, C - cb));
+    float* ring = lds + phase * K::RING;
+
+    int soff[K::ITER], sch[K::ITER], ssel[K::ITER];
+#pragma unroll
+    for (int it = 0; it < K::ITER; ++it) {
+        const int s = it * 256 + tid;
+        const int c = s / K::SC;
+        int r = s - c * K::SC;
+        int gy, gx, sel;
+        if (r < K::S2) { const int ly = r / (LW / 4); gy = y0 - R + i0 + ly; gx = x0 - R + (r - ly * (LW / 4)) * 4; sel = 1; }
+        else { r -= K::S2; const int ly = r / (K::TW / 4); gy = y0 + ly; gx = x0 + (r - ly * (K::TW / 4)) * 4; sel = 0; }
+        const bool in = (c < CC) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        soff[it] = in ? gy * W + gx : -1;
+        sch[it] = c;
+        ssel[it] = sel;
+    }
+    const float* base1 = f1 + ((size_t)b * C + cb) * plane;
+    const float* base2 = f2 + ((size_t)b * C + cb) * plane;
+    auto issue = [&](int stage_idx) {
+        float* dst = ring + (stage_idx % K::NS) * K::STAGE;
+        const int c0 = stage_idx * CC;
+#pragma unroll
+        for (int it = 0; it < K::ITER; ++it) {
+            const int gc = c0 + sch[it];
+            const bool in = soff[it] >= 0 && gc < cn;
+            const float* g = in ? (ssel[it] ? base2 : base1) + (size_t)gc * plane + soff[it] : kZeroLine;
+            __builtin_amdgcn_global_load_lds((gas_ptr)g, (lds_ptr)(dst + (it * 256 + wave * 64) * 4), 16, 0, 0);
+        }
+    };
+
+    float acc[DG][DD][2];
+#pragma unroll
+    for (int i = 0; i < DG; ++i)
+#pragma unroll
+        for (int j = 0; j < DD; ++j) { acc[i][j][0] = 0.f; acc[i][j][1] = 0.f; }
+
+    const unsigned rows_addr = (unsigned)(size_t)(lds_cfloat*)(ring + ty * LW + tx * 2);
+    const unsigned own_addr = (unsigned)(size_t)(lds_cfloat*)(ring + K::S2 * 4 + ty * K::TW + tx * 2);
+
+#pragma unroll
+    for (int st = 0; st < K::NS - 1; ++st) issue(st);
+
+    for (int k = 0; k < nchunk; ++k) {
+        vm_wait<K::ITER * (K::NS - 2)>();
+        __builtin_amdgcn_s_barrier();
+        issue(k + K::NS - 1);
+        const unsigned sb = (unsigned)((k % K::NS) * K::STAGE) * 4u;
+        constexpr int NCOL = NROW / 2, STEPS = CC * DG;
+        constexpr int PF = (2 * NCOL <= 15) ? 2 : 1;
+        v2f a[CC];
+        own_reads<K::SC * 16>(a, own_addr + sb, std::make_integer_sequence<int, CC>{});
+        v2f row[PF + 1][NCOL];
+        using Step0 = FwdStep<0, STEPS, PF, DG, DD, NCOL, K::SC * 16, LW * 4>;
+        Step0::template load<0>(row, rows_addr + sb);
+        if constexpr (PF > 1) Step0::template load<1>(row, rows_addr + sb);
+        Step0::template run<CC>(acc, row, a, rows_addr + sb);
+    }
+    vm_wait<0>();                                            // the zero-line tail loads: no LDS-DMA in flight beyond here
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // partial cost volumes of phases 1 .. PH-1 -> phase 0, one phase at a time through the idle rings
+    float* red = lds;
+#pragma unroll 1
+    for (int p = 1; p < PH; ++p) {
+        if (phase == p) {
+#pragma unroll
+            for (int i = 0; i < DG; ++i)
+#pragma unroll
+                for (int j = 0; j < DD; ++j)
+                    *reinterpret_cast<float2*>(red + ((i * DD + j) * 256 + tid) * 2) = make_float2(acc[i][j][0], acc[i][j][1]);
+        }
+        __syncthreads();
+        if (phase == 0) {
+#pragma unroll
+            for (int i = 0; i < DG; ++i)
+#pragma unroll
+                for (int j = 0; j < DD; ++j) {
+                    const float2 v = *reinterpret_cast<const float2*>(red + ((i * DD + j) * 256 + tid) * 2);
+                    acc[i][j][0] += v.x; acc[i][j][1] += v.y;
+                }
+        }
+        __syncthreads();
+    }
+    if (phase != 0 || py >= H || px >= W) return;
+    float* out = cv + ((size_t)b * DD * DD) * plane + (size_t)py * W + px;
+#pragma unroll
+    for (int i = 0; i < DG; ++i) {
+        if (i0 + i >= DD) break;
+#pragma unroll
+        for (int j = 0; j < DD; ++j)
+            *reinterpret_cast<float2*>(out + (size_t)((i0 + i) * DD + j) * plane) =
+                make_float2(acc[i][j][0] * inv_c, acc[i][j][1] * inv_c);
+    }
+}
+
+template <int R, int CC, int DG, int PH>
+int launch_fwd_ringp(const float* f1, const float* f2, float* cv, int B, int C, int H, int W, hipStream_t s) {
+    using K = RingPCfg<R, CC, DG, PH>;
+    const int tx = ceil_div(W, K::TW), ty = ceil_div(H, K::TYB);
+    hipLaunchKernelGGL((corr_fwd_ringp_kernel<R, CC, DG, PH>), dim3(tx * ty * B, K::NG), dim3(K::THREADS), 0, s,
+                       f1, f2, cv, C, H, W, tx, ty, 1.0f / C);
+    return unflow_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Large-map backward, "group split" ring kernel.  blockIdx.y selects the gradient:
 //   0: gf1[c][q] = (1/C) sum_ij g[ij][q]             * f2[c][q + (i-R, j-R)]
 //   1: gf2[c][q] = (1/C) sum_ij g[ij][q - (i-R,j-R)] * f1[c][q - (i-R, j-R)]   (a gather: no atomics)
@@ -893,19 +1044,24 @@ static inline int forced_bwd() { return 0; }
 static inline int forced_groups() { return 0; }
 #endif
 
+static inline bool mid_size(int variant) { return variant == 9 || variant == 12 || variant == 13; }   // levels 3, 4
+
 static int pick_variant(int B, int C, int H, int W) {
     const int f = forced_variant();
     if (f) return f;
     // measured on MI355X at the 832x256 pyramid shapes (tools/microbench.py corr):
     //   level 2 [16,32,64,208]: ring, all 81 displacements per workgroup (7)   37 us
     //   level 3 [16,64,32,104], level 4 [16,96,16,52]: ring, 3 displacement rows per workgroup (9)  29 / 30 us
-    //   levels 5, 6: one lane per output element (4)   14 / 11 us
+    //   levels 5, 6: one lane per output element (4)   14 / 12 us  (a whole-map LDS kernel -- one workgroup per sample and
+    //   displacement row, channels streamed through LDS -- measured 31 / 26 us: staging 2 x 106 KB per workgroup as dword
+    //   LDS-DMA pieces (W = 26 / 13 rows are not 16-byte aligned) costs more than the cached global reads it replaces)
     // d=8 (tools/microbench.py corr8): ring with 3 of the 17 rows per workgroup 125 / 52 / 46 us at levels 2 / 3 / 4
     // (tile kernel 234 / 128 / 85), one lane per element 29 / 15 us at levels 5 / 6 (tile kernel 158 / 226)
     const long px = (long)B * H * W;
     const bool dma_ok = ((W & 3) == 0);
     if (W >= 96 && px >= 131072) return dma_ok ? 7 : 1;
-    if (px >= 8192 && dma_ok) return 9;
+    if (px >= 32768 && dma_ok) return 12;      // level 3: two channel phases per workgroup (24.5 us; plain ring 28-29)
+    if (px >= 8192 && dma_ok) return 13;       // level 4: four channel phases (19.4 us; plain ring 29-30)
     if (px >= 32768) return 3;
     return 4;
 }
@@ -925,12 +1081,14 @@ extern "C" int unflow_corr_fwd(const float* f1, const float* f2, float* cv, int 
                 if (variant == 3) return launch_fwd<4, 1, 3, 8>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 7 && ring_ok) return launch_fwd_ring<4, 2, 9>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 9 && ring_ok) return launch_fwd_ring<4, 2, 3>(f1, f2, cv, B, C, H, W, s);
+                if (variant == 12 && ring_ok) return launch_fwd_ringp<4, 2, 3, 2>(f1, f2, cv, B, C, H, W, s);
+                if (variant == 13 && ring_ok) return launch_fwd_ringp<4, 2, 3, 4>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 10 && ring_ok) return launch_fwd_ring<4, 4, 3>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 11 && ring_ok) return launch_fwd_ring<4, 8, 3>(f1, f2, cv, B, C, H, W, s);
                 if (variant >= 7) return launch_fwd<4, 2, 9, 8>(f1, f2, cv, B, C, H, W, s);
                 break;
         case 8: variant = pick_variant(B, C, H, W);
-                if ((variant == 7 || variant == 9) && ring_ok) return launch_fwd_ring<8, 2, 3>(f1, f2, cv, B, C, H, W, s);
+                if ((variant == 7 || mid_size(variant)) && ring_ok) return launch_fwd_ring<8, 2, 3>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 4 || (variant == 3 && (long)B * H * W < 8192)) break;
                 return launch_fwd<8, 1, 6, 8>(f1, f2, cv, B, C, H, W, s);
         default: break;
@@ -963,10 +1121,10 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 if (ring_ok && fb == 5) return launch_bwd_gs<4, 4, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, groups, s);
                 // group-split ring kernel, 64x8 tiles, 4 channels per stage: levels 2-4 (83 / 35 / 20 us; the tile kernel
                 // with all 81 gradients per lane takes 107 us at level 2)
-                if (ring_ok && (fb == 4 || (fb == 0 && (variant == 7 || variant == 9))))
+                if (ring_ok && (fb == 4 || (fb == 0 && (variant == 7 || mid_size(variant)))))
                     return launch_bwd_gs<4, 4, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, groups, s);
                 if (fb == 6 || variant == 1 || variant == 7) return launch_bwd<4, 2, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                if (variant == 2 || variant == 3 || (variant == 9 && (long)B * H * W >= 32768))
+                if (variant == 2 || variant == 3 || (mid_size(variant) && (long)B * H * W >= 32768))
                     return launch_bwd<4, 1, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (fb != 2) {                           // small maps (levels 5, 6): whole-map kernel; UNFLOW_CORR_BWD=2: per-element
                     bool launched = false;
@@ -977,7 +1135,7 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
         }
         case 8: variant = pick_variant(B, C, H, W);
                 if (variant == 4 || (long)B * H * W < 8192) break;      // small maps: one lane per element (117 / 57 us at levels 5 / 6, tile kernel 283 / 378)
-                if ((variant == 7 || variant == 9) && (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0))
+                if ((variant == 7 || mid_size(variant)) && (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0))
                     return launch_bwd_gs<8, 1, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, 1, s);
                 return launch_bwd<8, 1, 6, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
         default: break;
