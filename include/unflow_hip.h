@@ -110,6 +110,11 @@ int unflow_ssim_loss_bwd(const float* img, const float* warped, const float* w, 
 /* the bare SSIM map of ssim.py:4-20 for [B,C,H,W] inputs (test/diagnostic surface). */
 int unflow_ssim_map(const float* x, const float* y, float* out, int B, int C, int H, int W,
                     void* stream);
+/* autograd of unflow_ssim_map w.r.t. both arguments (the reference's SSIM(x, y) is an ordinary differentiable
+ * function, pytorch_ssim/ssim.py:4-20): gmap [B,C,H,W] -> gx, gy [B,C,H,W] (either may be NULL).
+ * scratch: 4*B*C*H*W floats, caller-owned. */
+int unflow_ssim_map_bwd(const float* x, const float* y, const float* gmap, float* gx, float* gy,
+                        float* scratch, int B, int C, int H, int W, void* stream);
 
 /* ---- 2nd-order smoothness: cal_grad2_error + compute_loss_flow_smooth (one scale),
  * model_flow_paper.py:152-177 ----  flow [B,2,H,W] (un-divided; the /20 is inside), img [B,3,H,W].

@@ -400,6 +400,27 @@ def test_ssim_map_vs_oracle(ops):
         close(ops.ssim_map(x.cuda(), y.cuda()), R.SSIM(x, y), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize('shape', [(2, 3, 24, 40), (1, 1, 5, 7), (2, 3, 64, 208)])
+def test_ssim_map_is_differentiable_like_the_reference(ops, shape):
+    """SSIM(x, y) (pytorch_ssim/ssim.py:4-20) back-propagates into BOTH arguments in the reference; so does the HIP op."""
+    xc = rnd(41, shape, uniform=True).requires_grad_()
+    yc = (rnd(42, shape, uniform=True) * 0.7 + 0.1).requires_grad_()
+    g = rnd(43, shape)
+    sr = R.SSIM(xc, yc)
+    sr.backward(g)
+    x, y = dev(xc.detach()).requires_grad_(), dev(yc.detach()).requires_grad_()
+    sm = ops.ssim_map(x, y)
+    close(sm, sr, rtol=1e-4, atol=1e-5)
+    sm.backward(dev(g))
+    scale = max(xc.grad.abs().max().item(), yc.grad.abs().max().item())
+    close(x.grad, xc.grad, rtol=1e-3, atol=1e-4 * scale)
+    close(y.grad, yc.grad, rtol=1e-3, atol=1e-4 * scale)
+    # only one side needs a gradient
+    y2 = dev(yc.detach()).requires_grad_()
+    ops.ssim_map(x.detach(), y2).backward(dev(g))
+    close(y2.grad, yc.grad, rtol=1e-3, atol=1e-4 * scale)
+
+
 def test_reductions_are_reproducible(ops):
     """Per-sample reductions use fixed-order partial sums: two launches agree bitwise."""
     img = rnd(51, (8, 3, 256, 832), uniform=True).cuda()

@@ -31,6 +31,7 @@ SIGNATURES = {
     'unflow_ssim_loss_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     'unflow_ssim_loss_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     'unflow_ssim_map': [_P, _P, _P, _I, _I, _I, _I, _P],
+    'unflow_ssim_map_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'unflow_smooth2_fwd': [_P, _P, _P, _P, _I, _I, _I, _P],
     'unflow_smooth2_bwd': [_P, _P, _P, _P, _I, _I, _I, _P],
     'unflow_consis_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],

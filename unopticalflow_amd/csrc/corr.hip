@@ -1121,6 +1121,9 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 if (ring_ok && fb == 5) return launch_bwd_gs<4, 4, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, groups, s);
                 // group-split ring kernel, 64x8 tiles, 4 channels per stage: levels 2-4 (83 / 35 / 20 us; the tile kernel
                 // with all 81 gradients per lane takes 107 us at level 2)
+                // (measured and dropped: a persistent form -- 256 workgroups walking 4 items each, the next tile's gradient
+                // planes touched into L2 during the ring stages -- 109 us at level 2 against 95 for this one: the exposed
+                // gather is not what limits the kernel, and 1024 independently scheduled workgroups balance better)
                 if (ring_ok && (fb == 4 || (fb == 0 && (variant == 7 || mid_size(variant)))))
                     return launch_bwd_gs<4, 4, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, groups, s);
                 if (fb == 6 || variant == 1 || variant == 7) return launch_bwd<4, 2, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);

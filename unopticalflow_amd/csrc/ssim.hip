@@ -300,3 +300,91 @@ extern "C" int unflow_ssim_map(const float* x, const float* y, float* out, int B
                        (const float*)nullptr, out, (float*)nullptr, H, W);
     return unflow_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the SSIM map (the reference's free function SSIM(x, y), pytorch_ssim/ssim.py:4-20, back-propagates
+// through both arguments).  Not on the train step's path (compute_loss_ssim has its own fused kernels above); two
+// simple passes, one lane per pixel:
+//   pass 1: per pixel p the derivatives of  g[p] * SSIM[p]  w.r.t. the five pooled statistics at p
+//           (mu_x, mu_y, the two second moments -- same coefficient -- and the mixed moment) -> 4 planes of scratch;
+//   pass 2: every pooled statistic is a zero-padded 3x3 box mean, whose transpose is the same box mean:
+//           gx = P(c_mux) + 2 x P(c_ss) + y P(c_sxy),   gy = P(c_muy) + 2 y P(c_ss) + x P(c_sxy).
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ float box9(const float* __restrict__ p, int y, int x, int H, int W) {
+    float s = 0.f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) s += p[yy * W + xx];
+        }
+    return s / 9.0f;
+}
+
+__global__ void ssim_map_bwd_coef_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                         const float* __restrict__ g, float* __restrict__ coef, int H, int W, size_t n) {
+    const int plane = H * W;
+    const int pl = blockIdx.y;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= plane) return;
+    const int py = q / W, px = q - py * W;
+    const float* xp = x + (size_t)pl * plane;
+    const float* yp = y + (size_t)pl * plane;
+    float mx = 0.f, my = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = py + dy, xx = px + dx;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                const float a = xp[yy * W + xx], b = yp[yy * W + xx];
+                mx += a; my += b; sxx += a * a; syy += b * b; sxy += a * b;
+            }
+        }
+    mx /= 9.0f; my /= 9.0f; sxx /= 9.0f; syy /= 9.0f; sxy /= 9.0f;
+    const float C1 = 1e-4f, C2 = 9e-4f;
+    const float A = 2.0f * mx * my + C1, Bn = 2.0f * (sxy - mx * my) + C2;
+    const float D1 = mx * mx + my * my + C1, D2 = (sxx - mx * mx) + (syy - my * my) + C2;
+    const float d = D1 * D2, S = A * Bn / d;
+    const float gv = g[(size_t)pl * plane + q];
+    const float dA = Bn / d, dB = A / d, dD1 = -S / D1, dD2 = -S / D2;
+    const float c_mux = gv * (dA * 2.0f * my - dB * 2.0f * my + dD1 * 2.0f * mx - dD2 * 2.0f * mx);
+    const float c_muy = gv * (dA * 2.0f * mx - dB * 2.0f * mx + dD1 * 2.0f * my - dD2 * 2.0f * my);
+    const size_t o = (size_t)pl * plane + q;
+    coef[o] = c_mux;
+    coef[n + o] = c_muy;
+    coef[2 * n + o] = gv * dD2;            // d/d(second moment of x) = d/d(second moment of y)
+    coef[3 * n + o] = gv * dB * 2.0f;      // d/d(mixed moment)
+}
+
+__global__ void ssim_map_bwd_gather_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                           const float* __restrict__ coef, float* __restrict__ gx, float* __restrict__ gy,
+                                           int H, int W, size_t n) {
+    const int plane = H * W;
+    const int pl = blockIdx.y;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= plane) return;
+    const int py = q / W, px = q - py * W;
+    const size_t base = (size_t)pl * plane;
+    const float pmx = box9(coef + base, py, px, H, W), pmy = box9(coef + n + base, py, px, H, W);
+    const float pss = box9(coef + 2 * n + base, py, px, H, W), pxy = box9(coef + 3 * n + base, py, px, H, W);
+    const float xv = x[base + q], yv = y[base + q];
+    if (gx) gx[base + q] = pmx + 2.0f * xv * pss + yv * pxy;
+    if (gy) gy[base + q] = pmy + 2.0f * yv * pss + xv * pxy;
+}
+
+}  // namespace
+
+extern "C" int unflow_ssim_map_bwd(const float* x, const float* y, const float* gmap, float* gx, float* gy,
+                                   float* scratch, int B, int C, int H, int W, void* stream) {
+    UNFLOW_REQUIRE(x && y && gmap && scratch && (gx || gy) && B > 0 && C > 0 && H > 0 && W > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)B * C * H * W;
+    dim3 grid(ceil_div(H * W, 256), B * C);
+    hipLaunchKernelGGL(ssim_map_bwd_coef_kernel, grid, dim3(256), 0, s, x, y, gmap, scratch, H, W, n);
+    hipLaunchKernelGGL(ssim_map_bwd_gather_kernel, grid, dim3(256), 0, s, x, y, (const float*)scratch, gx, gy, H, W, n);
+    return unflow_launch_status();
+}

@@ -354,17 +354,39 @@ def ssim_loss(img, img_warped, w):
     return _SsimLoss.apply(img.detach(), img_warped, w.detach())
 
 
+class _SsimMap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        dev = _dev(x, y)
+        x, y = x.contiguous(), y.contiguous()
+        B, C, H, W = x.shape
+        out = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            _call('unflow_ssim_map', _ptr(x), _ptr(y), _ptr(out), B, C, H, W, _stream())
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        if gx is None and gy is None:
+            return None, None
+        scratch = torch.empty((4,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _call('unflow_ssim_map_bwd', _ptr(x), _ptr(y), _ptr(g.contiguous()), _ptr(gx), _ptr(gy), _ptr(scratch),
+                  B, C, H, W, _stream())
+        return gx, gy
+
+
 def ssim_map(x, y):
-    """SSIM(x, y) map of pytorch_ssim/ssim.py:4-20 (forward only)."""
-    dev = _dev(x, y)
-    if x.requires_grad or y.requires_grad:
-        raise RuntimeError('ssim_map is forward-only; the differentiable path is ssim_loss')
-    x, y = x.contiguous(), y.contiguous()
-    B, C, H, W = x.shape
-    out = torch.empty_like(x)
-    with torch.cuda.device(dev):
-        _call('unflow_ssim_map', _ptr(x), _ptr(y), _ptr(out), B, C, H, W, _stream())
-    return out
+    """SSIM(x, y) map of pytorch_ssim/ssim.py:4-20, differentiable in both arguments like the reference's function
+    (the train step itself uses the fused ``ssim_loss``)."""
+    if x.shape != y.shape:
+        raise ValueError('SSIM: shapes differ: {} vs {}'.format(tuple(x.shape), tuple(y.shape)))
+    return _SsimMap.apply(x, y)
 
 
 # ------------------------------------------------------------------------------------------
