@@ -86,9 +86,11 @@ int unflow_occ_weight_fwd(const float* img, const float* from_l, const float* fr
                           float* diff_l, float* diff_r, float* w_bwd, float* w_fwd,
                           uint8_t* valid_bwd, uint8_t* valid_fwd,
                           int B, int H, int W, void* stream);
-/* grad of diff = mean_c|img-from| w.r.t. from: gfrom[b,c,p] = -sign(img-from) * gdiff[b,p] / 3. */
+/* grad of diff = mean_c|img-from| w.r.t. from: gfrom[b,c,p] = -sign(img-from) * gdiff[b,p] / 3.
+ * img_batch: samples in `img` (B % img_batch == 0); sample b of `from` pairs with image b % img_batch -- the model
+ * runs both warp directions of a pair as ONE launch of 2B samples over the B centre images (img_batch = B). */
 int unflow_absdiff_bwd(const float* img, const float* from, const float* gdiff, float* gfrom,
-                       int B, int H, int W, void* stream);
+                       int B, int H, int W, int img_batch, void* stream);
 
 /* ---- masked mean: Model_flow.compute_loss_with_mask (one scale), model_flow_paper.py:93-97 ----
  * loss[b] = mean_p(diff*w) / (mean_p(w) + 1e-12).  partials: K=2.  sums[b] = {sum diff*w, sum w}
@@ -103,10 +105,11 @@ int unflow_masked_mean_bwd(const float* w, const float* sums, const float* gloss
  * x = img*w, y = warped*w; loss[b] = mean_{c,p} clamp((1-SSIM(x,y))/2, 0, 1) / (mean_p(w)+1e-12).
  * partials: K=2.  sums[b] = {sum clamp(..), sum w}. */
 int unflow_ssim_loss_fwd(const float* img, const float* warped, const float* w, float* loss,
-                         float* sums, float* partials, int B, int H, int W, void* stream);
-/* gradient w.r.t. warped only (img is a detached pyramid, w is detached). */
+                         float* sums, float* partials, int B, int H, int W, int img_batch, void* stream);
+/* gradient w.r.t. warped only (img is a detached pyramid, w is detached).  img_batch as for unflow_absdiff_bwd
+ * (img: [img_batch,3,H,W]; warped, w: B samples). */
 int unflow_ssim_loss_bwd(const float* img, const float* warped, const float* w, const float* sums,
-                         const float* gloss, float* gwarped, int B, int H, int W, void* stream);
+                         const float* gloss, float* gwarped, int B, int H, int W, int img_batch, void* stream);
 /* the bare SSIM map of ssim.py:4-20 for [B,C,H,W] inputs (test/diagnostic surface). */
 int unflow_ssim_map(const float* x, const float* y, float* out, int B, int C, int H, int W,
                     void* stream);
@@ -120,9 +123,9 @@ int unflow_ssim_map_bwd(const float* x, const float* y, const float* gmap, float
  * model_flow_paper.py:152-177 ----  flow [B,2,H,W] (un-divided; the /20 is inside), img [B,3,H,W].
  * partials: K=2. */
 int unflow_smooth2_fwd(const float* flow, const float* img, float* loss, float* partials,
-                       int B, int H, int W, void* stream);
+                       int B, int H, int W, int img_batch, void* stream);       /* img: [img_batch,3,H,W], see unflow_absdiff_bwd */
 int unflow_smooth2_bwd(const float* flow, const float* img, const float* gloss, float* gflow,
-                       int B, int H, int W, void* stream);
+                       int B, int H, int W, int img_batch, void* stream);
 
 /* ---- forward/backward consistency: compute_loss_flow_consis (one scale),
  * model_flow_paper.py:44-51,183-193 ----  grad flows to fwd_flow only.  partials: K=2. */

@@ -313,7 +313,7 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
         # a gradient that is numerically zero takes either sign, so two runs can differ by 4 * lr there
 
 
-def _rccl_single_rank(port, out_path):
+def _rccl_single_rank(rank, port, out_path):
     import os
     import torch.distributed as dist
     os.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
@@ -331,7 +331,7 @@ def _rccl_single_rank(port, out_path):
         model = get_model('flow')(cfg).cuda()
         model.load_state_dict(sd)
         tr = FlowTrainer(cfg, model, **kw)
-        losses, early = [], []
+        losses, early, first = [], [], None
         for _ in range(3):
             tr.grads.zero()
             pack = model(x)
@@ -339,10 +339,12 @@ def _rccl_single_rank(port, out_path):
             loss.backward()
             early.append(tr.grads.launched_early)
             tr.grads.all_reduce_mean()
+            if first is None:
+                first = tr.grads.flat.cpu()                # gradients of the first step: same weights on both sides
             tr.optimizer.step()
-            losses.append(float(loss))
+            losses.append(float(loss.detach()))
         torch.cuda.synchronize()
-        res[name] = {'losses': losses, 'early': early, 'chunks': tr.grads.chunks, 'grad': tr.grads.flat.cpu(),
+        res[name] = {'losses': losses, 'early': early, 'chunks': tr.grads.chunks, 'grad': first,
                      'params': [p.detach().cpu() for p in model.parameters()]}
     torch.save(res, out_path)
     dist.barrier()

@@ -421,6 +421,37 @@ def test_ssim_map_is_differentiable_like_the_reference(ops, shape):
     close(y2.grad, yc.grad, rtol=1e-3, atol=1e-4 * scale)
 
 
+def test_stacked_directions_equal_separate_launches(ops):
+    """The model runs both warp directions of a scale as one 2B launch per loss (centre image broadcast through
+    ``img_batch``): values and gradients must equal the per-direction calls bit for bit (same kernels, same order)."""
+    B, h, w = 3, 40, 72
+    img = dev(rnd(51, (B, 3, h, w), uniform=True))
+    wl = (img + dev(rnd(52, (B, 3, h, w), 0.1))).clamp(0, 1)
+    wr = (img + dev(rnd(53, (B, 3, h, w), 0.1))).clamp(0, 1)
+    wl[:, :, 3:9, 5:17] = 0.0
+    flows = dev(rnd(54, (2 * B, 2, h, w), 3.0))
+    gl = dev(rnd(55, (2 * B,)))
+    # separate
+    a, b = wl.clone().requires_grad_(), wr.clone().requires_grad_()
+    fa = flows.clone().requires_grad_()
+    d_l, d_r, w_b, w_f, _, _ = ops.occ_weight(img, a, b)
+    sep = [torch.cat((ops.masked_mean(d_l, w_b), ops.masked_mean(d_r, w_f))),
+           torch.cat((ops.ssim_loss(img, a, w_b), ops.ssim_loss(img, b, w_f))),
+           torch.cat((ops.smooth2_loss(fa[:B], img), ops.smooth2_loss(fa[B:], img)))]
+    (sum(sep) * gl).sum().backward()
+    # stacked
+    st = torch.cat((wl, wr)).requires_grad_()
+    fb = flows.clone().requires_grad_()
+    diff, wgt = ops.occ_weight_stacked(img, st)
+    assert torch.equal(diff, torch.cat((d_l, d_r))) and torch.equal(wgt, torch.cat((w_b, w_f)))
+    stk = [ops.masked_mean(diff, wgt), ops.ssim_loss(img, st, wgt), ops.smooth2_loss(fb, img)]
+    (sum(stk) * gl).sum().backward()
+    for x, y in zip(sep, stk):
+        assert torch.equal(x, y)
+    assert torch.equal(st.grad, torch.cat((a.grad, b.grad)))
+    assert torch.equal(fb.grad, fa.grad)
+
+
 def test_reductions_are_reproducible(ops):
     """Per-sample reductions use fixed-order partial sums: two launches agree bitwise."""
     img = rnd(51, (8, 3, 256, 832), uniform=True).cuda()

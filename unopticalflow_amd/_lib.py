@@ -25,15 +25,15 @@ SIGNATURES = {
     'unflow_warp_corr_fwd': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'unflow_warp_corr_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'unflow_occ_weight_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    'unflow_absdiff_bwd': [_P, _P, _P, _P, _I, _I, _I, _P],
+    'unflow_absdiff_bwd': [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     'unflow_masked_mean_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     'unflow_masked_mean_bwd': [_P, _P, _P, _P, _I, _I, _I, _P],
-    'unflow_ssim_loss_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    'unflow_ssim_loss_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    'unflow_ssim_loss_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'unflow_ssim_loss_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'unflow_ssim_map': [_P, _P, _P, _I, _I, _I, _I, _P],
     'unflow_ssim_map_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    'unflow_smooth2_fwd': [_P, _P, _P, _P, _I, _I, _I, _P],
-    'unflow_smooth2_bwd': [_P, _P, _P, _P, _I, _I, _I, _P],
+    'unflow_smooth2_fwd': [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'unflow_smooth2_bwd': [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     'unflow_consis_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     'unflow_consis_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     'unflow_bias_leaky_fwd': [_P, _P, _I, _I, _I, _I, ctypes.c_float, _P],
@@ -47,7 +47,7 @@ SIGNATURES = {
     'unflow_png_unfilter': [_P, _I, _I, _I],
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 

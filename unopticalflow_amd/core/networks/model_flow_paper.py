@@ -184,22 +184,25 @@ class Model_flow(nn.Module):
             imglr_pyramid = [torch.cat((a, b), 0) for a, b in zip(pl, pr)]
             img_pyramid = self.generate_img_pyramid(img, n)
 
-        # warp_flow_pyramid(imgl, flows_bwd) and (imgr, flows_fwd) (reference :221-222) as one 2B call per scale
-        warped = [w.split(B) for w in self.warp_flow_pyramid(imglr_pyramid, flows_lr)]
-        img_warped_pyramid_from_l = [w[0] for w in warped]
-        img_warped_pyramid_from_r = [w[1] for w in warped]
+        # warp_flow_pyramid(imgl, flows_bwd) and (imgr, flows_fwd) (reference :221-222) as one 2B call per scale:
+        # warped[s] = (img_from_l | img_from_r) [2B,3,h,w]
+        warped = self.warp_flow_pyramid(imglr_pyramid, flows_lr)
 
-        diff_bwd, diff_fwd, weight_bwd, weight_fwd = self.compute_diff_weight(
-            img_warped_pyramid_from_l, img_pyramid, img_warped_pyramid_from_r)
-        loss_pack['loss_pixel'] = self.compute_loss_with_mask(diff_fwd, weight_fwd) + \
-            self.compute_loss_with_mask(diff_bwd, weight_bwd)
-
-        loss_pack['loss_ssim'] = self.compute_loss_ssim(img_pyramid, img_warped_pyramid_from_r, weight_fwd) + \
-            self.compute_loss_ssim(img_pyramid, img_warped_pyramid_from_l, weight_bwd)
-
-        loss_pack['loss_flow_smooth'] = self.compute_loss_flow_smooth(optical_flows_fwd, img_pyramid) + \
-            self.compute_loss_flow_smooth(optical_flows_bwd, img_pyramid)
-
-        loss_pack['loss_flow_consis'] = self.compute_loss_flow_consis(optical_flows_fwd, optical_flows_bwd, weight_fwd)
+        # Every loss of the reference's :224-234 is per sample and per direction; the two directions of a scale share the
+        # centre image, so each kernel runs ONCE per scale over 2B samples (bwd | fwd) against the B centre images:
+        # compute_diff_weight :224-225, compute_loss_with_mask x2 :226-227, compute_loss_ssim x2 :229-230,
+        # compute_loss_flow_smooth x2 :232-233, compute_loss_flow_consis :235.  Sums over scales first, then fwd + bwd,
+        # exactly the reference's association.
+        pixel = ssim = smooth = consis = 0
+        for s in range(n):
+            diff, wgt = ops.occ_weight_stacked(img_pyramid[s], warped[s])       # (diff_bwd | diff_fwd), (weight_bwd | weight_fwd)
+            pixel = pixel + ops.masked_mean(diff, wgt)
+            ssim = ssim + ops.ssim_loss(img_pyramid[s], warped[s], wgt)
+            smooth = smooth + ops.smooth2_loss(flows_lr[s], img_pyramid[s])
+            consis = consis + ops.consis_loss(optical_flows_fwd[s], optical_flows_bwd[s], wgt[B:])
+        loss_pack['loss_pixel'] = pixel[B:] + pixel[:B]                         # fwd + bwd (:226-227)
+        loss_pack['loss_ssim'] = ssim[B:] + ssim[:B]
+        loss_pack['loss_flow_smooth'] = smooth[B:] + smooth[:B]
+        loss_pack['loss_flow_consis'] = consis
 
         return loss_pack

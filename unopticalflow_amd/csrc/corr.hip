@@ -707,23 +707,18 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC, TYB>::THREADS)) void corr_bwd_gs_k
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     const int i = min(grp * 3 + ii, DD - 1);      // rows past DD (last pair when DD % 3 != 0) are zeroed below
-                    // branch-free: clamp the gather position, load unconditionally, zero afterwards, so the
-                    // 54 loads of a lane go out back to back instead of as 54 exec-masked blocks
-                    const int sy = mode ? py + i - R : py, sx = mode ? px + p + j - R : px + p;
-                    const int pl = mode ? (2 * R - i) * DD + (2 * R - j) : i * DD + j;
+                    // Branch-free and mask-free: the gather position is clamped, validity is folded into the ADDRESS
+                    // (invalid -> a zero line) and the gf1 / gf2 variants are arithmetic in `mode`, so the 54 (102) loads
+                    // of a lane go out back to back.  Keeping a lane mask per value alive until the loads return
+                    // overflows the scalar registers (masks spill to VGPR lanes, ~30 scalar instructions per load).
+                    const int e = i * DD + j;
+                    const int sy = py + mode * (i - R), sx = px + p + mode * (j - R);
+                    const int pl = e + mode * ((DD * DD - 1) - 2 * e);        // gf2: plane (2R-i, 2R-j)
                     const bool ok = (grp * 3 + ii < DD) && (py < H) && (px + p < W) && sy >= 0 && sy < H && sx >= 0 && sx < W;
                     const int cy = min(max(sy, 0), H - 1), cx = min(max(sx, 0), W - 1);
-                    if constexpr (R <= 4) {
-                        if (RING_DBG(8)) { wr[ii][j][p] = (float)(ii + j + p) * inv_c; continue; }      // ablation: no gather
-                        float v = gb[(size_t)pl * plane + (size_t)cy * W + cx];
-                        v = ok ? v : 0.f;
-                        wr[ii][j][p] = v * inv_c;
-                    } else {
-                        // 102 gathers per lane: keeping 102 validity masks alive until the loads return overflows the
-                        // SGPR file (masks spill to VGPR lanes, values to scratch); fold validity into the address
-                        const float* src = ok ? gb + ((size_t)pl * plane + (size_t)cy * W + cx) : kZeroLine;
-                        wr[ii][j][p] = *src * inv_c;
-                    }
+                    if (RING_DBG(8)) { wr[ii][j][p] = (float)(ii + j + p) * inv_c; continue; }      // ablation (tuning builds): no gather
+                    const float* src = ok ? gb + ((size_t)pl * plane + (size_t)cy * W + cx) : kZeroLine;
+                    wr[ii][j][p] = *src * inv_c;
                 }
     }
 

@@ -56,12 +56,14 @@ __global__ void occ_weight_fwd_kernel(const float* __restrict__ img, const float
 }
 
 // d mean_c|img - from| / d from  (torch: abs' = sign, with sign(0) = 0)
+// img_b: samples in `img`; sample b of `from` is compared with image b % img_b (both warp directions of a pair share
+// the centre image, so the two directions run as one 2B launch)
 __global__ void absdiff_bwd_kernel(const float* __restrict__ img, const float* __restrict__ from,
-                                   const float* __restrict__ gdiff, float* __restrict__ gfrom, int B, int HW) {
+                                   const float* __restrict__ gdiff, float* __restrict__ gfrom, int B, int HW, int img_b) {
     const size_t n = (size_t)B * 3 * HW;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
         const size_t b = t / ((size_t)3 * HW), p = t % HW;
-        const float d = img[t] - from[t];
+        const float d = img[t - (b - b % img_b) * 3 * HW] - from[t];
         const float sg = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
         gfrom[t] = -(gdiff[b * HW + p] / 3.0f) * sg;
     }
@@ -134,12 +136,12 @@ __device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0
 
 __global__ __launch_bounds__(256) void smooth2_partial_kernel(const float* __restrict__ flow,
                                                               const float* __restrict__ img,
-                                                              float* __restrict__ partials, int H, int W) {
+                                                              float* __restrict__ partials, int H, int W, int img_b) {
     __shared__ float red[8];
     const int b = blockIdx.y;
     const int HW = H * W;
     const float* f = flow + (size_t)b * 2 * HW;
-    const float* im = img + (size_t)b * 3 * HW;
+    const float* im = img + (size_t)(b % img_b) * 3 * HW;
     float acc[2] = {0.f, 0.f};
     const int p0 = blockIdx.x * TILE;
 #pragma unroll 2
@@ -187,14 +189,14 @@ __global__ void smooth2_finalize_kernel(const float* __restrict__ partials, int 
 // gather form of the backward: pixel q collects the three second differences it takes part in.
 __global__ void smooth2_bwd_kernel(const float* __restrict__ flow, const float* __restrict__ img,
                                    const float* __restrict__ gloss, float* __restrict__ gflow,
-                                   int B, int H, int W) {
+                                   int B, int H, int W, int img_b) {
     const int HW = H * W;
     const size_t n = (size_t)B * HW;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
         const int b = (int)(t / HW), p = (int)(t - (size_t)b * HW);
         const int y = p / W, x = p - y * W;
         const float* f = flow + (size_t)b * 2 * HW;
-        const float* im = img + (size_t)b * 3 * HW;
+        const float* im = img + (size_t)(b % img_b) * 3 * HW;
         const float kx = gloss[b] / (2.0f * (2.0f * (float)H * (float)(W - 2))) / 20.0f;
         const float ky = gloss[b] / (2.0f * (2.0f * (float)(H - 2) * (float)W)) / 20.0f;
         float g[2] = {0.f, 0.f};
@@ -293,7 +295,7 @@ inline int flat_blocks(size_t n) {
 
 int unflow_ssim_blocks(int H, int W);   // ssim.hip
 
-extern "C" int unflow_abi_version(void) { return 2; }   // 2: + unflow_warp_corr_*
+extern "C" int unflow_abi_version(void) { return 3; }   // 2: + unflow_warp_corr_*; 3: img_batch on the 2B loss entries
 
 extern "C" int unflow_partials_per_sample(int H, int W) {
     if (H <= 0 || W <= 0) return UNFLOW_EINVAL;
@@ -313,11 +315,11 @@ extern "C" int unflow_occ_weight_fwd(const float* img, const float* from_l, cons
 }
 
 extern "C" int unflow_absdiff_bwd(const float* img, const float* from, const float* gdiff, float* gfrom,
-                                  int B, int H, int W, void* stream) {
-    UNFLOW_REQUIRE(img && from && gdiff && gfrom && B > 0 && H > 0 && W > 0);
+                                  int B, int H, int W, int img_batch, void* stream) {
+    UNFLOW_REQUIRE(img && from && gdiff && gfrom && B > 0 && H > 0 && W > 0 && img_batch > 0 && B % img_batch == 0);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(absdiff_bwd_kernel, dim3(flat_blocks((size_t)B * 3 * H * W)), dim3(256), 0, s, img, from,
-                       gdiff, gfrom, B, H * W);
+                       gdiff, gfrom, B, H * W, img_batch);
     return unflow_launch_status();
 }
 
@@ -342,21 +344,21 @@ extern "C" int unflow_masked_mean_bwd(const float* w, const float* sums, const f
 }
 
 extern "C" int unflow_smooth2_fwd(const float* flow, const float* img, float* loss, float* partials,
-                                  int B, int H, int W, void* stream) {
-    UNFLOW_REQUIRE(flow && img && loss && partials && B > 0 && H > 0 && W > 0);
+                                  int B, int H, int W, int img_batch, void* stream) {
+    UNFLOW_REQUIRE(flow && img && loss && partials && B > 0 && H > 0 && W > 0 && img_batch > 0 && B % img_batch == 0);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = ceil_div(H * W, TILE);
-    hipLaunchKernelGGL(smooth2_partial_kernel, dim3(nblk, B), dim3(256), 0, s, flow, img, partials, H, W);
+    hipLaunchKernelGGL(smooth2_partial_kernel, dim3(nblk, B), dim3(256), 0, s, flow, img, partials, H, W, img_batch);
     hipLaunchKernelGGL(smooth2_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, H, W);
     return unflow_launch_status();
 }
 
 extern "C" int unflow_smooth2_bwd(const float* flow, const float* img, const float* gloss, float* gflow,
-                                  int B, int H, int W, void* stream) {
-    UNFLOW_REQUIRE(flow && img && gloss && gflow && B > 0 && H > 0 && W > 0);
+                                  int B, int H, int W, int img_batch, void* stream) {
+    UNFLOW_REQUIRE(flow && img && gloss && gflow && B > 0 && H > 0 && W > 0 && img_batch > 0 && B % img_batch == 0);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(smooth2_bwd_kernel, dim3(flat_blocks((size_t)B * H * W)), dim3(256), 0, s, flow, img, gloss,
-                       gflow, B, H, W);
+                       gflow, B, H, W, img_batch);
     return unflow_launch_status();
 }
 

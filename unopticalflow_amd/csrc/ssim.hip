@@ -70,10 +70,10 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
                                                        const float* __restrict__ warped,
                                                        const float* __restrict__ wgt,
                                                        float* __restrict__ map_out,
-                                                       float* __restrict__ partials, int H, int W) {
+                                                       float* __restrict__ partials, int H, int W, int img_groups) {
     __shared__ float red[8];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int grp = blockIdx.y;
+    const int grp = blockIdx.y;                        // (img has img_groups groups: group grp reads image grp % img_groups)
     const int nsx = strips(W, 1), nch = chunks(H);
     const int job = blockIdx.x * 4 + wid;
     float acc[2] = {0.f, 0.f};
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
         const bool xin = (x >= 0 && x < W);
         const bool xout = xin && lane >= 1 && lane <= 62;
         const size_t plane = (size_t)H * W;
-        const float* ip = img + (size_t)grp * NC * plane;
+        const float* ip = img + (size_t)(grp % img_groups) * NC * plane;
         const float* wp = warped + (size_t)grp * NC * plane;
         const float* mp = WEIGHTED ? wgt + (size_t)grp * plane : nullptr;
         // all RS+2 input rows are requested before the first one is used: the strip costs one
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ wgt,
                                                        const float* __restrict__ sums,
                                                        const float* __restrict__ gloss,
-                                                       float* __restrict__ gwarped, int H, int W) {
+                                                       float* __restrict__ gwarped, int H, int W, int img_b) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int nsx = strips(W, 2), nch = chunks(H);
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__
     const bool xin = (x >= 0 && x < W);
     const bool xout = xin && lane >= 2 && lane <= 61;
     const size_t plane = (size_t)H * W;
-    const float* ip = img + (size_t)b * 3 * plane;
+    const float* ip = img + (size_t)(b % img_b) * 3 * plane;
     const float* wp = warped + (size_t)b * 3 * plane;
     const float* mp = wgt + (size_t)b * plane;
     float* gp = gwarped + (size_t)b * 3 * plane;
@@ -272,22 +272,22 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__
 int unflow_ssim_blocks(int H, int W) { return ceil_div(strips(W, 1) * chunks(H), 4); }
 
 extern "C" int unflow_ssim_loss_fwd(const float* img, const float* warped, const float* w, float* loss,
-                                    float* sums, float* partials, int B, int H, int W, void* stream) {
-    UNFLOW_REQUIRE(img && warped && w && loss && sums && partials && B > 0 && H > 0 && W > 0);
+                                    float* sums, float* partials, int B, int H, int W, int img_batch, void* stream) {
+    UNFLOW_REQUIRE(img && warped && w && loss && sums && partials && B > 0 && H > 0 && W > 0 && img_batch > 0 && B % img_batch == 0);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = unflow_ssim_blocks(H, W);
     hipLaunchKernelGGL((ssim_fwd_kernel<3, true, false>), dim3(nblk, B), dim3(256), 0, s, img, warped, w,
-                       (float*)nullptr, partials, H, W);
+                       (float*)nullptr, partials, H, W, img_batch);
     hipLaunchKernelGGL(ssim_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, sums, H, W);
     return unflow_launch_status();
 }
 
 extern "C" int unflow_ssim_loss_bwd(const float* img, const float* warped, const float* w, const float* sums,
-                                    const float* gloss, float* gwarped, int B, int H, int W, void* stream) {
-    UNFLOW_REQUIRE(img && warped && w && sums && gloss && gwarped && B > 0 && H > 0 && W > 0);
+                                    const float* gloss, float* gwarped, int B, int H, int W, int img_batch, void* stream) {
+    UNFLOW_REQUIRE(img && warped && w && sums && gloss && gwarped && B > 0 && H > 0 && W > 0 && img_batch > 0 && B % img_batch == 0);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = ceil_div(strips(W, 2) * chunks(H), 4);
-    hipLaunchKernelGGL(ssim_bwd_kernel, dim3(nblk, B), dim3(256), 0, s, img, warped, w, sums, gloss, gwarped, H, W);
+    hipLaunchKernelGGL(ssim_bwd_kernel, dim3(nblk, B), dim3(256), 0, s, img, warped, w, sums, gloss, gwarped, H, W, img_batch);
     return unflow_launch_status();
 }
 
@@ -297,7 +297,7 @@ extern "C" int unflow_ssim_map(const float* x, const float* y, float* out, int B
     hipStream_t s = (hipStream_t)stream;
     const int nblk = unflow_ssim_blocks(H, W);
     hipLaunchKernelGGL((ssim_fwd_kernel<1, false, true>), dim3(nblk, B * C), dim3(256), 0, s, x, y,
-                       (const float*)nullptr, out, (float*)nullptr, H, W);
+                       (const float*)nullptr, out, (float*)nullptr, H, W, B * C);
     return unflow_launch_status();
 }
 

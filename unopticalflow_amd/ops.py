@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 
-__all__ = ['corr', 'warp_flow', 'warp_flow_masked', 'warp_corr', 'occ_weight', 'masked_mean', 'ssim_loss',
+__all__ = ['corr', 'warp_flow', 'warp_flow_masked', 'warp_corr', 'occ_weight', 'occ_weight_stacked', 'masked_mean', 'ssim_loss',
            'ssim_map', 'smooth2_loss', 'consis_loss', 'bias_leaky_relu_', 'img_pyramid']
 
 
@@ -277,13 +277,53 @@ class _OccWeight(torch.autograd.Function):
             for k, (src, g) in enumerate(((from_l, g_l), (from_r, g_r))):
                 if ctx.needs_input_grad[k + 1] and g is not None:
                     gs = torch.empty_like(src)
-                    _call('unflow_absdiff_bwd', _ptr(img), _ptr(src), _ptr(g.contiguous()), _ptr(gs), B, H, W,
+                    _call('unflow_absdiff_bwd', _ptr(img), _ptr(src), _ptr(g.contiguous()), _ptr(gs), B, H, W, B,
                           _stream())
                     out[k + 1] = gs
         if ctx.needs_input_grad[0]:
             raise RuntimeError('occ_weight: the centre image is a detached pyramid level '
                                '(model_flow_paper.py:58); no gradient is defined for it')
         return tuple(out)
+
+
+class _OccWeight2(torch.autograd.Function):
+    """Both warp directions of a scale stacked on the batch axis: warped = (from_l | from_r) [2B,3,H,W] against the B centre
+    images -> diff = (diff_l | diff_r), weight = (w_bwd | w_fwd) [2B,1,H,W], so that every loss that follows runs as ONE
+    2B launch per scale instead of one per direction."""
+
+    @staticmethod
+    def forward(ctx, img, warped):
+        dev = _dev(img, warped)
+        img, warped = img.contiguous(), warped.contiguous()
+        B, C, H, W = img.shape
+        assert C == 3 and warped.shape[0] == 2 * B
+        diff = torch.empty((2 * B, 1, H, W), dtype=torch.float32, device=dev)
+        wgt = torch.empty((2 * B, 1, H, W), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _call('unflow_occ_weight_fwd', _ptr(img), _ptr(warped[:B]), _ptr(warped[B:]), _ptr(diff[:B]), _ptr(diff[B:]),
+                  _ptr(wgt[:B]), _ptr(wgt[B:]), _ptr(None), _ptr(None), B, H, W, _stream(),
+                  nbytes=B * H * W * 4 * 13, shape=(B, 3, H, W))
+        ctx.save_for_backward(img, warped)
+        ctx.mark_non_differentiable(wgt)                             # weight is .data (model_flow_paper.py:122)
+        return diff, wgt
+
+    @staticmethod
+    def backward(ctx, g, _gw):
+        img, warped = ctx.saved_tensors
+        B, C, H, W = img.shape
+        if not ctx.needs_input_grad[1] or g is None:
+            return None, None
+        gs = torch.empty_like(warped)
+        with torch.cuda.device(img.device):
+            _call('unflow_absdiff_bwd', _ptr(img), _ptr(warped), _ptr(g.contiguous()), _ptr(gs), 2 * B, H, W, B, _stream(),
+                  nbytes=4 * B * H * W * (3 + 2 * 7), shape=(2 * B, 3, H, W))
+        return None, gs
+
+
+def occ_weight_stacked(img, warped_lr):
+    """compute_diff_weight (model_flow_paper.py:108-132) for one scale with (from_l | from_r) stacked on the batch axis:
+    -> (diff [2B,1,H,W] = (diff_bwd | diff_fwd), weight [2B,1,H,W] = (weight_bwd | weight_fwd))."""
+    return _OccWeight2.apply(img, warped_lr)
 
 
 def occ_weight(img, img_from_l, img_from_r):
@@ -328,24 +368,24 @@ class _SsimLoss(torch.autograd.Function):
     def forward(ctx, img, warped, w):
         dev = _dev(img, warped, w)
         img, warped, w = img.contiguous(), warped.contiguous(), w.contiguous()
-        B, C, H, W = img.shape
-        assert C == 3
+        B, C, H, W = warped.shape                      # img may hold fewer samples: sample b pairs with image b % len(img)
+        assert C == 3 and B % img.shape[0] == 0 and w.shape[0] == B
         loss = torch.empty(B, dtype=torch.float32, device=dev)
         sums = torch.empty((B, 2), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _call('unflow_ssim_loss_fwd', _ptr(img), _ptr(warped), _ptr(w), _ptr(loss), _ptr(sums),
-                  _ptr(_partials(B, H, W, dev)), B, H, W, _stream(), nbytes=4 * B * H * W * 7, shape=(B, 3, H, W))
+                  _ptr(_partials(B, H, W, dev)), B, H, W, img.shape[0], _stream(), nbytes=4 * B * H * W * 7, shape=(B, 3, H, W))
         ctx.save_for_backward(img, warped, w, sums)
         return loss
 
     @staticmethod
     def backward(ctx, gl):
         img, warped, w, sums = ctx.saved_tensors
-        B, C, H, W = img.shape
+        B, C, H, W = warped.shape
         gw = torch.empty_like(warped)
         with torch.cuda.device(img.device):
             _call('unflow_ssim_loss_bwd', _ptr(img), _ptr(warped), _ptr(w), _ptr(sums), _ptr(gl.contiguous()),
-                  _ptr(gw), B, H, W, _stream(), nbytes=4 * B * H * W * 10, shape=(B, 3, H, W))
+                  _ptr(gw), B, H, W, img.shape[0], _stream(), nbytes=4 * B * H * W * 10, shape=(B, 3, H, W))
         return None, gw, None
 
 
@@ -397,11 +437,12 @@ class _Smooth2(torch.autograd.Function):
     def forward(ctx, flow, img):
         dev = _dev(flow, img)
         flow, img = flow.contiguous(), img.contiguous()
-        B, _, H, W = flow.shape
+        B, _, H, W = flow.shape                        # img may hold fewer samples: sample b pairs with image b % len(img)
+        assert B % img.shape[0] == 0
         loss = torch.empty(B, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _call('unflow_smooth2_fwd', _ptr(flow), _ptr(img), _ptr(loss), _ptr(_partials(B, H, W, dev)),
-                  B, H, W, _stream())
+                  B, H, W, img.shape[0], _stream())
         ctx.save_for_backward(flow, img)
         return loss
 
@@ -412,7 +453,7 @@ class _Smooth2(torch.autograd.Function):
         gflow = torch.empty_like(flow)
         with torch.cuda.device(flow.device):
             _call('unflow_smooth2_bwd', _ptr(flow), _ptr(img), _ptr(gl.contiguous()), _ptr(gflow), B, H, W,
-                  _stream())
+                  img.shape[0], _stream())
         return gflow, None
 
 
