@@ -94,6 +94,17 @@ def test_dma_ring_kernels_do_not_spill():
     assert checked >= 3      # ring<9 rows>, ring<3 rows>, group-split backward
 
 
+def test_torch_library_is_built_in_tree():
+    """build() also produces libunflow_torch.so (TORCH_LIBRARY(unflow_hip)); it resolves libunflow_hip.so through $ORIGIN."""
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build()
+    from unopticalflow_amd import torch_ops
+    assert os.path.exists(torch_ops.LIB_PATH)
+    dyn = subprocess.run(['readelf', '-d', torch_ops.LIB_PATH], capture_output=True, text=True).stdout
+    assert 'libunflow_hip.so' in dyn and '$ORIGIN' in dyn, dyn
+
+
 def test_host_library_has_no_hip_dependency():
     """libunflow_host.so (PNG unfilter for the DataLoader workers) must load without the HIP runtime."""
     import subprocess

@@ -133,7 +133,7 @@ def corr_bwd_sweep(B=16):
     """d=4 backward variants (tuning library): tile kernel, group-split ring kernel at 64x4 / 64x8 tiles."""
     lib = _lib.load()
     P = ops._ptr
-    envs = [{}] + [{'UNFLOW_CORR_BWD': v} for v in (4, 7, 8, 3)]
+    envs = [{}] + [{'UNFLOW_CORR_BWD': v, 'UNFLOW_CORR_GROUPS': g_} for v in (4, 3, 1, 6) for g_ in (1, 4)]
     for name, (C, h, w) in list(LEVELS.items())[:3]:
         f1 = torch.randn(B, C, h, w, device='cuda')
         f2 = torch.randn(B, C, h, w, device='cuda')
@@ -160,7 +160,7 @@ def ablate(B=16):
     C, h, w = LEVELS['L2']
     x = torch.randn(B, C, h, w, device='cuda'); g = torch.randn(B, C, h, w, device='cuda')
     gsrc = torch.empty_like(x); fl = _smooth_flow(B, h, w); gfl = torch.empty_like(fl)
-    for th in (8, 16):
+    for th in (8,):
         for dbg in (0, 1, 2, 4, 3):
             os.environ.update({'UNFLOW_WARP_TH': str(th), 'UNFLOW_WARP_DEBUG': str(dbg)})
             tb = timeit(lambda: lib.unflow_warp_bwd(P(x), P(fl), P(g), None, P(gsrc), P(gfl), B, C, h, w, 0, ops._stream()))
@@ -200,7 +200,7 @@ def corr_fwd_sweep(B=16):
     """d=4 forward variants (tuning library) at levels 2-4."""
     lib = _lib.load()
     P = ops._ptr
-    envs = [{}] + [{'UNFLOW_CORR_VARIANT': v} for v in (7, 9, 10, 12, 13)]
+    envs = [{}] + [{'UNFLOW_CORR_VARIANT': v} for v in (7, 9, 12, 13)]
     for name, (C, h, w) in list(LEVELS.items())[:3]:
         f1 = torch.randn(B, C, h, w, device='cuda'); f2 = torch.randn(B, C, h, w, device='cuda')
         cv = torch.empty(B, 81, h, w, device='cuda')

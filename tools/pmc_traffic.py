@@ -1,0 +1,68 @@
+"""Collect HBM traffic per launch of the cost-volume / warp entry points with rocprofv3 PMC passes and write
+profiles/r2_pmc_traffic.json (read by bench.py's `roofline.traffic`, keyed by the sha256 of the kernel sources).
+
+    python tools/pmc_traffic.py            (on the GPU box; ~3 min)
+
+FETCH_SIZE and WRITE_SIZE are collected in SEPARATE passes (they do not fit one), no trace domains mixed in.  On gfx950
+FETCH_SIZE reports half the bytes of wide coalesced streams (MI355X_MICROARCH.md, HBM): x2 before adding WRITE_SIZE (KB)."""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import sources_sha16   # noqa: E402
+
+ENTRIES = [('unflow_corr_bwd', 'L2'), ('unflow_corr_fwd', 'L2'), ('unflow_warp_bwd', 'L2'), ('unflow_warp_fwd', 'L2'),
+           ('unflow_corr_bwd', 'L3'), ('unflow_warp_bwd', 'L3')]
+REPS = 3
+SKIP = ('randn', 'distribution', 'elementwise', 'fill', 'Fill', 'copy', 'sin', 'cos', 'mul', 'add', 'stack', 'repeat', 'cat', 'arange')
+
+
+def one_pass(entry, lvl, counter):
+    out = tempfile.mkdtemp(prefix='pmc_')
+    env = dict(os.environ, TMPDIR='/tmp')
+    subprocess.run(['rocprofv3', '--pmc', counter, '--output-format', 'csv', '-d', out, '--',
+                    sys.executable, os.path.join(ROOT, 'tools', 'pmc_entry.py'), entry, lvl, str(REPS)],
+                   cwd='/tmp', env=env, check=True, capture_output=True, timeout=300)
+    per_kernel = {}
+    for f in glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r['Counter_Name'] != counter:
+                continue
+            name = r['Kernel_Name']
+            if 'anonymous namespace' not in name and 'unflow' not in name:      # torch's set-up kernels
+                continue
+            if 'at::native' in name:
+                continue
+            per_kernel.setdefault(name.split('(')[0][:70], []).append(float(r['Counter_Value']))
+    return per_kernel
+
+
+def main():
+    from tools.microbench import LEVELS
+    res = {'sources_sha16': sources_sha16(), 'reps': REPS,
+           'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, KB per dispatch summed over the kernels '
+                     'of one entry-point call; hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 wide-load correction)',
+           'entries': {}}
+    for entry, lvl in ENTRIES:
+        C, h, w = LEVELS[lvl]
+        fetch, write = one_pass(entry, lvl, 'FETCH_SIZE'), one_pass(entry, lvl, 'WRITE_SIZE')
+        f_kb = sum(sum(v) for v in fetch.values()) / REPS
+        w_kb = sum(sum(v) for v in write.values()) / REPS
+        key = '%s %s' % (entry, [16, C, h, w])
+        res['entries'][key] = {'fetch_size_kb_raw': round(f_kb, 1), 'write_size_kb': round(w_kb, 1),
+                               'hbm_bytes_per_launch': int((2 * f_kb + w_kb) * 1024),
+                               'kernels': {k: {'fetch_kb': round(sum(v) / REPS, 1), 'write_kb': round(sum(write.get(k, [0])) / REPS, 1)}
+                                           for k, v in fetch.items()}}
+        print(key, res['entries'][key]['hbm_bytes_per_launch'], flush=True)
+    os.makedirs(os.path.join(ROOT, 'gpurun_out', 'r2'), exist_ok=True)
+    json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'r2', 'r2_pmc_traffic.json'), 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()

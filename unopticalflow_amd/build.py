@@ -20,6 +20,7 @@ CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libunflow_hip.so')
 LIB_TUNING = os.path.join(PKG, 'libunflow_hip_tuning.so')
 HOST_LIB = os.path.join(PKG, 'libunflow_host.so')
+TORCH_LIB = os.path.join(PKG, 'libunflow_torch.so')
 SOURCES = ('corr.hip', 'warp.hip', 'warp_corr.hip', 'ssim.hip', 'photo.hip', 'elementwise.hip', 'elementwise_bf16.hip',
            'prepare.hip', 'png_host.cpp')
 HOST_SOURCES = ('png_host.cpp',)
@@ -77,6 +78,7 @@ def build(force=False, verbose=True, tuning=False):
         subprocess.run(cmd, check=True)
     if not tuning:
         build_host(force, verbose)
+        build_torch(force, verbose)
     return lib
 
 
@@ -90,6 +92,27 @@ def build_host(force=False, verbose=True):
             print(' '.join(cmd), flush=True)
         subprocess.run(cmd, check=True)
     return HOST_LIB
+
+
+def build_torch(force=False, verbose=True):
+    """libunflow_torch.so: TORCH_LIBRARY(unflow_hip) registration of the C ABI as dispatcher operators (csrc/torch_ops.cpp).
+    Host-only C++ compiled with g++ against the torch headers and linked to libunflow_hip.so (found through $ORIGIN)."""
+    src = os.path.join(CSRC, 'torch_ops.cpp')
+    if not (force or _newer(TORCH_LIB, [src, LIB] + _headers())):
+        return TORCH_LIB
+    import torch
+    from torch.utils import cpp_extension as ce
+    tlib = os.path.join(os.path.dirname(torch.__file__), 'lib')
+    rocm = os.environ.get('ROCM_PATH', '/opt/rocm')
+    cmd = [os.environ.get('CXX', 'g++'), '-O2', '-fPIC', '-shared', '-std=c++17', '-D__HIP_PLATFORM_AMD__=1', '-DUSE_ROCM=1',
+           '-D_GLIBCXX_USE_CXX11_ABI=%d' % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    cmd += ['-I' + d for d in ce.include_paths()] + ['-I' + os.path.join(rocm, 'include'), src, '-o', TORCH_LIB,
+            '-L' + tlib, '-ltorch', '-ltorch_cpu', '-lc10', '-lc10_hip', '-ltorch_hip', '-L' + PKG, '-lunflow_hip',
+            '-Wl,-rpath,$ORIGIN', '-Wl,-rpath,' + tlib]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return TORCH_LIB
 
 
 if __name__ == '__main__':

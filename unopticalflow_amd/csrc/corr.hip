@@ -305,7 +305,7 @@ struct RingCfg {
     static constexpr int S2 = LH * LW / 4, S1 = TYB * TW / 4, SC = S2 + S1;     // float4 slots per channel
     static constexpr int ITER = (CC * SC + 255) / 256;
     static constexpr int STAGE = ITER * 256 * 4;                                // floats per ring slot
-    static constexpr int WAVES = (DG * DD * 2 <= 96) ? 3 : 2;                   // occupancy the registers allow
+    static constexpr int WAVES = (DG * DD * 2 <= 96 && CC <= 2) ? 3 : 2;        // occupancy the registers allow
 };
 
 // Phase-ablation switches of the ring kernel (loads / compute / stores only) exist in tuning builds
@@ -1078,8 +1078,6 @@ extern "C" int unflow_corr_fwd(const float* f1, const float* f2, float* cv, int 
                 if (variant == 9 && ring_ok) return launch_fwd_ring<4, 2, 3>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 12 && ring_ok) return launch_fwd_ringp<4, 2, 3, 2>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 13 && ring_ok) return launch_fwd_ringp<4, 2, 3, 4>(f1, f2, cv, B, C, H, W, s);
-                if (variant == 10 && ring_ok) return launch_fwd_ring<4, 4, 3>(f1, f2, cv, B, C, H, W, s);
-                if (variant == 11 && ring_ok) return launch_fwd_ring<4, 8, 3>(f1, f2, cv, B, C, H, W, s);
                 if (variant >= 7) return launch_fwd<4, 2, 9, 8>(f1, f2, cv, B, C, H, W, s);
                 break;
         case 8: variant = pick_variant(B, C, H, W);

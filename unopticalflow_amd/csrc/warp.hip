@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void warp_fwd_tile_kernel(const float* __restr
 // SPLIT: the channels of a tile are spread over gridDim.y workgroups; their flow-gradient partials are
 // added atomically into a zeroed gflow (otherwise gflow is written once, reproducibly).
 template <int PPT, int WIN, int CC, bool SPLIT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PPT == 4 ? 3 : 4))) void warp_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow,
+__global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow,
                                                             const float* __restrict__ gout, float* __restrict__ gsrc,
                                                             float* __restrict__ gflow, int C, int H, int W, int ac,
                                                             int TW, int TH, int tiles_x, int tiles_y, int cpg, int vec_ok, int dbg) {
@@ -629,7 +629,7 @@ extern "C" int unflow_warp_bwd(const float* src, const float* flow, const float*
     if (gsrc) unflow_zero_async(gsrc, (size_t)B * C * H * W, s);
     const int ac = align_corners ? 1 : 0;
     if (use_tiles(mask, C, H, W) && wenv("UNFLOW_WARP_TILES", 1)) {
-        const int th = wenv("UNFLOW_WARP_TH", 8);              // 2 px per lane: 152 VGPRs (3 workgroups per CU); 4 px needs 256
+        const int th = 8;                                       // 64x8 tiles, 2 px per lane: 152 VGPRs, 3 workgroups per CU
         const TilePlan p = plan_tiles(B, C, H, W, th, 4, wenv("UNFLOW_WARP_WGS", 512));   // level 2: 512 tiles, all channels in one workgroup
         dim3 tgrid(p.tiles_x * p.tiles_y * B, p.groups);
         const int vec_ok = ((W & 3) == 0 && (((size_t)src) & 15) == 0) ? 1 : 0;
@@ -637,7 +637,7 @@ extern "C" int unflow_warp_bwd(const float* src, const float* flow, const float*
 #define LAUNCH_T(PPT, WIN, SPLIT) hipLaunchKernelGGL((warp_bwd_tile_kernel<PPT, WIN, 4, SPLIT>), tgrid, dim3(256), 0, s, src, flow, \
                                                      gout, gsrc, gflow, C, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y, p.cpg, vec_ok, wenv("UNFLOW_WARP_DEBUG", 0))
 #define LAUNCH_S(PPT, WIN) do { if (p.groups > 1) LAUNCH_T(PPT, WIN, true); else LAUNCH_T(PPT, WIN, false); } while (0)
-        if (p.TH == 16) LAUNCH_S(4, 1600); else LAUNCH_S(2, 1024);
+        LAUNCH_S(2, 1024);                                      // (4 px per lane would need 256 VGPRs: one wave per SIMD)
 #undef LAUNCH_S
 #undef LAUNCH_T
         return unflow_launch_status();

@@ -55,7 +55,7 @@ struct FusedCfg {
     static constexpr int ITER = (CC * SC + 255) / 256;
     static constexpr int STAGE = ITER * 256 * 4;                                 // floats per ring slot
     static constexpr int WT = CC * LH * LW;                                      // floats of the warped tile
-    static constexpr int WAVES = (DG * DD * 2 <= 96) ? 3 : 2;
+    static constexpr int WAVES = 2;                                              // (134 VGPRs with 3 displacement rows, 256 with 9)
     static_assert(SWX % 4 == 0 && SWX + 1 <= 255, "ds_read2_b32 offsets are 8-bit dword counts");
     static_assert(SWX >= LW + 4 && SWH >= LH + 1, "the window must hold the halo plus one tap row / column and the alignment slack");
 };

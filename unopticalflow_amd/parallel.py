@@ -149,6 +149,38 @@ class FlatGradients:
         self.flat.mul_(1.0 / world)
 
 
+class PlainGradients:
+    """Single-process counterpart of FlatGradients with the same small interface.  Without an exchange step there is
+    no reason to alias the gradients into one buffer: ``zero()`` drops them (``grad = None``), so backward ASSIGNS each
+    parameter's gradient instead of launching a read-add-write per parameter into a pre-zeroed buffer (98 extra
+    kernels and one 20 MB fill per step on the 832x256 step: ~0.5 ms of 27)."""
+
+    overlap = False
+    chunks = 0
+    launched_early = 0
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError('no trainable parameters')
+        self.numel = sum(p.numel() for p in self.params)
+
+    def zero(self):
+        for p in self.params:
+            p.grad = None
+
+    def all_reduce_mean(self):
+        return None
+
+    def check_views(self):
+        return None
+
+    @property
+    def flat(self):
+        """The gradients as one vector (a copy; diagnostics and tests)."""
+        return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params])
+
+
 def broadcast_parameters(module, src=0, group=None, single_rank=False):
     """Rank ``src``'s weights to everyone (DataParallel's per-step replicate, done once)."""
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not single_rank):

@@ -10,7 +10,7 @@ holds no kernel code, which lets the multi-process logic be exercised on CPU wit
 import torch
 
 from .core.config import generate_loss_weights_dict
-from .parallel import FlatGradients, broadcast_parameters
+from .parallel import FlatGradients, PlainGradients, broadcast_parameters
 
 
 class FlowTrainer:
@@ -24,8 +24,13 @@ class FlowTrainer:
             broadcast_parameters(model, single_rank=single_rank_collectives)
         # gradients leave for RCCL piece by piece during backward, except under hipGraph replay (collectives stay
         # outside the captured graph)
-        self.grads = FlatGradients(params, chunks=allreduce_chunks, overlap=(distributed and not use_graph),
-                                   single_rank_collectives=(distributed and single_rank_collectives))
+        # several ranks: one flat buffer that the all-reduce pieces are cut from; one process: plain per-parameter gradients
+        # (assigned by backward, nothing to pre-zero or accumulate into)
+        if distributed:
+            self.grads = FlatGradients(params, chunks=allreduce_chunks, overlap=not use_graph,
+                                       single_rank_collectives=single_rank_collectives)
+        else:
+            self.grads = PlainGradients(params)
         self.distributed = distributed
         kw = {}
         if fused_adam is None:
