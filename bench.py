@@ -55,7 +55,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=B_PER_GPU, help='triplets per GPU (8 = BASELINE config)')
     ap.add_argument('--hw', type=int, nargs=2, default=[H, W], metavar=('H', 'W'),
-                    help='frame size (default 256 832 = the BASELINE metric; 448 1024 = config 4, not in the shipped find-db)')
+                    help='frame size (default 256 832 = the BASELINE metric; 448 1024 with --batch 4 = config 4; both are in the shipped find-db)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8, help='triplets in the CPU-baseline sample step (8 = the bench batch)')
     ap.add_argument('--no-kernel-timing', action='store_true')

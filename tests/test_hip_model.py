@@ -384,13 +384,7 @@ def test_hipgraph_replay_matches_eager():
         model = get_model('flow')(cfg).cuda()
         model.load_state_dict(sd)
         tr = FlowTrainer(cfg, model, use_graph=mode)
-        if mode:                       # the graph is built from the first batch after 3 warm-up steps on it: rewind
-            tr._build_graph(xs[0])
-            model.load_state_dict(sd)
-            for st in tr.optimizer.state.values():      # the graph holds these very tensors: reset them in place
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
         out[mode] = [float(tr.step(x)[0]) for x in xs]
+    # the capture's warm-up iterations are rolled back by the trainer itself: same trajectory as eager from step 0
     np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-4)
-    np.testing.assert_allclose(out[True], out[False], rtol=5e-3)        # later steps: after (re-started) Adam updates
+    np.testing.assert_allclose(out[True], out[False], rtol=5e-3)        # later steps follow Adam's sign-normalised updates

@@ -25,6 +25,25 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _on(dev):
+    """Device guard for a launch: nothing to do (and nothing to pay: torch.cuda.device() costs ~10 us of host time per
+    entry, ~150 times per step) when the tensors already live on the current device, which is the one-process-per-GPU case."""
+    if dev.index is None or dev.index == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(dev)
+
+
 def _dev(*tensors):
     """All operands must be fp32 tensors on one HIP device."""
     dev = None
@@ -113,7 +132,7 @@ class _Corr(torch.autograd.Function):
         f1, f2 = f1.contiguous(), f2.contiguous()
         B, C, H, W = f1.shape
         cv = torch.empty((B, (2 * d + 1) ** 2, H, W), dtype=f1.dtype, device=f1.device)
-        with torch.cuda.device(f1.device):
+        with _on(f1.device):
             _call('unflow_corr_fwd', _ptr(f1), _ptr(f2), _ptr(cv), B, C, H, W, d, _stream(),      # algorithmic bytes: read
                   nbytes=4 * B * H * W * (2 * C + (2 * d + 1) ** 2), shape=(B, C, H, W))          # f1, f2 once, write cv once
         ctx.save_for_backward(f1, f2)
@@ -126,7 +145,7 @@ class _Corr(torch.autograd.Function):
         B, C, H, W = f1.shape
         g = g.contiguous()
         gf1, gf2 = torch.empty_like(f1), torch.empty_like(f2)
-        with torch.cuda.device(f1.device):
+        with _on(f1.device):
             _call('unflow_corr_bwd', _ptr(f1), _ptr(f2), _ptr(g), _ptr(gf1), _ptr(gf2), B, C, H, W, ctx.d,
                   _stream(), nbytes=4 * B * H * W * (4 * C + (2 * ctx.d + 1) ** 2), shape=(B, C, H, W))
         return gf1, gf2, None
@@ -149,7 +168,7 @@ class _Warp(torch.autograd.Function):
         B, C, H, W = x.shape
         out = torch.empty_like(x)
         mask = torch.empty((B, 1, H, W), dtype=torch.uint8, device=x.device) if use_mask else None
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _call('unflow_warp_fwd', _ptr(x), _ptr(flow), _ptr(out), _ptr(mask), B, C, H, W,
                   int(align_corners), _stream(), nbytes=B * H * W * (8 * C + 8 + (1 if use_mask else 0)),
                   shape=(B, C, H, W))
@@ -167,7 +186,7 @@ class _Warp(torch.autograd.Function):
         g = g.contiguous()
         gsrc = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gflow = torch.empty_like(flow)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _call('unflow_warp_bwd', _ptr(x), _ptr(flow), _ptr(g), _ptr(mask), _ptr(gsrc), _ptr(gflow),
                   B, C, H, W, ctx.ac, _stream(),
                   nbytes=4 * B * H * W * ((3 * C + 4) if gsrc is not None else (2 * C + 4)), shape=(B, C, H, W))
@@ -207,7 +226,7 @@ class _WarpCorr(torch.autograd.Function):
         f1, f2, flow = f1.contiguous(), f2.contiguous(), flow.contiguous()
         B, C, H, W = f1.shape
         cv = torch.empty((B, (2 * d + 1) ** 2, H, W), dtype=f1.dtype, device=f1.device)
-        with torch.cuda.device(f1.device):
+        with _on(f1.device):
             # algorithmic bytes: those of the two ops it replaces: warp 4*n*(2C+2) + corr 4*n*(2C+D^2)
             _call('unflow_warp_corr_fwd', _ptr(f1), _ptr(f2), _ptr(flow), _ptr(cv), B, C, H, W, d, int(align_corners),
                   _stream(), nbytes=4 * B * H * W * (4 * C + 2 + (2 * d + 1) ** 2), shape=(B, C, H, W))
@@ -225,7 +244,7 @@ class _WarpCorr(torch.autograd.Function):
         gflow = torch.empty_like(flow)
         scratch = torch.empty((2,) + tuple(f2.shape), dtype=f2.dtype, device=f2.device)     # warped map | its gradient: dies here
         D2 = (2 * ctx.d + 1) ** 2
-        with torch.cuda.device(f1.device):
+        with _on(f1.device):
             _call('unflow_warp_corr_bwd', _ptr(f1), _ptr(f2), _ptr(flow), _ptr(g), _ptr(gf1), _ptr(gf2), _ptr(gflow),
                   _ptr(scratch), B, C, H, W, ctx.d, ctx.ac, _stream(),
                   nbytes=4 * B * H * W * ((4 * C + D2) + (3 * C + 4)), shape=(B, C, H, W))
@@ -260,7 +279,7 @@ class _OccWeight(torch.autograd.Function):
         f = lambda: torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
         u = lambda: torch.empty((B, 1, H, W), dtype=torch.uint8, device=dev)
         diff_l, diff_r, w_bwd, w_fwd, v_bwd, v_fwd = f(), f(), f(), f(), u(), u()
-        with torch.cuda.device(dev):
+        with _on(dev):
             _call('unflow_occ_weight_fwd', _ptr(img), _ptr(from_l), _ptr(from_r), _ptr(diff_l), _ptr(diff_r),
                   _ptr(w_bwd), _ptr(w_fwd), _ptr(v_bwd), _ptr(v_fwd), B, H, W, _stream(),
                   nbytes=B * H * W * (4 * 13 + 2), shape=(B, 3, H, W))
@@ -273,7 +292,7 @@ class _OccWeight(torch.autograd.Function):
         img, from_l, from_r = ctx.saved_tensors
         B, C, H, W = img.shape
         out = [None, None, None]
-        with torch.cuda.device(img.device):
+        with _on(img.device):
             for k, (src, g) in enumerate(((from_l, g_l), (from_r, g_r))):
                 if ctx.needs_input_grad[k + 1] and g is not None:
                     gs = torch.empty_like(src)
@@ -299,7 +318,7 @@ class _OccWeight2(torch.autograd.Function):
         assert C == 3 and warped.shape[0] == 2 * B
         diff = torch.empty((2 * B, 1, H, W), dtype=torch.float32, device=dev)
         wgt = torch.empty((2 * B, 1, H, W), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _call('unflow_occ_weight_fwd', _ptr(img), _ptr(warped[:B]), _ptr(warped[B:]), _ptr(diff[:B]), _ptr(diff[B:]),
                   _ptr(wgt[:B]), _ptr(wgt[B:]), _ptr(None), _ptr(None), B, H, W, _stream(),
                   nbytes=B * H * W * 4 * 13, shape=(B, 3, H, W))
@@ -314,7 +333,7 @@ class _OccWeight2(torch.autograd.Function):
         if not ctx.needs_input_grad[1] or g is None:
             return None, None
         gs = torch.empty_like(warped)
-        with torch.cuda.device(img.device):
+        with _on(img.device):
             _call('unflow_absdiff_bwd', _ptr(img), _ptr(warped), _ptr(g.contiguous()), _ptr(gs), 2 * B, H, W, B, _stream(),
                   nbytes=4 * B * H * W * (3 + 2 * 7), shape=(2 * B, 3, H, W))
         return None, gs
@@ -341,7 +360,7 @@ class _MaskedMean(torch.autograd.Function):
         B, _, H, W = diff.shape
         loss = torch.empty(B, dtype=torch.float32, device=dev)
         sums = torch.empty((B, 2), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _call('unflow_masked_mean_fwd', _ptr(diff), _ptr(w), _ptr(loss), _ptr(sums),
                   _ptr(_partials(B, H, W, dev)), B, H, W, _stream())
         ctx.save_for_backward(w, sums)
@@ -352,7 +371,7 @@ class _MaskedMean(torch.autograd.Function):
         w, sums = ctx.saved_tensors
         B, _, H, W = w.shape
         gdiff = torch.empty_like(w)
-        with torch.cuda.device(w.device):
+        with _on(w.device):
             _call('unflow_masked_mean_bwd', _ptr(w), _ptr(sums), _ptr(gl.contiguous()), _ptr(gdiff), B, H, W,
                   _stream())
         return gdiff, None
@@ -372,7 +391,7 @@ class _SsimLoss(torch.autograd.Function):
         assert C == 3 and B % img.shape[0] == 0 and w.shape[0] == B
         loss = torch.empty(B, dtype=torch.float32, device=dev)
         sums = torch.empty((B, 2), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _call('unflow_ssim_loss_fwd', _ptr(img), _ptr(warped), _ptr(w), _ptr(loss), _ptr(sums),
                   _ptr(_partials(B, H, W, dev)), B, H, W, img.shape[0], _stream(), nbytes=4 * B * H * W * 7, shape=(B, 3, H, W))
         ctx.save_for_backward(img, warped, w, sums)
@@ -383,7 +402,7 @@ class _SsimLoss(torch.autograd.Function):
         img, warped, w, sums = ctx.saved_tensors
         B, C, H, W = warped.shape
         gw = torch.empty_like(warped)
-        with torch.cuda.device(img.device):
+        with _on(img.device):
             _call('unflow_ssim_loss_bwd', _ptr(img), _ptr(warped), _ptr(w), _ptr(sums), _ptr(gl.contiguous()),
                   _ptr(gw), B, H, W, img.shape[0], _stream(), nbytes=4 * B * H * W * 10, shape=(B, 3, H, W))
         return None, gw, None
@@ -401,7 +420,7 @@ class _SsimMap(torch.autograd.Function):
         x, y = x.contiguous(), y.contiguous()
         B, C, H, W = x.shape
         out = torch.empty_like(x)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _call('unflow_ssim_map', _ptr(x), _ptr(y), _ptr(out), B, C, H, W, _stream())
         ctx.save_for_backward(x, y)
         return out
@@ -415,7 +434,7 @@ class _SsimMap(torch.autograd.Function):
         if gx is None and gy is None:
             return None, None
         scratch = torch.empty((4,) + tuple(x.shape), dtype=x.dtype, device=x.device)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _call('unflow_ssim_map_bwd', _ptr(x), _ptr(y), _ptr(g.contiguous()), _ptr(gx), _ptr(gy), _ptr(scratch),
                   B, C, H, W, _stream())
         return gx, gy
@@ -440,7 +459,7 @@ class _Smooth2(torch.autograd.Function):
         B, _, H, W = flow.shape                        # img may hold fewer samples: sample b pairs with image b % len(img)
         assert B % img.shape[0] == 0
         loss = torch.empty(B, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _call('unflow_smooth2_fwd', _ptr(flow), _ptr(img), _ptr(loss), _ptr(_partials(B, H, W, dev)),
                   B, H, W, img.shape[0], _stream())
         ctx.save_for_backward(flow, img)
@@ -451,7 +470,7 @@ class _Smooth2(torch.autograd.Function):
         flow, img = ctx.saved_tensors
         B, _, H, W = flow.shape
         gflow = torch.empty_like(flow)
-        with torch.cuda.device(flow.device):
+        with _on(flow.device):
             _call('unflow_smooth2_bwd', _ptr(flow), _ptr(img), _ptr(gl.contiguous()), _ptr(gflow), B, H, W,
                   img.shape[0], _stream())
         return gflow, None
@@ -470,7 +489,7 @@ class _Consis(torch.autograd.Function):
         B, _, H, W = ff.shape
         loss = torch.empty(B, dtype=torch.float32, device=dev)
         sums = torch.empty((B, 2), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _call('unflow_consis_fwd', _ptr(ff), _ptr(fb), _ptr(w), _ptr(loss), _ptr(sums),
                   _ptr(_partials(B, H, W, dev)), B, H, W, _stream())
         ctx.save_for_backward(ff, fb, w, sums)
@@ -481,7 +500,7 @@ class _Consis(torch.autograd.Function):
         ff, fb, w, sums = ctx.saved_tensors
         B, _, H, W = ff.shape
         g = torch.empty_like(ff)
-        with torch.cuda.device(ff.device):
+        with _on(ff.device):
             _call('unflow_consis_bwd', _ptr(ff), _ptr(fb), _ptr(w), _ptr(sums), _ptr(gl.contiguous()), _ptr(g),
                   B, H, W, _stream())
         return g, None, None
@@ -527,7 +546,7 @@ def _bias_leaky_backward(ctx, ga, gb):
     gbias = torch.empty(C, dtype=torch.float32, device=y.device)
     npart = _lib.load().unflow_bias_leaky_partials(N, C, H, W)
     part = torch.empty(npart, dtype=torch.float32, device=y.device)
-    with torch.cuda.device(y.device):
+    with _on(y.device):
         _call('unflow_bias_leaky_bwd2_bf16' if half else 'unflow_bias_leaky_bwd2', _ptr(y), _ptr(ga), sa, _ptr(gb), sb,
               _ptr(gin), _ptr(gbias), _ptr(part), N, C, H, W, ctypes.c_float(ctx.slope), _stream(),
               nbytes=(3 if gb is None else 4) * y.element_size() * N * C * H * W, shape=(N, C, H, W))
@@ -542,7 +561,7 @@ def _bias_leaky_forward(ctx, y, bias, slope):
     if not y.is_contiguous():
         raise RuntimeError('bias_leaky_relu_ works in place on a contiguous NCHW convolution output')
     N, C, H, W = y.shape
-    with torch.cuda.device(y.device):
+    with _on(y.device):
         _call('unflow_bias_leaky_fwd_bf16' if half else 'unflow_bias_leaky_fwd', _ptr(y), _ptr(bias), N, C, H, W,
               ctypes.c_float(slope), _stream(), nbytes=2 * y.element_size() * N * C * H * W, shape=(N, C, H, W))
     ctx.mark_dirty(y)
@@ -596,7 +615,7 @@ def img_pyramid(img):
         raise ValueError('img_pyramid needs H and W to be multiples of 4, got %dx%d' % (H, W))
     half = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=dev)
     quarter = torch.empty((N, C, H // 4, W // 4), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _call('unflow_img_pyramid', _ptr(img), _ptr(half), _ptr(quarter), N * C, H, W, _stream(),
               nbytes=N * C * H * W * 4 * 21 // 16, shape=(N, C, H, W))
     return half, quarter
@@ -642,7 +661,7 @@ def prepare_triplets(images, img_hw, flips=None, device=None, src_is_rgb=True, s
     buf = host.to(dev, non_blocking=True)
     out = torch.empty((B, 3, 3 * H, W), dtype=torch.float32, device=dev)
     base = buf.data_ptr()
-    with torch.cuda.device(dev):
+    with _on(dev):
         _call('unflow_prepare_triplets', ctypes.c_void_p(base), ctypes.c_void_p(base), ctypes.c_void_p(base + 8 * B),
               ctypes.c_void_p(base + 16 * B), _ptr(out), B, H, W,
               1 if src_is_rgb else 0, _stream(), nbytes=sum(sizes) + out.numel() * 4, shape=(B, 3, 3 * H, W))

@@ -63,16 +63,29 @@ class FlowTrainer:
         return loss, loss_pack
 
     def _build_graph(self, inputs):
+        """Capture forward + loss + backward (+ Adam) once.  The three warm-up iterations PyTorch needs before a capture
+        (MIOpen picks its solvers, Adam creates its state) run on the first batch too, but must not count as training:
+        parameters and optimizer state are restored afterwards (Adam's step counters included), so the replayed
+        trajectory is the eager one."""
         self._static_in = inputs.clone()
+        saved_model = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                  # warm-up off the capture: MIOpen picks its solvers here
-            for _ in range(3):
+        with torch.cuda.stream(side):                  # warm-up off the capture
+            for it in range(3):
                 self._eager_fwd_bwd(self._static_in)
                 if not self.distributed:
                     self.optimizer.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        with torch.no_grad():
+            for k, v in self.model.state_dict().items():
+                v.copy_(saved_model[k])
+            if not self.distributed:                   # zero Adam's moments and counters in place (the graph keeps these tensors)
+                for st in self.optimizer.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             loss, pack = self._eager_fwd_bwd(self._static_in)
