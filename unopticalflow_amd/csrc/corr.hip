@@ -1049,7 +1049,10 @@ static int pick_variant(int B, int C, int H, int W) {
     //   level 3 [16,64,32,104], level 4 [16,96,16,52]: ring, 3 displacement rows per workgroup (9)  29 / 30 us
     //   levels 5, 6: one lane per output element (4)   14 / 12 us  (a whole-map LDS kernel -- one workgroup per sample and
     //   displacement row, channels streamed through LDS -- measured 31 / 26 us: staging 2 x 106 KB per workgroup as dword
-    //   LDS-DMA pieces (W = 26 / 13 rows are not 16-byte aligned) costs more than the cached global reads it replaces)
+    //   LDS-DMA pieces (W = 26 / 13 rows are not 16-byte aligned) costs more than the cached global reads it replaces; a
+    //   row-per-lane kernel -- a lane keeps the 9 accumulators of one displacement row, 16 channel phases per workgroup,
+    //   1 + 9 cached loads per 9 FMAs instead of 18 -- measured 23 / 14 us: fewer, fatter lanes lose the memory-level
+    //   parallelism that 67 k thin lanes have)
     // d=8 (tools/microbench.py corr8): ring with 3 of the 17 rows per workgroup 125 / 52 / 46 us at levels 2 / 3 / 4
     // (tile kernel 234 / 128 / 85), one lane per element 29 / 15 us at levels 5 / 6 (tile kernel 158 / 226)
     const long px = (long)B * H * W;
