@@ -237,6 +237,33 @@ def fused(B=16):
                 name, B, C, h, w, kind, tfu, nb / tfu / 1e3, tsep, (a - cv).abs().max().item()), flush=True)
 
 
+def stamps(B=16):
+    """In-kernel s_memtime stamps of the group-split cost-volume backward (tuning library): where a wave's cycles go."""
+    lib = _lib.load()
+    P = ops._ptr
+    names = ['gather+prologue', 'vmcnt wait + barrier', 'finish (grp 0)', 'DMA issue', 'rows + hand-off', 'tail']
+    for lvl in ('L2', 'L3', 'L4'):
+        C, h, w = LEVELS[lvl]
+        f1 = torch.randn(B, C, h, w, device='cuda'); f2 = torch.randn(B, C, h, w, device='cuda')
+        gc = torch.randn(B, 81, h, w, device='cuda'); gf1, gf2 = torch.empty_like(f1), torch.empty_like(f2)
+        buf = torch.zeros(1024 * 3 * 8, dtype=torch.int64, device='cuda')
+        us = timeit(lambda: lib.unflow_corr_bwd(P(f1), P(f2), P(gc), P(gf1), P(gf2), B, C, h, w, 4, ops._stream()))
+        print('%s  UNFLOW_CORR_BWD=%s  %.1f us' % (lvl, os.environ.get('UNFLOW_CORR_BWD', '-'), us), flush=True)
+        os.environ['UNFLOW_STAMP_PTR'] = str(buf.data_ptr())
+        lib.unflow_corr_bwd(P(f1), P(f2), P(gc), P(gf1), P(gf2), B, C, h, w, 4, ops._stream())
+        torch.cuda.synchronize()
+        os.environ.pop('UNFLOW_STAMP_PTR')
+        t = buf.view(1024, 3, 8)[:, :, :6].double().cpu()
+        used = t.sum(2) > 0
+        for grp in range(3):
+            m = t[:, grp][used[:, grp]]
+            if m.numel() == 0:
+                continue
+            med = m.median(0).values
+            print('%s group %d (%d workgroups): total %6.0f cycles | ' % (lvl, grp, m.shape[0], med.sum()) +
+                  '  '.join('%s %4.1f%%' % (n, 100 * v / med.sum()) for n, v in zip(names, med.tolist())), flush=True)
+
+
 def losses(B=8):
     for s in range(3):
         h, w = 256 >> s, 832 >> s

@@ -355,6 +355,7 @@ __global__ __launch_bounds__(256, (RingCfg<R, CC, DG>::WAVES)) void corr_fwd_rin
     const float* base1 = f1 + (size_t)b * C * plane;
     const float* base2 = f2 + (size_t)b * C * plane;
 
+    gfloat* zline = zero_line();
     auto issue = [&](int stage_idx) {
         float* dst = ring + (stage_idx & (K::NS - 1)) * K::STAGE;
         const int c0 = stage_idx * CC;
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(256, (RingCfg<R, CC, DG>::WAVES)) void corr_fwd_rin
         for (int it = 0; it < K::ITER; ++it) {
             const int gc = c0 + sch[it];
             const bool in = soff[it] >= 0 && gc < C;
-            const float* g = in ? (ssel[it] ? base2 : base1) + (size_t)gc * plane + soff[it] : kZeroLine;
+            gfloat* g = in ? (gfloat*)((ssel[it] ? base2 : base1) + (size_t)gc * plane + soff[it]) : zline;
             __builtin_amdgcn_global_load_lds((gas_ptr)g, (lds_ptr)(dst + (it * 256 + wave * 64) * 4), 16, 0, 0);
         }
     };
@@ -502,6 +503,7 @@ __global__ __launch_bounds__((RingPCfg<R, CC, DG, PH>::THREADS)) void corr_fwd_r
     }
     const float* base1 = f1 + ((size_t)b * C + cb) * plane;
     const float* base2 = f2 + ((size_t)b * C + cb) * plane;
+    gfloat* zline = zero_line();
     auto issue = [&](int stage_idx) {
         float* dst = ring + (stage_idx % K::NS) * K::STAGE;
         const int c0 = stage_idx * CC;
@@ -509,7 +511,7 @@ __global__ __launch_bounds__((RingPCfg<R, CC, DG, PH>::THREADS)) void corr_fwd_r
         for (int it = 0; it < K::ITER; ++it) {
             const int gc = c0 + sch[it];
             const bool in = soff[it] >= 0 && gc < cn;
-            const float* g = in ? (ssel[it] ? base2 : base1) + (size_t)gc * plane + soff[it] : kZeroLine;
+            gfloat* g = in ? (gfloat*)((ssel[it] ? base2 : base1) + (size_t)gc * plane + soff[it]) : zline;
             __builtin_amdgcn_global_load_lds((gas_ptr)g, (lds_ptr)(dst + (it * 256 + wave * 64) * 4), 16, 0, 0);
         }
     };
@@ -628,8 +630,43 @@ __device__ __forceinline__ void slab_write(unsigned addr, const v2f (&v)[CC], st
     (lds_write_b64<Cs * GL * 8>(addr, v[Cs]), ...);
 }
 
+// A lane's share of the upstream gradient, laid out for packed FMAs.  A lane owns pixels x (even) and x + 1 and reads a
+// halo row as R + 1 aligned float pairs row[k] = (f[x + 2k], f[x + 2k + 1]).  Pixel x needs f[x + j], pixel x + 1 needs
+// f[x + 1 + j]: both walk the SAME aligned pairs if pixel x pairs its displacements (0,1)(2,3).. and pixel x + 1 pairs
+// (1,2)(3,4)..; the two leftovers (j = 2R of pixel x, j = 0 of pixel x + 1) are single FMAs.  So a row-step is 2R
+// v_pk_fma_f32 + 2 v_fma_f32 instead of 2 (2R + 1) v_fma_f32, with no register moves: the pairs are pairs as loaded.
+// (v_pk_fma_f32 is what the fp32 VALU peak is quoted on; a plain v_fma_f32 is half of it.  Letting hipcc's SLP
+// vectoriser pack the old per-pixel FMAs cost a v_mov per pair and lost.)
+template <int R>
+struct GsWeights {
+    v2f p0[3][R];      // pixel x:     (g[2k], g[2k+1])      x row[k],     k = 0 .. R-1
+    float s0[3];       //              g[2R]                 x row[R].x
+    v2f p1[3][R];      // pixel x + 1: (g[2k-1], g[2k])      x row[k],     k = 1 .. R   (stored at k - 1)
+    float s1[3];       //              g[0]                  x row[0].y
+    __device__ __forceinline__ void set(int ii, int j, int p, float v) {      // constant indices after unrolling
+        if (p == 0) {
+            if (j == 2 * R) s0[ii] = v;
+            else if (j & 1) p0[ii][j / 2].y = v;
+            else p0[ii][j / 2].x = v;
+        } else {
+            if (j == 0) s1[ii] = v;
+            else if ((j + 1) & 1) p1[ii][(j + 1) / 2 - 1].y = v;
+            else p1[ii][(j + 1) / 2 - 1].x = v;
+        }
+    }
+    __device__ __forceinline__ void pin() {          // consumers stay where this is called (see the kernel)
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) { asm volatile("" : "+v"(p0[ii][k])); asm volatile("" : "+v"(p1[ii][k])); }
+            asm volatile("" : "+v"(s0[ii]));
+            asm volatile("" : "+v"(s1[ii]));
+        }
+    }
+};
+
 // One row-step of the backward pipeline: ST = c * 3 + i.
-template <int ST, int STEPS, int PF, int DD, int NCOL, int CH_BYTES, int ROW_BYTES>
+template <int ST, int STEPS, int PF, int R, int NCOL, int CH_BYTES, int ROW_BYTES>
 struct GsStep {
     template <int Q, int... Ks>
     static __device__ __forceinline__ void load_cols(v2f (&row)[PF + 1][NCOL], unsigned addr,
@@ -642,22 +679,23 @@ struct GsStep {
         if constexpr (Q < STEPS) load_cols<Q>(row, addr, std::make_integer_sequence<int, NCOL>{});
     }
     template <int CC>
-    static __device__ __forceinline__ void run(const float (&wr)[3][DD][2], float (&acc)[CC][2][2],
+    static __device__ __forceinline__ void run(const GsWeights<R>& w, v2f (&acc)[CC][2],
                                                v2f (&row)[PF + 1][NCOL], unsigned addr) {
+        static_assert(NCOL == R + 1, "a halo row is R + 1 float pairs");
         if constexpr (ST < STEPS) {
             load<ST + PF>(row, addr);
             constexpr int newer = (STEPS - 1 - ST < PF ? STEPS - 1 - ST : PF) * NCOL;
             lds_wait<newer>();
             constexpr int c = ST / 3, i = ST % 3, rb = ST % (PF + 1);
 #pragma unroll
-            for (int j = 0; j < DD; ++j) {
-                const float r0 = (j & 1) ? row[rb][j / 2].y : row[rb][j / 2].x;
-                const float r1 = ((j + 1) & 1) ? row[rb][(j + 1) / 2].y : row[rb][(j + 1) / 2].x;
-                acc[c][j & 1][0] = fmaf(wr[i][j][0], r0, acc[c][j & 1][0]);
-                acc[c][j & 1][1] = fmaf(wr[i][j][1], r1, acc[c][j & 1][1]);
+            for (int k = 0; k < R; ++k) {
+                acc[c][0] = __builtin_elementwise_fma(w.p0[i][k], row[rb][k], acc[c][0]);
+                acc[c][1] = __builtin_elementwise_fma(w.p1[i][k], row[rb][k + 1], acc[c][1]);
             }
+            acc[c][0].x = fmaf(w.s0[i], row[rb][R].x, acc[c][0].x);
+            acc[c][1].y = fmaf(w.s1[i], row[rb][0].y, acc[c][1].y);
             __builtin_amdgcn_sched_barrier(0);
-            GsStep<ST + 1, STEPS, PF, DD, NCOL, CH_BYTES, ROW_BYTES>::template run<CC>(wr, acc, row, addr);
+            GsStep<ST + 1, STEPS, PF, R, NCOL, CH_BYTES, ROW_BYTES>::template run<CC>(w, acc, row, addr);
         }
     }
 };
@@ -666,8 +704,21 @@ template <int R, int CC, int TYB>
 __global__ __launch_bounds__((BwdGsCfg<R, CC, TYB>::THREADS)) void corr_bwd_gs_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                          const float* __restrict__ g, float* __restrict__ gf1,
                                                          float* __restrict__ gf2, int Ctot, int cpg, int H, int W,
-                                                         int tiles_x, int tiles_y, float inv_c, int dbg) {
+                                                         int tiles_x, int tiles_y, float inv_c, int dbg, unsigned long long* stamps) {
     using K = BwdGsCfg<R, CC, TYB>;
+    // In-kernel stamps (tuning builds, UNFLOW_STAMP_PTR): cycles per segment of the stage loop, summed per wave
+    //   0 gather + prologue | 1 vmcnt wait + barrier | 2 finish (group 0: slab read, add, store) | 3 DMA issue |
+    //   4 row pipeline (FMAs) + partial hand-off | 5 tail
+    // (32-bit counters, no stamp inside the row pipeline: its hand-counted lgkmcnt waits must stay as they are)
+#ifdef UNFLOW_TUNING
+    unsigned seg[6] = {0, 0, 0, 0, 0, 0}, tlast;
+    { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); tlast = (unsigned)t_; }
+#define STAMP(IDX) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+        seg[IDX] += (unsigned)t_ - tlast; tlast = (unsigned)t_; } while (0)
+#else
+#define STAMP(IDX) do { } while (0)
+#endif
     constexpr int DD = K::DD, LW = K::LW, NROW = 2 + 2 * R, NCOL = NROW / 2, GL = K::GL;
     static_assert(K::NS >= 3 && K::NS <= 6, "ring depth (the counted vmcnt waits cover NS-2 <= 4 store groups)");
     __shared__ __attribute__((aligned(16))) float lds[K::NS * K::STAGE + 2 * K::RED];
@@ -697,36 +748,55 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC, TYB>::THREADS)) void corr_bwd_gs_k
 
     // this wave pair's 3 displacement rows of the upstream gradient -> registers
     // (mode 1: displacement-flipped and gathered from q + (i'-R, j'-R))
-    float wr[3][DD][2];
+    // Both streams of this kernel go through buffer descriptors: the hardware range check returns 0 for an offset past
+    // num_records, so "outside the image" is an offset with kOut added instead of a branch or a select on a 64-bit
+    // address.  (The first version selected between the real address and a zero line per value: hipcc re-derived the
+    // zero line's address through the GOT each time -- s_getpc + s_load + lgkmcnt(0) -- and wrapped every load in an
+    // EXEC-masked branch; ~30 instructions per gathered value, and the gather was 30-45 % of a workgroup's lifetime.)
+    // Requires 81 * plane * 4 and Ctot * plane * 4 < kOut (checked by the launcher).
+    constexpr unsigned kOut = 0x40000000u;
+
+    // this wave pair's 3 displacement rows of the upstream gradient -> registers
+    // (mode 1: displacement-flipped and gathered from q + (i'-R, j'-R))
+    GsWeights<R> wr;
     {
         const float* gb = g + (size_t)b * DD * DD * plane;
+        const auto grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gb), 0, (int)(DD * DD * plane * 4), 0x00020000);
+        unsigned colB[DD][2];
 #pragma unroll
-        for (int ii = 0; ii < 3; ++ii)
+        for (int j = 0; j < DD; ++j)
 #pragma unroll
-            for (int j = 0; j < DD; ++j)
+            for (int p = 0; p < 2; ++p) {
+                const int sx = px + p + mode * (j - R);
+                colB[j][p] = ((unsigned)sx < (unsigned)W) ? (unsigned)sx * 4u : kOut;
+            }
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii) {
+            const int gi = grp * 3 + ii;                  // rows past DD (last pair when DD % 3 != 0) read as zero
+            const int i = min(gi, DD - 1);
+            const int sy = py + mode * (i - R);
+            const unsigned rowB = (gi < DD && (unsigned)sy < (unsigned)H) ? (unsigned)(sy * W) * 4u : kOut;
+#pragma unroll
+            for (int j = 0; j < DD; ++j) {
+                const int e = i * DD + j;
+                const int pl = e + mode * ((DD * DD - 1) - 2 * e);            // gf2: plane (2R-i, 2R-j)
+                const unsigned planeB = (unsigned)pl * (unsigned)plane * 4u;  // wave-uniform
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    const int i = min(grp * 3 + ii, DD - 1);      // rows past DD (last pair when DD % 3 != 0) are zeroed below
-                    // Branch-free and mask-free: the gather position is clamped, validity is folded into the ADDRESS
-                    // (invalid -> a zero line) and the gf1 / gf2 variants are arithmetic in `mode`, so the 54 (102) loads
-                    // of a lane go out back to back.  Keeping a lane mask per value alive until the loads return
-                    // overflows the scalar registers (masks spill to VGPR lanes, ~30 scalar instructions per load).
-                    const int e = i * DD + j;
-                    const int sy = py + mode * (i - R), sx = px + p + mode * (j - R);
-                    const int pl = e + mode * ((DD * DD - 1) - 2 * e);        // gf2: plane (2R-i, 2R-j)
-                    const bool ok = (grp * 3 + ii < DD) && (py < H) && (px + p < W) && sy >= 0 && sy < H && sx >= 0 && sx < W;
-                    const int cy = min(max(sy, 0), H - 1), cx = min(max(sx, 0), W - 1);
-                    if (RING_DBG(8)) { wr[ii][j][p] = (float)(ii + j + p) * inv_c; continue; }      // ablation (tuning builds): no gather
-                    const float* src = ok ? gb + ((size_t)pl * plane + (size_t)cy * W + cx) : kZeroLine;
-                    wr[ii][j][p] = *src * inv_c;
+                    if (RING_DBG(8)) { wr.set(ii, j, p, (float)(ii + j + p) * inv_c); continue; }      // ablation (tuning builds): no gather
+                    const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(grs, (int)(rowB + colB[j][p] + planeB), 0, 0);
+                    wr.set(ii, j, p, __uint_as_float(v) * inv_c);
                 }
+            }
+        }
     }
 
     const float* baseF = F + ((size_t)b * Ctot + c_begin) * plane;
-    // per-lane DMA slot descriptors, computed once: plane offset of the slot's 16 bytes (or -1 outside the
-    // image / in the padding) and its channel within the stage.  (Recomputing them per stage cost ~70 %
-    // extra VALU instructions; with ~100 VGPRs there is room to keep them.)
-    int soff[K::ITER], sch[K::ITER];
+    const auto frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(baseF), 0, (int)((size_t)C * plane * 4), 0x00020000);
+    // per-lane DMA slot descriptor, computed once: byte offset of the slot's 16 bytes within the first stage's CC planes,
+    // or kOut outside the image / in the padding.  A stage adds its (uniform) channel offset; channels past C fall
+    // outside num_records and arrive as zeros.
+    unsigned slotB[K::ITER];
 #pragma unroll
     for (int it = 0; it < K::ITER; ++it) {
         const int s = it * K::THREADS + (int)threadIdx.x;
@@ -735,20 +805,16 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC, TYB>::THREADS)) void corr_bwd_gs_k
         const int ly = r / (LW / 4);
         const int gy = y0 - R + ly, gx = x0 - R + (r - ly * (LW / 4)) * 4;
         const bool in = (c < CC) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        soff[it] = in ? gy * W + gx : -1;
-        sch[it] = c;
-        asm volatile("" : "+v"(soff[it]), "+v"(sch[it]));      // materialise once; do not re-derive in the loop
+        slotB[it] = in ? ((unsigned)c * (unsigned)plane + (unsigned)(gy * W + gx)) * 4u : kOut;
+        asm volatile("" : "+v"(slotB[it]));      // materialise once; do not re-derive in the loop
     }
     auto issue = [&](int stage_idx) {
         float* dst = ring + (stage_idx % K::NS) * K::STAGE;
-        const int c0 = stage_idx * CC;
+        const unsigned stageB = (unsigned)(stage_idx * CC) * (unsigned)plane * 4u;
 #pragma unroll
-        for (int it = 0; it < K::ITER; ++it) {
-            const int gc = c0 + sch[it];
-            const bool in = soff[it] >= 0 && gc < C;
-            const float* gp = in ? baseF + (size_t)gc * plane + soff[it] : kZeroLine;
-            __builtin_amdgcn_global_load_lds((gas_ptr)gp, (lds_ptr)(dst + (it * K::THREADS + wave * 64) * 4), 16, 0, 0);
-        }
+        for (int it = 0; it < K::ITER; ++it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(frs, (lds_ptr)(dst + (it * K::THREADS + wave * 64) * 4), 16,
+                                                 (int)(slotB[it] + stageB), 0, 0, 0);
     };
 
     // rows of this pair start 3*grp below the tile's first halo row
@@ -777,15 +843,11 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC, TYB>::THREADS)) void corr_bwd_gs_k
     };
 
     vm_wait<0>();                                    // the gradient loads are done before the first DMA goes out
-#pragma unroll
-    for (int ii = 0; ii < 3; ++ii)
-#pragma unroll
-        for (int j = 0; j < DD; ++j) {               // pin their consumers here too (else hipcc sinks them into the
-            asm volatile("" : "+v"(wr[ii][j][0]));   // loop and drains vmcnt(0) with the DMA in flight)
-            asm volatile("" : "+v"(wr[ii][j][1]));
-        }
+    wr.pin();                                        // pin their consumers here too (else hipcc sinks them into the
+                                                     // loop and drains vmcnt(0) with the DMA in flight)
 #pragma unroll
     for (int st = 0; st < K::NS - 1; ++st) issue(st);
+    STAMP(0);
 
     float keep[CC][2];                               // pair 0: its own partials of the previous stage
 #pragma unroll
@@ -804,40 +866,59 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC, TYB>::THREADS)) void corr_bwd_gs_k
             else vm_wait<D + 4 * CC>();
         }
         __builtin_amdgcn_s_barrier();                // stage k landed for all; slot k-1 and red[(k-1)&1] are complete
+        STAMP(1);
         if (grp == 0 && k > 0) finish(k - 1, keep);
+        STAMP(2);
         issue(k + K::NS - 1);
+        STAMP(3);
 
         // row reads in flight ahead of their FMAs: 2 row-steps at R=4, 1 at R=8 (lgkmcnt allows <= 15 reads, and 768
         // threads must fit 170 VGPRs each)
         constexpr int PF = (2 * NCOL <= 15) ? 2 : 1, STEPS = CC * 3;
         const unsigned abase = rows_addr + (unsigned)((k % K::NS) * K::STAGE) * 4u;
-        float acc[CC][2][2];
+        v2f acc[CC][2];                              // [channel][pixel]: two partial sums each (the halves of the packed FMAs)
 #pragma unroll
-        for (int c = 0; c < CC; ++c) { acc[c][0][0] = 0.f; acc[c][0][1] = 0.f; acc[c][1][0] = 0.f; acc[c][1][1] = 0.f; }
+        for (int c = 0; c < CC; ++c) { acc[c][0] = v2f{0.f, 0.f}; acc[c][1] = v2f{0.f, 0.f}; }
         v2f row[PF + 1][NCOL];
-        using Step0 = GsStep<0, STEPS, PF, DD, NCOL, K::SC * 16, LW * 4>;
+        using Step0 = GsStep<0, STEPS, PF, R, NCOL, K::SC * 16, LW * 4>;
         if constexpr (PF > 0) Step0::template load<0>(row, abase);
         if constexpr (PF > 1) Step0::template load<1>(row, abase);
         Step0::template run<CC>(wr, acc, row, abase);
 
         if (grp == 0) {
 #pragma unroll
-            for (int c = 0; c < CC; ++c) { keep[c][0] = acc[c][0][0] + acc[c][1][0]; keep[c][1] = acc[c][0][1] + acc[c][1][1]; }
+            for (int c = 0; c < CC; ++c) { keep[c][0] = acc[c][0].x + acc[c][0].y; keep[c][1] = acc[c][1].x + acc[c][1].y; }
         } else {
             const unsigned wa = red_addr + (unsigned)((k & 1) * K::RED + (grp - 1) * CC * GL * 2) * 4u;
             v2f pv[CC];
 #pragma unroll
             for (int c = 0; c < CC; ++c) {
-                pv[c].x = acc[c][0][0] + acc[c][1][0];
-                pv[c].y = acc[c][0][1] + acc[c][1][1];
+                pv[c].x = acc[c][0].x + acc[c][0].y;
+                pv[c].y = acc[c][1].x + acc[c][1].y;
             }
             slab_write<GL, CC>(wa, pv, std::make_integer_sequence<int, CC>{});
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slab written before the next barrier
         }
+        STAMP(4);
     }
     vm_wait<0>();
     __builtin_amdgcn_s_barrier();
     if (grp == 0) finish(nchunk - 1, keep);
+    STAMP(5);
+#ifdef UNFLOW_TUNING
+    if (stamps && (threadIdx.x % GL) == 0 && blockIdx.y == 0 && blockIdx.x < 1024) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) stamps[((size_t)blockIdx.x * K::NGRP + grp) * 8 + q] = seg[q];
+    }
+#endif
+#undef STAMP
+}
+
+// The group-split backward addresses one sample's gradient planes and one sample's feature planes through 32-bit
+// buffer offsets, with bit 30 marking "outside": both extents must stay below 1 GiB.
+static inline bool gs_offsets_fit(int C, int H, int W, int R) {
+    const size_t plane = (size_t)H * W * 4, dd = (size_t)(2 * R + 1) * (2 * R + 1);
+    return dd * plane < (1u << 30) && (size_t)C * plane < (1u << 30);
 }
 
 template <int R, int CC, int TYB>
@@ -853,8 +934,12 @@ int launch_bwd_gs(const float* f1, const float* f2, const float* g, float* gf1, 
 #else
     const int dbg = 0;
 #endif
+    unsigned long long* stamps = nullptr;
+#ifdef UNFLOW_TUNING
+    if (const char* sp = getenv("UNFLOW_STAMP_PTR")) stamps = (unsigned long long*)strtoull(sp, nullptr, 0);     // 1024 * NGRP * 8 u64
+#endif
     hipLaunchKernelGGL((corr_bwd_gs_kernel<R, CC, TYB>), dim3(tx * ty * B * 2, ceil_div(C, cpg)), dim3(K::THREADS), 0, s,
-                       f1, f2, g, gf1, gf2, C, cpg, H, W, tx, ty, 1.0f / C, dbg);
+                       f1, f2, g, gf1, gf2, C, cpg, H, W, tx, ty, 1.0f / C, dbg, stamps);
     return unflow_launch_status();
 }
 
@@ -885,6 +970,7 @@ __global__ __launch_bounds__(256, 3) void corr_bwd_small_kernel(const float* __r
     const int y = live ? q / W : 0, x = live ? q - y * W : 0;
     const int c0 = blockIdx.y * cch;
 
+    gfloat* zline = zero_line();
     float wr[DD][DD];
     const float* gb = g + (size_t)b * DD * DD * plane;
 #pragma unroll
@@ -894,7 +980,9 @@ __global__ __launch_bounds__(256, 3) void corr_bwd_small_kernel(const float* __r
             const int sy = mode ? y + i - R : y, sx = mode ? x + j - R : x;
             const int pl = mode ? (2 * R - i) * DD + (2 * R - j) : i * DD + j;
             const bool ok = live && sy >= 0 && sy < H && sx >= 0 && sx < W;
-            const float* src = ok ? gb + (size_t)pl * plane + sy * W + sx : kZeroLine;   // validity folded into the address
+            const int cy = min(max(sy, 0), H - 1), cx = min(max(sx, 0), W - 1);
+            gfloat* real = (gfloat*)(gb + (size_t)pl * plane + cy * W + cx);         // computed unconditionally: a select, no branch
+            gfloat* src = ok ? real : zline;                                         // validity folded into the address
             wr[i][j] = *src * inv_c;
         }
 
@@ -1105,7 +1193,8 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
         case 2: return launch_bwd<2, 2, 5, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
         case 4: {
                 variant = pick_variant(B, C, H, W);
-                const bool ring_ok = (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0);   // LDS-DMA moves aligned 16-byte pieces
+                const bool ring_ok = (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0)     // LDS-DMA moves aligned 16-byte pieces
+                                     && gs_offsets_fit(C, H, W, 4);
                 const int fb = forced_bwd();
                 // work items (64x8 tile, gradient) of the group-split ring kernel; smaller maps split the channels over
                 // workgroups until every CU has one (measured: level 3 = 256 items, 1 group: 35 us; level 4 = 64 items,
@@ -1134,7 +1223,7 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
         }
         case 8: variant = pick_variant(B, C, H, W);
                 if (variant == 4 || (long)B * H * W < 8192) break;      // small maps: one lane per element (117 / 57 us at levels 5 / 6, tile kernel 283 / 378)
-                if ((variant == 7 || mid_size(variant)) && (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0))
+                if ((variant == 7 || mid_size(variant)) && (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0) && gs_offsets_fit(C, H, W, 8))
                     return launch_bwd_gs<8, 1, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, 1, s);
                 return launch_bwd<8, 1, 6, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
         default: break;

@@ -21,6 +21,17 @@ typedef __attribute__((address_space(3))) const v2f lds_cfloat2;
 
 __device__ __attribute__((aligned(16))) float kZeroLine[4] = {0.f, 0.f, 0.f, 0.f};    // source of out-of-image DMA slots
 
+// Its address, fetched ONCE per wave into a scalar register pair.  Naming kZeroLine at the point of use makes hipcc
+// re-derive it there every time (s_getpc + s_load through the GOT + s_waitcnt lgkmcnt(0)) and, since that is expensive,
+// wrap each `ok ? p : kZeroLine` in an EXEC-masked branch: 58 scalar-memory round trips and 56 branches in the
+// gradient gather of the group-split backward alone.
+typedef __attribute__((address_space(1))) const float gfloat;       // explicit global address space: a laundered generic
+__device__ __forceinline__ gfloat* zero_line() {                     // pointer would turn every load behind it into flat_load
+    gfloat* z = (gfloat*)kZeroLine;
+    asm volatile("" : "+s"(z));
+    return z;
+}
+
 typedef __attribute__((address_space(1))) const void* gas_ptr;
 typedef __attribute__((address_space(3))) void* lds_ptr;
 

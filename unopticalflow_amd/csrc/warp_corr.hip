@@ -158,6 +158,7 @@ __global__ __launch_bounds__(256, (FusedCfg<R, CC, DG, NS, SWX, SWH>::WAVES)) vo
     }
     const float* base1 = f1 + (size_t)b * C * plane;
     const float* base2 = f2 + (size_t)b * C * plane;
+    gfloat* zline = zero_line();
     auto issue = [&](int stage_idx) {
         float* dst = ring + (stage_idx % K::NS) * K::STAGE;
         const int c0 = stage_idx * CC;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256, (FusedCfg<R, CC, DG, NS, SWX, SWH>::WAVES)) vo
             const bool win = s - c * K::SC < K::S2;
             const int gc = c0 + c;
             const bool in = soff[it] >= 0 && gc < C;
-            const float* g = in ? (win ? base2 : base1) + (size_t)gc * plane + soff[it] : kZeroLine;
+            gfloat* g = in ? (gfloat*)((win ? base2 : base1) + (size_t)gc * plane + soff[it]) : zline;
             __builtin_amdgcn_global_load_lds((gas_ptr)g, (lds_ptr)(dst + (it * 256 + wave * 64) * 4), 16, 0, 0);
         }
     };
