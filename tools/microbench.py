@@ -237,31 +237,48 @@ def fused(B=16):
                 name, B, C, h, w, kind, tfu, nb / tfu / 1e3, tsep, (a - cv).abs().max().item()), flush=True)
 
 
+def _stamp_report(tag, buf, names):
+    t = buf.view(1024, 3, 8).cpu()
+    seg = t[:, :, :len(names)].double()
+    first, last = t[:, :, 6].double(), t[:, :, 7].double()
+    used = seg.sum(2) > 0
+    t0 = first[used].min()
+    for grp in range(3):
+        u = used[:, grp]
+        if not u.any():
+            continue
+        m = seg[:, grp][u]
+        med = m.median(0).values
+        st, en = first[:, grp][u] - t0, last[:, grp][u] - t0
+        print('%s wave group %d (%d workgroups): %6.0f ticks | ' % (tag, grp, m.shape[0], med.sum()) +
+              '  '.join('%s %4.1f%%' % (n, 100 * v / med.sum()) for n, v in zip(names, med.tolist())) +
+              ' | starts %.0f..%.0f, ends %.0f..%.0f (median %.0f)' % (st.min(), st.max(), en.min(), en.max(), en.median()), flush=True)
+
+
 def stamps(B=16):
-    """In-kernel s_memtime stamps of the group-split cost-volume backward (tuning library): where a wave's cycles go."""
+    """In-kernel s_memtime stamps (tuning library): where a wave's cycles go in the group-split cost-volume backward and
+    in the ring forward, and when workgroups start / end."""
     lib = _lib.load()
     P = ops._ptr
-    names = ['gather+prologue', 'vmcnt wait + barrier', 'finish (grp 0)', 'DMA issue', 'rows + hand-off', 'tail']
+    bwd_names = ['gather+prologue', 'vmcnt wait + barrier', 'finish (grp 0)', 'DMA issue', 'rows + hand-off', 'tail']
+    fwd_names = ['set-up+prologue', 'vmcnt wait + barrier', 'DMA issue', 'row pipeline', 'store issue']
     for lvl in ('L2', 'L3', 'L4'):
         C, h, w = LEVELS[lvl]
         f1 = torch.randn(B, C, h, w, device='cuda'); f2 = torch.randn(B, C, h, w, device='cuda')
         gc = torch.randn(B, 81, h, w, device='cuda'); gf1, gf2 = torch.empty_like(f1), torch.empty_like(f2)
-        buf = torch.zeros(1024 * 3 * 8, dtype=torch.int64, device='cuda')
-        us = timeit(lambda: lib.unflow_corr_bwd(P(f1), P(f2), P(gc), P(gf1), P(gf2), B, C, h, w, 4, ops._stream()))
-        print('%s  UNFLOW_CORR_BWD=%s  %.1f us' % (lvl, os.environ.get('UNFLOW_CORR_BWD', '-'), us), flush=True)
-        os.environ['UNFLOW_STAMP_PTR'] = str(buf.data_ptr())
-        lib.unflow_corr_bwd(P(f1), P(f2), P(gc), P(gf1), P(gf2), B, C, h, w, 4, ops._stream())
-        torch.cuda.synchronize()
-        os.environ.pop('UNFLOW_STAMP_PTR')
-        t = buf.view(1024, 3, 8)[:, :, :6].double().cpu()
-        used = t.sum(2) > 0
-        for grp in range(3):
-            m = t[:, grp][used[:, grp]]
-            if m.numel() == 0:
-                continue
-            med = m.median(0).values
-            print('%s group %d (%d workgroups): total %6.0f cycles | ' % (lvl, grp, m.shape[0], med.sum()) +
-                  '  '.join('%s %4.1f%%' % (n, 100 * v / med.sum()) for n, v in zip(names, med.tolist())), flush=True)
+        cv = torch.empty_like(gc)
+        calls = {'bwd': lambda: lib.unflow_corr_bwd(P(f1), P(f2), P(gc), P(gf1), P(gf2), B, C, h, w, 4, ops._stream())}
+        if lvl == 'L2':
+            calls['fwd'] = lambda: lib.unflow_corr_fwd(P(f1), P(f2), P(cv), B, C, h, w, 4, ops._stream())
+        for kind, fn in calls.items():
+            buf = torch.zeros(1024 * 3 * 8, dtype=torch.int64, device='cuda')
+            us = timeit(fn)
+            print('%s %s  UNFLOW_CORR_BWD=%s  %.1f us' % (lvl, kind, os.environ.get('UNFLOW_CORR_BWD', '-'), us), flush=True)
+            os.environ['UNFLOW_STAMP_PTR'] = str(buf.data_ptr())
+            fn()
+            torch.cuda.synchronize()
+            os.environ.pop('UNFLOW_STAMP_PTR')
+            _stamp_report('%s %s' % (lvl, kind), buf, bwd_names if kind == 'bwd' else fwd_names)
 
 
 def losses(B=8):

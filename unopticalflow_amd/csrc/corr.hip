@@ -302,7 +302,10 @@ struct RingCfg {
     static constexpr int NG = (DD + DG - 1) / DG;
     static constexpr int TW = 64, TYB = 8, NS = 4;
     static constexpr int LW = TW + 2 * R, LH = TYB + DG - 1;
-    static constexpr int S2 = LH * LW / 4, S1 = TYB * TW / 4, SC = S2 + S1;     // float4 slots per channel
+    // float4 slots per channel: the f2 halo tile (padded to whole 64-slot pieces, so that every wave-instruction of the
+    // DMA reads ONE tensor and can go through that tensor's buffer descriptor), then the f1 tile
+    static constexpr int S2 = LH * LW / 4, S2P = (S2 + 63) / 64 * 64, S1 = TYB * TW / 4, SC = S2P + S1;
+    static_assert(S1 % 64 == 0, "the f1 tile is whole DMA pieces");
     static constexpr int ITER = (CC * SC + 255) / 256;
     static constexpr int STAGE = ITER * 256 * 4;                                // floats per ring slot
     static constexpr int WAVES = (DG * DD * 2 <= 96 && CC <= 2) ? 3 : 2;        // occupancy the registers allow
@@ -316,13 +319,76 @@ struct RingCfg {
 #define RING_DBG(bit) 0
 #endif
 
+// In-kernel stamps (tuning builds, UNFLOW_STAMP_PTR = device address of 1024 x 3 x 8 u64): cycles per named segment,
+// summed per wave with s_memtime; slot 6 / 7 of a row hold the wave's first and last stamp (the timeline across
+// workgroups).  32-bit counters; never place a stamp inside a hand-counted lgkmcnt / vmcnt section (its own
+// s_waitcnt lgkmcnt(0) drains the LDS reads).
+#ifdef UNFLOW_TUNING
+#define STAMP_DECL() unsigned seg[6] = {0, 0, 0, 0, 0, 0}, tlast; unsigned long long t_first, t_now; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_first) :: "memory"); tlast = (unsigned)t_first; t_now = t_first
+#define STAMP(IDX) do { __builtin_amdgcn_sched_barrier(0); \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+        seg[IDX] += (unsigned)t_now - tlast; tlast = (unsigned)t_now; } while (0)
+#define STAMP_WRITE(buf, row, lane0) do { if ((buf) && (lane0) && (row) < 1024 * 3) { \
+        _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) (buf)[(size_t)(row) * 8 + q_] = seg[q_]; \
+        (buf)[(size_t)(row) * 8 + 6] = t_first; (buf)[(size_t)(row) * 8 + 7] = t_now; } } while (0)
+#else
+#define STAMP_DECL() do { } while (0)
+#define STAMP(IDX) do { } while (0)
+#define STAMP_WRITE(buf, row, lane0) do { } while (0)
+#endif
+static inline unsigned long long* stamp_buffer() {
+#ifdef UNFLOW_TUNING
+    if (const char* sp = getenv("UNFLOW_STAMP_PTR")) return (unsigned long long*)strtoull(sp, nullptr, 0);
+#endif
+    return nullptr;
+}
+
+// The DMA slots of one ring stage (forward kernels): slot s = it * 256 + tid covers 16 bytes; within a channel the
+// first S2P slots are the f2 halo tile (S2 real ones), the rest the f1 tile.  Per lane: the byte offset of its slot inside
+// the stage's first CC planes of a sample, or kOutOfRange (outside the image / padding / beyond CC) -- the buffer
+// descriptor's range check turns those, and channels past the last one, into zeros.  Per wave-instruction: which tensor.
+constexpr unsigned kOutOfRange = 0x40000000u;       // both tensors' per-sample extents stay below this (fwd_offsets_fit)
+
+template <class K, int R, int CC>
+struct FwdSlots {
+    unsigned off[K::ITER];
+    bool from_f2[K::ITER];                          // wave-uniform
+    __device__ __forceinline__ void setup(int tid, int wave, int x0, int y0, int i0, int H, int W, unsigned plane) {
+        constexpr int LW4 = K::LW / 4, TW4 = K::TW / 4;
+#pragma unroll
+        for (int it = 0; it < K::ITER; ++it) {
+            const int s = it * 256 + tid;
+            const int c = s / K::SC;
+            int r = s - c * K::SC;
+            int gy, gx;
+            bool real = c < CC;
+            if (r < K::S2P) { const int ly = r / LW4; gy = y0 - R + i0 + ly; gx = x0 - R + (r - ly * LW4) * 4; real = real && r < K::S2; }
+            else { r -= K::S2P; const int ly = r / TW4; gy = y0 + ly; gx = x0 + (r - ly * TW4) * 4; }
+            const bool in = real & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+            off[it] = in ? ((unsigned)c * plane + (unsigned)(gy * W + gx)) * 4u : kOutOfRange;
+            asm volatile("" : "+v"(off[it]));       // materialise once; do not re-derive in the loop
+            from_f2[it] = ((it * 256 + wave * 64) % K::SC) < K::S2P;
+        }
+    }
+    template <class RS>
+    __device__ __forceinline__ void issue(const RS& rs1, const RS& rs2, float* dst, int wave, unsigned stageB) const {
+#pragma unroll
+        for (int it = 0; it < K::ITER; ++it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(from_f2[it] ? rs2 : rs1, (lds_ptr)(dst + (it * 256 + wave * 64) * 4), 16,
+                                                     (int)(off[it] + stageB), 0, 0, 0);
+    }
+};
+
 template <int R, int CC, int DG>
 __global__ __launch_bounds__(256, (RingCfg<R, CC, DG>::WAVES)) void corr_fwd_ring_kernel(
     const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ cv, int C, int H, int W,
-    int tiles_x, int tiles_y, float inv_c, int dbg) {
+    int tiles_x, int tiles_y, float inv_c, int dbg, unsigned long long* stamps) {
     using K = RingCfg<R, CC, DG>;
     constexpr int DD = K::DD, LW = K::LW, NROW = 2 + 2 * R;
     __shared__ __attribute__((aligned(16))) float ring[K::NS * K::STAGE];
+    // stamp segments: 0 set-up + prologue DMA issue | 1 vmcnt wait + barrier | 2 DMA issue | 3 row pipeline | 4 store issue
+    STAMP_DECL();
 
     const int total = gridDim.x;
     int t = xcd_remap(blockIdx.x, total);
@@ -330,61 +396,38 @@ __global__ __launch_bounds__(256, (RingCfg<R, CC, DG>::WAVES)) void corr_fwd_rin
     const int by = t % tiles_y;
     const int b = t / tiles_y;
     const int i0 = blockIdx.y * DG;                          // first displacement row of this workgroup
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, wave = threadIdx.x >> 6;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: the DMA descriptor choice is scalar
     const int x0 = bx * K::TW, y0 = by * K::TYB;
     const int px = x0 + tx * 2, py = y0 + ty;
     const size_t plane = (size_t)H * W;
     const int nchunk = (C + CC - 1) / CC;
 
-    // per-lane, per-slot source description (loop invariant): channel within the stage and the
-    // element offset inside a channel plane, or -1 for slots outside the image / padding
-    int soff[K::ITER], sch[K::ITER], ssel[K::ITER];
-#pragma unroll
-    for (int it = 0; it < K::ITER; ++it) {
-        const int s = it * 256 + threadIdx.x;
-        const int c = s / K::SC;
-        int r = s - c * K::SC;
-        int gy, gx, sel;
-        if (r < K::S2) { const int ly = r / (LW / 4); gy = y0 - R + i0 + ly; gx = x0 - R + (r - ly * (LW / 4)) * 4; sel = 1; }
-        else { r -= K::S2; const int ly = r / (K::TW / 4); gy = y0 + ly; gx = x0 + (r - ly * (K::TW / 4)) * 4; sel = 0; }
-        const bool in = (c < CC) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        soff[it] = in ? gy * W + gx : -1;
-        sch[it] = c;
-        ssel[it] = sel;
-    }
-    const float* base1 = f1 + (size_t)b * C * plane;
-    const float* base2 = f2 + (size_t)b * C * plane;
-
-    gfloat* zline = zero_line();
-    auto issue = [&](int stage_idx) {
-        float* dst = ring + (stage_idx & (K::NS - 1)) * K::STAGE;
-        const int c0 = stage_idx * CC;
-#pragma unroll
-        for (int it = 0; it < K::ITER; ++it) {
-            const int gc = c0 + sch[it];
-            const bool in = soff[it] >= 0 && gc < C;
-            gfloat* g = in ? (gfloat*)((ssel[it] ? base2 : base1) + (size_t)gc * plane + soff[it]) : zline;
-            __builtin_amdgcn_global_load_lds((gas_ptr)g, (lds_ptr)(dst + (it * 256 + wave * 64) * 4), 16, 0, 0);
-        }
+    FwdSlots<K, R, CC> slots;
+    slots.setup(threadIdx.x, wave, x0, y0, i0, H, W, (unsigned)plane);
+    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f1 + (size_t)b * C * plane), 0, (int)((size_t)C * plane * 4), 0x00020000);
+    const auto rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f2 + (size_t)b * C * plane), 0, (int)((size_t)C * plane * 4), 0x00020000);
+    auto issue = [&](int stage_idx) {       // stages beyond the last channel fall outside num_records: zeros
+        slots.issue(rs1, rs2, ring + (stage_idx & (K::NS - 1)) * K::STAGE, wave, (unsigned)(stage_idx * CC) * (unsigned)plane * 4u);
     };
 
-    float acc[DG][DD][2];
-#pragma unroll
-    for (int i = 0; i < DG; ++i)
-#pragma unroll
-        for (int j = 0; j < DD; ++j) { acc[i][j][0] = 0.f; acc[i][j][1] = 0.f; }
+    FwdAcc<DG, R> acc;
+    acc.zero();
 
     const unsigned rows_addr = (unsigned)(size_t)(lds_cfloat*)(ring + ty * LW + tx * 2);
-    const unsigned own_addr = (unsigned)(size_t)(lds_cfloat*)(ring + K::S2 * 4 + ty * K::TW + tx * 2);
+    const unsigned own_addr = (unsigned)(size_t)(lds_cfloat*)(ring + K::S2P * 4 + ty * K::TW + tx * 2);
 
 #pragma unroll
-    for (int st = 0; st < K::NS - 1; ++st) if (!RING_DBG(4)) issue(st);       // stages beyond nchunk read the zero line
+    for (int st = 0; st < K::NS - 1; ++st) if (!RING_DBG(4)) issue(st);
+    STAMP(0);
 
     for (int k = 0; k < nchunk; ++k) {
         // all but the newest (NS-2) stages have landed -> stage k is complete for this wave ...
         vm_wait<K::ITER * (K::NS - 2)>();
         __builtin_amdgcn_s_barrier();                        // ... and for every wave; slot (k-1) is free
+        STAMP(1);
         if (!RING_DBG(4)) issue(k + K::NS - 1);
+        STAMP(2);
         const int sbase = (k & (K::NS - 1)) * K::STAGE;
         if (RING_DBG(2)) continue;
         // CC*DG row-steps per stage as one software pipeline (FwdStep): reads of step s+PF are in
@@ -400,8 +443,10 @@ __global__ __launch_bounds__(256, (RingCfg<R, CC, DG>::WAVES)) void corr_fwd_rin
         Step0::template load<0>(row, abase);
         if constexpr (PF > 1) Step0::template load<1>(row, abase);
         Step0::template run<CC>(acc, row, a, abase);
+        STAMP(3);
     }
-    vm_wait<0>();                                            // drain the zero-line tail loads
+    vm_wait<0>();                                            // drain the tail stages (all zeros)
+    STAMP(1);
 
     if (py >= H || px >= W) return;
     float* out = cv + ((size_t)b * DD * DD) * plane + (size_t)py * W + px;
@@ -410,7 +455,7 @@ __global__ __launch_bounds__(256, (RingCfg<R, CC, DG>::WAVES)) void corr_fwd_rin
 #pragma unroll
         for (int i = 0; i < DG; ++i)
 #pragma unroll
-            for (int j = 0; j < DD; ++j) sum += acc[i][j][0] + acc[i][j][1];
+            for (int j = 0; j < DD; ++j) sum += acc.get(i, j, 0) + acc.get(i, j, 1);
         out[0] = sum;
         return;
     }
@@ -420,8 +465,10 @@ __global__ __launch_bounds__(256, (RingCfg<R, CC, DG>::WAVES)) void corr_fwd_rin
 #pragma unroll
         for (int j = 0; j < DD; ++j)
             *reinterpret_cast<float2*>(out + (size_t)((i0 + i) * DD + j) * plane) =
-                make_float2(acc[i][j][0] * inv_c, acc[i][j][1] * inv_c);
+                make_float2(acc.get(i, j, 0) * inv_c, acc.get(i, j, 1) * inv_c);
     }
+    STAMP(4);
+    STAMP_WRITE(stamps, blockIdx.y == 0 ? (int)blockIdx.x * 3 + (wave < 3 ? wave : 2) : 1 << 30, (threadIdx.x & 63) == 0 && wave < 3);
 }
 
 template <int R, int CC, int DG>
@@ -435,7 +482,7 @@ int launch_fwd_ring(const float* f1, const float* f2, float* cv, int B, int C, i
     const int dbg = 0;
 #endif
     hipLaunchKernelGGL((corr_fwd_ring_kernel<R, CC, DG>), dim3(tx * ty * B, K::NG), dim3(256), 0, s, f1, f2, cv, C, H, W,
-                       tx, ty, 1.0f / C, dbg);
+                       tx, ty, 1.0f / C, dbg, stamp_buffer());
     return unflow_launch_status();
 }
 
@@ -453,7 +500,7 @@ struct RingPCfg {
     static constexpr int NG = (DD + DG - 1) / DG;
     static constexpr int TW = 64, TYB = 8, NS = 3;
     static constexpr int LW = TW + 2 * R, LH = TYB + DG - 1;
-    static constexpr int S2 = LH * LW / 4, S1 = TYB * TW / 4, SC = S2 + S1;
+    static constexpr int S2 = LH * LW / 4, S2P = (S2 + 63) / 64 * 64, S1 = TYB * TW / 4, SC = S2P + S1;      // as RingCfg
     static constexpr int ITER = (CC * SC + 255) / 256;
     static constexpr int STAGE = ITER * 256 * 4;
     static constexpr int RING = NS * STAGE;                                     // floats per phase
@@ -476,7 +523,8 @@ __global__ __launch_bounds__((RingPCfg<R, CC, DG, PH>::THREADS)) void corr_fwd_r
     const int i0 = blockIdx.y * DG;
     const int phase = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);      // wave-uniform
     const int tid = threadIdx.x & 255;
-    const int tx = tid & 31, ty = tid >> 5, wave = tid >> 6;
+    const int tx = tid & 31, ty = tid >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = bx * K::TW, y0 = by * K::TYB;
     const int px = x0 + tx * 2, py = y0 + ty;
     const size_t plane = (size_t)H * W;
@@ -487,43 +535,20 @@ __global__ __launch_bounds__((RingPCfg<R, CC, DG, PH>::THREADS)) void corr_fwd_r
     const int cn = max(0, min(cpp, C - cb));
     float* ring = lds + phase * K::RING;
 
-    int soff[K::ITER], sch[K::ITER], ssel[K::ITER];
-#pragma unroll
-    for (int it = 0; it < K::ITER; ++it) {
-        const int s = it * 256 + tid;
-        const int c = s / K::SC;
-        int r = s - c * K::SC;
-        int gy, gx, sel;
-        if (r < K::S2) { const int ly = r / (LW / 4); gy = y0 - R + i0 + ly; gx = x0 - R + (r - ly * (LW / 4)) * 4; sel = 1; }
-        else { r -= K::S2; const int ly = r / (K::TW / 4); gy = y0 + ly; gx = x0 + (r - ly * (K::TW / 4)) * 4; sel = 0; }
-        const bool in = (c < CC) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        soff[it] = in ? gy * W + gx : -1;
-        sch[it] = c;
-        ssel[it] = sel;
-    }
-    const float* base1 = f1 + ((size_t)b * C + cb) * plane;
-    const float* base2 = f2 + ((size_t)b * C + cb) * plane;
-    gfloat* zline = zero_line();
+    FwdSlots<K, R, CC> slots;
+    slots.setup(tid, wave, x0, y0, i0, H, W, (unsigned)plane);
+    // this phase's channels only: the rest of the sample lies beyond num_records and arrives as zeros
+    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f1 + ((size_t)b * C + cb) * plane), 0, (int)((size_t)cn * plane * 4), 0x00020000);
+    const auto rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f2 + ((size_t)b * C + cb) * plane), 0, (int)((size_t)cn * plane * 4), 0x00020000);
     auto issue = [&](int stage_idx) {
-        float* dst = ring + (stage_idx % K::NS) * K::STAGE;
-        const int c0 = stage_idx * CC;
-#pragma unroll
-        for (int it = 0; it < K::ITER; ++it) {
-            const int gc = c0 + sch[it];
-            const bool in = soff[it] >= 0 && gc < cn;
-            gfloat* g = in ? (gfloat*)((ssel[it] ? base2 : base1) + (size_t)gc * plane + soff[it]) : zline;
-            __builtin_amdgcn_global_load_lds((gas_ptr)g, (lds_ptr)(dst + (it * 256 + wave * 64) * 4), 16, 0, 0);
-        }
+        slots.issue(rs1, rs2, ring + (stage_idx % K::NS) * K::STAGE, wave, (unsigned)(stage_idx * CC) * (unsigned)plane * 4u);
     };
 
-    float acc[DG][DD][2];
-#pragma unroll
-    for (int i = 0; i < DG; ++i)
-#pragma unroll
-        for (int j = 0; j < DD; ++j) { acc[i][j][0] = 0.f; acc[i][j][1] = 0.f; }
+    FwdAcc<DG, R> acc;
+    acc.zero();
 
     const unsigned rows_addr = (unsigned)(size_t)(lds_cfloat*)(ring + ty * LW + tx * 2);
-    const unsigned own_addr = (unsigned)(size_t)(lds_cfloat*)(ring + K::S2 * 4 + ty * K::TW + tx * 2);
+    const unsigned own_addr = (unsigned)(size_t)(lds_cfloat*)(ring + K::S2P * 4 + ty * K::TW + tx * 2);
 
 #pragma unroll
     for (int st = 0; st < K::NS - 1; ++st) issue(st);
@@ -543,7 +568,7 @@ __global__ __launch_bounds__((RingPCfg<R, CC, DG, PH>::THREADS)) void corr_fwd_r
         if constexpr (PF > 1) Step0::template load<1>(row, rows_addr + sb);
         Step0::template run<CC>(acc, row, a, rows_addr + sb);
     }
-    vm_wait<0>();                                            // the zero-line tail loads: no LDS-DMA in flight beyond here
+    vm_wait<0>();                                            // the all-zero tail stages: no LDS-DMA in flight beyond here
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -556,7 +581,7 @@ __global__ __launch_bounds__((RingPCfg<R, CC, DG, PH>::THREADS)) void corr_fwd_r
             for (int i = 0; i < DG; ++i)
 #pragma unroll
                 for (int j = 0; j < DD; ++j)
-                    *reinterpret_cast<float2*>(red + ((i * DD + j) * 256 + tid) * 2) = make_float2(acc[i][j][0], acc[i][j][1]);
+                    *reinterpret_cast<float2*>(red + ((i * DD + j) * 256 + tid) * 2) = make_float2(acc.get(i, j, 0), acc.get(i, j, 1));
         }
         __syncthreads();
         if (phase == 0) {
@@ -565,7 +590,7 @@ __global__ __launch_bounds__((RingPCfg<R, CC, DG, PH>::THREADS)) void corr_fwd_r
 #pragma unroll
                 for (int j = 0; j < DD; ++j) {
                     const float2 v = *reinterpret_cast<const float2*>(red + ((i * DD + j) * 256 + tid) * 2);
-                    acc[i][j][0] += v.x; acc[i][j][1] += v.y;
+                    acc.add(i, j, 0, v.x); acc.add(i, j, 1, v.y);
                 }
         }
         __syncthreads();
@@ -578,7 +603,7 @@ __global__ __launch_bounds__((RingPCfg<R, CC, DG, PH>::THREADS)) void corr_fwd_r
 #pragma unroll
         for (int j = 0; j < DD; ++j)
             *reinterpret_cast<float2*>(out + (size_t)((i0 + i) * DD + j) * plane) =
-                make_float2(acc[i][j][0] * inv_c, acc[i][j][1] * inv_c);
+                make_float2(acc.get(i, j, 0) * inv_c, acc.get(i, j, 1) * inv_c);
     }
 }
 
@@ -706,19 +731,9 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC, TYB>::THREADS)) void corr_bwd_gs_k
                                                          float* __restrict__ gf2, int Ctot, int cpg, int H, int W,
                                                          int tiles_x, int tiles_y, float inv_c, int dbg, unsigned long long* stamps) {
     using K = BwdGsCfg<R, CC, TYB>;
-    // In-kernel stamps (tuning builds, UNFLOW_STAMP_PTR): cycles per segment of the stage loop, summed per wave
-    //   0 gather + prologue | 1 vmcnt wait + barrier | 2 finish (group 0: slab read, add, store) | 3 DMA issue |
-    //   4 row pipeline (FMAs) + partial hand-off | 5 tail
-    // (32-bit counters, no stamp inside the row pipeline: its hand-counted lgkmcnt waits must stay as they are)
-#ifdef UNFLOW_TUNING
-    unsigned seg[6] = {0, 0, 0, 0, 0, 0}, tlast;
-    { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); tlast = (unsigned)t_; }
-#define STAMP(IDX) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
-        seg[IDX] += (unsigned)t_ - tlast; tlast = (unsigned)t_; } while (0)
-#else
-#define STAMP(IDX) do { } while (0)
-#endif
+    // stamp segments: 0 gather + prologue | 1 vmcnt wait + barrier | 2 finish (group 0: slab read, add, store) | 3 DMA issue |
+    //                 4 row pipeline (FMAs) + partial hand-off | 5 tail
+    STAMP_DECL();
     constexpr int DD = K::DD, LW = K::LW, NROW = 2 + 2 * R, NCOL = NROW / 2, GL = K::GL;
     static_assert(K::NS >= 3 && K::NS <= 6, "ring depth (the counted vmcnt waits cover NS-2 <= 4 store groups)");
     __shared__ __attribute__((aligned(16))) float lds[K::NS * K::STAGE + 2 * K::RED];
@@ -756,6 +771,32 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC, TYB>::THREADS)) void corr_bwd_gs_k
     // Requires 81 * plane * 4 and Ctot * plane * 4 < kOut (checked by the launcher).
     constexpr unsigned kOut = 0x40000000u;
 
+    const float* baseF = F + ((size_t)b * Ctot + c_begin) * plane;
+    const auto frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(baseF), 0, (int)((size_t)C * plane * 4), 0x00020000);
+    // per-lane DMA slot descriptor, computed once: byte offset of the slot's 16 bytes within the first stage's CC planes,
+    // or kOut outside the image / in the padding.  A stage adds its (uniform) channel offset; channels past C fall
+    // outside num_records and arrive as zeros.
+    unsigned slotB[K::ITER];
+#pragma unroll
+    for (int it = 0; it < K::ITER; ++it) {
+        const int s = it * K::THREADS + (int)threadIdx.x;
+        const int c = s / K::SC;
+        const int r = s - c * K::SC;
+        const int ly = r / (LW / 4);
+        const int gy = y0 - R + ly, gx = x0 - R + (r - ly * (LW / 4)) * 4;
+        const bool in = (c < CC) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        slotB[it] = in ? ((unsigned)c * (unsigned)plane + (unsigned)(gy * W + gx)) * 4u : kOut;
+        asm volatile("" : "+v"(slotB[it]));      // materialise once; do not re-derive in the loop
+    }
+    auto issue = [&](int stage_idx) {
+        float* dst = ring + (stage_idx % K::NS) * K::STAGE;
+        const unsigned stageB = (unsigned)(stage_idx * CC) * (unsigned)plane * 4u;
+#pragma unroll
+        for (int it = 0; it < K::ITER; ++it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(frs, (lds_ptr)(dst + (it * K::THREADS + wave * 64) * 4), 16,
+                                                 (int)(slotB[it] + stageB), 0, 0, 0);
+    };
+
     // this wave pair's 3 displacement rows of the upstream gradient -> registers
     // (mode 1: displacement-flipped and gathered from q + (i'-R, j'-R))
     GsWeights<R> wr;
@@ -791,32 +832,6 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC, TYB>::THREADS)) void corr_bwd_gs_k
         }
     }
 
-    const float* baseF = F + ((size_t)b * Ctot + c_begin) * plane;
-    const auto frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(baseF), 0, (int)((size_t)C * plane * 4), 0x00020000);
-    // per-lane DMA slot descriptor, computed once: byte offset of the slot's 16 bytes within the first stage's CC planes,
-    // or kOut outside the image / in the padding.  A stage adds its (uniform) channel offset; channels past C fall
-    // outside num_records and arrive as zeros.
-    unsigned slotB[K::ITER];
-#pragma unroll
-    for (int it = 0; it < K::ITER; ++it) {
-        const int s = it * K::THREADS + (int)threadIdx.x;
-        const int c = s / K::SC;
-        const int r = s - c * K::SC;
-        const int ly = r / (LW / 4);
-        const int gy = y0 - R + ly, gx = x0 - R + (r - ly * (LW / 4)) * 4;
-        const bool in = (c < CC) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        slotB[it] = in ? ((unsigned)c * (unsigned)plane + (unsigned)(gy * W + gx)) * 4u : kOut;
-        asm volatile("" : "+v"(slotB[it]));      // materialise once; do not re-derive in the loop
-    }
-    auto issue = [&](int stage_idx) {
-        float* dst = ring + (stage_idx % K::NS) * K::STAGE;
-        const unsigned stageB = (unsigned)(stage_idx * CC) * (unsigned)plane * 4u;
-#pragma unroll
-        for (int it = 0; it < K::ITER; ++it)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(frs, (lds_ptr)(dst + (it * K::THREADS + wave * 64) * 4), 16,
-                                                 (int)(slotB[it] + stageB), 0, 0, 0);
-    };
-
     // rows of this pair start 3*grp below the tile's first halo row
     const unsigned rows_addr = (unsigned)(size_t)(lds_cfloat*)(ring + (ty + 3 * grp) * LW + tx * 2);
     float* op = out + (((size_t)b * Ctot + c_begin) * H + py) * W + px;
@@ -845,6 +860,8 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC, TYB>::THREADS)) void corr_bwd_gs_k
     vm_wait<0>();                                    // the gradient loads are done before the first DMA goes out
     wr.pin();                                        // pin their consumers here too (else hipcc sinks them into the
                                                      // loop and drains vmcnt(0) with the DMA in flight)
+    // (measured: issuing the first ring stages BEFORE the gather, to hide their latency behind it, costs 4 us at level 2 --
+    // the gather's loads queue behind 36 KB of DMA -- and gains < 1 us at levels 3 / 4)
 #pragma unroll
     for (int st = 0; st < K::NS - 1; ++st) issue(st);
     STAMP(0);
@@ -905,13 +922,7 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC, TYB>::THREADS)) void corr_bwd_gs_k
     __builtin_amdgcn_s_barrier();
     if (grp == 0) finish(nchunk - 1, keep);
     STAMP(5);
-#ifdef UNFLOW_TUNING
-    if (stamps && (threadIdx.x % GL) == 0 && blockIdx.y == 0 && blockIdx.x < 1024) {
-#pragma unroll
-        for (int q = 0; q < 6; ++q) stamps[((size_t)blockIdx.x * K::NGRP + grp) * 8 + q] = seg[q];
-    }
-#endif
-#undef STAMP
+    STAMP_WRITE(stamps, blockIdx.y == 0 ? (int)blockIdx.x * K::NGRP + grp : 1 << 30, (threadIdx.x % GL) == 0);
 }
 
 // The group-split backward addresses one sample's gradient planes and one sample's feature planes through 32-bit
@@ -934,10 +945,7 @@ int launch_bwd_gs(const float* f1, const float* f2, const float* g, float* gf1, 
 #else
     const int dbg = 0;
 #endif
-    unsigned long long* stamps = nullptr;
-#ifdef UNFLOW_TUNING
-    if (const char* sp = getenv("UNFLOW_STAMP_PTR")) stamps = (unsigned long long*)strtoull(sp, nullptr, 0);     // 1024 * NGRP * 8 u64
-#endif
+    unsigned long long* stamps = stamp_buffer();
     hipLaunchKernelGGL((corr_bwd_gs_kernel<R, CC, TYB>), dim3(tx * ty * B * 2, ceil_div(C, cpg)), dim3(K::THREADS), 0, s,
                        f1, f2, g, gf1, gf2, C, cpg, H, W, tx, ty, 1.0f / C, dbg, stamps);
     return unflow_launch_status();
@@ -1157,7 +1165,8 @@ extern "C" int unflow_corr_fwd(const float* f1, const float* f2, float* cv, int 
     UNFLOW_REQUIRE(f1 && f2 && cv && B > 0 && C > 0 && H > 0 && W > 0 && d >= 0);
     hipStream_t s = (hipStream_t)stream;
     int variant = 4;
-    const bool ring_ok = (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0);     // LDS-DMA moves aligned 16-byte pieces
+    const bool ring_ok = (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0)      // LDS-DMA moves aligned 16-byte pieces
+                         && (size_t)C * H * W * 4 < kOutOfRange;                        // 32-bit buffer offsets, bit 30 = "outside"
     switch (d) {
         case 1: return launch_fwd<1, 2, 3, 8>(f1, f2, cv, B, C, H, W, s);
         case 2: return launch_fwd<2, 2, 5, 8>(f1, f2, cv, B, C, H, W, s);

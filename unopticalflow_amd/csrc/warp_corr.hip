@@ -174,11 +174,8 @@ __global__ __launch_bounds__(256, (FusedCfg<R, CC, DG, NS, SWX, SWH>::WAVES)) vo
         }
     };
 
-    float acc[DG][DD][2];
-#pragma unroll
-    for (int i = 0; i < DG; ++i)
-#pragma unroll
-        for (int j = 0; j < DD; ++j) { acc[i][j][0] = 0.f; acc[i][j][1] = 0.f; }
+    FwdAcc<DG, R> acc;
+    acc.zero();
 
     const unsigned ring_addr = (unsigned)(size_t)(lds_cfloat*)ring;
     const unsigned wt_addr = (unsigned)(size_t)(lds_cfloat*)wt;
@@ -278,7 +275,7 @@ __global__ __launch_bounds__(256, (FusedCfg<R, CC, DG, NS, SWX, SWH>::WAVES)) vo
 #pragma unroll
         for (int j = 0; j < DD; ++j)
             *reinterpret_cast<float2*>(out + (size_t)((i0 + i) * DD + j) * plane) =
-                make_float2(acc[i][j][0] * inv_c, acc[i][j][1] * inv_c);
+                make_float2(acc.get(i, j, 0) * inv_c, acc.get(i, j, 1) * inv_c);
     }
 }
 
