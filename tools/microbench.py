@@ -112,7 +112,7 @@ def warp_c(B=16):
     P = ops._ptr
     envs = [{}]
     if os.environ.get('UNFLOW_MICROBENCH_TUNING') == '1':
-        envs = [{'UNFLOW_WARP_TILES': 0}] + [{'UNFLOW_WARP_TH': th, 'UNFLOW_WARP_WGS': n} for th in (8,) for n in (256, 512, 1024, 2048)]
+        envs = [{'UNFLOW_WARP_TILES': 0}] + [{'UNFLOW_WARP_BWD': k, 'UNFLOW_WARP_WGS': n} for k in (0, 1) for n in (256, 512)]
     for name, (C, h, w) in list(LEVELS.items())[:4]:
         x = torch.randn(B, C, h, w, device='cuda')
         g = torch.randn(B, C, h, w, device='cuda')
@@ -160,12 +160,13 @@ def ablate(B=16):
     C, h, w = LEVELS['L2']
     x = torch.randn(B, C, h, w, device='cuda'); g = torch.randn(B, C, h, w, device='cuda')
     gsrc = torch.empty_like(x); fl = _smooth_flow(B, h, w); gfl = torch.empty_like(fl)
-    for th in (8,):
-        for dbg in (0, 1, 2, 4, 3):
-            os.environ.update({'UNFLOW_WARP_TH': str(th), 'UNFLOW_WARP_DEBUG': str(dbg)})
+    for kern in (0, 1):
+        for dbg in ((0, 1, 2, 4, 3) if kern == 0 else (0, 1, 4, 8, 12)):
+            os.environ.update({'UNFLOW_WARP_BWD': str(kern), 'UNFLOW_WARP_DEBUG': str(dbg)})
             tb = timeit(lambda: lib.unflow_warp_bwd(P(x), P(fl), P(g), None, P(gsrc), P(gfl), B, C, h, w, 0, ops._stream()))
-            print('warp_bwd L2 TH=%d dbg=%d (1 no LDS adds, 2 no flush, 4 no global atomics): %7.1f us' % (th, dbg, tb), flush=True)
-    os.environ.pop('UNFLOW_WARP_DEBUG'); os.environ.pop('UNFLOW_WARP_TH')
+            print('warp_bwd L2 %s dbg=%d (1 no LDS adds / no cell phase, 2 no flush, 4 no global atomics): %7.1f us' % (
+                'cell-gather' if kern else 'LDS-accumulator', dbg, tb), flush=True)
+    os.environ.pop('UNFLOW_WARP_DEBUG'); os.environ.pop('UNFLOW_WARP_BWD')
     tz = timeit(lambda: gsrc.zero_())
     print('zero-fill of gsrc alone: %.1f us' % tz, flush=True)
     f1 = torch.randn(B, C, h, w, device='cuda'); f2 = torch.randn(B, C, h, w, device='cuda')

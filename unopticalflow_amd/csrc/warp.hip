@@ -556,6 +556,237 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward through LDS tiles, "cell gather" form (the shipped one).  The scatter of the source gradient is turned
+// around inside the workgroup: every pixel posts its id at the position of its nw tap (the marker table the tile
+// kernel above uses to find race-free pixels); then every CELL of the source window looks up the <= 4 pixels whose
+// se / sw / ne / nw tap lands on it -- once per tile -- and per channel computes its sum from their upstream gradients
+// (staged in LDS by pixel id) and adds it to global memory with one row-contiguous float atomic.  No LDS
+// accumulator, no read-add-write passes, no flush pass: per chunk two barriers instead of seven and about half
+// the LDS operations.  Pixels that lost their marker cell to another pixel (the flow compresses there: a few per
+// cent of a smooth flow) add their four taps with global atomics themselves.
+// ---------------------------------------------------------------------------------------------
+template <int PPT, int WIN, int CC, bool SPLIT>
+__global__ __launch_bounds__(256) void warp_bwd_cell_kernel(const float* __restrict__ src, const float* __restrict__ flow,
+                                                            const float* __restrict__ gout, float* __restrict__ gsrc,
+                                                            float* __restrict__ gflow, int C, int H, int W, int ac,
+                                                            int TW, int TH, int tiles_x, int tiles_y, int cpg, int vec_ok, int dbg) {
+    constexpr int WINP = WIN + 256;                 // + one private (always zero) cell per thread for taps that do not exist
+    constexpr int NPX = PPT * 256;                  // pixel ids; id NPX is the "nobody" entry (gradient 0)
+    constexpr int CPT = (WIN + 255) / 256;          // window cells per thread
+    constexpr int MK = WIN + WIN / 4 + 136;         // (wh + 1) x (rs + 1) marker cells
+    __shared__ __attribute__((aligned(16))) float s_src[CC * WINP];
+    __shared__ float s_g[CC][NPX + 1];              // upstream gradients of the chunk by pixel id
+    __shared__ float s_w[4][NPX];                   // tap weights (nw, ne, sw, se) by pixel id
+    __shared__ float s_dup[CC * WINP];              // side accumulator for the pixels the cells cannot find (LDS atomics)
+    __shared__ unsigned char s_flag[WINP];          // window cells that receive something through s_dup
+    __shared__ int s_mark[MK];
+    __shared__ int s_box[16];
+    int t = blockIdx.x;
+    const int bx = t % tiles_x; t /= tiles_x;
+    const int by = t % tiles_y;
+    const int b = t / tiles_y;
+    const int c_begin = blockIdx.y * cpg, c_end = min(C, c_begin + cpg);
+    const int plane = H * W;
+    TileCtx<PPT> k;
+    tile_setup<PPT>(k, flow + (size_t)b * 2 * plane, H, W, ac, bx * TW, by * TH, TW, TH, s_box);
+    const float* sp = src + (size_t)b * C * plane;
+    const float* gp = gout + (size_t)b * C * plane;
+    float* dp = gsrc ? gsrc + (size_t)b * C * plane : nullptr;
+    float gix[PPT], giy[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) { gix[q] = 0.f; giy[q] = 0.f; }
+
+    Window<WIN> w;
+    const bool fits = window_setup<WIN, PPT>(w, k, W, vec_ok != 0);
+    if (k.ww == 0) {
+        // no tap inside the image: both gradients are zero
+    } else if (!fits) {
+        // taps spread beyond the LDS window: per-tap global gathers and atomics for this tile
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            if (!k.live[q]) continue;
+            const Taps& tp = k.t[q];
+#pragma unroll 2
+            for (int c = c_begin; c < c_end; ++c) {
+                const float* p = sp + (size_t)c * plane;
+                const float g = gp[(size_t)c * plane + k.pix[q]];
+                const float a = tp.v_nw ? p[tp.o_nw] : 0.f, bq = tp.v_ne ? p[tp.o_ne] : 0.f;
+                const float cq = tp.v_sw ? p[tp.o_sw] : 0.f, dq = tp.v_se ? p[tp.o_se] : 0.f;
+                gix[q] += g * ((bq - a) * tp.s + (dq - cq) * tp.n);
+                giy[q] += g * ((cq - a) * tp.e + (dq - bq) * tp.w);
+                if (dp) {
+                    float* d = dp + (size_t)c * plane;
+                    if (tp.v_nw) atomicAdd(d + tp.o_nw, g * tp.nw);
+                    if (tp.v_ne) atomicAdd(d + tp.o_ne, g * tp.ne);
+                    if (tp.v_sw) atomicAdd(d + tp.o_sw, g * tp.sw);
+                    if (tp.v_se) atomicAdd(d + tp.o_se, g * tp.se);
+                }
+            }
+        }
+    } else {
+        // LDS offsets of the four taps for the flow gradient (taps that do not exist read this thread's zero cell)
+        int o_nw[PPT], o_ne[PPT], o_sw[PPT], o_se[PPT];
+        const int mine = WIN + (int)threadIdx.x;
+        {
+            int l_nw[PPT], l_ne[PPT], l_sw[PPT], l_se[PPT];
+            tap_offsets<WIN, PPT>(w, k, l_nw, l_ne, l_sw, l_se);
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                const Taps& tp = k.t[q];
+                o_nw[q] = (k.live[q] && tp.v_nw) ? l_nw[q] : mine;
+                o_ne[q] = (k.live[q] && tp.v_ne) ? l_ne[q] : mine;
+                o_sw[q] = (k.live[q] && tp.v_sw) ? l_sw[q] : mine;
+                o_se[q] = (k.live[q] && tp.v_se) ? l_se[q] : mine;
+            }
+        }
+        const int mrs = w.rs + 1, msz = (w.wh + 1) * mrs;
+        for (int i = threadIdx.x; i < msz; i += 256) s_mark[i] = -1;
+        if (threadIdx.x < CC) s_g[threadIdx.x][NPX] = 0.f;
+        int cell[PPT];
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const Taps& tp = k.t[q];
+            const int id = q * 256 + (int)threadIdx.x;
+            s_w[0][id] = tp.nw; s_w[1][id] = tp.ne; s_w[2][id] = tp.sw; s_w[3][id] = tp.se;     // zero where the tap does not exist
+            const bool any = k.live[q] && (tp.v_nw || tp.v_ne || tp.v_sw || tp.v_se);
+            cell[q] = any ? (tp.y0 + 1 - w.wy0) * mrs + (tp.x0 + 1 - w.wxa) : -1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PPT; ++q)
+            if (cell[q] >= 0) s_mark[cell[q]] = q * 256 + (int)threadIdx.x;
+        __syncthreads();
+        bool solo[PPT];                                  // this pixel is the one the cells will find
+        bool any_dup = false;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            solo[q] = cell[q] < 0 || s_mark[cell[q]] == q * 256 + (int)threadIdx.x;
+            any_dup = any_dup || !solo[q];
+        }
+        // (s_src too: a last chunk with fewer than CC channels multiplies whatever the other planes hold by g == 0)
+        for (int i = threadIdx.x; i < CC * WINP; i += 256) { s_dup[i] = 0.f; s_src[i] = 0.f; }
+        for (int i = threadIdx.x; i < WINP; i += 256) s_flag[i] = 0;
+        any_dup = __syncthreads_or(any_dup ? 1 : 0) != 0;      // (also: the fills are done before the first chunk is staged)
+        if (any_dup) {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q)
+                if (!solo[q]) { s_flag[o_nw[q]] = 1; s_flag[o_ne[q]] = 1; s_flag[o_sw[q]] = 1; s_flag[o_se[q]] = 1; }
+            __syncthreads();
+        }
+
+        // this thread's window cells: who lands here with which weight (loop invariant), and where the cell is in the plane
+        int cid[CPT][4], coff[CPT];
+        float cw[CPT][4];
+        bool via_dup[CPT];
+        const int used = w.rs * w.wh;
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            const int e = u * 256 + (int)threadIdx.x;
+            const bool in = e < used;
+            via_dup[u] = any_dup && in && s_flag[e] != 0;
+            const int row = in ? e / w.rs : 0, col = in ? e - row * w.rs : 0;
+            coff[u] = in ? (w.wy0 + row) * W + w.wxa + col : -1;
+            // marker position of a pixel = its nw tap + (1, 1): the cell's own position holds the pixel whose SE tap is here
+            const int m = row * mrs + col;
+            const int ids[4] = {in ? s_mark[m + mrs + 1] : -1, in ? s_mark[m + mrs] : -1, in ? s_mark[m + 1] : -1, in ? s_mark[m] : -1};
+#pragma unroll
+            for (int tk = 0; tk < 4; ++tk) {             // tk: 0 nw, 1 ne, 2 sw, 3 se
+                cid[u][tk] = ids[tk] >= 0 ? ids[tk] : NPX;
+                cw[u][tk] = ids[tk] >= 0 ? s_w[tk][ids[tk]] : 0.f;
+            }
+        }
+
+        for (int c0 = c_begin; c0 < c_end; c0 += CC) {
+            const int nc = min(CC, c_end - c0);
+            window_stage<WINP, WIN, CC>(s_src, w, sp + (size_t)c0 * plane, plane, W, nc);
+            float g[PPT][CC];                                 // upstream gradients of the chunk: in flight with the window pieces
+#pragma unroll
+            for (int q = 0; q < PPT; ++q)
+#pragma unroll
+                for (int c = 0; c < CC; ++c)
+                    g[q][c] = (k.live[q] && c < nc) ? gp[(size_t)(c0 + c) * plane + k.pix[q]] : 0.f;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q)
+#pragma unroll
+                for (int c = 0; c < CC; ++c) s_g[c][q * 256 + (int)threadIdx.x] = g[q][c];
+            stage_fence();                                    // window staged, gradients posted
+            // channels beyond nc hold an older chunk's (finite) values and g == 0: they add nothing
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                const Taps& tp = k.t[q];
+#pragma unroll
+                for (int c = 0; c < CC; ++c) {
+                    const float* win = s_src + c * WINP;
+                    const float gv = g[q][c];
+                    const float a = win[o_nw[q]], bq = win[o_ne[q]], cq = win[o_sw[q]], dq = win[o_se[q]];
+                    gix[q] += gv * ((bq - a) * tp.s + (dq - cq) * tp.n);
+                    giy[q] += gv * ((cq - a) * tp.e + (dq - bq) * tp.w);
+                }
+                __builtin_amdgcn_sched_barrier(0);            // one pixel's taps in flight at a time (registers)
+            }
+            if (dp && !WARP_DBG(1)) {
+                if (any_dup) {                                // workgroup-uniform
+                    // the pixels the cells cannot find add their taps to the side accumulator (taps that do not exist land
+                    // in the thread's private cell, which nobody reads)
+#pragma unroll
+                    for (int q = 0; q < PPT; ++q) {
+                        if (solo[q] || WARP_DBG(8)) continue;
+                        const Taps& tp = k.t[q];
+#pragma unroll
+                        for (int c = 0; c < CC; ++c) {
+                            float* acc = s_dup + c * WINP;
+                            atomicAdd(acc + o_nw[q], g[q][c] * tp.nw);
+                            atomicAdd(acc + o_ne[q], g[q][c] * tp.ne);
+                            atomicAdd(acc + o_sw[q], g[q][c] * tp.sw);
+                            atomicAdd(acc + o_se[q], g[q][c] * tp.se);
+                        }
+                    }
+                    __syncthreads();
+                }
+                // the four waves walk the chunk's planes in rotated order: at any moment their atomics go to four different
+                // planes instead of neighbouring lines of one (measured: 16.5 -> 9.3 us of atomics at level 2)
+                auto cells = [&](auto rot) {
+#pragma unroll
+                    for (int u = 0; u < CPT; ++u) {
+                        if (coff[u] < 0) continue;
+                        const int e = u * 256 + (int)threadIdx.x;  // = the cell's offset inside the packed window
+#pragma unroll
+                        for (int kk = 0; kk < CC; ++kk) {
+                            constexpr int ROT = decltype(rot)::value;
+                            const int c = (kk + ROT) % CC;
+                            // fixed order nw, ne, sw, se: a cell's value does not depend on the launch geometry
+                            float r = s_g[c][cid[u][0]] * cw[u][0];
+                            r = fmaf(s_g[c][cid[u][1]], cw[u][1], r);
+                            r = fmaf(s_g[c][cid[u][2]], cw[u][2], r);
+                            r = fmaf(s_g[c][cid[u][3]], cw[u][3], r);
+                            if (via_dup[u]) { r += s_dup[c * WINP + e]; s_dup[c * WINP + e] = 0.f; }
+                            if (c < nc && r != 0.f && !WARP_DBG(4)) atomicAdd(dp + (size_t)(c0 + c) * plane + coff[u], r);
+                        }
+                    }
+                };
+                const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+                if (wave == 0) cells(std::integral_constant<int, 0>{});
+                else if (wave == 1) cells(std::integral_constant<int, 1>{});
+                else if (wave == 2) cells(std::integral_constant<int, 2>{});
+                else cells(std::integral_constant<int, 3>{});
+            }
+            __syncthreads();                                  // s_src / s_g / s_dup may be overwritten
+        }
+    }
+    const float mx = ac ? (float)(W - 1) * 0.5f : (float)W * 0.5f;
+    const float my = ac ? (float)(H - 1) * 0.5f : (float)H * 0.5f;
+    const float dx = (float)(W > 1 ? W - 1 : 1), dy = (float)(H > 1 ? H - 1 : 1);
+    float* gf = gflow + (size_t)b * 2 * plane;
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        if (!k.live[q]) continue;
+        const float vx = (gix[q] * mx) / dx * 2.0f, vy = (giy[q] * my) / dy * 2.0f;
+        if (SPLIT) { atomicAdd(gf + k.pix[q], vx); atomicAdd(gf + plane + k.pix[q], vy); }
+        else { gf[k.pix[q]] = vx; gf[plane + k.pix[q]] = vy; }
+    }
+}
+
 // Tile geometry for an H x W map with C channels: tiles as wide as the map allows up to 64 (52 for the 13 * 2^k wide
 // KITTI levels: no dead lanes), channel groups so that the launch has >= ~1024 workgroups.
 struct TilePlan { int TW, TH, tiles_x, tiles_y, groups, cpg; };
@@ -634,10 +865,11 @@ extern "C" int unflow_warp_bwd(const float* src, const float* flow, const float*
         dim3 tgrid(p.tiles_x * p.tiles_y * B, p.groups);
         const int vec_ok = ((W & 3) == 0 && (((size_t)src) & 15) == 0) ? 1 : 0;
         if (p.groups > 1) unflow_zero_async(gflow, (size_t)B * 2 * H * W, s);     // channel groups add their partials
-#define LAUNCH_T(PPT, WIN, SPLIT) hipLaunchKernelGGL((warp_bwd_tile_kernel<PPT, WIN, 4, SPLIT>), tgrid, dim3(256), 0, s, src, flow, \
+#define LAUNCH_T(KERNEL, PPT, WIN, SPLIT) hipLaunchKernelGGL((KERNEL<PPT, WIN, 4, SPLIT>), tgrid, dim3(256), 0, s, src, flow, \
                                                      gout, gsrc, gflow, C, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y, p.cpg, vec_ok, wenv("UNFLOW_WARP_DEBUG", 0))
-#define LAUNCH_S(PPT, WIN) do { if (p.groups > 1) LAUNCH_T(PPT, WIN, true); else LAUNCH_T(PPT, WIN, false); } while (0)
-        LAUNCH_S(2, 1024);                                      // (4 px per lane would need 256 VGPRs: one wave per SIMD)
+#define LAUNCH_S(KERNEL, PPT, WIN) do { if (p.groups > 1) LAUNCH_T(KERNEL, PPT, WIN, true); else LAUNCH_T(KERNEL, PPT, WIN, false); } while (0)
+        if (wenv("UNFLOW_WARP_BWD", 1) == 0) LAUNCH_S(warp_bwd_tile_kernel, 2, 1024);     // tuning builds: the LDS-accumulator form
+        else LAUNCH_S(warp_bwd_cell_kernel, 2, 1024);           // (4 px per lane would need 256 VGPRs: one wave per SIMD)
 #undef LAUNCH_S
 #undef LAUNCH_T
         return unflow_launch_status();
