@@ -61,6 +61,7 @@ def parse():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'], help='conv-stack precision (bf16: BASELINE config 3; the headline metric is fp32)')
     ap.add_argument('--graph', type=int, default=0, help='1: replay the step as a hipGraph (kernel timing events are then off)')
+    ap.add_argument('--channels-last', type=int, default=-1, help='memory format of the conv stacks: 1 channels_last (NHWC), 0 NCHW; default: 1 for fp32, 0 for bf16 (cfg.channels_last)')
     ap.add_argument('--fused', type=int, default=0, help='1: warp + cost volume of each decoder level as one kernel (cfg.fused_warp_corr)')
     ap.add_argument('--force-ddp', action='store_true', help='N = 1 only: run the step through the RCCL data-parallel path with a one-rank communicator')
     return ap.parse_args()
@@ -169,7 +170,8 @@ def main():
 
     cfg = types.SimpleNamespace(mode='flow', dataset='kitti_depth', num_scales=3, h_flow_consist_alpha=3.0,
                                 h_flow_consist_beta=0.05, w_ssim=0.85, w_flow_smooth=10.0, w_flow_consis=0.01,
-                                lr=1e-4, align_corners=False, precision=args.precision, fused_warp_corr=bool(args.fused))
+                                lr=1e-4, align_corners=False, precision=args.precision, fused_warp_corr=bool(args.fused),
+                                channels_last=(args.precision == 'fp32') if args.channels_last < 0 else bool(args.channels_last))
     torch.manual_seed(1234)                       # same random init on every rank
     if os.environ.get('UNFLOW_MIOPEN_FIND', '1') == '1':
         from unopticalflow_amd.tuning import enable_miopen_tuning
@@ -284,6 +286,7 @@ def main():
                                    'fwd+bwd+Adam (BASELINE configs[%d])' % (fw, fh, args.batch, args.precision,
                                                                             (1 if args.precision == 'fp32' else 2) if (fh, fw) == (H, W) else 3),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
+                       'conv_memory_format': 'channels_last' if cfg.channels_last else 'NCHW',
                        'triplets_per_s': round(pairs / 2 / dt, 2)},
             'roofline': roof, 'cpu_baseline': base,
             # whole-step lower bound on the conv stacks' MFMA utilisation: conv FLOPs / (entire step time);

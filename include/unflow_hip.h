@@ -155,6 +155,16 @@ int unflow_bias_leaky_bwd2(const float* y, const float* gout, long long gout_str
                            long long gout2_stride, float* gin, float* gbias, float* partials,
                            int N, int C, int H, int W, float slope, void* stream);
 
+/* Channels-last twins (the fp32 conv stacks run in torch.channels_last: MIOpen's implicit-GEMM solvers are NHWC
+ * kernels and need no transposes then): y / gin dense [P][C], P = N*H*W pixels, C a multiple of 4 (<= 1024);
+ * gout / gout2 may be channel slices of wider NHWC tensors -- pixel stride in elements (>= C, multiple of 4).
+ * Same arithmetic and the same fixed-order bias-gradient reduction as the NCHW entries. */
+int unflow_bias_leaky_fwd_nhwc(float* y, const float* bias, long long P, int C, float slope, void* stream);
+int unflow_bias_leaky_partials_nhwc(long long P, int C);
+int unflow_bias_leaky_bwd2_nhwc(const float* y, const float* gout, long long gout_pstride, const float* gout2,
+                                long long gout2_pstride, float* gin, float* gbias, float* partials,
+                                long long P, int C, float slope, void* stream);
+
 /* bf16 activations (the bf16 conv-stack option: torch.autocast around the reference's conv() blocks): y, gout,
  * gout2, gin are bf16 (raw uint16_t), bias / gbias / partials fp32; arithmetic in fp32, one round-to-nearest-even
  * per element; gbias sums the rounded gin values.  Same scratch size (unflow_bias_leaky_partials). */

@@ -57,7 +57,7 @@ def _worker(rank, world, port, steps, out_path):
     assert trainer.grads.overlap and early == [trainer.grads.chunks] * steps, early   # all pieces sent by the hooks
     trainer.grads.check_views()
     if rank == 0:
-        torch.save({'grad': trainer.grads.flat.clone(), 'params': [p.detach().clone() for p in model.parameters()],
+        torch.save({'grad': trainer.grads.vector(), 'params': [p.detach().clone() for p in model.parameters()],
                     'loss': loss}, out_path)
     dist.barrier()
     dist.destroy_process_group()
@@ -76,7 +76,7 @@ def test_two_ranks_match_single_process(tmp_path, steps):
     x = R.synthetic_triplets(2 * world, H, W, seed=5, structured=True)
     for _ in range(steps):
         trainer.step(x)
-    g_ref = trainer.grads.flat
+    g_ref = trainer.grads.vector()
     scale = g_ref.abs().max().item()
     np.testing.assert_allclose(got['grad'].numpy(), g_ref.numpy(), rtol=1e-4, atol=1e-5 * scale)
     for a, b in zip(got['params'], model.parameters()):

@@ -242,7 +242,7 @@ def test_bf16_step_at_kitti_size():
         pack = model(x)
         tr.total_loss(pack).backward()
         assert all(torch.isfinite(p.grad).all() for p in model.parameters())
-        norms[prec] = float(tr.grads.flat.double().norm())
+        norms[prec] = float(tr.grads.vector().double().norm())
         packs[prec] = {k: v.detach().float().cpu() for k, v in pack.items()}
         tr.optimizer.step()
         assert all(torch.isfinite(p).all() for p in model.parameters())
@@ -277,7 +277,7 @@ def _gpu_rank(rank, world, port, out_path):
         early = trainer.grads.launched_early
         trainer.grads.all_reduce_mean()
         if first is None:
-            first = trainer.grads.flat.cpu()
+            first = trainer.grads.vector().cpu()
         trainer.optimizer.step()
     torch.cuda.synchronize()
     if rank == 0:
@@ -305,7 +305,7 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     trainer = FlowTrainer(cfg, model, distributed=False)
     x = R.synthetic_triplets(4, 64, 128, seed=5, structured=True).cuda()
     trainer.step(x)
-    g_ref = trainer.grads.flat.cpu()                          # gradients of the first step (same weights on both sides)
+    g_ref = trainer.grads.vector().cpu()                          # gradients of the first step (same weights on both sides)
     trainer.step(x)
     np.testing.assert_allclose(got['grad'].numpy(), g_ref.numpy(), rtol=2e-3, atol=2e-4 * g_ref.abs().max().item())
     for a, b in zip(got['params'], model.parameters()):
@@ -340,7 +340,7 @@ def _rccl_single_rank(rank, port, out_path):
             early.append(tr.grads.launched_early)
             tr.grads.all_reduce_mean()
             if first is None:
-                first = tr.grads.flat.cpu()                # gradients of the first step: same weights on both sides
+                first = tr.grads.vector().cpu()                # gradients of the first step: same weights on both sides
             tr.optimizer.step()
             losses.append(float(loss.detach()))
         torch.cuda.synchronize()

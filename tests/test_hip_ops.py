@@ -512,6 +512,35 @@ def test_bias_leaky_two_consumers(ops, shape):
     close(yg2.grad, yc2.grad, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize('shape', [(16, 128, 64, 208), (4, 32, 16, 52), (2, 96, 7, 9), (3, 196, 4, 13), (1, 16, 5, 6), (2, 8, 1, 1)])
+def test_bias_leaky_channels_last(ops, shape):
+    """The same epilogue on channels_last (NHWC) activations -- what the fp32 conv stacks produce: forward bit-equal,
+    backward with one dense gradient and one channel slice of a channels_last cat gradient added in the kernel."""
+    N, C, H, W = shape
+    CL = torch.channels_last
+    y0, bias, other = rnd(81, shape), rnd(82, (C,), 0.3), rnd(83, (N, 4, H, W))
+    wa, wb = rnd(84, shape), rnd(85, (N, C + 4, H, W))
+
+    def graph(act_a, act_b, oth):
+        return (act_a * wa.to(act_a.device)).sum() + (torch.cat((oth, act_b), 1) * wb.to(act_a.device)).sum()
+    yc, bc = y0.clone().requires_grad_(), bias.clone().requires_grad_()
+    ref = torch.nn.functional.leaky_relu(yc + bc.view(1, C, 1, 1), 0.1)
+    graph(ref, ref, other).backward()
+    yg, bg = y0.cuda().contiguous(memory_format=CL).requires_grad_(), bias.cuda().requires_grad_()
+    a, b = ops.bias_leaky_relu_(yg * 1.0, bg, 0.1, consumers=2)
+    assert a.data_ptr() == b.data_ptr() and a.stride() == yg.stride() and torch.equal(a.cpu(), ref.detach())
+    graph(a, b, other.cuda().contiguous(memory_format=CL)).backward()
+    close(yg.grad, yc.grad, rtol=1e-6, atol=1e-6)
+    close(bg.grad, bc.grad, rtol=1e-4, atol=1e-4 * bc.grad.abs().max().item())
+    # a gradient that arrives in NCHW order (a consumer outside the channels_last island) is re-laid out first
+    yg2, bg2 = y0.cuda().contiguous(memory_format=CL).requires_grad_(), bias.cuda().requires_grad_()
+    out = ops.bias_leaky_relu_(yg2 * 1.0, bg2, 0.1)
+    out.backward(wa.cuda())
+    yc2 = y0.clone().requires_grad_()
+    torch.nn.functional.leaky_relu(yc2 + bias.view(1, C, 1, 1), 0.1).backward(wa)
+    assert torch.equal(yg2.grad.cpu(), yc2.grad)
+
+
 @pytest.mark.parametrize('shape', [(16, 128, 64, 208), (2, 5, 7, 9), (3, 8, 4, 4), (2, 16, 8, 26)])
 def test_bias_leaky_bf16(ops, shape):
     """bf16 conv-stack option: same epilogue on bf16 activations -- fp32 arithmetic, one rounding per element."""

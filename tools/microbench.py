@@ -282,6 +282,24 @@ def stamps(B=16):
             _stamp_report('%s %s' % (lvl, kind), buf, bwd_names if kind == 'bwd' else fwd_names)
 
 
+def epilogue(B=16):
+    """conv() epilogue (bias + LeakyReLU, in place) and its backward on NCHW and channels_last activations."""
+    for (C, h, w, n) in ((128, 64, 208, B), (32, 64, 208, B), (96, 16, 52, B), (16, 128, 416, 24)):
+        for cl in (False, True):
+            y = torch.randn(n, C, h, w, device='cuda')
+            g = torch.randn(n, C, h, w, device='cuda')
+            if cl:
+                y, g = y.contiguous(memory_format=torch.channels_last), g.contiguous(memory_format=torch.channels_last)
+            bias = torch.randn(C, device='cuda', requires_grad=True)
+            tf = timeit(lambda: ops.bias_leaky_relu_(y, bias.detach(), 0.1))
+            yy = y.clone().requires_grad_()
+            out = ops.bias_leaky_relu_(yy * 1.0, bias, 0.1)
+            tb = timeit(lambda: torch.autograd.grad(out, (yy, bias), g, retain_graph=True))
+            nb = y.numel() * 4
+            print('epilogue [%d,%d,%d,%d] %-13s fwd %6.1f us (%5.0f GB/s)   bwd (incl. the x*1.0 node) %6.1f us (%5.0f GB/s)' % (
+                n, C, h, w, 'channels_last' if cl else 'NCHW', tf, 2 * nb / tf / 1e3, tb, 3 * nb / tb / 1e3), flush=True)
+
+
 def losses(B=8):
     for s in range(3):
         h, w = 256 >> s, 832 >> s

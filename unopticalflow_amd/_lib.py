@@ -40,6 +40,9 @@ SIGNATURES = {
     'unflow_bias_leaky_partials': [_I, _I, _I, _I],
     'unflow_bias_leaky_bwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, _P],
     'unflow_bias_leaky_bwd2': [_P, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, _P],
+    'unflow_bias_leaky_fwd_nhwc': [_P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P],
+    'unflow_bias_leaky_partials_nhwc': [ctypes.c_longlong, _I],
+    'unflow_bias_leaky_bwd2_nhwc': [_P, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P],
     'unflow_bias_leaky_fwd_bf16': [_P, _P, _I, _I, _I, _I, ctypes.c_float, _P],
     'unflow_bias_leaky_bwd2_bf16': [_P, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, _P],
     'unflow_img_pyramid': [_P, _P, _P, _I, _I, _I, _P],
@@ -47,7 +50,7 @@ SIGNATURES = {
     'unflow_png_unfilter': [_P, _I, _I, _I],
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 

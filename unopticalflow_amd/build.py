@@ -54,7 +54,7 @@ def _compile(hipcc, src, obj, extra, verbose):
 def build(force=False, verbose=True, tuning=False):
     """Returns the path of the (re)built library."""
     lib = LIB_TUNING if tuning else LIB
-    extra = ('-DUNFLOW_TUNING',) if tuning else ()
+    extra = ('-DUNFLOW_TUNING',) + tuple(os.environ.get('UNFLOW_TUNING_EXTRA_FLAGS', '').split()) if tuning else ()
     objdir = os.path.join(PKG, '_obj_tuning' if tuning else '_obj')
     os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')

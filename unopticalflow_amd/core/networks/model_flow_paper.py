@@ -19,7 +19,8 @@ class Model_flow(nn.Module):
       * the 1/8-scale image warp the reference computes and discards
         (model_flow_paper.py:62-66 with num_scales=3) is not computed.
     ``cfg.align_corners`` (optional, default False) selects the grid_sample generation;
-    ``cfg.precision`` (optional, 'fp32' | 'bf16') the conv-stack precision.
+    ``cfg.precision`` (optional, 'fp32' | 'bf16') the conv-stack precision; ``cfg.channels_last`` (optional, default:
+    True for fp32) the memory format of the conv stacks' activations and weights.
     """
 
     def __init__(self, cfg):
@@ -30,8 +31,14 @@ class Model_flow(nn.Module):
         self.precision = getattr(cfg, 'precision', 'fp32')
         if self.precision not in ('fp32', 'bf16'):
             raise ValueError('precision must be fp32 or bf16, got {}'.format(self.precision))
-        self.fpyramid = FeaturePyramid()
-        self.pwc_model = PWC_tf(align_corners=self.align_corners, fused_warp_corr=bool(getattr(cfg, 'fused_warp_corr', False)))
+        # fp32 conv stacks run on channels_last tensors (NHWC: no MIOpen transposes); the bf16 option keeps NCHW
+        cl = getattr(cfg, 'channels_last', None)
+        self.channels_last = (self.precision == 'fp32') if cl is None else bool(cl)
+        if self.channels_last and self.precision != 'fp32':
+            raise ValueError('channels_last conv stacks are fp32 only (the bf16 epilogue kernels are NCHW)')
+        self.fpyramid = FeaturePyramid(channels_last=self.channels_last)
+        self.pwc_model = PWC_tf(align_corners=self.align_corners, fused_warp_corr=bool(getattr(cfg, 'fused_warp_corr', False)),
+                                channels_last=self.channels_last)
         if cfg.mode == 'depth' or cfg.mode == 'flowposenet':
             # Stage 2 training
             for param in self.fpyramid.parameters():

@@ -1,6 +1,7 @@
+import torch
 import torch.nn as nn
 
-from .net_utils import conv
+from .net_utils import conv, weights_to_channels_last, CL
 
 _CHANNELS = (16, 32, 64, 96, 128, 196)
 
@@ -9,21 +10,29 @@ class FeaturePyramid(nn.Module):
     """Six (stride-2, stride-1) conv pairs; returns the six stride-1 outputs
     (reference feature_pyramid.py:8-36).  Module names conv1..conv12 fix the checkpoint keys."""
 
-    def __init__(self):
+    def __init__(self, channels_last=False):
+        """``channels_last``: run the twelve convolutions on channels_last (NHWC) tensors -- MIOpen's implicit-GEMM
+        solvers are NHWC kernels and need no transposes then -- and hand the features out as plain NCHW tensors (what
+        the cost volume / warp kernels and the decoder's cat read)."""
         super(FeaturePyramid, self).__init__()
+        self.channels_last = bool(channels_last)
         cin = 3
         for lvl, cout in enumerate(_CHANNELS):
             self.add_module('conv%d' % (2 * lvl + 1), conv(cin, cout, kernel_size=3, stride=2))
             self.add_module('conv%d' % (2 * lvl + 2), conv(cout, cout, kernel_size=3, stride=1))
             cin = cout
+        if self.channels_last:
+            weights_to_channels_last(self)
 
     def forward(self, img):
-        outs, t, last = [], img, len(_CHANNELS) - 1
+        cl = self.channels_last and img.is_cuda and img.dtype == torch.float32 and not torch.is_autocast_enabled()
+        outs, t, last = [], (img.contiguous(memory_format=CL) if cl else img), len(_CHANNELS) - 1
         for lvl in range(len(_CHANNELS)):
             t = getattr(self, 'conv%d' % (2 * lvl + 1))(t)
             if lvl < last:      # two consumers (the next level and the caller): one handle each, see ConvLeaky
                 t, out = getattr(self, 'conv%d' % (2 * lvl + 2))(t, 2)
             else:
                 t = out = getattr(self, 'conv%d' % (2 * lvl + 2))(t)
-            outs.append(out)
+            # level 1 is never read by the decoder (pwc_tf.py:108-179): it stays as it is
+            outs.append(out.contiguous() if (cl and lvl > 0) else out)
         return tuple(outs)

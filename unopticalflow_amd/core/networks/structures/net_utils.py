@@ -20,6 +20,19 @@ class ConvLeaky(nn.Sequential):
         return ops.bias_leaky_relu_(y, c.bias, self[1].negative_slope, consumers)
 
 
+CL = torch.channels_last
+
+
+def weights_to_channels_last(module):
+    """Store every 4-d convolution weight of ``module`` in channels_last order (same shape, same state-dict keys and
+    values; ``load_state_dict`` copies into it whatever the source layout).  With channels_last activations MIOpen is
+    called with NHWC tensors and would otherwise re-lay the weight out on every call."""
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            m.weight.data = m.weight.data.contiguous(memory_format=CL)
+    return module
+
+
 def conv(in_planes, out_planes, kernel_size=3, stride=1, padding=1, dilation=1):
     """Conv2d(bias) + LeakyReLU(0.1) (reference net_utils.py:7-11)."""
     return ConvLeaky(

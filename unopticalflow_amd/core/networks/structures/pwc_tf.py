@@ -3,7 +3,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .... import ops
-from .net_utils import conv, warp_flow
+from .net_utils import conv, warp_flow, weights_to_channels_last, CL
 
 _DD = (128, 128, 96, 64, 32)                       # decoder widths (reference pwc_tf.py:25)
 _FEAT = {6: 0, 5: 128, 4: 96, 3: 64, 2: 32}        # channels of the pyramid level fed to each decoder
@@ -17,8 +17,13 @@ class PWC_tf(nn.Module):
     reference checkpoint.
     """
 
-    def __init__(self, md=4, align_corners=False, fused_warp_corr=False):
+    def __init__(self, md=4, align_corners=False, fused_warp_corr=False, channels_last=False):
         super(PWC_tf, self).__init__()
+        # True: the decoder and context convolutions run on channels_last (NHWC) tensors (MIOpen's implicit-GEMM
+        # solvers are NHWC kernels; on NCHW tensors each call is wrapped in transposes).  Cost volume, warp, flows and
+        # everything outside this module stay NCHW: the decoder input is re-laid out once per level, the 2-channel
+        # flows once on the way out.
+        self.channels_last = bool(channels_last)
         self.corr = self.corr_naive
         # True: warp + cost volume of a level as ONE kernel (ops.warp_corr; the warped features never reach HBM).
         # Measured on MI355X (profiles/r2_fused_warp_corr.txt): at parity with the two separate kernels at level 2 and
@@ -38,6 +43,11 @@ class PWC_tf(nn.Module):
         for k, (cin, cout, dil) in enumerate(ctx):
             self.add_module('dc_conv%d' % (k + 1), conv(cin, cout, kernel_size=3, stride=1, padding=dil, dilation=dil))
         self.dc_conv7 = self.predict_flow(32)
+        if self.channels_last:
+            weights_to_channels_last(self)
+
+    def _cl(self, x):
+        return self.channels_last and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
 
     def predict_flow(self, in_planes):
         return nn.Conv2d(in_planes, 2, kernel_size=3, stride=1, padding=1, bias=True)
@@ -55,6 +65,8 @@ class PWC_tf(nn.Module):
         consumers; it is taken as two handles (ConvLeaky(consumers=2)) so the gradients are summed inside
         the epilogue's backward kernel."""
         c = [getattr(self, 'conv%d_%d' % (lvl, k)) for k in range(5)]
+        if self._cl(x):
+            x = x.contiguous(memory_format=CL)
         x0, x0b = c[0](x, 2)
         x1, x1b = c[1](x0, 2)
         x2, x2b = c[2](torch.cat((x0b, x1), 1), 2)
@@ -63,7 +75,7 @@ class PWC_tf(nn.Module):
             x4, x4b = c[4](torch.cat((x2b, x3), 1), 2)
         else:
             x4 = x4b = c[4](torch.cat((x2b, x3), 1))
-        return getattr(self, 'predict_flow%d' % lvl)(torch.cat((x3b, x4), 1)).float(), x4b
+        return getattr(self, 'predict_flow%d' % lvl)(torch.cat((x3b, x4), 1)).float().contiguous(), x4b
 
     def forward(self, feature_list_1, feature_list_2, img_hw):
         f1 = dict(zip(range(1, 7), feature_list_1))
@@ -79,8 +91,9 @@ class PWC_tf(nn.Module):
             flow, x4 = self._decoder(lvl, torch.cat((cv, f1[lvl], up), 1))
             flow = flow + up
             level_flow[lvl] = flow
-        x = self.dc_conv4(self.dc_conv3(self.dc_conv2(self.dc_conv1(torch.cat([level_flow[2], x4], 1)))))
-        level_flow[2] = level_flow[2] + self.dc_conv7(self.dc_conv6(self.dc_conv5(x))).float()
+        fl2 = level_flow[2].contiguous(memory_format=CL) if self._cl(x4) else level_flow[2]
+        x = self.dc_conv4(self.dc_conv3(self.dc_conv2(self.dc_conv1(torch.cat([fl2, x4], 1)))))
+        level_flow[2] = level_flow[2] + self.dc_conv7(self.dc_conv6(self.dc_conv5(x))).float().contiguous()
         img_h, img_w = img_hw[0], img_hw[1]
         return [F.interpolate(level_flow[lvl] * 4.0, [img_h // (1 << k), img_w // (1 << k)], mode='bilinear')
                 for k, lvl in enumerate((2, 3, 4, 5))]

@@ -714,8 +714,13 @@ struct GsStep {
             constexpr int c = ST / 3, i = ST % 3, rb = ST % (PF + 1);
 #pragma unroll
             for (int k = 0; k < R; ++k) {
+#ifdef UNFLOW_NO_PK_BWD      // experiment (tools/): the same accumulators with scalar FMAs
+                acc[c][0].x = fmaf(w.p0[i][k].x, row[rb][k].x, acc[c][0].x); acc[c][0].y = fmaf(w.p0[i][k].y, row[rb][k].y, acc[c][0].y);
+                acc[c][1].x = fmaf(w.p1[i][k].x, row[rb][k + 1].x, acc[c][1].x); acc[c][1].y = fmaf(w.p1[i][k].y, row[rb][k + 1].y, acc[c][1].y);
+#else
                 acc[c][0] = __builtin_elementwise_fma(w.p0[i][k], row[rb][k], acc[c][0]);
                 acc[c][1] = __builtin_elementwise_fma(w.p1[i][k], row[rb][k + 1], acc[c][1]);
+#endif
             }
             acc[c][0].x = fmaf(w.s0[i], row[rb][R].x, acc[c][0].x);
             acc[c][1].y = fmaf(w.s1[i], row[rb][0].y, acc[c][1].y);

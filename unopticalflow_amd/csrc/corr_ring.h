@@ -66,9 +66,12 @@ __device__ __forceinline__ void own_reads(v2f (&a)[CC], unsigned addr, std::inte
 // pixel x + 1's (1,2)(3,4).. makes BOTH walk the same aligned pairs, with the own-pixel value broadcast:
 //   p0[i][k]   = (cv[i][2k],   cv[i][2k+1]) of pixel x      += a.x * row[k]       k = 0 .. R-1;   s0[i] = cv[i][2R]  += a.x * row[R].x
 //   p1[i][k-1] = (cv[i][2k-1], cv[i][2k])   of pixel x + 1  += a.y * row[k]       k = 1 .. R;     s1[i] = cv[i][0]   += a.y * row[0].y
-// = 2R v_pk_fma_f32 + 2 v_fma_f32 per row-step instead of 2 (2R + 1) v_fma_f32, no register moves.  At two waves per
-// SIMD a wave issues one VALU instruction every ~5 cycles whatever it is (tools/probes/valu_rate.hip), so instruction
-// count, not FLOPs, is what the row pipeline pays for.
+// = 2R v_pk_fma_f32 + 2 v_fma_f32 per row-step instead of 2 (2R + 1) v_fma_f32, no register moves.
+// MEASURED: the packed form wins in isolation (level 2: 35.8 -> 34.3 us back-to-back launches) and LOSES inside the
+// train step (41.8 vs 36.3 us between MIOpen's MFMA kernels, tools/gpu_r2_j.sh) -- v_pk_fma_f32 draws more power and
+// the clock it gets there is lower (tools/probes/valu_rate.hip: same tick count, 1.65x the wall time) -- so the forward
+// row pipeline ships with scalar FMAs on this accumulator layout (-DUNFLOW_PK_FWD builds the packed form); the
+// backward kernel, with a third of the accumulators and three waves per SIMD, keeps the packed form (93.1 vs 94.7 us).
 template <int DG, int R>
 struct FwdAcc {
     v2f p0[DG][R];
@@ -127,8 +130,13 @@ struct FwdStep {
             const v2f ax = v2f{a[c].x, a[c].x}, ay = v2f{a[c].y, a[c].y};
 #pragma unroll
             for (int k = 0; k < R; ++k) {
+#ifdef UNFLOW_PK_FWD         // experiment (tools/, UNFLOW_TUNING_EXTRA_FLAGS): packed FMAs on the same accumulators
                 acc.p0[i][k] = __builtin_elementwise_fma(ax, row[rb][k], acc.p0[i][k]);
                 acc.p1[i][k] = __builtin_elementwise_fma(ay, row[rb][k + 1], acc.p1[i][k]);
+#else
+                acc.p0[i][k].x = fmaf(a[c].x, row[rb][k].x, acc.p0[i][k].x); acc.p0[i][k].y = fmaf(a[c].x, row[rb][k].y, acc.p0[i][k].y);
+                acc.p1[i][k].x = fmaf(a[c].y, row[rb][k + 1].x, acc.p1[i][k].x); acc.p1[i][k].y = fmaf(a[c].y, row[rb][k + 1].y, acc.p1[i][k].y);
+#endif
             }
             acc.s0[i] = fmaf(a[c].x, row[rb][R].x, acc.s0[i]);
             acc.s1[i] = fmaf(a[c].y, row[rb][0].y, acc.s1[i]);

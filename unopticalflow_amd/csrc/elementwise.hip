@@ -95,6 +95,91 @@ __global__ void bias_grad_finalize_kernel(const float* __restrict__ partials, in
     if (threadIdx.x == 0) gbias[c] = s;
 }
 
+
+// ---- channels-last (NHWC) twins: the conv stacks run in channels_last (MIOpen's implicit-GEMM solvers are NHWC
+// kernels; on NCHW tensors each of them is wrapped in batched_transpose launches, 2.2 ms of a 26 ms step), so their
+// epilogue has to work on [P = N*H*W pixels][C] too.  A workgroup = QUADS channel quads x ROWS pixel rows
+// (QUADS = C/4, ROWS = 256 / QUADS): a thread keeps ONE channel quad (its bias / its bias-gradient sum stay in
+// registers) and walks pixels; consecutive threads read consecutive 16-byte pieces.
+constexpr int NHWC_PIX = 128;      // pixels per workgroup
+constexpr int NHWC_UNROLL = 4;     // pixels in flight per thread
+
+__device__ __forceinline__ float4 leaky4(float4 v, float slope) {
+    v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+    v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void bias_leaky_fwd_nhwc_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                                  long long P, int C, int rows, float slope) {
+    const int quads = C >> 2;
+    const int q = threadIdx.x % quads, r = threadIdx.x / quads;
+    if (r >= rows) return;
+    const float4 b = *reinterpret_cast<const float4*>(bias + q * 4);
+    const long long p0 = (long long)blockIdx.x * NHWC_PIX, p1 = min(p0 + NHWC_PIX, P);
+    for (long long p = p0 + r; p < p1; p += (long long)rows * NHWC_UNROLL) {
+        float4 v[NHWC_UNROLL];
+#pragma unroll
+        for (int u = 0; u < NHWC_UNROLL; ++u)
+            if (p + (long long)u * rows < p1) v[u] = reinterpret_cast<const float4*>(y + (p + (long long)u * rows) * C)[q];
+#pragma unroll
+        for (int u = 0; u < NHWC_UNROLL; ++u)
+            if (p + (long long)u * rows < p1) {
+                float4 t = v[u];
+                t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
+                reinterpret_cast<float4*>(y + (p + (long long)u * rows) * C)[q] = leaky4(t, slope);
+            }
+    }
+}
+
+// gin[p][c] = (gout[p][c] [+ gout2[p][c]]) * (y > 0 ? 1 : slope); gout / gout2 may be channel slices of wider NHWC
+// tensors: pixel stride in elements.  partials[c * nblocks + block] = the workgroup's sum for channel c, rows added in
+// a fixed order (bitwise reproducible), finished by bias_grad_finalize_kernel.
+template <bool TWO>
+__global__ __launch_bounds__(256) void bias_leaky_bwd_nhwc_kernel(const float* __restrict__ y, const float* __restrict__ gout,
+                                                                  long long gps, const float* __restrict__ gout2, long long gps2,
+                                                                  float* __restrict__ gin, float* __restrict__ partials,
+                                                                  long long P, int C, int rows, float slope) {
+    extern __shared__ float red[];                 // [rows][C]
+    const int quads = C >> 2;
+    const int q = threadIdx.x % quads, r = threadIdx.x / quads;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) {
+        const long long p0 = (long long)blockIdx.x * NHWC_PIX, p1 = min(p0 + NHWC_PIX, P);
+        for (long long p = p0 + r; p < p1; p += (long long)rows * NHWC_UNROLL) {
+            float4 v[NHWC_UNROLL], g[NHWC_UNROLL], h[NHWC_UNROLL];
+#pragma unroll
+            for (int u = 0; u < NHWC_UNROLL; ++u) {
+                const long long pp = p + (long long)u * rows;
+                if (pp < p1) {
+                    v[u] = reinterpret_cast<const float4*>(y + pp * C)[q];
+                    g[u] = reinterpret_cast<const float4*>(gout + pp * gps)[q];
+                    if (TWO) h[u] = reinterpret_cast<const float4*>(gout2 + pp * gps2)[q];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NHWC_UNROLL; ++u) {
+                const long long pp = p + (long long)u * rows;
+                if (pp < p1) {
+                    float4 t = g[u];
+                    if (TWO) { t.x += h[u].x; t.y += h[u].y; t.z += h[u].z; t.w += h[u].w; }
+                    t.x = v[u].x > 0.f ? t.x : t.x * slope; t.y = v[u].y > 0.f ? t.y : t.y * slope;
+                    t.z = v[u].z > 0.f ? t.z : t.z * slope; t.w = v[u].w > 0.f ? t.w : t.w * slope;
+                    reinterpret_cast<float4*>(gin + pp * C)[q] = t;
+                    acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(red + r * C + q * 4) = acc;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int k = 0; k < rows; ++k) s += red[k * C + c];
+        partials[(size_t)c * gridDim.x + blockIdx.x] = s;
+    }
+}
+
 // one lane = one 4x4 input block: 4 float4 row reads -> four 2x2 means and one 4x4 mean, summed in
 // ATen's adaptive_avg_pool2d order (row-major over the window, then * 1/count: exact for 4 and 16).
 __global__ void img_pyramid_kernel(const float* __restrict__ img, float* __restrict__ s1, float* __restrict__ s2,
@@ -161,6 +246,46 @@ extern "C" int unflow_bias_leaky_bwd2(const float* y, const float* gout, long lo
 extern "C" int unflow_bias_leaky_bwd(const float* y, const float* gout, float* gin, float* gbias, float* partials,
                                      int N, int C, int H, int W, float slope, void* stream) {
     return unflow_bias_leaky_bwd2(y, gout, (long long)C * H * W, nullptr, 0, gin, gbias, partials, N, C, H, W, slope, stream);
+}
+
+
+// channels-last twins: y / gin dense [P][C] (P = N*H*W), C a multiple of 4 and <= 1024
+static inline int nhwc_rows(int C) { const int r = 256 / (C >> 2); return r < 1 ? 1 : r; }
+
+extern "C" int unflow_bias_leaky_fwd_nhwc(float* y, const float* bias, long long P, int C, float slope, void* stream) {
+    UNFLOW_REQUIRE(y && bias && P > 0 && C >= 4 && (C & 3) == 0 && C <= 1024 && (((size_t)y | (size_t)bias) & 15) == 0);
+    const long long blocks = (P + NHWC_PIX - 1) / NHWC_PIX;
+    UNFLOW_REQUIRE(blocks < (1ll << 31));
+    hipLaunchKernelGGL(bias_leaky_fwd_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, bias, P, C,
+                       nhwc_rows(C), slope);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_bias_leaky_partials_nhwc(long long P, int C) {
+    if (P <= 0 || C <= 0) return UNFLOW_EINVAL;
+    const long long n = (P + NHWC_PIX - 1) / NHWC_PIX * C;
+    return n < (1ll << 31) ? (int)n : UNFLOW_EINVAL;
+}
+
+extern "C" int unflow_bias_leaky_bwd2_nhwc(const float* y, const float* gout, long long gout_pstride, const float* gout2,
+                                           long long gout2_pstride, float* gin, float* gbias, float* partials,
+                                           long long P, int C, float slope, void* stream) {
+    UNFLOW_REQUIRE(y && gout && gin && gbias && partials && P > 0 && C >= 4 && (C & 3) == 0 && C <= 1024);
+    UNFLOW_REQUIRE(gout_pstride >= C && (gout_pstride & 3) == 0 && (((size_t)gout | (size_t)y | (size_t)gin) & 15) == 0);
+    UNFLOW_REQUIRE(!gout2 || (gout2_pstride >= C && (gout2_pstride & 3) == 0 && ((size_t)gout2 & 15) == 0));
+    const long long blocks = (P + NHWC_PIX - 1) / NHWC_PIX;
+    UNFLOW_REQUIRE(blocks * C < (1ll << 31));
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = nhwc_rows(C);
+    const size_t shmem = (size_t)rows * C * sizeof(float);
+    if (gout2)
+        hipLaunchKernelGGL(bias_leaky_bwd_nhwc_kernel<true>, dim3((unsigned)blocks), dim3(256), shmem, s, y, gout, gout_pstride,
+                           gout2, gout2_pstride, gin, partials, P, C, rows, slope);
+    else
+        hipLaunchKernelGGL(bias_leaky_bwd_nhwc_kernel<false>, dim3((unsigned)blocks), dim3(256), shmem, s, y, gout, gout_pstride,
+                           gout2, gout2_pstride, gin, partials, P, C, rows, slope);
+    hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3(C), dim3(256), 0, s, partials, (int)blocks, gbias);
+    return unflow_launch_status();
 }
 
 extern "C" int unflow_img_pyramid(const float* img, float* half, float* quarter, int planes, int H, int W,

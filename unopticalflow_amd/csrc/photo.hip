@@ -295,7 +295,7 @@ inline int flat_blocks(size_t n) {
 
 int unflow_ssim_blocks(int H, int W);   // ssim.hip
 
-extern "C" int unflow_abi_version(void) { return 3; }   // 2: + unflow_warp_corr_*; 3: img_batch on the 2B loss entries
+extern "C" int unflow_abi_version(void) { return 4; }   // 2: + unflow_warp_corr_*; 3: img_batch on the 2B loss entries; 4: + *_nhwc epilogues
 
 extern "C" int unflow_partials_per_sample(int H, int W) {
     if (H <= 0 || W <= 0) return UNFLOW_EINVAL;

@@ -528,6 +528,26 @@ def _sample_strided(g, shape):
     return g, (st[0] if N > 1 else C * H * W)
 
 
+def _is_nhwc(t):
+    """Dense channels_last 4-d tensor that is not ALSO plain-contiguous (C == 1 or H == W == 1 are both)."""
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
+
+
+def _pixel_strided(g, shape):
+    """(tensor, pixel stride in elements) for a gradient in channels_last order whose C values of a pixel are dense --
+    a channels_last tensor or a channel slice of a wider one (a torch.cat operand's gradient); anything else is
+    converted first."""
+    N, C, H, W = shape
+    st = g.stride()
+    ps = st[3] if W > 1 else (st[2] if H > 1 else (st[0] if N > 1 else C))
+    ok = (st[1] == 1 and ps >= C and ps % 4 == 0 and g.data_ptr() % 16 == 0 and (W == 1 or st[3] == ps)
+          and (H == 1 or st[2] == W * ps) and (N == 1 or st[0] == H * W * ps))
+    if not ok:
+        g = g.contiguous(memory_format=torch.channels_last)
+        ps = C
+    return g, ps
+
+
 def _bias_leaky_backward(ctx, ga, gb):
     (y,) = ctx.saved_tensors
     N, C, H, W = y.shape
@@ -538,12 +558,24 @@ def _bias_leaky_backward(ctx, ga, gb):
     half = y.dtype == torch.bfloat16
     if ga.dtype != y.dtype or (gb is not None and gb.dtype != y.dtype):
         raise TypeError('gradient dtype %s does not match the activation (%s)' % (ga.dtype, y.dtype))
+    gin = torch.empty_like(y)                         # (keeps y's memory format)
+    gbias = torch.empty(C, dtype=torch.float32, device=y.device)
+    if ctx.nhwc:
+        ga, sa = _pixel_strided(ga, y.shape)
+        sb = 0
+        if gb is not None:
+            gb, sb = _pixel_strided(gb, y.shape)
+        P = N * H * W
+        part = torch.empty(_lib.load().unflow_bias_leaky_partials_nhwc(P, C), dtype=torch.float32, device=y.device)
+        with _on(y.device):
+            _call('unflow_bias_leaky_bwd2_nhwc', _ptr(y), _ptr(ga), sa, _ptr(gb), sb, _ptr(gin), _ptr(gbias), _ptr(part),
+                  P, C, ctypes.c_float(ctx.slope), _stream(),
+                  nbytes=(3 if gb is None else 4) * y.element_size() * N * C * H * W, shape=(N, C, H, W))
+        return gin, gbias, None
     ga, sa = _sample_strided(ga, y.shape)
     sb = 0
     if gb is not None:
         gb, sb = _sample_strided(gb, y.shape)
-    gin = torch.empty_like(y)
-    gbias = torch.empty(C, dtype=torch.float32, device=y.device)
     npart = _lib.load().unflow_bias_leaky_partials(N, C, H, W)
     part = torch.empty(npart, dtype=torch.float32, device=y.device)
     with _on(y.device):
@@ -558,15 +590,24 @@ def _bias_leaky_forward(ctx, y, bias, slope):
     _dev(None if half else y, bias)
     if half and (not y.is_cuda or y.device != bias.device):
         raise RuntimeError('bias_leaky_relu_: activation and bias must be on the same HIP device')
-    if not y.is_contiguous():
-        raise RuntimeError('bias_leaky_relu_ works in place on a contiguous NCHW convolution output')
     N, C, H, W = y.shape
-    with _on(y.device):
-        _call('unflow_bias_leaky_fwd_bf16' if half else 'unflow_bias_leaky_fwd', _ptr(y), _ptr(bias), N, C, H, W,
-              ctypes.c_float(slope), _stream(), nbytes=2 * y.element_size() * N * C * H * W, shape=(N, C, H, W))
+    nhwc = _is_nhwc(y)
+    if nhwc:
+        if half or C % 4:
+            raise RuntimeError('bias_leaky_relu_: the channels_last epilogue is fp32 with C %% 4 == 0 (got %s, C=%d)' % (y.dtype, C))
+        with _on(y.device):
+            _call('unflow_bias_leaky_fwd_nhwc', _ptr(y), _ptr(bias), N * H * W, C, ctypes.c_float(slope), _stream(),
+                  nbytes=2 * y.element_size() * N * C * H * W, shape=(N, C, H, W))
+    else:
+        if not y.is_contiguous():
+            raise RuntimeError('bias_leaky_relu_ works in place on a contiguous (NCHW or channels_last) convolution output')
+        with _on(y.device):
+            _call('unflow_bias_leaky_fwd_bf16' if half else 'unflow_bias_leaky_fwd', _ptr(y), _ptr(bias), N, C, H, W,
+                  ctypes.c_float(slope), _stream(), nbytes=2 * y.element_size() * N * C * H * W, shape=(N, C, H, W))
     ctx.mark_dirty(y)
     ctx.save_for_backward(y)
     ctx.slope = slope
+    ctx.nhwc = nhwc
     ctx.set_materialize_grads(False)
 
 

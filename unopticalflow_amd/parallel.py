@@ -64,7 +64,9 @@ class FlatGradients:
         off, offsets = 0, []
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            # a view with the PARAMETER's strides (channels_last convolution weights are dense but not row-major): the
+            # fused optimizer walks parameter, gradient and moments by memory offset, so their layouts must agree
+            p.grad = self.flat[off:off + n].as_strided(p.size(), p.stride())
             offsets.append(off)
             off += n
         self.group = group
@@ -124,6 +126,11 @@ class FlatGradients:
         self._works = [None] * self.chunks
         self.launched_early = 0
 
+    def vector(self):
+        """The gradients as one vector in LOGICAL element order, parameter by parameter (a copy).  ``flat`` itself is
+        in memory order, which differs for channels_last weights; compare runs with this."""
+        return torch.cat([p.grad.reshape(-1) for p in self.params])
+
     def check_views(self):
         """Guard against something (e.g. ``zero_grad(set_to_none=True)``) having detached a view."""
         base = self.flat.data_ptr()
@@ -175,10 +182,13 @@ class PlainGradients:
     def check_views(self):
         return None
 
+    def vector(self):
+        """The gradients as one vector in logical element order (a copy; diagnostics and tests)."""
+        return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params])
+
     @property
     def flat(self):
-        """The gradients as one vector (a copy; diagnostics and tests)."""
-        return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params])
+        return self.vector()
 
 
 def broadcast_parameters(module, src=0, group=None, single_rank=False):

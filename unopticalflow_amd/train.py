@@ -188,6 +188,7 @@ def main(argv=None):
     ap.add_argument('--align_corners', type=int, default=0, help='grid_sample generation: 0 torch>=1.3, 1 torch 1.2.0.')
     ap.add_argument('--num_iterations', type=int, default=None, help='override the yaml value.')
     ap.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'bf16'], help='conv-stack precision.')
+    ap.add_argument('--channels_last', type=int, default=None, help='memory format of the conv stacks (1 NHWC, 0 NCHW); default: 1 for fp32.')
     ap.add_argument('--miopen_find', type=int, default=1, help='1: use the shipped MIOpen find-db + benchmark mode.')
     ap.add_argument('--graph', type=int, default=0, help='1: replay the train step as a hipGraph.')
     ap.add_argument('--host_input', type=int, default=0, help='1: resize/flip/scale on the CPU workers (PIL) instead of the GPU.')
