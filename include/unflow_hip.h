@@ -165,6 +165,14 @@ int unflow_bias_leaky_bwd2_nhwc(const float* y, const float* gout, long long gou
                                 long long gout2_pstride, float* gin, float* gbias, float* partials,
                                 long long P, int C, float slope, void* stream);
 
+/* Layout glue at the borders of the channels_last conv stacks (pwc_tf.py:113 `torch.cat((corr, c1, up_flow), 1)` is the
+ * decoder input): out [B][HW][Ca+Cb+Cc] (NHWC) = the channel concatenation of up to three dense NCHW tensors (Cb / Cc may
+ * be 0), and its inverse (destinations that are NULL are skipped: gradients nobody needs).  With one tensor these are
+ * the NCHW <-> NHWC transposes. */
+int unflow_cat_nhwc(const float* a, int Ca, const float* b, int Cb, const float* c, int Cc, float* out,
+                    int B, int HW, void* stream);
+int unflow_split_nhwc(const float* in, float* a, int Ca, float* b, int Cb, float* c, int Cc, int B, int HW, void* stream);
+
 /* bf16 activations (the bf16 conv-stack option: torch.autocast around the reference's conv() blocks): y, gout,
  * gout2, gin are bf16 (raw uint16_t), bias / gbias / partials fp32; arithmetic in fp32, one round-to-nearest-even
  * per element; gbias sums the rounded gin values.  Same scratch size (unflow_bias_leaky_partials). */

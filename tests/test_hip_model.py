@@ -83,11 +83,13 @@ def test_module_128_golden(golden, ac):
             if ac == 0:
                 # full gradient tensors of the first pyramid layer (end of the whole backward chain), the widest level-2
                 # decoder layer (fed by cost volume + warp) and the last context layer: every element within 1e-3 of the
-                # tensor's largest gradient
+                # tensor's largest gradient.  (conv2_0: 2e-3 -- its weight gradient is an NHWC split-K implicit GEMM whose
+                # partial sums meet in fp32 atomics; run to run 0-0.03 % of its 132,480 elements land between 1.0e-3 and
+                # 1.25e-3 of the largest one)
                 named = dict(model.named_parameters())
-                for name in ('fpyramid.conv1.0.weight', 'pwc_model.conv2_0.0.weight', 'pwc_model.dc_conv7.weight'):
+                for name, tol in (('fpyramid.conv1.0.weight', 1e-3), ('pwc_model.conv2_0.0.weight', 2e-3), ('pwc_model.dc_conv7.weight', 1e-3)):
                     ref_g = g['gradfull_' + name + tag]
-                    close(named[name].grad, ref_g, rtol=0, atol=1e-3 * np.abs(ref_g).max(), what='grad ' + name)
+                    close(named[name].grad, ref_g, rtol=0, atol=tol * np.abs(ref_g).max(), what='grad ' + name)
         opt.step()
         # step 0 is pure forward parity (1e-4); later steps follow Adam updates, whose sign-normalised
         # steps amplify conv-rounding differences between MIOpen solvers and MKL-DNN (observed 4e-4)
@@ -364,7 +366,8 @@ def test_rccl_path_with_one_rank_matches_plain_step(tmp_path):
     res = torch.load(out)
     assert res['ddp']['early'] == [res['ddp']['chunks']] * 3          # every piece left from a hook during backward
     assert res['plain']['early'] == [0] * 3
-    np.testing.assert_allclose(res['ddp']['losses'], res['plain']['losses'], rtol=2e-4)
+    np.testing.assert_allclose(res['ddp']['losses'][:2], res['plain']['losses'][:2], rtol=2e-5)   # same weights, then one Adam step
+    np.testing.assert_allclose(res['ddp']['losses'], res['plain']['losses'], rtol=5e-4)           # third loss: two sign-normalised updates of run-dependent last bits
     g = res['plain']['grad']
     np.testing.assert_allclose(res['ddp']['grad'].numpy(), g.numpy(), rtol=2e-3, atol=2e-4 * g.abs().max().item())
     for a, b in zip(res['ddp']['params'], res['plain']['params']):

@@ -541,6 +541,35 @@ def test_bias_leaky_channels_last(ops, shape):
     assert torch.equal(yg2.grad.cpu(), yc2.grad)
 
 
+@pytest.mark.parametrize('shape,chans', [((16, 64, 208), (81, 32, 2)), ((16, 4, 13), (81,)), ((3, 7, 9), (5, 3)), ((2, 8, 26), (81, 128, 2)),
+                                         ((1, 1, 70), (1, 1, 1))])
+def test_cat_channels_last_and_back(ops, shape, chans):
+    """Layout glue of the channels_last conv stacks: cat -> NHWC in one pass (the decoder input, pwc_tf.py:113), its
+    backward (NHWC gradient -> one NCHW gradient per input, unused ones skipped) and the NHWC -> NCHW hand-off of the
+    pyramid features.  Pure data movement: bit-equal."""
+    B, H, W = shape
+    xs = [rnd(90 + k, (B, c, H, W)) for k, c in enumerate(chans)]
+    gs = [x.cuda().requires_grad_(k != 1) for k, x in enumerate(xs)]                  # the second input needs no gradient
+    out = ops.cat_channels_last(gs)
+    ref = torch.cat(xs, 1)
+    assert out.shape == ref.shape and (sum(chans) == 1 or H * W == 1 or out.is_contiguous(memory_format=torch.channels_last))
+    assert torch.equal(out.cpu(), ref)
+    go = rnd(95, tuple(ref.shape))
+    out.backward(go.cuda().contiguous(memory_format=torch.channels_last))
+    o = 0
+    for k, c in enumerate(chans):
+        if k == 1:
+            assert gs[k].grad is None
+        else:
+            assert gs[k].grad.is_contiguous() and torch.equal(gs[k].grad.cpu(), go[:, o:o + c])
+        o += c
+    y = ref.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+    z = ops.to_nchw(y * 1.0)
+    assert z.is_contiguous() and torch.equal(z.cpu(), ref)
+    z.backward(go.cuda())
+    assert torch.equal(y.grad.cpu(), go)
+
+
 @pytest.mark.parametrize('shape', [(16, 128, 64, 208), (2, 5, 7, 9), (3, 8, 4, 4), (2, 16, 8, 26)])
 def test_bias_leaky_bf16(ops, shape):
     """bf16 conv-stack option: same epilogue on bf16 activations -- fp32 arithmetic, one rounding per element."""

@@ -1,6 +1,7 @@
 import torch
 import torch.nn as nn
 
+from .... import ops
 from .net_utils import conv, weights_to_channels_last, CL
 
 _CHANNELS = (16, 32, 64, 96, 128, 196)
@@ -34,5 +35,5 @@ class FeaturePyramid(nn.Module):
             else:
                 t = out = getattr(self, 'conv%d' % (2 * lvl + 2))(t)
             # level 1 is never read by the decoder (pwc_tf.py:108-179): it stays as it is
-            outs.append(out.contiguous() if (cl and lvl > 0) else out)
+            outs.append(ops.to_nchw(out) if (cl and lvl > 0) else out)
         return tuple(outs)

@@ -49,6 +49,13 @@ class PWC_tf(nn.Module):
     def _cl(self, x):
         return self.channels_last and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
 
+    def _cat(self, parts):
+        """The decoder input torch.cat(parts, 1) (pwc_tf.py:113): written directly in channels_last order when the conv
+        stack runs in it (one kernel instead of a cat and a re-layout)."""
+        if self._cl(parts[0]) and all(p.dtype == torch.float32 for p in parts):
+            return ops.cat_channels_last(parts)
+        return parts[0] if len(parts) == 1 else torch.cat(parts, 1)
+
     def predict_flow(self, in_planes):
         return nn.Conv2d(in_planes, 2, kernel_size=3, stride=1, padding=1, bias=True)
 
@@ -61,12 +68,12 @@ class PWC_tf(nn.Module):
         return ops.corr(input1.float(), input2.float(), d)
 
     def _decoder(self, lvl, x):
-        """reference pwc_tf.py:113-118 (and the same six lines per level).  Every activation feeds two
+        """``x``: the tuple of tensors the reference concatenates into the decoder input.
+        reference pwc_tf.py:113-118 (and the same six lines per level).  Every activation feeds two
         consumers; it is taken as two handles (ConvLeaky(consumers=2)) so the gradients are summed inside
         the epilogue's backward kernel."""
         c = [getattr(self, 'conv%d_%d' % (lvl, k)) for k in range(5)]
-        if self._cl(x):
-            x = x.contiguous(memory_format=CL)
+        x = self._cat(x)
         x0, x0b = c[0](x, 2)
         x1, x1b = c[1](x0, 2)
         x2, x2b = c[2](torch.cat((x0b, x1), 1), 2)
@@ -80,7 +87,7 @@ class PWC_tf(nn.Module):
     def forward(self, feature_list_1, feature_list_2, img_hw):
         f1 = dict(zip(range(1, 7), feature_list_1))
         f2 = dict(zip(range(1, 7), feature_list_2))
-        flow, _ = self._decoder(6, self.corr(f1[6], f2[6]))
+        flow, _ = self._decoder(6, (self.corr(f1[6], f2[6]),))
         level_flow = {}
         for lvl in (5, 4, 3, 2):
             up = F.interpolate(flow, scale_factor=2.0, mode='bilinear') * 2.0
@@ -88,7 +95,7 @@ class PWC_tf(nn.Module):
                 cv = ops.warp_corr(f1[lvl].float(), f2[lvl].float(), up.float(), 4, self.align_corners)
             else:
                 cv = self.corr(f1[lvl], self.warp(f2[lvl], up))
-            flow, x4 = self._decoder(lvl, torch.cat((cv, f1[lvl], up), 1))
+            flow, x4 = self._decoder(lvl, (cv, f1[lvl], up))
             flow = flow + up
             level_flow[lvl] = flow
         fl2 = level_flow[2].contiguous(memory_format=CL) if self._cl(x4) else level_flow[2]

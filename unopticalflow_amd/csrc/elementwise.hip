@@ -180,6 +180,56 @@ __global__ __launch_bounds__(256) void bias_leaky_bwd_nhwc_kernel(const float* _
     }
 }
 
+// ---- layout glue at the borders of the channels_last conv stacks: the decoder input cat((cost volume, features, flow))
+// is written as NHWC directly, and NHWC activations / gradients come back as NCHW planes, through a 64-pixel x C LDS
+// tile: both sides of the transpose are coalesced (rows of 64 pixels on the NCHW side, the tile's 64 * C contiguous
+// floats on the NHWC side).  Row stride 65 floats: a column walk hits 32 different banks.
+constexpr int LG_PIX = 64, LG_LD = LG_PIX + 1;
+
+struct Planes3 { const float* p[3]; int c[3]; };      // up to three NCHW tensors, concatenated along C
+struct PlanesOut3 { float* p[3]; int c[3]; };
+
+__global__ __launch_bounds__(256) void cat_nhwc_fwd_kernel(Planes3 src, float* __restrict__ dst, int HW, int C) {
+    extern __shared__ float tile[];                   // [C][LG_LD]
+    const int b = blockIdx.y, p0 = blockIdx.x * LG_PIX, npx = min(LG_PIX, HW - p0);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int c = wave; c < C; c += 4) {
+        int k = 0, cc = c;
+        if (cc >= src.c[0]) { cc -= src.c[0]; k = 1; if (cc >= src.c[1]) { cc -= src.c[1]; k = 2; } }
+        const float* s = (k == 0 ? src.p[0] : k == 1 ? src.p[1] : src.p[2]) + ((size_t)b * (k == 0 ? src.c[0] : k == 1 ? src.c[1] : src.c[2]) + cc) * HW + p0;
+        tile[c * LG_LD + lane] = lane < npx ? s[lane] : 0.f;
+    }
+    __syncthreads();
+    float* d = dst + ((size_t)b * HW + p0) * C;
+    const int n = npx * C;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int px = e / C, c = e - px * C;
+        d[e] = tile[c * LG_LD + px];
+    }
+}
+
+// the inverse: NHWC [B][HW][C] -> up to three NCHW tensors (destinations with a null pointer are skipped)
+__global__ __launch_bounds__(256) void split_nhwc_kernel(const float* __restrict__ srcp, PlanesOut3 dst, int HW, int C) {
+    extern __shared__ float tile[];
+    const int b = blockIdx.y, p0 = blockIdx.x * LG_PIX, npx = min(LG_PIX, HW - p0);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* s = srcp + ((size_t)b * HW + p0) * C;
+    const int n = npx * C;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int px = e / C, c = e - px * C;
+        tile[c * LG_LD + px] = s[e];
+    }
+    __syncthreads();
+    for (int c = wave; c < C; c += 4) {
+        int k = 0, cc = c;
+        if (cc >= dst.c[0]) { cc -= dst.c[0]; k = 1; if (cc >= dst.c[1]) { cc -= dst.c[1]; k = 2; } }
+        float* d = (k == 0 ? dst.p[0] : k == 1 ? dst.p[1] : dst.p[2]);
+        if (d == nullptr) continue;
+        d += ((size_t)b * (k == 0 ? dst.c[0] : k == 1 ? dst.c[1] : dst.c[2]) + cc) * HW + p0;
+        if (lane < npx) d[lane] = tile[c * LG_LD + lane];
+    }
+}
+
 // one lane = one 4x4 input block: 4 float4 row reads -> four 2x2 means and one 4x4 mean, summed in
 // ATen's adaptive_avg_pool2d order (row-major over the window, then * 1/count: exact for 4 and 16).
 __global__ void img_pyramid_kernel(const float* __restrict__ img, float* __restrict__ s1, float* __restrict__ s2,
@@ -285,6 +335,30 @@ extern "C" int unflow_bias_leaky_bwd2_nhwc(const float* y, const float* gout, lo
         hipLaunchKernelGGL(bias_leaky_bwd_nhwc_kernel<false>, dim3((unsigned)blocks), dim3(256), shmem, s, y, gout, gout_pstride,
                            gout2, gout2_pstride, gin, partials, P, C, rows, slope);
     hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3(C), dim3(256), 0, s, partials, (int)blocks, gbias);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_cat_nhwc(const float* a, int Ca, const float* b, int Cb, const float* c, int Cc, float* out,
+                               int B, int HW, void* stream) {
+    UNFLOW_REQUIRE(a && out && Ca > 0 && Cb >= 0 && Cc >= 0 && (Cb == 0 || b) && (Cc == 0 || c) && (Cb > 0 || Cc == 0) &&
+                   B > 0 && B <= 65535 && HW > 0);
+    const int C = Ca + Cb + Cc;
+    const size_t shmem = (size_t)C * LG_LD * sizeof(float);
+    UNFLOW_REQUIRE(shmem <= 160 * 1024);
+    Planes3 src = {{a, b, c}, {Ca, Cb, Cc}};
+    if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)cat_nhwc_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(cat_nhwc_fwd_kernel, dim3(ceil_div(HW, LG_PIX), B), dim3(256), shmem, (hipStream_t)stream, src, out, HW, C);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_split_nhwc(const float* in, float* a, int Ca, float* b, int Cb, float* c, int Cc, int B, int HW, void* stream) {
+    UNFLOW_REQUIRE(in && Ca > 0 && Cb >= 0 && Cc >= 0 && (Cb > 0 || Cc == 0) && B > 0 && B <= 65535 && HW > 0);
+    const int C = Ca + Cb + Cc;
+    const size_t shmem = (size_t)C * LG_LD * sizeof(float);
+    UNFLOW_REQUIRE(shmem <= 160 * 1024);
+    PlanesOut3 dst = {{a, b, c}, {Ca, Cb, Cc}};
+    if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)split_nhwc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(split_nhwc_kernel, dim3(ceil_div(HW, LG_PIX), B), dim3(256), shmem, (hipStream_t)stream, in, dst, HW, C);
     return unflow_launch_status();
 }
 

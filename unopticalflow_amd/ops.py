@@ -646,6 +646,82 @@ def bias_leaky_relu_(y, bias, negative_slope=0.1, consumers=1):
     return _BiasLeaky.apply(y, bias, float(negative_slope))
 
 
+class _CatChannelsLast(torch.autograd.Function):
+    """cat(tensors, 1) of up to three NCHW tensors, produced directly in channels_last order; backward hands each input
+    its NCHW gradient (one kernel each way)."""
+
+    @staticmethod
+    def forward(ctx, *ts):
+        dev = _dev(*ts)
+        ts = [t.contiguous() for t in ts]
+        B, _, H, W = ts[0].shape
+        cs = [t.shape[1] for t in ts] + [0] * (3 - len(ts))
+        out = torch.empty((B, sum(cs), H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        ps = [_ptr(t) for t in ts] + [None] * (3 - len(ts))
+        with _on(dev):
+            _call('unflow_cat_nhwc', ps[0], cs[0], ps[1], cs[1], ps[2], cs[2], _ptr(out), B, H * W, _stream(),
+                  nbytes=8 * out.numel(), shape=tuple(out.shape))
+        ctx.cs = cs
+        ctx.n = len(ts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = g.shape
+        if not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.contiguous(memory_format=torch.channels_last)
+        need = [ctx.needs_input_grad[k] for k in range(ctx.n)] + [False] * (3 - ctx.n)
+        outs = [torch.empty((B, ctx.cs[k], H, W), dtype=torch.float32, device=g.device) if need[k] else None for k in range(3)]
+        if any(need):
+            with _on(g.device):
+                _call('unflow_split_nhwc', _ptr(g), _ptr(outs[0]), ctx.cs[0], _ptr(outs[1]), ctx.cs[1], _ptr(outs[2]), ctx.cs[2],
+                      B, H * W, _stream(), nbytes=8 * g.numel(), shape=(B, C, H, W))
+        return tuple(outs[:ctx.n])
+
+
+class _ToNCHW(torch.autograd.Function):
+    """A channels_last activation as a plain NCHW tensor (and its gradient back into channels_last)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, C, H, W = x.shape
+        out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+        with _on(x.device):
+            _call('unflow_split_nhwc', _ptr(x), _ptr(out), C, None, 0, None, 0, B, H * W, _stream(),
+                  nbytes=8 * x.numel(), shape=(B, C, H, W))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = g.shape
+        g = g.contiguous()
+        out = torch.empty((B, C, H, W), dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
+        with _on(g.device):
+            _call('unflow_cat_nhwc', _ptr(g), C, None, 0, None, 0, _ptr(out), B, H * W, _stream(),
+                  nbytes=8 * g.numel(), shape=(B, C, H, W))
+        return out
+
+
+def cat_channels_last(tensors):
+    """``torch.cat(tensors, 1).contiguous(memory_format=torch.channels_last)`` for up to three fp32 NCHW tensors in ONE
+    pass (the decoder input of pwc_tf.py:113 at the border of the channels_last conv stack)."""
+    tensors = tuple(tensors)
+    if not 1 <= len(tensors) <= 3:
+        raise ValueError('cat_channels_last takes 1 to 3 tensors, got %d' % len(tensors))
+    if any(t.dtype != torch.float32 or t.dim() != 4 or t.shape[0] != tensors[0].shape[0] or t.shape[2:] != tensors[0].shape[2:]
+           for t in tensors):
+        raise ValueError('cat_channels_last: fp32 [B, C_k, H, W] tensors with equal B, H, W expected')
+    return _CatChannelsLast.apply(*tensors)
+
+
+def to_nchw(x):
+    """A dense channels_last fp32 activation as a contiguous NCHW tensor (one transposing kernel each way)."""
+    if x.dtype != torch.float32 or not _is_nhwc(x):
+        return x.contiguous()
+    _dev(x)
+    return _ToNCHW.apply(x)
+
+
 def img_pyramid(img):
     """Scales 1 and 2 of generate_img_pyramid (model_flow_paper.py:54-60) for a contiguous [N,C,H,W]
     image batch: (2x2 box means [N,C,H/2,W/2], 4x4 box means [N,C,H/4,W/4]).  No gradient (``.data``)."""
