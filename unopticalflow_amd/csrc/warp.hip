@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// Backward through LDS tiles, "cell gather" form (the shipped one).  The scatter of the source gradient is turned
+// Backward through LDS tiles, "cell gather" form (shipped for maps below 32768 pixels per launch: pyramid level 4).  The scatter of the source gradient is turned
 // around inside the workgroup: every pixel posts its id at the position of its nw tap (the marker table the tile
 // kernel above uses to find race-free pixels); then every CELL of the source window looks up the <= 4 pixels whose
 // se / sw / ne / nw tap lands on it -- once per tile -- and per channel computes its sum from their upstream gradients
@@ -868,7 +868,11 @@ extern "C" int unflow_warp_bwd(const float* src, const float* flow, const float*
 #define LAUNCH_T(KERNEL, PPT, WIN, SPLIT) hipLaunchKernelGGL((KERNEL<PPT, WIN, 4, SPLIT>), tgrid, dim3(256), 0, s, src, flow, \
                                                      gout, gsrc, gflow, C, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y, p.cpg, vec_ok, wenv("UNFLOW_WARP_DEBUG", 0))
 #define LAUNCH_S(KERNEL, PPT, WIN) do { if (p.groups > 1) LAUNCH_T(KERNEL, PPT, WIN, true); else LAUNCH_T(KERNEL, PPT, WIN, false); } while (0)
-        if (wenv("UNFLOW_WARP_BWD", 1) == 0) LAUNCH_S(warp_bwd_tile_kernel, 2, 1024);     // tuning builds: the LDS-accumulator form
+        // Two forms of the same tile kernel.  In the train step (in-step A/B, tools/gpu_r2_k.sh; network flows, not the
+        // microbench's synthetic field): levels 2 / 3 accumulate-and-flush 55.8 / 39.6 us vs cell gather 57.4 / 41.1; level 4
+        // 25.2 vs 23.7.  (Back-to-back launches on a smooth synthetic flow favour the cell form everywhere: 49 / 32 / 18 vs 52 / 33 / 18.)
+        const int form = wenv("UNFLOW_WARP_BWD", (long)B * H * W < 32768 ? 1 : 0);
+        if (form == 0) LAUNCH_S(warp_bwd_tile_kernel, 2, 1024);
         else LAUNCH_S(warp_bwd_cell_kernel, 2, 1024);           // (4 px per lane would need 256 VGPRs: one wave per SIMD)
 #undef LAUNCH_S
 #undef LAUNCH_T
