@@ -195,7 +195,7 @@ def main():
         trainer.step(inputs)
     CW = ('unflow_corr_fwd', 'unflow_corr_bwd', 'unflow_warp_fwd', 'unflow_warp_bwd', 'unflow_warp_corr_fwd', 'unflow_warp_corr_bwd')
     if not args.no_kernel_timing:
-        ops.kernel_timer.enable(CW)                # every cost-volume / warp launch of the timed steps, on its own stream
+        ops.kernel_timer.enable(CW, reserve=32 * args.steps)     # every cost-volume / warp launch of the timed steps: kernel-exact event pairs
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -232,8 +232,8 @@ def main():
 
     survey = None
     if rank == 0 and world == 1 and not args.no_kernel_timing:
-        # per-entry-point timings of ALL hand-written kernels: 3 extra (untimed) steps with a HIP-event pair
-        # around every C call
+        # per-entry-point timings of ALL hand-written kernels: 3 extra (untimed) steps with an event pair attached to
+        # the kernels of every C call
         ops.kernel_timer.enable(True)
         for _ in range(3):
             trainer.step(inputs)

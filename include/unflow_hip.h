@@ -36,6 +36,19 @@ extern "C" {
 /* ABI version of this header (bumped on any signature change). */
 int unflow_abi_version(void);
 
+/* ---- kernel-exact timing (bench.py's roofline legs; nothing in the reference corresponds) ----
+ * unflow_timing_begin() arms a fresh HIP event pair for the CALLING THREAD and returns its slot id; until
+ * unflow_timing_end(), the kernels this thread launches through the library carry the pair (hipExtLaunchKernelGGL): `start` is
+ * stamped when the first of them begins, `stop` when the last one ends.  unflow_timing_elapsed_us(slot, &us) after the stream has
+ * been synchronised; UNFLOW_EINVAL for a slot that saw no launch.  unflow_timing_reset() makes the slot ids start over (the event
+ * pairs are kept and re-used); unflow_timing_reserve(n) creates n pairs ahead of a timed loop.  Do not arm while the stream is
+ * being captured into a hipGraph. */
+int unflow_timing_reserve(int n);
+int unflow_timing_begin(void);
+int unflow_timing_end(void);
+int unflow_timing_elapsed_us(int slot, float* us);
+int unflow_timing_reset(void);
+
 /* Number of float slots per sample a `partials` buffer needs for an H x W map (K = 2 included;
  * multiply by B). */
 int unflow_partials_per_sample(int H, int W);

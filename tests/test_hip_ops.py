@@ -621,6 +621,32 @@ def test_img_pyramid_vs_oracle(ops, shape):
     close(quarter, ref[2], rtol=0, atol=3e-7)
 
 
+def test_kernel_exact_timing_slots(ops):
+    """bench.py's roofline legs: a timed C call carries an event pair on its kernels (unflow_timing_begin /
+    hipExtLaunchKernelGGL).  The slot's time is positive, not longer than a hipEventRecord bracket around the same call,
+    and an entry point with two launches (zero-fill + kernel) reports one span."""
+    f1, f2 = rnd(1, (8, 32, 64, 208)).cuda(), rnd(2, (8, 32, 64, 208)).cuda()
+    fl = (rnd(3, (8, 2, 64, 208)) * 2).cuda().requires_grad_()
+    for _ in range(2):
+        ops.corr(f1, f2, 4)
+    torch.cuda.synchronize()
+    ops.kernel_timer.enable(('unflow_corr_fwd', 'unflow_warp_bwd'), reserve=8)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.corr(f1, f2, 4)
+    e1.record()
+    x = f2.clone().requires_grad_()
+    ops.warp_flow(x, fl).sum().backward()
+    torch.cuda.synchronize()
+    ops.kernel_timer.disable()
+    rows = {r['entry']: r for r in ops.kernel_timer.rows()}
+    assert set(rows) == {'unflow_corr_fwd', 'unflow_warp_bwd'}
+    us = rows['unflow_corr_fwd']['avg_us']
+    assert 2.0 < us <= e0.elapsed_time(e1) * 1e3 + 0.5
+    assert rows['unflow_warp_bwd']['launches'] == 1 and rows['unflow_warp_bwd']['avg_us'] > 2.0
+    assert ops.kernel_timer.rows() == []                      # slots are handed back
+
+
 # ------------------------------------------------------------------------------------ randomised shapes
 def test_fuzz_shapes_against_oracle(ops):
     """30 random (B, C, H, W, d) draws: every kernel-selection branch (tile / ring / group / generic paths,

@@ -16,6 +16,11 @@ _I = ctypes.c_int
 # name -> argument types (all return int)
 SIGNATURES = {
     'unflow_abi_version': [],
+    'unflow_timing_reserve': [_I],
+    'unflow_timing_begin': [],
+    'unflow_timing_end': [],
+    'unflow_timing_elapsed_us': [_I, _P],
+    'unflow_timing_reset': [],
     'unflow_partials_per_sample': [_I, _I],
     'unflow_corr_fwd': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     'unflow_corr_bwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -52,7 +57,7 @@ SIGNATURES = {
     'unflow_png_unfilter': [_P, _I, _I, _I],
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels of libunflow_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "../../include/unflow_hip.h"
 
@@ -9,6 +10,24 @@
 #define UNFLOW_REQUIRE(cond) do { if (!(cond)) return UNFLOW_EINVAL; } while (0)
 
 static inline int unflow_launch_status() { return (int)hipGetLastError(); }
+
+// Every kernel of the library is launched through UNFLOW_LAUNCH.  Normally that is hipLaunchKernelGGL.  When the calling
+// thread has armed a timing slot (unflow_timing_begin, photo.hip -- bench.py's roofline legs), the launches of the entry
+// point carry the slot's events (hipExtLaunchKernelGGL): the command processor stamps `start` when the entry point's FIRST
+// kernel begins and `stop` when its LAST one ends, so start -> stop is what a kernel trace reports for them -- without the
+// few microseconds of marker packets that hipEventRecord brackets add around a short kernel.
+struct UnflowTimingArm { hipEvent_t start, stop; bool started; };
+UnflowTimingArm& unflow_timing_arm();             // this thread's armed pair (stop == nullptr: none)
+#define UNFLOW_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                        \
+    do {                                                                                                              \
+        UnflowTimingArm& arm_ = unflow_timing_arm();                                                                  \
+        if (arm_.stop) {                                                                                              \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, arm_.started ? nullptr : arm_.start, arm_.stop, 0, __VA_ARGS__); \
+            arm_.started = true;                                                                                      \
+        } else {                                                                                                      \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                      \
+        }                                                                                                             \
+    } while (0)
 
 __host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
@@ -29,7 +48,7 @@ __global__ static void unflow_zero_kernel(float* __restrict__ p, size_t n) {
 static inline void unflow_zero_async(float* p, size_t n, hipStream_t s) {
     const size_t want = (n / 4 + 255) / 256;
     const int blocks = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
-    hipLaunchKernelGGL(unflow_zero_kernel, dim3(blocks), dim3(256), 0, s, p, n);
+    UNFLOW_LAUNCH(unflow_zero_kernel, dim3(blocks), dim3(256), 0, s, p, n);
 }
 
 // 64-lane butterfly sum (DPP/ds_swizzle shuffles, no LDS).

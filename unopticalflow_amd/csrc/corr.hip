@@ -481,7 +481,7 @@ int launch_fwd_ring(const float* f1, const float* f2, float* cv, int B, int C, i
 #else
     const int dbg = 0;
 #endif
-    hipLaunchKernelGGL((corr_fwd_ring_kernel<R, CC, DG>), dim3(tx * ty * B, K::NG), dim3(256), 0, s, f1, f2, cv, C, H, W,
+    UNFLOW_LAUNCH((corr_fwd_ring_kernel<R, CC, DG>), dim3(tx * ty * B, K::NG), dim3(256), 0, s, f1, f2, cv, C, H, W,
                        tx, ty, 1.0f / C, dbg, stamp_buffer());
     return unflow_launch_status();
 }
@@ -611,7 +611,7 @@ template <int R, int CC, int DG, int PH>
 int launch_fwd_ringp(const float* f1, const float* f2, float* cv, int B, int C, int H, int W, hipStream_t s) {
     using K = RingPCfg<R, CC, DG, PH>;
     const int tx = ceil_div(W, K::TW), ty = ceil_div(H, K::TYB);
-    hipLaunchKernelGGL((corr_fwd_ringp_kernel<R, CC, DG, PH>), dim3(tx * ty * B, K::NG), dim3(K::THREADS), 0, s,
+    UNFLOW_LAUNCH((corr_fwd_ringp_kernel<R, CC, DG, PH>), dim3(tx * ty * B, K::NG), dim3(K::THREADS), 0, s,
                        f1, f2, cv, C, H, W, tx, ty, 1.0f / C);
     return unflow_launch_status();
 }
@@ -951,7 +951,7 @@ int launch_bwd_gs(const float* f1, const float* f2, const float* g, float* gf1, 
     const int dbg = 0;
 #endif
     unsigned long long* stamps = stamp_buffer();
-    hipLaunchKernelGGL((corr_bwd_gs_kernel<R, CC, TYB>), dim3(tx * ty * B * 2, ceil_div(C, cpg)), dim3(K::THREADS), 0, s,
+    UNFLOW_LAUNCH((corr_bwd_gs_kernel<R, CC, TYB>), dim3(tx * ty * B * 2, ceil_div(C, cpg)), dim3(K::THREADS), 0, s,
                        f1, f2, g, gf1, gf2, C, cpg, H, W, tx, ty, 1.0f / C, dbg, stamps);
     return unflow_launch_status();
 }
@@ -1044,7 +1044,7 @@ int launch_bwd_small(const float* f1, const float* f2, const float* g, float* gf
     if ((size_t)cch * pplane * sizeof(float) > 40 * 1024) cch = (int)(40 * 1024 / sizeof(float) / pplane) / csub * csub;
     if (cch < csub || cch < 1) return 0;
     dim3 grid(ceil_div(plane, pxl), ceil_div(C, cch), 2 * B);
-    hipLaunchKernelGGL((corr_bwd_small_kernel<R>), grid, dim3(256), (size_t)cch * pplane * sizeof(float), s,
+    UNFLOW_LAUNCH((corr_bwd_small_kernel<R>), grid, dim3(256), (size_t)cch * pplane * sizeof(float), s,
                        f1, f2, g, gf1, gf2, C, H, W, pxl, cch, 1.0f / C);
     *launched = true;
     return unflow_launch_status();
@@ -1100,7 +1100,7 @@ template <int R, int PX, int DG, int CC>
 int launch_fwd(const float* f1, const float* f2, float* cv, int B, int C, int H, int W, hipStream_t s) {
     using K = CorrCfg<R, PX, DG, CC>;
     dim3 grid(ceil_div(W, K::TW), ceil_div(H, TY), B * K::NG);
-    hipLaunchKernelGGL((corr_fwd_kernel<R, PX, DG, CC>), grid, dim3(256), 0, s, f1, f2, cv, C, H, W, 1.0f / C);
+    UNFLOW_LAUNCH((corr_fwd_kernel<R, PX, DG, CC>), grid, dim3(256), 0, s, f1, f2, cv, C, H, W, 1.0f / C);
     return unflow_launch_status();
 }
 
@@ -1113,8 +1113,8 @@ int launch_bwd(const float* f1, const float* f2, const float* g, float* gf1, flo
         unflow_zero_async(gf1, (size_t)B * C * H * W, s);
         unflow_zero_async(gf2, (size_t)B * C * H * W, s);
     }
-    hipLaunchKernelGGL((corr_bwd_kernel<R, PX, DG, CC, 0>), grid, dim3(256), 0, s, f2, g, gf1, C, H, W, 1.0f / C);
-    hipLaunchKernelGGL((corr_bwd_kernel<R, PX, DG, CC, 1>), grid, dim3(256), 0, s, f1, g, gf2, C, H, W, 1.0f / C);
+    UNFLOW_LAUNCH((corr_bwd_kernel<R, PX, DG, CC, 0>), grid, dim3(256), 0, s, f2, g, gf1, C, H, W, 1.0f / C);
+    UNFLOW_LAUNCH((corr_bwd_kernel<R, PX, DG, CC, 1>), grid, dim3(256), 0, s, f1, g, gf2, C, H, W, 1.0f / C);
     return unflow_launch_status();
 }
 
@@ -1193,7 +1193,7 @@ extern "C" int unflow_corr_fwd(const float* f1, const float* f2, float* cv, int 
     }
     const size_t n = (size_t)B * (2 * d + 1) * (2 * d + 1) * H * W;
     const int blocks = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
-    hipLaunchKernelGGL(corr_fwd_generic, dim3(blocks), dim3(256), 0, s, f1, f2, cv, B, C, H, W, d, 1.0f / C);
+    UNFLOW_LAUNCH(corr_fwd_generic, dim3(blocks), dim3(256), 0, s, f1, f2, cv, B, C, H, W, d, 1.0f / C);
     return unflow_launch_status();
 }
 
@@ -1244,6 +1244,6 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
     }
     const size_t n = (size_t)B * C * H * W;
     const int blocks = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
-    hipLaunchKernelGGL(corr_bwd_generic, dim3(blocks), dim3(256), 0, s, f1, f2, gcv, gf1, gf2, B, C, H, W, d, 1.0f / C);
+    UNFLOW_LAUNCH(corr_bwd_generic, dim3(blocks), dim3(256), 0, s, f1, f2, gcv, gf1, gf2, B, C, H, W, d, 1.0f / C);
     return unflow_launch_status();
 }

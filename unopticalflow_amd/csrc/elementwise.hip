@@ -263,7 +263,7 @@ extern "C" int unflow_bias_leaky_fwd(float* y, const float* bias, int N, int C, 
                                      void* stream) {
     UNFLOW_REQUIRE(y && bias && N > 0 && C > 0 && H > 0 && W > 0 && N <= 65535 && C <= 65535);
     const int HW = H * W;
-    hipLaunchKernelGGL(bias_leaky_fwd_kernel, dim3(ceil_div(HW, EW_TILE), C, N), dim3(256), 0, (hipStream_t)stream,
+    UNFLOW_LAUNCH(bias_leaky_fwd_kernel, dim3(ceil_div(HW, EW_TILE), C, N), dim3(256), 0, (hipStream_t)stream,
                        y, bias, C, HW, slope);
     return unflow_launch_status();
 }
@@ -284,12 +284,12 @@ extern "C" int unflow_bias_leaky_bwd2(const float* y, const float* gout, long lo
                        (!gout2 || ((gout2_stride & 3) == 0 && ((size_t)gout2 & 15) == 0)));
     hipStream_t s = (hipStream_t)stream;
     if (gout2)
-        hipLaunchKernelGGL(bias_leaky_bwd_kernel<true>, dim3(nchunk, C, N), dim3(256), 0, s, y, gout, gout_stride, gout2,
+        UNFLOW_LAUNCH(bias_leaky_bwd_kernel<true>, dim3(nchunk, C, N), dim3(256), 0, s, y, gout, gout_stride, gout2,
                            gout2_stride, gin, partials, C, HW, slope);
     else
-        hipLaunchKernelGGL(bias_leaky_bwd_kernel<false>, dim3(nchunk, C, N), dim3(256), 0, s, y, gout, gout_stride, gout2,
+        UNFLOW_LAUNCH(bias_leaky_bwd_kernel<false>, dim3(nchunk, C, N), dim3(256), 0, s, y, gout, gout_stride, gout2,
                            gout2_stride, gin, partials, C, HW, slope);
-    hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3(C), dim3(256), 0, s, partials, N * nchunk, gbias);
+    UNFLOW_LAUNCH(bias_grad_finalize_kernel, dim3(C), dim3(256), 0, s, partials, N * nchunk, gbias);
     return unflow_launch_status();
 }
 
@@ -306,7 +306,7 @@ extern "C" int unflow_bias_leaky_fwd_nhwc(float* y, const float* bias, long long
     UNFLOW_REQUIRE(y && bias && P > 0 && C >= 4 && (C & 3) == 0 && C <= 1024 && (((size_t)y | (size_t)bias) & 15) == 0);
     const long long blocks = (P + NHWC_PIX - 1) / NHWC_PIX;
     UNFLOW_REQUIRE(blocks < (1ll << 31));
-    hipLaunchKernelGGL(bias_leaky_fwd_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, bias, P, C,
+    UNFLOW_LAUNCH(bias_leaky_fwd_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, bias, P, C,
                        nhwc_rows(C), slope);
     return unflow_launch_status();
 }
@@ -329,12 +329,12 @@ extern "C" int unflow_bias_leaky_bwd2_nhwc(const float* y, const float* gout, lo
     const int rows = nhwc_rows(C);
     const size_t shmem = (size_t)rows * C * sizeof(float);
     if (gout2)
-        hipLaunchKernelGGL(bias_leaky_bwd_nhwc_kernel<true>, dim3((unsigned)blocks), dim3(256), shmem, s, y, gout, gout_pstride,
+        UNFLOW_LAUNCH(bias_leaky_bwd_nhwc_kernel<true>, dim3((unsigned)blocks), dim3(256), shmem, s, y, gout, gout_pstride,
                            gout2, gout2_pstride, gin, partials, P, C, rows, slope);
     else
-        hipLaunchKernelGGL(bias_leaky_bwd_nhwc_kernel<false>, dim3((unsigned)blocks), dim3(256), shmem, s, y, gout, gout_pstride,
+        UNFLOW_LAUNCH(bias_leaky_bwd_nhwc_kernel<false>, dim3((unsigned)blocks), dim3(256), shmem, s, y, gout, gout_pstride,
                            gout2, gout2_pstride, gin, partials, P, C, rows, slope);
-    hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3(C), dim3(256), 0, s, partials, (int)blocks, gbias);
+    UNFLOW_LAUNCH(bias_grad_finalize_kernel, dim3(C), dim3(256), 0, s, partials, (int)blocks, gbias);
     return unflow_launch_status();
 }
 
@@ -347,7 +347,7 @@ extern "C" int unflow_cat_nhwc(const float* a, int Ca, const float* b, int Cb, c
     UNFLOW_REQUIRE(shmem <= 160 * 1024);
     Planes3 src = {{a, b, c}, {Ca, Cb, Cc}};
     if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)cat_nhwc_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(cat_nhwc_fwd_kernel, dim3(ceil_div(HW, LG_PIX), B), dim3(256), shmem, (hipStream_t)stream, src, out, HW, C);
+    UNFLOW_LAUNCH(cat_nhwc_fwd_kernel, dim3(ceil_div(HW, LG_PIX), B), dim3(256), shmem, (hipStream_t)stream, src, out, HW, C);
     return unflow_launch_status();
 }
 
@@ -358,7 +358,7 @@ extern "C" int unflow_split_nhwc(const float* in, float* a, int Ca, float* b, in
     UNFLOW_REQUIRE(shmem <= 160 * 1024);
     PlanesOut3 dst = {{a, b, c}, {Ca, Cb, Cc}};
     if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)split_nhwc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(split_nhwc_kernel, dim3(ceil_div(HW, LG_PIX), B), dim3(256), shmem, (hipStream_t)stream, in, dst, HW, C);
+    UNFLOW_LAUNCH(split_nhwc_kernel, dim3(ceil_div(HW, LG_PIX), B), dim3(256), shmem, (hipStream_t)stream, in, dst, HW, C);
     return unflow_launch_status();
 }
 
@@ -367,6 +367,6 @@ extern "C" int unflow_img_pyramid(const float* img, float* half, float* quarter,
     UNFLOW_REQUIRE(img && half && quarter && planes > 0 && H > 0 && W > 0 && (H & 3) == 0 && (W & 3) == 0);
     const size_t n = (size_t)planes * (H >> 2) * (W >> 2);
     const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(img_pyramid_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, half, quarter, planes, H, W);
+    UNFLOW_LAUNCH(img_pyramid_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, half, quarter, planes, H, W);
     return unflow_launch_status();
 }

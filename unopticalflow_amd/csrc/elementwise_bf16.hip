@@ -112,7 +112,7 @@ extern "C" int unflow_bias_leaky_fwd_bf16(uint16_t* y, const float* bias, int N,
                                           void* stream) {
     UNFLOW_REQUIRE(y && bias && N > 0 && C > 0 && H > 0 && W > 0 && N <= 65535 && C <= 65535);
     const int HW = H * W;
-    hipLaunchKernelGGL(bias_leaky_fwd_bf16_kernel, dim3(ceil_div(HW, EWH_TILE), C, N), dim3(256), 0, (hipStream_t)stream,
+    UNFLOW_LAUNCH(bias_leaky_fwd_bf16_kernel, dim3(ceil_div(HW, EWH_TILE), C, N), dim3(256), 0, (hipStream_t)stream,
                        y, bias, C, HW, slope);
     return unflow_launch_status();
 }
@@ -128,11 +128,11 @@ extern "C" int unflow_bias_leaky_bwd2_bf16(const uint16_t* y, const uint16_t* go
                        (!gout2 || ((gout2_stride & 7) == 0 && ((size_t)gout2 & 15) == 0)));
     hipStream_t s = (hipStream_t)stream;
     if (gout2)
-        hipLaunchKernelGGL(bias_leaky_bwd_bf16_kernel<true>, dim3(nchunk, C, N), dim3(256), 0, s, y, gout, gout_stride, gout2,
+        UNFLOW_LAUNCH(bias_leaky_bwd_bf16_kernel<true>, dim3(nchunk, C, N), dim3(256), 0, s, y, gout, gout_stride, gout2,
                            gout2_stride, gin, partials, C, HW, slope);
     else
-        hipLaunchKernelGGL(bias_leaky_bwd_bf16_kernel<false>, dim3(nchunk, C, N), dim3(256), 0, s, y, gout, gout_stride, gout2,
+        UNFLOW_LAUNCH(bias_leaky_bwd_bf16_kernel<false>, dim3(nchunk, C, N), dim3(256), 0, s, y, gout, gout_stride, gout2,
                            gout2_stride, gin, partials, C, HW, slope);
-    hipLaunchKernelGGL(bias_grad_finalize_bf16_kernel, dim3(C), dim3(256), 0, s, partials, N * nchunk, gbias);
+    UNFLOW_LAUNCH(bias_grad_finalize_bf16_kernel, dim3(C), dim3(256), 0, s, partials, N * nchunk, gbias);
     return unflow_launch_status();
 }

@@ -295,7 +295,74 @@ inline int flat_blocks(size_t n) {
 
 int unflow_ssim_blocks(int H, int W);   // ssim.hip
 
-extern "C" int unflow_abi_version(void) { return 4; }   // 2: + unflow_warp_corr_*; 3: img_batch on the 2B loss entries; 4: + *_nhwc epilogues
+extern "C" int unflow_abi_version(void) { return 5; }   // 2: + unflow_warp_corr_*; 3: img_batch on the 2B loss entries; 4: + *_nhwc epilogues; 5: + unflow_timing_*
+
+// ---- kernel-exact timing slots (see UNFLOW_LAUNCH in common.h) ----
+#include <mutex>
+#include <vector>
+namespace {
+struct TimingSlot { hipEvent_t start, stop; bool used; };
+std::mutex g_timing_mutex;
+std::vector<TimingSlot> g_timing_slots;
+thread_local UnflowTimingArm t_arm = {nullptr, nullptr, false};
+thread_local int t_slot = -1;
+}  // namespace
+UnflowTimingArm& unflow_timing_arm() { return t_arm; }
+
+// event pairs are created once and re-used after unflow_timing_reset(): arming a slot inside a timed loop costs no hipEventCreate
+static int timing_grow(size_t n) {                   // (caller holds the mutex)
+    while (g_timing_slots.size() < n) {
+        TimingSlot sl = {nullptr, nullptr, false};
+        if (hipEventCreate(&sl.start) != hipSuccess || hipEventCreate(&sl.stop) != hipSuccess) return UNFLOW_EINVAL;
+        g_timing_slots.push_back(sl);
+    }
+    return 0;
+}
+static size_t g_timing_next = 0;
+
+extern "C" int unflow_timing_reserve(int n) {
+    if (n < 0) return UNFLOW_EINVAL;
+    std::lock_guard<std::mutex> lock(g_timing_mutex);
+    return timing_grow((size_t)n);
+}
+
+extern "C" int unflow_timing_begin(void) {
+    if (t_arm.stop) return UNFLOW_EINVAL;            // already armed
+    std::lock_guard<std::mutex> lock(g_timing_mutex);
+    if (timing_grow(g_timing_next + 1) != 0) return UNFLOW_EINVAL;
+    t_slot = (int)g_timing_next++;
+    g_timing_slots[t_slot].used = false;
+    t_arm = {g_timing_slots[t_slot].start, g_timing_slots[t_slot].stop, false};
+    return t_slot;
+}
+
+extern "C" int unflow_timing_end(void) {
+    if (!t_arm.stop) return UNFLOW_EINVAL;
+    {
+        std::lock_guard<std::mutex> lock(g_timing_mutex);
+        g_timing_slots[t_slot].used = t_arm.started;
+    }
+    t_arm = {nullptr, nullptr, false};
+    t_slot = -1;
+    return 0;
+}
+
+extern "C" int unflow_timing_elapsed_us(int slot, float* us) {
+    std::lock_guard<std::mutex> lock(g_timing_mutex);
+    if (!us || slot < 0 || slot >= (int)g_timing_next || !g_timing_slots[slot].used) return UNFLOW_EINVAL;
+    float ms = 0.f;
+    const hipError_t e = hipEventElapsedTime(&ms, g_timing_slots[slot].start, g_timing_slots[slot].stop);
+    if (e != hipSuccess) return (int)e;
+    *us = ms * 1000.f;
+    return 0;
+}
+
+extern "C" int unflow_timing_reset(void) {
+    if (t_arm.stop) return UNFLOW_EINVAL;
+    std::lock_guard<std::mutex> lock(g_timing_mutex);
+    g_timing_next = 0;                               // slot ids start over; the event pairs are kept for re-use
+    return 0;
+}
 
 extern "C" int unflow_partials_per_sample(int H, int W) {
     if (H <= 0 || W <= 0) return UNFLOW_EINVAL;
@@ -309,7 +376,7 @@ extern "C" int unflow_occ_weight_fwd(const float* img, const float* from_l, cons
                                      uint8_t* valid_bwd, uint8_t* valid_fwd, int B, int H, int W, void* stream) {
     UNFLOW_REQUIRE(img && from_l && from_r && diff_l && diff_r && w_bwd && w_fwd && B > 0 && H > 0 && W > 0);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(occ_weight_fwd_kernel, dim3(flat_blocks((size_t)B * H * W)), dim3(256), 0, s, img, from_l,
+    UNFLOW_LAUNCH(occ_weight_fwd_kernel, dim3(flat_blocks((size_t)B * H * W)), dim3(256), 0, s, img, from_l,
                        from_r, diff_l, diff_r, w_bwd, w_fwd, valid_bwd, valid_fwd, B, H * W);
     return unflow_launch_status();
 }
@@ -318,7 +385,7 @@ extern "C" int unflow_absdiff_bwd(const float* img, const float* from, const flo
                                   int B, int H, int W, int img_batch, void* stream) {
     UNFLOW_REQUIRE(img && from && gdiff && gfrom && B > 0 && H > 0 && W > 0 && img_batch > 0 && B % img_batch == 0);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(absdiff_bwd_kernel, dim3(flat_blocks((size_t)B * 3 * H * W)), dim3(256), 0, s, img, from,
+    UNFLOW_LAUNCH(absdiff_bwd_kernel, dim3(flat_blocks((size_t)B * 3 * H * W)), dim3(256), 0, s, img, from,
                        gdiff, gfrom, B, H * W, img_batch);
     return unflow_launch_status();
 }
@@ -328,8 +395,8 @@ extern "C" int unflow_masked_mean_fwd(const float* diff, const float* w, float* 
     UNFLOW_REQUIRE(diff && w && loss && sums && partials && B > 0 && H > 0 && W > 0);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = ceil_div(H * W, TILE);
-    hipLaunchKernelGGL(masked_mean_partial_kernel, dim3(nblk, B), dim3(256), 0, s, diff, w, partials, H * W);
-    hipLaunchKernelGGL(ratio_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, sums,
+    UNFLOW_LAUNCH(masked_mean_partial_kernel, dim3(nblk, B), dim3(256), 0, s, diff, w, partials, H * W);
+    UNFLOW_LAUNCH(ratio_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, sums,
                        (float)H * (float)W, (float)H * (float)W);
     return unflow_launch_status();
 }
@@ -338,7 +405,7 @@ extern "C" int unflow_masked_mean_bwd(const float* w, const float* sums, const f
                                       int B, int H, int W, void* stream) {
     UNFLOW_REQUIRE(w && sums && gloss && gdiff && B > 0 && H > 0 && W > 0);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(masked_mean_bwd_kernel, dim3(flat_blocks((size_t)B * H * W)), dim3(256), 0, s, w, sums,
+    UNFLOW_LAUNCH(masked_mean_bwd_kernel, dim3(flat_blocks((size_t)B * H * W)), dim3(256), 0, s, w, sums,
                        gloss, gdiff, B, H * W);
     return unflow_launch_status();
 }
@@ -348,8 +415,8 @@ extern "C" int unflow_smooth2_fwd(const float* flow, const float* img, float* lo
     UNFLOW_REQUIRE(flow && img && loss && partials && B > 0 && H > 0 && W > 0 && img_batch > 0 && B % img_batch == 0);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = ceil_div(H * W, TILE);
-    hipLaunchKernelGGL(smooth2_partial_kernel, dim3(nblk, B), dim3(256), 0, s, flow, img, partials, H, W, img_batch);
-    hipLaunchKernelGGL(smooth2_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, H, W);
+    UNFLOW_LAUNCH(smooth2_partial_kernel, dim3(nblk, B), dim3(256), 0, s, flow, img, partials, H, W, img_batch);
+    UNFLOW_LAUNCH(smooth2_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, H, W);
     return unflow_launch_status();
 }
 
@@ -357,7 +424,7 @@ extern "C" int unflow_smooth2_bwd(const float* flow, const float* img, const flo
                                   int B, int H, int W, int img_batch, void* stream) {
     UNFLOW_REQUIRE(flow && img && gloss && gflow && B > 0 && H > 0 && W > 0 && img_batch > 0 && B % img_batch == 0);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(smooth2_bwd_kernel, dim3(flat_blocks((size_t)B * H * W)), dim3(256), 0, s, flow, img, gloss,
+    UNFLOW_LAUNCH(smooth2_bwd_kernel, dim3(flat_blocks((size_t)B * H * W)), dim3(256), 0, s, flow, img, gloss,
                        gflow, B, H, W, img_batch);
     return unflow_launch_status();
 }
@@ -367,9 +434,9 @@ extern "C" int unflow_consis_fwd(const float* fwd_flow, const float* bwd_flow, c
     UNFLOW_REQUIRE(fwd_flow && bwd_flow && w_fwd && loss && sums && partials && B > 0 && H > 0 && W > 0);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = ceil_div(H * W, TILE);
-    hipLaunchKernelGGL(consis_partial_kernel, dim3(nblk, B), dim3(256), 0, s, fwd_flow, bwd_flow, w_fwd, partials,
+    UNFLOW_LAUNCH(consis_partial_kernel, dim3(nblk, B), dim3(256), 0, s, fwd_flow, bwd_flow, w_fwd, partials,
                        H * W);
-    hipLaunchKernelGGL(ratio_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, sums,
+    UNFLOW_LAUNCH(ratio_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, sums,
                        2.0f * (float)H * (float)W, (float)H * (float)W);
     return unflow_launch_status();
 }
@@ -379,7 +446,7 @@ extern "C" int unflow_consis_bwd(const float* fwd_flow, const float* bwd_flow, c
                                  void* stream) {
     UNFLOW_REQUIRE(fwd_flow && bwd_flow && w_fwd && sums && gloss && gflow && B > 0 && H > 0 && W > 0);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(consis_bwd_kernel, dim3(flat_blocks((size_t)B * H * W)), dim3(256), 0, s, fwd_flow, bwd_flow,
+    UNFLOW_LAUNCH(consis_bwd_kernel, dim3(flat_blocks((size_t)B * H * W)), dim3(256), 0, s, fwd_flow, bwd_flow,
                        w_fwd, sums, gloss, gflow, B, H * W);
     return unflow_launch_status();
 }

@@ -90,6 +90,6 @@ extern "C" int unflow_prepare_triplets(const unsigned char* src, const long long
     if (!src || !offsets || !dims || !dst || B <= 0 || H <= 0 || W <= 0 || (W & 3)) return UNFLOW_EINVAL;
     const int quads = 3 * H * (W >> 2);
     dim3 grid((quads + 255) / 256, 1, B);
-    prepare_triplets_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, offsets, dims, flip, dst, H, W, swap_rb);
+    UNFLOW_LAUNCH(prepare_triplets_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, offsets, dims, flip, dst, H, W, swap_rb);
     return (int)hipGetLastError();
 }

@@ -276,9 +276,9 @@ extern "C" int unflow_ssim_loss_fwd(const float* img, const float* warped, const
     UNFLOW_REQUIRE(img && warped && w && loss && sums && partials && B > 0 && H > 0 && W > 0 && img_batch > 0 && B % img_batch == 0);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = unflow_ssim_blocks(H, W);
-    hipLaunchKernelGGL((ssim_fwd_kernel<3, true, false>), dim3(nblk, B), dim3(256), 0, s, img, warped, w,
+    UNFLOW_LAUNCH((ssim_fwd_kernel<3, true, false>), dim3(nblk, B), dim3(256), 0, s, img, warped, w,
                        (float*)nullptr, partials, H, W, img_batch);
-    hipLaunchKernelGGL(ssim_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, sums, H, W);
+    UNFLOW_LAUNCH(ssim_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, sums, H, W);
     return unflow_launch_status();
 }
 
@@ -287,7 +287,7 @@ extern "C" int unflow_ssim_loss_bwd(const float* img, const float* warped, const
     UNFLOW_REQUIRE(img && warped && w && sums && gloss && gwarped && B > 0 && H > 0 && W > 0 && img_batch > 0 && B % img_batch == 0);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = ceil_div(strips(W, 2) * chunks(H), 4);
-    hipLaunchKernelGGL(ssim_bwd_kernel, dim3(nblk, B), dim3(256), 0, s, img, warped, w, sums, gloss, gwarped, H, W, img_batch);
+    UNFLOW_LAUNCH(ssim_bwd_kernel, dim3(nblk, B), dim3(256), 0, s, img, warped, w, sums, gloss, gwarped, H, W, img_batch);
     return unflow_launch_status();
 }
 
@@ -296,7 +296,7 @@ extern "C" int unflow_ssim_map(const float* x, const float* y, float* out, int B
     UNFLOW_REQUIRE(x && y && out && B > 0 && C > 0 && H > 0 && W > 0);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = unflow_ssim_blocks(H, W);
-    hipLaunchKernelGGL((ssim_fwd_kernel<1, false, true>), dim3(nblk, B * C), dim3(256), 0, s, x, y,
+    UNFLOW_LAUNCH((ssim_fwd_kernel<1, false, true>), dim3(nblk, B * C), dim3(256), 0, s, x, y,
                        (const float*)nullptr, out, (float*)nullptr, H, W, B * C);
     return unflow_launch_status();
 }
@@ -384,7 +384,7 @@ extern "C" int unflow_ssim_map_bwd(const float* x, const float* y, const float* 
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)B * C * H * W;
     dim3 grid(ceil_div(H * W, 256), B * C);
-    hipLaunchKernelGGL(ssim_map_bwd_coef_kernel, grid, dim3(256), 0, s, x, y, gmap, scratch, H, W, n);
-    hipLaunchKernelGGL(ssim_map_bwd_gather_kernel, grid, dim3(256), 0, s, x, y, (const float*)scratch, gx, gy, H, W, n);
+    UNFLOW_LAUNCH(ssim_map_bwd_coef_kernel, grid, dim3(256), 0, s, x, y, gmap, scratch, H, W, n);
+    UNFLOW_LAUNCH(ssim_map_bwd_gather_kernel, grid, dim3(256), 0, s, x, y, (const float*)scratch, gx, gy, H, W, n);
     return unflow_launch_status();
 }

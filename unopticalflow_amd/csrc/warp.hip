@@ -832,7 +832,7 @@ extern "C" int unflow_warp_fwd(const float* src, const float* flow, float* out, 
         const TilePlan p = plan_tiles(B, C, H, W, th, 8, wenv("UNFLOW_WARP_WGS", 1024));
         dim3 grid(p.tiles_x * p.tiles_y * B, p.groups);
         const int vec_ok = ((W & 3) == 0 && (((size_t)src) & 15) == 0) ? 1 : 0;
-#define LAUNCH_T(PPT, WIN) hipLaunchKernelGGL((warp_fwd_tile_kernel<PPT, WIN, 8>), grid, dim3(256), 0, s, src, flow, out, \
+#define LAUNCH_T(PPT, WIN) UNFLOW_LAUNCH((warp_fwd_tile_kernel<PPT, WIN, 8>), grid, dim3(256), 0, s, src, flow, out, \
                                               C, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y, p.cpg, vec_ok)
         if (p.TH == 16) LAUNCH_T(4, 1600); else LAUNCH_T(2, 1024);
 #undef LAUNCH_T
@@ -840,14 +840,14 @@ extern "C" int unflow_warp_fwd(const float* src, const float* flow, float* out, 
     }
     dim3 grid(ceil_div(W, 64), H, B);
     if (C <= 4) {
-        if (mask) hipLaunchKernelGGL((warp_fwd_kernel<1, true>), grid, dim3(64, 1), 0, s, src, flow, out, mask, C, H, W, ac);
-        else      hipLaunchKernelGGL((warp_fwd_kernel<1, false>), grid, dim3(64, 1), 0, s, src, flow, out, mask, C, H, W, ac);
+        if (mask) UNFLOW_LAUNCH((warp_fwd_kernel<1, true>), grid, dim3(64, 1), 0, s, src, flow, out, mask, C, H, W, ac);
+        else      UNFLOW_LAUNCH((warp_fwd_kernel<1, false>), grid, dim3(64, 1), 0, s, src, flow, out, mask, C, H, W, ac);
     } else if ((long)grid.x * H * B < 4096 && C >= 64) {      // small maps: more channel phases per workgroup
-        if (mask) hipLaunchKernelGGL((warp_fwd_kernel<16, true>), grid, dim3(64, 16), 0, s, src, flow, out, mask, C, H, W, ac);
-        else      hipLaunchKernelGGL((warp_fwd_kernel<16, false>), grid, dim3(64, 16), 0, s, src, flow, out, mask, C, H, W, ac);
+        if (mask) UNFLOW_LAUNCH((warp_fwd_kernel<16, true>), grid, dim3(64, 16), 0, s, src, flow, out, mask, C, H, W, ac);
+        else      UNFLOW_LAUNCH((warp_fwd_kernel<16, false>), grid, dim3(64, 16), 0, s, src, flow, out, mask, C, H, W, ac);
     } else {
-        if (mask) hipLaunchKernelGGL((warp_fwd_kernel<4, true>), grid, dim3(64, 4), 0, s, src, flow, out, mask, C, H, W, ac);
-        else      hipLaunchKernelGGL((warp_fwd_kernel<4, false>), grid, dim3(64, 4), 0, s, src, flow, out, mask, C, H, W, ac);
+        if (mask) UNFLOW_LAUNCH((warp_fwd_kernel<4, true>), grid, dim3(64, 4), 0, s, src, flow, out, mask, C, H, W, ac);
+        else      UNFLOW_LAUNCH((warp_fwd_kernel<4, false>), grid, dim3(64, 4), 0, s, src, flow, out, mask, C, H, W, ac);
     }
     return unflow_launch_status();
 }
@@ -865,7 +865,7 @@ extern "C" int unflow_warp_bwd(const float* src, const float* flow, const float*
         dim3 tgrid(p.tiles_x * p.tiles_y * B, p.groups);
         const int vec_ok = ((W & 3) == 0 && (((size_t)src) & 15) == 0) ? 1 : 0;
         if (p.groups > 1) unflow_zero_async(gflow, (size_t)B * 2 * H * W, s);     // channel groups add their partials
-#define LAUNCH_T(KERNEL, PPT, WIN, SPLIT) hipLaunchKernelGGL((KERNEL<PPT, WIN, 4, SPLIT>), tgrid, dim3(256), 0, s, src, flow, \
+#define LAUNCH_T(KERNEL, PPT, WIN, SPLIT) UNFLOW_LAUNCH((KERNEL<PPT, WIN, 4, SPLIT>), tgrid, dim3(256), 0, s, src, flow, \
                                                      gout, gsrc, gflow, C, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y, p.cpg, vec_ok, wenv("UNFLOW_WARP_DEBUG", 0))
 #define LAUNCH_S(KERNEL, PPT, WIN) do { if (p.groups > 1) LAUNCH_T(KERNEL, PPT, WIN, true); else LAUNCH_T(KERNEL, PPT, WIN, false); } while (0)
         // Two forms of the same tile kernel.  In the train step (in-step A/B, tools/gpu_r2_k.sh; network flows, not the
@@ -879,7 +879,7 @@ extern "C" int unflow_warp_bwd(const float* src, const float* flow, const float*
         return unflow_launch_status();
     }
     dim3 grid(ceil_div(W, 64), H, B);
-#define LAUNCH(NY, M, G) hipLaunchKernelGGL((warp_bwd_kernel<NY, M, G>), grid, dim3(64, NY), 0, s, src, flow, gout, mask, gsrc, gflow, C, H, W, ac)
+#define LAUNCH(NY, M, G) UNFLOW_LAUNCH((warp_bwd_kernel<NY, M, G>), grid, dim3(64, NY), 0, s, src, flow, gout, mask, gsrc, gflow, C, H, W, ac)
     // few pixels, many channels (pyramid levels 4-6): 16 channel phases per workgroup instead of 4 -- the launch
     // has too few pixel rows to fill the chip, and the per-wave channel loop is a serial chain of atomics
     const bool small_map = (long)grid.x * H * B < 4096 && C >= 64;

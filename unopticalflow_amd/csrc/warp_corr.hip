@@ -284,7 +284,7 @@ int launch_fused_fwd(const float* f1, const float* f2, const float* flow, float*
                      hipStream_t s) {
     using K = FusedCfg<R, CC, DG, NS, SWX, SWH>;
     const int tx = ceil_div(W, K::TW), ty = ceil_div(H, K::TYB);
-    hipLaunchKernelGGL((warp_corr_fwd_kernel<R, CC, DG, NS, SWX, SWH>), dim3(tx * ty * B, K::NG), dim3(256), 0, s,
+    UNFLOW_LAUNCH((warp_corr_fwd_kernel<R, CC, DG, NS, SWX, SWH>), dim3(tx * ty * B, K::NG), dim3(256), 0, s,
                        f1, f2, flow, cv, C, H, W, tx, ty, 1.0f / C, ac);
     return unflow_launch_status();
 }

@@ -67,50 +67,59 @@ def _call(name, *args, nbytes=0, shape=None):
     DESIGN.md section 3); only used when bench.py's kernel timing is on."""
     lib = _lib.load()
     if kernel_timer.names is not None and (kernel_timer.names is True or name in kernel_timer.names):
-        ev0 = kernel_timer.start()
-        _lib.check(getattr(lib, name)(*args), name)
-        kernel_timer.stop(name, shape, ev0, nbytes)
+        slot = lib.unflow_timing_begin()
+        if slot < 0:
+            raise RuntimeError('unflow_timing_begin failed (%d)' % slot)
+        try:
+            _lib.check(getattr(lib, name)(*args), name)
+        finally:
+            lib.unflow_timing_end()
+        kernel_timer.table.setdefault((name, shape), []).append((slot, nbytes))
         return
     _lib.check(getattr(lib, name)(*args), name)
 
 
 class _KernelTimer:
-    """HIP-event timing of C entry points on the stream they are launched on (bench.py's roofline legs).
-    Disabled by default: no events, no overhead.  ``enable(names)`` times every call of the named entry points
-    (``True``: all of them) until ``disable()``; ``rows()`` groups the launches by (entry point, shape)."""
+    """Kernel-exact timing of C entry points (bench.py's roofline legs): the library launches the kernels of a timed call
+    with a HIP event pair attached (``unflow_timing_begin`` / hipExtLaunchKernelGGL), so a row is first-kernel-begin to
+    last-kernel-end on the stream the kernels run on -- what a rocprofv3 kernel trace reports, without the marker
+    packets of a hipEventRecord bracket.  Disabled by default: no events, no overhead.  ``enable(names)`` times every
+    call of the named entry points (``True``: all of them) until ``disable()``; ``rows()`` groups the launches by
+    (entry point, shape).  Not under hipGraph capture."""
 
     def __init__(self):
         self.names = None
         self.table = {}
 
-    def enable(self, names=True):
+    def enable(self, names=True, reserve=0):
+        """``reserve``: event pairs to create now, so that arming a slot inside the timed loop costs no hipEventCreate."""
         self.names = names if names is True else frozenset(names)
         self.table = {}
+        if reserve:
+            _lib.load().unflow_timing_reserve(int(reserve))
 
     def disable(self):
         self.names = None
 
-    def start(self):
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()                       # torch's current stream == the stream handed to the kernel
-        return ev
-
-    def stop(self, name, shape, ev0, nbytes):
-        ev1 = torch.cuda.Event(enable_timing=True)
-        ev1.record()
-        self.table.setdefault((name, shape), []).append((ev0, ev1, nbytes))
-
     def rows(self):
         """-> list of dicts (entry point, shape, launches, mean us, total us, algorithmic bytes, GB/s), heaviest first;
-        call after a device synchronize."""
+        call after a device synchronize.  Frees the library's event pairs."""
+        lib = _lib.load()
         rows = []
+        us = ctypes.c_float()
         for (name, shape), v in self.table.items():
-            ms = sum(a.elapsed_time(b) for a, b, _ in v)
-            nb = sum(n for _, _, n in v)
-            rows.append({'entry': name, 'shape': list(shape) if shape else None, 'launches': len(v),
-                         'avg_us': round(ms * 1e3 / len(v), 2), 'total_us': ms * 1e3, 'total_bytes': nb,
-                         'algorithmic_GBps': round(nb / (ms * 1e-3) / 1e9, 1) if ms > 0 and nb else None})
+            tot, n, nb = 0.0, 0, 0
+            for slot, nbytes in v:
+                if lib.unflow_timing_elapsed_us(slot, ctypes.byref(us)) == 0:        # (a call that launched nothing has no time)
+                    tot += us.value; n += 1; nb += nbytes
+            if n == 0:
+                continue
+            rows.append({'entry': name, 'shape': list(shape) if shape else None, 'launches': n,
+                         'avg_us': round(tot / n, 2), 'total_us': tot, 'total_bytes': nb,
+                         'algorithmic_GBps': round(nb / (tot * 1e-6) / 1e9, 1) if tot > 0 and nb else None})
         rows.sort(key=lambda r: -r['total_us'])
+        self.table = {}
+        lib.unflow_timing_reset()
         return rows
 
 
