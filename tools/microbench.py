@@ -197,6 +197,21 @@ def pmc_l2(B=16):
         torch.cuda.synchronize()
 
 
+def corr_split_sweep(B=16):
+    """Channel slices of the small-map forward (tuning library): 1 = per-element kernel."""
+    lib = _lib.load()
+    P = ops._ptr
+    for lvl, d in (('L5', 4), ('L6', 4), ('L5', 8), ('L6', 8)):
+        C, h, w = LEVELS[lvl]
+        f1 = torch.randn(B, C, h, w, device='cuda'); f2 = torch.randn(B, C, h, w, device='cuda')
+        cv = torch.empty(B, (2 * d + 1) ** 2, h, w, device='cuda')
+
+        def run(tag):
+            t = timeit(lambda: lib.unflow_corr_fwd(P(f1), P(f2), P(cv), B, C, h, w, d, ops._stream()))
+            print('corr_fwd d=%d %s %-18s %6.1f us' % (d, lvl, tag, t), flush=True)
+        _sweep([{'UNFLOW_CORR_SPLIT': k} for k in (1, 2, 4, 8)], run)
+
+
 def corr_fwd_sweep(B=16):
     """d=4 forward variants (tuning library) at levels 2-4."""
     lib = _lib.load()

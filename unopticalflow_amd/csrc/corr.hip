@@ -1071,6 +1071,47 @@ __global__ void corr_fwd_generic(const float* __restrict__ f1, const float* __re
     }
 }
 
+// Small maps (pyramid levels 5, 6: a few hundred pixels, 128-196 channels): the per-element kernel above is one serial chain of
+// C dependent-latency load pairs per lane (~15 us for 1.5 MB at level 6).  Here a workgroup = 64 consecutive outputs x CS channel
+// slices (one wave per slice, the same coalescing along x); the slices' partial sums meet in LDS and are added in a fixed order.
+template <int CS>
+__global__ __launch_bounds__(64 * CS) void corr_fwd_split_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                                 float* __restrict__ cv, int B, int C, int H, int W, int R, float inv_c) {
+    __shared__ float red[CS][64];
+    const int DD = 2 * R + 1;
+    const size_t n = (size_t)B * DD * DD * H * W, plane = (size_t)H * W;
+    const int lane = threadIdx.x & 63, slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t t = (size_t)blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (t < n) {
+        const int x = t % W, y = (t / W) % H, ij = (t / plane) % (DD * DD);
+        const int b = t / (plane * DD * DD);
+        const int sy = y + ij / DD - R, sx = x + ij % DD - R;
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
+            const int per = (C + CS - 1) / CS, c0 = slice * per, c1 = min(C, c0 + per);
+            const float* p1 = f1 + ((size_t)b * C * H + y) * W + x;
+            const float* p2 = f2 + ((size_t)b * C * H + sy) * W + sx;
+            float a0 = 0.f, a1 = 0.f;
+            int c = c0;
+#pragma unroll 4
+            for (; c + 1 < c1; c += 2) {
+                a0 = fmaf(p1[c * plane], p2[c * plane], a0);
+                a1 = fmaf(p1[(c + 1) * plane], p2[(c + 1) * plane], a1);
+            }
+            if (c < c1) a0 = fmaf(p1[c * plane], p2[c * plane], a0);
+            s = a0 + a1;
+        }
+    }
+    red[slice][lane] = s;
+    __syncthreads();
+    if (slice == 0 && t < n) {
+        float tot = red[0][lane];
+#pragma unroll
+        for (int k = 1; k < CS; ++k) tot += red[k][lane];
+        cv[t] = tot * inv_c;
+    }
+}
+
 __global__ void corr_bwd_generic(const float* __restrict__ f1, const float* __restrict__ f2,
                                  const float* __restrict__ g, float* __restrict__ gf1,
                                  float* __restrict__ gf2, int B, int C, int H, int W, int R, float inv_c) {
@@ -1132,10 +1173,12 @@ int launch_bwd(const float* f1, const float* f2, const float* g, float* gf1, flo
 #ifdef UNFLOW_TUNING
 static int env_int(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
 static int forced_variant() { return env_int("UNFLOW_CORR_VARIANT"); }      // re-read per call: one process sweeps them
+static int forced_split() { return env_int("UNFLOW_CORR_SPLIT"); }
 static int forced_bwd() { return env_int("UNFLOW_CORR_BWD"); }
 static int forced_groups() { return env_int("UNFLOW_CORR_GROUPS"); }
 #else
 static inline int forced_variant() { return 0; }
+static inline int forced_split() { return 0; }
 static inline int forced_bwd() { return 0; }
 static inline int forced_groups() { return 0; }
 #endif
@@ -1192,6 +1235,17 @@ extern "C" int unflow_corr_fwd(const float* f1, const float* f2, float* cv, int 
         default: break;
     }
     const size_t n = (size_t)B * (2 * d + 1) * (2 * d + 1) * H * W;
+    // few outputs, many channels: split the channels over the waves of a workgroup (tools/microbench.py corr_split_sweep; level 6,
+    // 67 k outputs x 196 channels: 11.7 / 9.5 / 7.7 / 9.0 us with 1 / 2 / 4 / 8 slices; at level 5, 269 k outputs already fill the
+    // chip: 14.5 / 16.0 / 16.4 / 20.8 us)
+    const int split = forced_split() ? forced_split() : (C >= 64 && n < 98304 ? 4 : 0);
+    if (split == 8 || split == 4 || split == 2) {
+        const dim3 grid((unsigned)((n + 63) / 64));
+        if (split == 8) UNFLOW_LAUNCH((corr_fwd_split_kernel<8>), grid, dim3(512), 0, s, f1, f2, cv, B, C, H, W, d, 1.0f / C);
+        else if (split == 4) UNFLOW_LAUNCH((corr_fwd_split_kernel<4>), grid, dim3(256), 0, s, f1, f2, cv, B, C, H, W, d, 1.0f / C);
+        else UNFLOW_LAUNCH((corr_fwd_split_kernel<2>), grid, dim3(128), 0, s, f1, f2, cv, B, C, H, W, d, 1.0f / C);
+        return unflow_launch_status();
+    }
     const int blocks = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
     UNFLOW_LAUNCH(corr_fwd_generic, dim3(blocks), dim3(256), 0, s, f1, f2, cv, B, C, H, W, d, 1.0f / C);
     return unflow_launch_status();
