@@ -270,6 +270,40 @@ __device__ __forceinline__ void stage_fence() {
     __syncthreads();                                      // ... and everyone else's
 }
 
+// The same window moved through REGISTERS (vec windows only): window_fetch issues the loads of the next chunk, which then fly
+// under the current chunk's arithmetic; window_commit writes them to LDS once the current chunk is done with the window.
+// (LDS-DMA cannot be used for this: with a DMA in flight hipcc drains vmcnt(0) before every compiler-visible LDS access.)
+template <int WIN, int CC>
+struct WindowRegs { float4 v[(CC + 3) / 4][Window<WIN>::MAXP]; };
+
+template <int WIN, int CC>
+__device__ __forceinline__ void window_fetch(WindowRegs<WIN, CC>& r, const Window<WIN>& w, const float* __restrict__ planes,
+                                             int plane, int nc) {
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int cc = 0; cc < (CC + 3) / 4; ++cc) {
+        const int c = wave + 4 * cc;
+        const float* g = planes + (size_t)c * plane;
+#pragma unroll
+        for (int p = 0; p < Window<WIN>::MAXP; ++p)
+            r.v[cc][p] = (c < nc && p < w.per_ch && w.goff[p] >= 0) ? *reinterpret_cast<const float4*>(g + w.goff[p])
+                                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+template <int STRIDE, int WIN, int CC>
+__device__ __forceinline__ void window_commit(float* __restrict__ dst, const WindowRegs<WIN, CC>& r, const Window<WIN>& w, int nc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int cc = 0; cc < (CC + 3) / 4; ++cc) {
+        const int c = wave + 4 * cc;
+#pragma unroll
+        for (int p = 0; p < Window<WIN>::MAXP; ++p)
+            if (c < nc && p < w.per_ch && w.goff[p] >= 0)
+                *reinterpret_cast<float4*>(dst + c * STRIDE + p * 256 + lane * 4) = r.v[cc][p];
+    }
+}
+
 // LDS offsets of a pixel's four taps inside the packed window (0 for pixels that sample nothing)
 template <int WIN, int PPT>
 __device__ __forceinline__ void tap_offsets(const Window<WIN>& w, const TileCtx<PPT>& k, int (&l_nw)[PPT], int (&l_ne)[PPT],
@@ -454,16 +488,43 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const float* __restr
         }
         for (int i = threadIdx.x; i < CC * WINP; i += 256) { s_acc[i] = 0.f; s_src[i] = 0.f; }
         __syncthreads();                                      // (the staging below must not be overtaken by this fill)
-        for (int c0 = c_begin; c0 < c_end; c0 += CC) {
-            const int nc = min(CC, c_end - c0);
-            window_stage<WINP, WIN, CC>(s_src, w, sp + (size_t)c0 * plane, plane, W, nc);
-            float g[PPT][CC];                                 // upstream gradients of the chunk: in flight with the window pieces
+        // Software pipeline over the channel chunks (vec windows): the NEXT chunk's window pieces and upstream gradients are
+        // requested into registers before the current chunk's arithmetic and written to LDS after it, so their latency
+        // (one HBM round trip per chunk, 4-8 chunks per workgroup, nothing else resident to hide it at levels 3 / 4) is off
+        // the critical path.
+        WindowRegs<WIN, CC> wnext;
+        float gnext[PPT][CC];
+        auto fetch = [&](int c0n) {
+            const int ncn = min(CC, c_end - c0n);
+            window_fetch<WIN, CC>(wnext, w, sp + (size_t)c0n * plane, plane, ncn);
 #pragma unroll
             for (int q = 0; q < PPT; ++q)
 #pragma unroll
                 for (int c = 0; c < CC; ++c)
-                    g[q][c] = (k.live[q] && c < nc) ? gp[(size_t)(c0 + c) * plane + k.pix[q]] : 0.f;
-            stage_fence();                                    // window staged, accumulator zero
+                    gnext[q][c] = (k.live[q] && c < ncn) ? gp[(size_t)(c0n + c) * plane + k.pix[q]] : 0.f;
+        };
+        if (w.vec) fetch(c_begin);
+        for (int c0 = c_begin; c0 < c_end; c0 += CC) {
+            const int nc = min(CC, c_end - c0);
+            float g[PPT][CC];                                 // upstream gradients of the chunk
+            if (w.vec) {
+                window_commit<WINP, WIN, CC>(s_src, wnext, w, nc);
+#pragma unroll
+                for (int q = 0; q < PPT; ++q)
+#pragma unroll
+                    for (int c = 0; c < CC; ++c) g[q][c] = gnext[q][c];
+                __syncthreads();                              // window staged, accumulator zero
+                if (c0 + CC < c_end) fetch(c0 + CC);
+                __builtin_amdgcn_sched_barrier(0);            // (the requests go out here, not where their values are used)
+            } else {
+                window_stage<WINP, WIN, CC>(s_src, w, sp + (size_t)c0 * plane, plane, W, nc);
+#pragma unroll
+                for (int q = 0; q < PPT; ++q)
+#pragma unroll
+                    for (int c = 0; c < CC; ++c)
+                        g[q][c] = (k.live[q] && c < nc) ? gp[(size_t)(c0 + c) * plane + k.pix[q]] : 0.f;
+                stage_fence();                                // window staged, accumulator zero
+            }
             // channels beyond nc hold an older chunk's (finite) values and g == 0: they add nothing
 #pragma unroll
             for (int q = 0; q < PPT; ++q) {
@@ -697,20 +758,45 @@ __global__ __launch_bounds__(256) void warp_bwd_cell_kernel(const float* __restr
             }
         }
 
-        for (int c0 = c_begin; c0 < c_end; c0 += CC) {
-            const int nc = min(CC, c_end - c0);
-            window_stage<WINP, WIN, CC>(s_src, w, sp + (size_t)c0 * plane, plane, W, nc);
-            float g[PPT][CC];                                 // upstream gradients of the chunk: in flight with the window pieces
+        // the next chunk's window pieces and upstream gradients are requested before this chunk's arithmetic (see the
+        // accumulate-and-flush kernel above)
+        WindowRegs<WIN, CC> wnext;
+        float gnext[PPT][CC];
+        auto fetch = [&](int c0n) {
+            const int ncn = min(CC, c_end - c0n);
+            window_fetch<WIN, CC>(wnext, w, sp + (size_t)c0n * plane, plane, ncn);
 #pragma unroll
             for (int q = 0; q < PPT; ++q)
 #pragma unroll
                 for (int c = 0; c < CC; ++c)
-                    g[q][c] = (k.live[q] && c < nc) ? gp[(size_t)(c0 + c) * plane + k.pix[q]] : 0.f;
+                    gnext[q][c] = (k.live[q] && c < ncn) ? gp[(size_t)(c0n + c) * plane + k.pix[q]] : 0.f;
+        };
+        if (w.vec) fetch(c_begin);
+        for (int c0 = c_begin; c0 < c_end; c0 += CC) {
+            const int nc = min(CC, c_end - c0);
+            float g[PPT][CC];                                 // upstream gradients of the chunk
+            if (w.vec) {
+                window_commit<WINP, WIN, CC>(s_src, wnext, w, nc);
 #pragma unroll
-            for (int q = 0; q < PPT; ++q)
+                for (int q = 0; q < PPT; ++q)
 #pragma unroll
-                for (int c = 0; c < CC; ++c) s_g[c][q * 256 + (int)threadIdx.x] = g[q][c];
-            stage_fence();                                    // window staged, gradients posted
+                    for (int c = 0; c < CC; ++c) { g[q][c] = gnext[q][c]; s_g[c][q * 256 + (int)threadIdx.x] = g[q][c]; }
+                __syncthreads();                              // window staged, gradients posted
+                if (c0 + CC < c_end) fetch(c0 + CC);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                window_stage<WINP, WIN, CC>(s_src, w, sp + (size_t)c0 * plane, plane, W, nc);
+#pragma unroll
+                for (int q = 0; q < PPT; ++q)
+#pragma unroll
+                    for (int c = 0; c < CC; ++c)
+                        g[q][c] = (k.live[q] && c < nc) ? gp[(size_t)(c0 + c) * plane + k.pix[q]] : 0.f;
+#pragma unroll
+                for (int q = 0; q < PPT; ++q)
+#pragma unroll
+                    for (int c = 0; c < CC; ++c) s_g[c][q * 256 + (int)threadIdx.x] = g[q][c];
+                stage_fence();                                // window staged, gradients posted
+            }
             // channels beyond nc hold an older chunk's (finite) values and g == 0: they add nothing
 #pragma unroll
             for (int q = 0; q < PPT; ++q) {
