@@ -112,7 +112,7 @@ def warp_c(B=16):
     P = ops._ptr
     envs = [{}]
     if os.environ.get('UNFLOW_MICROBENCH_TUNING') == '1':
-        envs = [{'UNFLOW_WARP_TILES': 0}] + [{'UNFLOW_WARP_BWD': k, 'UNFLOW_WARP_WGS': n} for k in (0, 1) for n in (256, 512)]
+        envs = [{'UNFLOW_WARP_TILES': 0}] + [{'UNFLOW_WARP_BWD': k, 'UNFLOW_WARP_WGS': n, 'UNFLOW_WARP_MINPIX': 128} for k in (0, 1) for n in (256, 512, 1024)]
     for name, (C, h, w) in list(LEVELS.items())[:4]:
         x = torch.randn(B, C, h, w, device='cuda')
         g = torch.randn(B, C, h, w, device='cuda')

@@ -895,9 +895,6 @@ inline TilePlan plan_tiles(int B, int C, int H, int W, int TH, int CC, int want_
 
 }  // namespace
 
-// Feature maps (no mask, >= 8 channels) go through the LDS-tile kernels.
-// Feature maps (no mask, >= 8 channels, >= 512 pixels: pyramid levels 2-4) go through the LDS-tile kernels.
-static bool use_tiles(const uint8_t* mask, int C, int H, int W) { return mask == nullptr && C >= 8 && W >= 8 && H * W >= 512; }
 
 // Tuning builds (tools/, -DUNFLOW_TUNING) may override the tile height / workgroup target; the shipped library
 // never reads the environment.
@@ -907,6 +904,9 @@ static int wenv(const char* n, int dflt) { const char* e = getenv(n); return e ?
 #else
 static inline int wenv(const char*, int dflt) { return dflt; }
 #endif
+
+// Feature maps (no mask, >= 8 channels, >= 512 pixels: pyramid levels 2-4) go through the LDS-tile kernels.
+static bool use_tiles(const uint8_t* mask, int C, int H, int W) { return mask == nullptr && C >= 8 && W >= 8 && H * W >= wenv("UNFLOW_WARP_MINPIX", 512); }
 
 extern "C" int unflow_warp_fwd(const float* src, const float* flow, float* out, uint8_t* mask,
                                int B, int C, int H, int W, int align_corners, void* stream) {
