@@ -5,9 +5,9 @@ replicate / scatter / gather on GPU 0).  Samples are independent and every loss 
 value that is batch-meaned (train.py:147-150), so averaging the per-rank gradients of equal
 per-rank batches reproduces DataParallel's global-batch mean exactly.
 
-All 98 parameter gradients live in ONE flat fp32 buffer (5,134,324 elements = 20.5 MB): backward
-accumulates straight into views of it, and a step needs a few large all-reduces over xGMI instead of 98
-small ones; ``zero_grad`` is one memset.  The buffer is cut into ``chunks`` pieces on parameter
+All 98 parameter gradients travel in ONE flat fp32 buffer (5,134,324 elements = 20.5 MB): a step needs a few large
+all-reduces over xGMI instead of 98 small ones.  Backward assigns the gradients as in a single-process run; a piece of the
+buffer is filled with one multi-tensor copy the moment its last gradient exists.  The buffer is cut into ``chunks`` pieces on parameter
 boundaries; a piece is handed to RCCL (async, on RCCL's own stream) the moment backward has produced
 its last gradient, so all but the final piece (the first pyramid layers, 2 % of the bytes) travel
 while backward is still computing.
@@ -51,22 +51,30 @@ class FlatGradients:
     overlap: launch each piece from a post-accumulate-grad hook while backward is still running
     (``all_reduce_mean`` then only launches what is left and waits).  Without it everything is launched
     after backward (used when the step is replayed as a hipGraph: collectives stay outside the graph).
+    pack: how the gradients get into the buffer.  False: ``p.grad`` ARE views of the pre-zeroed buffer and backward accumulates
+    into them (98 read-add-write kernels + a 20 MB fill per step).  True (what FlowTrainer uses): ``zero()`` drops the
+    gradients, backward ASSIGNS them as in a single-process run, and a piece is copied into the buffer with one
+    multi-tensor copy the moment its last gradient exists (then ``p.grad`` is re-pointed at the buffer, so the optimizer
+    reads the reduced values) -- the data-parallel step then costs what the single-process step costs plus the exchange.
     """
 
-    def __init__(self, params, chunks=4, group=None, overlap=False, single_rank_collectives=False):
+    def __init__(self, params, chunks=4, group=None, overlap=False, single_rank_collectives=False, pack=False):
         self.single_rank_collectives = bool(single_rank_collectives)
+        self.pack = bool(pack)
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError('no trainable parameters')
         dev, dtype = self.params[0].device, self.params[0].dtype
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(self.numel, device=dev, dtype=dtype)
-        off, offsets = 0, []
+        off, offsets, self.views = 0, [], []
         for p in self.params:
             n = p.numel()
             # a view with the PARAMETER's strides (channels_last convolution weights are dense but not row-major): the
             # fused optimizer walks parameter, gradient and moments by memory offset, so their layouts must agree
-            p.grad = self.flat[off:off + n].as_strided(p.size(), p.stride())
+            self.views.append(self.flat[off:off + n].as_strided(p.size(), p.stride()))
+            if not self.pack:
+                p.grad = self.views[-1]
             offsets.append(off)
             off += n
         self.group = group
@@ -79,9 +87,11 @@ class FlatGradients:
                 bounds.append(i + 1)
         bounds.append(len(self.params))
         self.pieces = []                                  # (first element, one past the last, number of params)
+        self._piece_params = []                           # parameter index range of each piece
         for a, b in zip(bounds[:-1], bounds[1:]):
             end = offsets[b] if b < len(self.params) else self.numel
             self.pieces.append((offsets[a], end, b - a))
+            self._piece_params.append((a, b))
         self.chunks = len(self.pieces)
         self._piece_of = {}
         for k, (a, b) in enumerate(zip(bounds[:-1], bounds[1:])):
@@ -89,6 +99,8 @@ class FlatGradients:
                 self._piece_of[id(p)] = k
         self._left = [n for _, _, n in self.pieces]
         self._works = [None] * self.chunks
+        self._packed = [False] * self.chunks
+        self._sources = None                              # gradient tensors of a captured hipGraph (remember_sources)
         self.launched_early = 0                           # pieces sent from a hook during the last backward
         self.overlap = False
         self._hooks = []
@@ -103,9 +115,33 @@ class FlatGradients:
             return False
         return dist.get_world_size(self.group) > 1 or self.single_rank_collectives
 
+    def _averaging_op(self):
+        """RCCL averages in the collective itself; gloo (the CPU tests) sums and the buffer is scaled afterwards."""
+        return dist.ReduceOp.AVG if dist.get_backend(self.group) == 'nccl' else dist.ReduceOp.SUM
+
+    def _pack_piece(self, k):
+        """Copy the (assigned) gradients of piece k into the buffer and re-point ``p.grad`` at it."""
+        if self._packed[k]:
+            return
+        a, b = self._piece_params[k]
+        dst, src = [], []
+        for i in range(a, b):
+            g = self._sources[i] if self._sources is not None else self.params[i].grad
+            if g is None:
+                self.views[i].zero_()                     # a parameter the loss did not reach
+            elif g.data_ptr() != self.views[i].data_ptr():
+                dst.append(self.views[i]); src.append(g)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        for i in range(a, b):
+            self.params[i].grad = self.views[i]
+        self._packed[k] = True
+
     def _launch(self, k):
+        if self.pack:
+            self._pack_piece(k)
         a, b, _ = self.pieces[k]
-        self._works[k] = dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works[k] = dist.all_reduce(self.flat[a:b], op=self._averaging_op(), group=self.group, async_op=True)
 
     def enable_overlap(self):
         if self.overlap:
@@ -120,19 +156,32 @@ class FlatGradients:
                 self.launched_early += 1
         self._hooks = [p.register_post_accumulate_grad_hook(hook) for p in self.params]
 
+    def remember_sources(self):
+        """After a hipGraph capture of forward + backward: the tensors backward assigned as gradients are the graph's own
+        static buffers, rewritten by every replay; ``pack`` copies from them from now on."""
+        if self.pack:
+            self._sources = [p.grad for p in self.params]
+
     def zero(self):
-        self.flat.zero_()
+        if self.pack:
+            if self._sources is None:                     # (under graph replay the captured backward does not read p.grad)
+                for p in self.params:
+                    p.grad = None
+        else:
+            self.flat.zero_()
         self._left = [n for _, _, n in self.pieces]
         self._works = [None] * self.chunks
+        self._packed = [False] * self.chunks
         self.launched_early = 0
 
     def vector(self):
         """The gradients as one vector in LOGICAL element order, parameter by parameter (a copy).  ``flat`` itself is
         in memory order, which differs for channels_last weights; compare runs with this."""
-        return torch.cat([p.grad.reshape(-1) for p in self.params])
+        return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params])
 
     def check_views(self):
-        """Guard against something (e.g. ``zero_grad(set_to_none=True)``) having detached a view."""
+        """Guard against something (e.g. ``zero_grad(set_to_none=True)``) having detached a view.  (pack mode: valid after
+        ``all_reduce_mean`` of a step that exchanged.)"""
         base = self.flat.data_ptr()
         off = 0
         for p in self.params:
@@ -153,7 +202,9 @@ class FlatGradients:
         for w in self._works:
             w.wait()
         self._works = [None] * self.chunks
-        self.flat.mul_(1.0 / world)
+        self._packed = [False] * self.chunks              # (a hipGraph replay has no zero() between two exchanges)
+        if self._averaging_op() != dist.ReduceOp.AVG and world > 1:
+            self.flat.mul_(1.0 / world)
 
 
 class PlainGradients:

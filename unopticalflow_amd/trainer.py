@@ -28,7 +28,7 @@ class FlowTrainer:
         # (assigned by backward, nothing to pre-zero or accumulate into)
         if distributed:
             self.grads = FlatGradients(params, chunks=allreduce_chunks, overlap=not use_graph,
-                                       single_rank_collectives=single_rank_collectives)
+                                       single_rank_collectives=single_rank_collectives, pack=True)
         else:
             self.grads = PlainGradients(params)
         self.distributed = distributed
@@ -93,6 +93,8 @@ class FlowTrainer:
                 self.optimizer.step()
             self._static_loss = loss.detach()
             self._static_pack = {k: v.detach() for k, v in pack.items()}
+        if self.distributed:
+            self.grads.remember_sources()              # replays rewrite these tensors; the exchange copies from them
 
     def _graph_step(self, inputs):
         if self._graph is None:
