@@ -753,8 +753,7 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC, TYB>::THREADS)) void corr_bwd_gs_k
 
     // work item = (tile, gradient): the two gradients of a tile are neighbours in the XCD-local order, so the
     // upstream-gradient planes both of them read are fetched from HBM once and served from that XCD's L2 the second time
-    // (`pair`: one workgroup computes BOTH gradients of its tile, one after the other -- the second gather then finds the
-    // planes in L2)
+    // (`pair`, tuning builds: one workgroup computes BOTH gradients of its tile, one after the other; see launch_bwd_gs)
     int t = xcd_remap(blockIdx.x, gridDim.x);
     int mode_first = 0, mode_last = 1;
     if (!pair) { mode_first = mode_last = t & 1; t >>= 1; }
@@ -963,10 +962,11 @@ int launch_bwd_gs(const float* f1, const float* f2, const float* g, float* gf1, 
     const int dbg = 0;
 #endif
     unsigned long long* stamps = stamp_buffer();
-    // One workgroup per tile computing both gradients in turn (its second gather finds the planes in L2) once that still
-    // leaves two rounds of workgroups; otherwise one workgroup per (tile, gradient).  Level 2: 88.6 / 92.3 -> 86.6 / 88.3 us
-    // (tuning build), levels 3 / 4 (256 / 64 tiles): 37 -> 62, 22 -> 32 us.
-    const int pair = forced_pair() >= 0 ? forced_pair() : (tx * ty * B >= 512 && groups == 1 ? 1 : 0);
+    // `pair` (tuning builds, UNFLOW_CORR_PAIR=1): one workgroup per tile computing both gradients in turn.  Measured at level 2:
+    // 2-4 us faster on one box (88.6 / 92.3 -> 86.6 / 88.3 us), but the second gather no longer meets the first in L2 -- by then the
+    // tile's planes are evicted -- and HBM traffic goes from 186 MB (1.05x algorithmic) to 241 MB (1.35x): not shipped.  Levels 3 / 4
+    // (256 / 64 tiles) lose outright: 37 -> 62, 22 -> 32 us.
+    const int pair = forced_pair() > 0 ? 1 : 0;
     UNFLOW_LAUNCH((corr_bwd_gs_kernel<R, CC, TYB>), dim3(tx * ty * B * (pair ? 1 : 2), ceil_div(C, cpg)), dim3(K::THREADS), 0, s,
                        f1, f2, g, gf1, gf2, C, cpg, H, W, tx, ty, 1.0f / C, dbg, stamps, pair);
     return unflow_launch_status();
