@@ -197,25 +197,6 @@ def pmc_l2(B=16):
         torch.cuda.synchronize()
 
 
-def corr_pair_sweep(B=16):
-    """Group-split backward: one workgroup per (tile, gradient) vs one per tile computing both gradients in turn (tuning library)."""
-    lib = _lib.load()
-    P = ops._ptr
-    for lvl in ('L2', 'L3', 'L4'):
-        C, h, w = LEVELS[lvl]
-        f1 = torch.randn(B, C, h, w, device='cuda'); f2 = torch.randn(B, C, h, w, device='cuda')
-        gc = torch.randn(B, 81, h, w, device='cuda'); gf1, gf2 = torch.empty_like(f1), torch.empty_like(f2)
-        ref = []
-
-        def run(tag):
-            t = timeit(lambda: lib.unflow_corr_bwd(P(f1), P(f2), P(gc), P(gf1), P(gf2), B, C, h, w, 4, ops._stream()))
-            if not ref:
-                ref.extend([gf1.clone(), gf2.clone()])
-            err = max((gf1 - ref[0]).abs().max().item(), (gf2 - ref[1]).abs().max().item())
-            print('corr_bwd %s %-14s %6.1f us   max|diff vs first| %.2e' % (lvl, tag, t, err), flush=True)
-        _sweep([{'UNFLOW_CORR_PAIR': k} for k in (0, 1, 0, 1)], run)
-
-
 def corr_split_sweep(B=16):
     """Channel slices of the small-map forward (tuning library): 1 = per-element kernel."""
     lib = _lib.load()

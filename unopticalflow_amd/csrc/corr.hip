@@ -337,12 +337,6 @@ struct RingCfg {
 #define STAMP(IDX) do { } while (0)
 #define STAMP_WRITE(buf, row, lane0) do { } while (0)
 #endif
-static inline int forced_pair() {        // tuning builds: UNFLOW_CORR_PAIR = 0 / 1; -1: the launcher's rule
-#ifdef UNFLOW_TUNING
-    if (const char* e = getenv("UNFLOW_CORR_PAIR")) return atoi(e);
-#endif
-    return -1;
-}
 static inline unsigned long long* stamp_buffer() {
 #ifdef UNFLOW_TUNING
     if (const char* sp = getenv("UNFLOW_STAMP_PTR")) return (unsigned long long*)strtoull(sp, nullptr, 0);
@@ -740,7 +734,7 @@ template <int R, int CC, int TYB>
 __global__ __launch_bounds__((BwdGsCfg<R, CC, TYB>::THREADS)) void corr_bwd_gs_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                          const float* __restrict__ g, float* __restrict__ gf1,
                                                          float* __restrict__ gf2, int Ctot, int cpg, int H, int W,
-                                                         int tiles_x, int tiles_y, float inv_c, int dbg, unsigned long long* stamps, int pair) {
+                                                         int tiles_x, int tiles_y, float inv_c, int dbg, unsigned long long* stamps) {
     using K = BwdGsCfg<R, CC, TYB>;
     // stamp segments: 0 gather + prologue | 1 vmcnt wait + barrier | 2 finish (group 0: slab read, add, store) | 3 DMA issue |
     //                 4 row pipeline (FMAs) + partial hand-off | 5 tail
@@ -753,10 +747,10 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC, TYB>::THREADS)) void corr_bwd_gs_k
 
     // work item = (tile, gradient): the two gradients of a tile are neighbours in the XCD-local order, so the
     // upstream-gradient planes both of them read are fetched from HBM once and served from that XCD's L2 the second time
-    // (`pair`, tuning builds: one workgroup computes BOTH gradients of its tile, one after the other; see launch_bwd_gs)
     int t = xcd_remap(blockIdx.x, gridDim.x);
-    int mode_first = 0, mode_last = 1;
-    if (!pair) { mode_first = mode_last = t & 1; t >>= 1; }
+    const int mode = t & 1; t >>= 1;
+    const float* __restrict__ F = mode ? f1 : f2;
+    float* __restrict__ out = mode ? gf2 : gf1;
     const int bx = t % tiles_x; t /= tiles_x;
     const int by = t % tiles_y;
     const int b = t / tiles_y;
@@ -774,10 +768,6 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC, TYB>::THREADS)) void corr_bwd_gs_k
 
     // this wave pair's 3 displacement rows of the upstream gradient -> registers
     // (mode 1: displacement-flipped and gathered from q + (i'-R, j'-R))
-#pragma unroll 1
-    for (int mode = mode_first; mode <= mode_last; ++mode) {
-    const float* __restrict__ F = mode ? f1 : f2;
-    float* __restrict__ out = mode ? gf2 : gf1;
     // Both streams of this kernel go through buffer descriptors: the hardware range check returns 0 for an offset past
     // num_records, so "outside the image" is an offset with kOut added instead of a branch or a select on a 64-bit
     // address.  (The first version selected between the real address and a zero line per value: hipcc re-derived the
@@ -937,7 +927,6 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC, TYB>::THREADS)) void corr_bwd_gs_k
     __builtin_amdgcn_s_barrier();
     if (grp == 0) finish(nchunk - 1, keep);
     STAMP(5);
-    }   // mode
     STAMP_WRITE(stamps, blockIdx.y == 0 ? (int)blockIdx.x * K::NGRP + grp : 1 << 30, (threadIdx.x % GL) == 0);
 }
 
@@ -962,13 +951,8 @@ int launch_bwd_gs(const float* f1, const float* f2, const float* g, float* gf1, 
     const int dbg = 0;
 #endif
     unsigned long long* stamps = stamp_buffer();
-    // `pair` (tuning builds, UNFLOW_CORR_PAIR=1): one workgroup per tile computing both gradients in turn.  Measured at level 2:
-    // 2-4 us faster on one box (88.6 / 92.3 -> 86.6 / 88.3 us), but the second gather no longer meets the first in L2 -- by then the
-    // tile's planes are evicted -- and HBM traffic goes from 186 MB (1.05x algorithmic) to 241 MB (1.35x): not shipped.  Levels 3 / 4
-    // (256 / 64 tiles) lose outright: 37 -> 62, 22 -> 32 us.
-    const int pair = forced_pair() > 0 ? 1 : 0;
-    UNFLOW_LAUNCH((corr_bwd_gs_kernel<R, CC, TYB>), dim3(tx * ty * B * (pair ? 1 : 2), ceil_div(C, cpg)), dim3(K::THREADS), 0, s,
-                       f1, f2, g, gf1, gf2, C, cpg, H, W, tx, ty, 1.0f / C, dbg, stamps, pair);
+    UNFLOW_LAUNCH((corr_bwd_gs_kernel<R, CC, TYB>), dim3(tx * ty * B * 2, ceil_div(C, cpg)), dim3(K::THREADS), 0, s,
+                       f1, f2, g, gf1, gf2, C, cpg, H, W, tx, ty, 1.0f / C, dbg, stamps);
     return unflow_launch_status();
 }
 
