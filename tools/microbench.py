@@ -315,6 +315,21 @@ def epilogue(B=16):
                 n, C, h, w, 'channels_last' if cl else 'NCHW', tf, 2 * nb / tf / 1e3, tb, 3 * nb / tb / 1e3), flush=True)
 
 
+def layout(B=16):
+    """Layout glue of the channels_last conv stacks: cat -> NHWC (decoder input) and NHWC -> NCHW (pyramid features), against torch."""
+    CL = torch.channels_last
+    for (chans, h, w, n) in (((81, 32, 2), 64, 208, B), ((81, 64, 2), 32, 104, B), ((32,), 64, 208, 24)):
+        xs = [torch.randn(n, c, h, w, device='cuda') for c in chans]
+        nb = 8 * n * sum(chans) * h * w
+        t_k = timeit(lambda: ops.cat_channels_last(xs))
+        t_t = timeit(lambda: torch.cat(xs, 1).contiguous(memory_format=CL))
+        y = ops.cat_channels_last(xs)
+        t_b = timeit(lambda: ops.to_nchw(y))
+        t_bt = timeit(lambda: y.contiguous())
+        print('layout [%d,%s,%d,%d]  cat->NHWC %6.1f us (%5.0f GB/s; torch cat + contiguous %6.1f)   NHWC->NCHW %6.1f us (%5.0f GB/s; torch %6.1f)' % (
+            n, '+'.join(map(str, chans)), h, w, t_k, nb / t_k / 1e3, t_t, t_b, nb / t_b / 1e3, t_bt), flush=True)
+
+
 def losses(B=8):
     for s in range(3):
         h, w = 256 >> s, 832 >> s

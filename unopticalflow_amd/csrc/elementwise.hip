@@ -189,15 +189,32 @@ constexpr int LG_PIX = 64, LG_LD = LG_PIX + 1;
 struct Planes3 { const float* p[3]; int c[3]; };      // up to three NCHW tensors, concatenated along C
 struct PlanesOut3 { float* p[3]; int c[3]; };
 
+// (both loops keep LG_UNROLL loads in flight per lane before the dependent LDS / global writes: a one-load-at-a-time loop
+// is a chain of memory round trips)
+constexpr int LG_UNROLL = 8;
+
+__device__ __forceinline__ const float* plane_of(const Planes3& src, int b, int c, int HW) {
+    int k = 0, cc = c;
+    if (cc >= src.c[0]) { cc -= src.c[0]; k = 1; if (cc >= src.c[1]) { cc -= src.c[1]; k = 2; } }
+    return (k == 0 ? src.p[0] : k == 1 ? src.p[1] : src.p[2]) + ((size_t)b * (k == 0 ? src.c[0] : k == 1 ? src.c[1] : src.c[2]) + cc) * HW;
+}
+
 __global__ __launch_bounds__(256) void cat_nhwc_fwd_kernel(Planes3 src, float* __restrict__ dst, int HW, int C) {
     extern __shared__ float tile[];                   // [C][LG_LD]
     const int b = blockIdx.y, p0 = blockIdx.x * LG_PIX, npx = min(LG_PIX, HW - p0);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int c = wave; c < C; c += 4) {
-        int k = 0, cc = c;
-        if (cc >= src.c[0]) { cc -= src.c[0]; k = 1; if (cc >= src.c[1]) { cc -= src.c[1]; k = 2; } }
-        const float* s = (k == 0 ? src.p[0] : k == 1 ? src.p[1] : src.p[2]) + ((size_t)b * (k == 0 ? src.c[0] : k == 1 ? src.c[1] : src.c[2]) + cc) * HW + p0;
-        tile[c * LG_LD + lane] = lane < npx ? s[lane] : 0.f;
+    for (int c0 = wave; c0 < C; c0 += 4 * LG_UNROLL) {
+        float v[LG_UNROLL];
+#pragma unroll
+        for (int u = 0; u < LG_UNROLL; ++u) {
+            const int c = c0 + 4 * u;
+            v[u] = (c < C && lane < npx) ? plane_of(src, b, c, HW)[p0 + lane] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < LG_UNROLL; ++u) {
+            const int c = c0 + 4 * u;
+            if (c < C) tile[c * LG_LD + lane] = v[u];
+        }
     }
     __syncthreads();
     float* d = dst + ((size_t)b * HW + p0) * C;
@@ -215,9 +232,15 @@ __global__ __launch_bounds__(256) void split_nhwc_kernel(const float* __restrict
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* s = srcp + ((size_t)b * HW + p0) * C;
     const int n = npx * C;
-    for (int e = threadIdx.x; e < n; e += 256) {
-        const int px = e / C, c = e - px * C;
-        tile[c * LG_LD + px] = s[e];
+    for (int e0 = threadIdx.x; e0 < n; e0 += 256 * LG_UNROLL) {
+        float v[LG_UNROLL];
+#pragma unroll
+        for (int u = 0; u < LG_UNROLL; ++u) v[u] = (e0 + 256 * u < n) ? s[e0 + 256 * u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < LG_UNROLL; ++u) {
+            const int e = e0 + 256 * u;
+            if (e < n) { const int px = e / C, c = e - px * C; tile[c * LG_LD + px] = v[u]; }
+        }
     }
     __syncthreads();
     for (int c = wave; c < C; c += 4) {
