@@ -112,6 +112,36 @@ def test_flat_gradient_pieces_cover_buffer():
     assert 4 < many.chunks <= 98 and many.pieces[-1][1] == many.numel and sum(n for _, _, n in many.pieces) == 98
 
 
+def test_packed_gradients_single_rank_group():
+    """FlatGradients(pack=True), the trainer's mode: backward assigns the gradients, a piece is copied into the buffer when
+    its last gradient exists (three hooks per piece, not one per parameter), ``p.grad`` then aliases the buffer; a parameter
+    the loss did not reach contributes zeros."""
+    os.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    init_distributed('gloo', force=True)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 4), torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+        unused = torch.nn.Parameter(torch.ones(7))
+        params = list(net.parameters()) + [unused]
+        fg = FlatGradients(params, chunks=2, overlap=True, single_rank_collectives=True, pack=True)
+        assert len(fg._hooks) == 6 and all(p.grad is None for p in params)
+        x = torch.randn(3, 6)
+        for _ in range(2):                                   # the second step must not see the first one's buffer contents
+            fg.zero()
+            assert all(p.grad is None for p in params)
+            net(x).square().sum().backward()
+            want = [p.grad.clone() for p in net.parameters()]
+            assert fg.launched_early >= 1                    # the piece without the unused parameter left from a hook
+            fg.all_reduce_mean()
+            fg.check_views()
+            for p, w in zip(net.parameters(), want):
+                assert torch.equal(p.grad, w)
+            assert torch.equal(unused.grad, torch.zeros(7))
+            assert torch.equal(fg.vector(), torch.cat([w.reshape(-1) for w in want] + [torch.zeros(7)]))
+    finally:
+        dist.destroy_process_group()
+
+
 def test_shard_batch_requires_divisible():
     with pytest.raises(ValueError):
         shard_batch(torch.zeros(3, 1), 0, 2)
