@@ -195,6 +195,12 @@ int unflow_bias_leaky_bwd2_bf16(const uint16_t* y, const uint16_t* gout, long lo
                                 const uint16_t* gout2, long long gout2_stride, uint16_t* gin, float* gbias,
                                 float* partials, int N, int C, int H, int W, float slope, void* stream);
 
+/* ... and their channels_last twins ([P][C] bf16, C % 4 == 0; scratch size: unflow_bias_leaky_partials_nhwc). */
+int unflow_bias_leaky_fwd_nhwc_bf16(uint16_t* y, const float* bias, long long P, int C, float slope, void* stream);
+int unflow_bias_leaky_bwd2_nhwc_bf16(const uint16_t* y, const uint16_t* gout, long long gout_pstride, const uint16_t* gout2,
+                                     long long gout2_pstride, uint16_t* gin, float* gbias, float* partials,
+                                     long long P, int C, float slope, void* stream);
+
 /* ---- image pyramid: Model_flow.generate_img_pyramid scales 1 and 2, model_flow_paper.py:54-60 ----
  * img [planes,H,W] (planes = B*C, any leading layout) -> half [planes,H/2,W/2] (2x2 box means) and
  * quarter [planes,H/4,W/4] (4x4 box means of img).  H, W multiples of 4. */

@@ -235,8 +235,8 @@ def test_bf16_step_at_kitti_size():
     from unopticalflow_amd.trainer import FlowTrainer
     x = R.synthetic_triplets(8, 256, 832, seed=3, structured=True).cuda()
     packs, norms = {}, {}
-    for prec in ('fp32', 'bf16'):
-        cfg = R.default_cfg(precision=prec)
+    for prec in ('fp32', 'bf16', 'bf16 channels_last'):
+        cfg = R.default_cfg(precision=prec.split()[0], channels_last=(True if prec != 'bf16' else False))
         model = get_model('flow')(cfg).cuda()
         model.load_state_dict(R.seeded_state_dict(model, 1234, 0.25))
         tr = FlowTrainer(cfg, model)
@@ -248,10 +248,11 @@ def test_bf16_step_at_kitti_size():
         packs[prec] = {k: v.detach().float().cpu() for k, v in pack.items()}
         tr.optimizer.step()
         assert all(torch.isfinite(p).all() for p in model.parameters())
-    for k in ('loss_pixel', 'loss_ssim', 'loss_flow_consis'):
-        close(packs['bf16'][k], packs['fp32'][k], rtol=3e-2, what=k)
-    close(packs['bf16']['loss_flow_smooth'], packs['fp32']['loss_flow_smooth'], rtol=1.0, what='smooth')
-    assert abs(norms['bf16'] - norms['fp32']) <= 0.25 * norms['fp32'], norms
+    for prec in ('bf16', 'bf16 channels_last'):          # (NCHW and NHWC conv stacks: MIOpen picks different bf16 kernels)
+        for k in ('loss_pixel', 'loss_ssim', 'loss_flow_consis'):
+            close(packs[prec][k], packs['fp32'][k], rtol=3e-2, what=prec + ' ' + k)
+        close(packs[prec]['loss_flow_smooth'], packs['fp32']['loss_flow_smooth'], rtol=1.0, what=prec + ' smooth')
+        assert abs(norms[prec] - norms['fp32']) <= 0.25 * norms['fp32'], norms
 
 
 # ------------------------------------------------------------------------------------ two ranks on one GPU

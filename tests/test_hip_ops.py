@@ -593,6 +593,28 @@ def test_bias_leaky_bf16(ops, shape):
     assert torch.equal(one.cpu(), ref_out)
 
 
+@pytest.mark.parametrize('shape', [(16, 128, 64, 208), (2, 196, 4, 13), (3, 8, 4, 4), (2, 96, 8, 26)])
+def test_bias_leaky_bf16_channels_last(ops, shape):
+    """The bf16 epilogue on channels_last activations (the bf16 conv stacks with cfg.channels_last): same arithmetic as the NCHW
+    bf16 kernels -- fp32 math, one rounding per element, bias gradient over the rounded values."""
+    N, C, H, W = shape
+    CL = torch.channels_last
+    y0 = rnd(72, shape).to(torch.bfloat16)
+    bias = rnd(73, (C,), 0.3)
+    ga, gcat = rnd(74, shape).to(torch.bfloat16), rnd(75, (N, C + 8, H, W)).to(torch.bfloat16)
+    act = torch.nn.functional.leaky_relu(y0.float() + bias.view(1, C, 1, 1), 0.1)
+    ref_out = act.to(torch.bfloat16)
+    gsum = ga.float() + gcat[:, 8:].float()
+    ref_gin = (gsum * torch.where(ref_out.float() > 0, 1.0, 0.1)).to(torch.bfloat16)
+    yg, bg = y0.cuda().contiguous(memory_format=CL).requires_grad_(), bias.cuda().requires_grad_()
+    a, b = ops.bias_leaky_relu_(yg * 1.0, bg, 0.1, consumers=2)
+    assert a.dtype == torch.bfloat16 and a.stride() == yg.stride() and torch.equal(a.cpu(), ref_out)
+    torch.autograd.backward([a, b], [ga.cuda().contiguous(memory_format=CL), gcat.cuda().contiguous(memory_format=CL)[:, 8:]])
+    assert yg.grad.dtype == torch.bfloat16 and torch.equal(yg.grad.cpu(), ref_gin)
+    want = ref_gin.float().sum((0, 2, 3))
+    close(bg.grad, want, rtol=1e-4, atol=1e-4 * want.abs().max().item())
+
+
 def test_conv_block_matches_reference_block(ops):
     from unopticalflow_amd import conv as conv_hip
     torch.manual_seed(0)

@@ -32,13 +32,20 @@ def run(cl):
     if cl:
         m = m.to(memory_format=torch.channels_last); img = img.contiguous(memory_format=torch.channels_last); x = x.contiguous(memory_format=torch.channels_last)
     x.requires_grad_()
+    amp = os.environ.get('AMP', '0') == '1'            # AMP=1: the bf16 conv-stack option (torch.autocast)
+
+    def step():
+        m.zero_grad()
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
+            loss = m(img, x)
+        loss.backward()
     for _ in range(3):
-        m.zero_grad(); m(img, x).backward()
+        step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10):
-        m.zero_grad(); m(img, x).backward()
+        step()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / 10 * 1e3
 
 for cl in (False, True, False, True):
-    print('channels_last=%s find=%s: %.2f ms' % (cl, torch.backends.cudnn.benchmark, run(cl)), flush=True)
+    print('channels_last=%s find=%s bf16=%s: %.2f ms' % (cl, torch.backends.cudnn.benchmark, os.environ.get('AMP', '0'), run(cl)), flush=True)

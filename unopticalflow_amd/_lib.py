@@ -48,6 +48,8 @@ SIGNATURES = {
     'unflow_bias_leaky_fwd_nhwc': [_P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P],
     'unflow_bias_leaky_partials_nhwc': [ctypes.c_longlong, _I],
     'unflow_bias_leaky_bwd2_nhwc': [_P, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P],
+    'unflow_bias_leaky_fwd_nhwc_bf16': [_P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P],
+    'unflow_bias_leaky_bwd2_nhwc_bf16': [_P, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P],
     'unflow_cat_nhwc': [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P],
     'unflow_split_nhwc': [_P, _P, _I, _P, _I, _P, _I, _I, _I, _P],
     'unflow_bias_leaky_fwd_bf16': [_P, _P, _I, _I, _I, _I, ctypes.c_float, _P],
@@ -57,7 +59,7 @@ SIGNATURES = {
     'unflow_png_unfilter': [_P, _I, _I, _I],
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 

@@ -31,11 +31,9 @@ class Model_flow(nn.Module):
         self.precision = getattr(cfg, 'precision', 'fp32')
         if self.precision not in ('fp32', 'bf16'):
             raise ValueError('precision must be fp32 or bf16, got {}'.format(self.precision))
-        # fp32 conv stacks run on channels_last tensors (NHWC: no MIOpen transposes); the bf16 option keeps NCHW
+        # fp32 conv stacks run on channels_last tensors (NHWC: no MIOpen transposes); the bf16 option defaults to NCHW (opt in: cfg.channels_last)
         cl = getattr(cfg, 'channels_last', None)
         self.channels_last = (self.precision == 'fp32') if cl is None else bool(cl)
-        if self.channels_last and self.precision != 'fp32':
-            raise ValueError('channels_last conv stacks are fp32 only (the bf16 epilogue kernels are NCHW)')
         self.fpyramid = FeaturePyramid(channels_last=self.channels_last)
         self.pwc_model = PWC_tf(align_corners=self.align_corners, fused_warp_corr=bool(getattr(cfg, 'fused_warp_corr', False)),
                                 channels_last=self.channels_last)

@@ -26,7 +26,7 @@ class FeaturePyramid(nn.Module):
             weights_to_channels_last(self)
 
     def forward(self, img):
-        cl = self.channels_last and img.is_cuda and img.dtype == torch.float32 and not torch.is_autocast_enabled()
+        cl = self.channels_last and img.is_cuda and img.dtype == torch.float32      # (under bf16 autocast the convs then produce bf16 NHWC)
         outs, t, last = [], (img.contiguous(memory_format=CL) if cl else img), len(_CHANNELS) - 1
         for lvl in range(len(_CHANNELS)):
             t = getattr(self, 'conv%d' % (2 * lvl + 1))(t)

@@ -47,13 +47,15 @@ class PWC_tf(nn.Module):
             weights_to_channels_last(self)
 
     def _cl(self, x):
-        return self.channels_last and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+        return self.channels_last and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
 
     def _cat(self, parts):
         """The decoder input torch.cat(parts, 1) (pwc_tf.py:113): written directly in channels_last order when the conv
         stack runs in it (one kernel instead of a cat and a re-layout)."""
-        if self._cl(parts[0]) and all(p.dtype == torch.float32 for p in parts):
-            return ops.cat_channels_last(parts)
+        if self._cl(parts[0]):
+            # (bf16 option: the pyramid features are bf16; the cat is fp32 like torch.cat's type promotion, the convolution's
+            # autocast then casts the NHWC tensor)
+            return ops.cat_channels_last([p.float() for p in parts])
         return parts[0] if len(parts) == 1 else torch.cat(parts, 1)
 
     def predict_flow(self, in_planes):

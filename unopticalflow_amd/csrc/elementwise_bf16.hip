@@ -106,6 +106,88 @@ __global__ void bias_grad_finalize_bf16_kernel(const float* __restrict__ partial
     if (threadIdx.x == 0) gbias[blockIdx.x] = acc[0];
 }
 
+// ---- channels-last (NHWC) twins for the bf16 conv stacks: [P = N*H*W pixels][C] bf16, C % 4 == 0.  Same geometry as the fp32
+// NHWC epilogue (elementwise.hip): a thread keeps one channel quad (8 bytes per access) and walks pixels, 4 in flight.
+constexpr int HN_PIX = 128, HN_UNROLL = 4;
+struct alignas(8) bf4 { unsigned short v[4]; };
+
+__global__ __launch_bounds__(256) void bias_leaky_fwd_nhwc_bf16_kernel(unsigned short* __restrict__ y, const float* __restrict__ bias,
+                                                                       long long P, int C, int rows, float slope) {
+    const int quads = C >> 2;
+    const int q = threadIdx.x % quads, r = threadIdx.x / quads;
+    if (r >= rows) return;
+    const float4 b = *reinterpret_cast<const float4*>(bias + q * 4);
+    const float bb[4] = {b.x, b.y, b.z, b.w};
+    const long long p0 = (long long)blockIdx.x * HN_PIX, p1 = min(p0 + HN_PIX, P);
+    for (long long p = p0 + r; p < p1; p += (long long)rows * HN_UNROLL) {
+        bf4 v[HN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < HN_UNROLL; ++u)
+            if (p + (long long)u * rows < p1) v[u] = reinterpret_cast<const bf4*>(y + (p + (long long)u * rows) * C)[q];
+#pragma unroll
+        for (int u = 0; u < HN_UNROLL; ++u)
+            if (p + (long long)u * rows < p1) {
+                bf4 t = v[u];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float f = bf2f(t.v[k]) + bb[k];
+                    t.v[k] = f2bf(f > 0.f ? f : f * slope);
+                }
+                reinterpret_cast<bf4*>(y + (p + (long long)u * rows) * C)[q] = t;
+            }
+    }
+}
+
+template <bool TWO>
+__global__ __launch_bounds__(256) void bias_leaky_bwd_nhwc_bf16_kernel(const unsigned short* __restrict__ y,
+                                                                       const unsigned short* __restrict__ gout, long long gps,
+                                                                       const unsigned short* __restrict__ gout2, long long gps2,
+                                                                       unsigned short* __restrict__ gin, float* __restrict__ partials,
+                                                                       long long P, int C, int rows, float slope) {
+    extern __shared__ float red[];                 // [rows][C]
+    const int quads = C >> 2;
+    const int q = threadIdx.x % quads, r = threadIdx.x / quads;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows) {
+        const long long p0 = (long long)blockIdx.x * HN_PIX, p1 = min(p0 + HN_PIX, P);
+        for (long long p = p0 + r; p < p1; p += (long long)rows * HN_UNROLL) {
+            bf4 v[HN_UNROLL], g[HN_UNROLL], h[HN_UNROLL];
+#pragma unroll
+            for (int u = 0; u < HN_UNROLL; ++u) {
+                const long long pp = p + (long long)u * rows;
+                if (pp < p1) {
+                    v[u] = reinterpret_cast<const bf4*>(y + pp * C)[q];
+                    g[u] = reinterpret_cast<const bf4*>(gout + pp * gps)[q];
+                    if (TWO) h[u] = reinterpret_cast<const bf4*>(gout2 + pp * gps2)[q];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < HN_UNROLL; ++u) {
+                const long long pp = p + (long long)u * rows;
+                if (pp < p1) {
+                    bf4 t;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float f = bf2f(g[u].v[k]);
+                        if (TWO) f += bf2f(h[u].v[k]);
+                        f = bf2f(v[u].v[k]) > 0.f ? f : f * slope;
+                        t.v[k] = f2bf(f);
+                        acc[k] += bf2f(t.v[k]);          // the rounded value, as in the NCHW kernel
+                    }
+                    reinterpret_cast<bf4*>(gin + pp * C)[q] = t;
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(red + r * C + q * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int k = 0; k < rows; ++k) s += red[k * C + c];
+        partials[(size_t)c * gridDim.x + blockIdx.x] = s;
+    }
+}
+
 }  // namespace
 
 extern "C" int unflow_bias_leaky_fwd_bf16(uint16_t* y, const float* bias, int N, int C, int H, int W, float slope,
@@ -134,5 +216,38 @@ extern "C" int unflow_bias_leaky_bwd2_bf16(const uint16_t* y, const uint16_t* go
         UNFLOW_LAUNCH(bias_leaky_bwd_bf16_kernel<false>, dim3(nchunk, C, N), dim3(256), 0, s, y, gout, gout_stride, gout2,
                            gout2_stride, gin, partials, C, HW, slope);
     UNFLOW_LAUNCH(bias_grad_finalize_bf16_kernel, dim3(C), dim3(256), 0, s, partials, N * nchunk, gbias);
+    return unflow_launch_status();
+}
+
+// channels-last twins: y / gin dense [P][C] bf16 (P = N*H*W), C a multiple of 4 and <= 1024; scratch as unflow_bias_leaky_partials_nhwc
+static inline int hn_rows(int C) { const int r = 256 / (C >> 2); return r < 1 ? 1 : r; }
+
+extern "C" int unflow_bias_leaky_fwd_nhwc_bf16(uint16_t* y, const float* bias, long long P, int C, float slope, void* stream) {
+    UNFLOW_REQUIRE(y && bias && P > 0 && C >= 4 && (C & 3) == 0 && C <= 1024 && ((size_t)y & 7) == 0 && ((size_t)bias & 15) == 0);
+    const long long blocks = (P + HN_PIX - 1) / HN_PIX;
+    UNFLOW_REQUIRE(blocks < (1ll << 31));
+    UNFLOW_LAUNCH(bias_leaky_fwd_nhwc_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, bias, P, C,
+                  hn_rows(C), slope);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_bias_leaky_bwd2_nhwc_bf16(const uint16_t* y, const uint16_t* gout, long long gout_pstride, const uint16_t* gout2,
+                                                long long gout2_pstride, uint16_t* gin, float* gbias, float* partials,
+                                                long long P, int C, float slope, void* stream) {
+    UNFLOW_REQUIRE(y && gout && gin && gbias && partials && P > 0 && C >= 4 && (C & 3) == 0 && C <= 1024);
+    UNFLOW_REQUIRE(gout_pstride >= C && (gout_pstride & 3) == 0 && (((size_t)gout | (size_t)y | (size_t)gin) & 7) == 0);
+    UNFLOW_REQUIRE(!gout2 || (gout2_pstride >= C && (gout2_pstride & 3) == 0 && ((size_t)gout2 & 7) == 0));
+    const long long blocks = (P + HN_PIX - 1) / HN_PIX;
+    UNFLOW_REQUIRE(blocks * C < (1ll << 31));
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = hn_rows(C);
+    const size_t shmem = (size_t)rows * C * sizeof(float);
+    if (gout2)
+        UNFLOW_LAUNCH(bias_leaky_bwd_nhwc_bf16_kernel<true>, dim3((unsigned)blocks), dim3(256), shmem, s, y, gout, gout_pstride,
+                      gout2, gout2_pstride, gin, partials, P, C, rows, slope);
+    else
+        UNFLOW_LAUNCH(bias_leaky_bwd_nhwc_bf16_kernel<false>, dim3((unsigned)blocks), dim3(256), shmem, s, y, gout, gout_pstride,
+                      gout2, gout2_pstride, gin, partials, P, C, rows, slope);
+    UNFLOW_LAUNCH(bias_grad_finalize_bf16_kernel, dim3(C), dim3(256), 0, s, partials, (int)blocks, gbias);
     return unflow_launch_status();
 }

@@ -577,8 +577,8 @@ def _bias_leaky_backward(ctx, ga, gb):
         P = N * H * W
         part = torch.empty(_lib.load().unflow_bias_leaky_partials_nhwc(P, C), dtype=torch.float32, device=y.device)
         with _on(y.device):
-            _call('unflow_bias_leaky_bwd2_nhwc', _ptr(y), _ptr(ga), sa, _ptr(gb), sb, _ptr(gin), _ptr(gbias), _ptr(part),
-                  P, C, ctypes.c_float(ctx.slope), _stream(),
+            _call('unflow_bias_leaky_bwd2_nhwc_bf16' if half else 'unflow_bias_leaky_bwd2_nhwc', _ptr(y), _ptr(ga), sa, _ptr(gb), sb,
+                  _ptr(gin), _ptr(gbias), _ptr(part), P, C, ctypes.c_float(ctx.slope), _stream(),
                   nbytes=(3 if gb is None else 4) * y.element_size() * N * C * H * W, shape=(N, C, H, W))
         return gin, gbias, None
     ga, sa = _sample_strided(ga, y.shape)
@@ -602,10 +602,11 @@ def _bias_leaky_forward(ctx, y, bias, slope):
     N, C, H, W = y.shape
     nhwc = _is_nhwc(y)
     if nhwc:
-        if half or C % 4:
-            raise RuntimeError('bias_leaky_relu_: the channels_last epilogue is fp32 with C %% 4 == 0 (got %s, C=%d)' % (y.dtype, C))
+        if C % 4:
+            raise RuntimeError('bias_leaky_relu_: the channels_last epilogue needs C %% 4 == 0 (got C=%d)' % C)
         with _on(y.device):
-            _call('unflow_bias_leaky_fwd_nhwc', _ptr(y), _ptr(bias), N * H * W, C, ctypes.c_float(slope), _stream(),
+            _call('unflow_bias_leaky_fwd_nhwc_bf16' if half else 'unflow_bias_leaky_fwd_nhwc', _ptr(y), _ptr(bias), N * H * W, C,
+                  ctypes.c_float(slope), _stream(),
                   nbytes=2 * y.element_size() * N * C * H * W, shape=(N, C, H, W))
     else:
         if not y.is_contiguous():

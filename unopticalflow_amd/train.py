@@ -112,7 +112,7 @@ def train(cfg):
         measured_picks = bool(torch.backends.cudnn.benchmark)
     if getattr(cfg, 'channels_last', None) is None:
         # NHWC conv stacks pay off with MIOpen's measured solver picks (the shipped find-db), not with its heuristics
-        cfg.channels_last = bool(getattr(cfg, 'precision', 'fp32') == 'fp32' and measured_picks)
+        cfg.channels_last = bool(measured_picks)
         if rank == 0 and tuple(cfg.img_hw) not in ((256, 832), (448, 1024)):
             print('MIOpen find mode: the shipped find-db covers 832x256 (bs 8/GPU) and 1024x448 (bs 4/GPU); other shapes are '
                   'measured once during the first iterations (20+ minutes for a full-size shape) -- pass --miopen_find 0 to skip that.', flush=True)
