@@ -168,3 +168,24 @@ def test_miopen_tuning_paths(monkeypatch):
         assert tuning.enable_miopen_tuning(benchmark=False) == '/some/where' and not torch.backends.cudnn.benchmark
     finally:
         torch.backends.cudnn.benchmark = saved
+
+
+def test_channels_last_stride_helpers():
+    """Host logic of the channels_last epilogue (no GPU): which gradients can be read in place as pixel-strided NHWC data (a
+    dense channels_last tensor, or a 4-aligned channel slice of one -- what autograd hands out for a torch.cat operand) and
+    which have to be re-laid out first."""
+    from unopticalflow_amd import ops
+    CL = torch.channels_last
+    x = torch.zeros(2, 8, 5, 6).contiguous(memory_format=CL)
+    assert ops._is_nhwc(x) and not ops._is_nhwc(torch.zeros(2, 8, 5, 6)) and not ops._is_nhwc(torch.zeros(2, 1, 5, 6).contiguous(memory_format=CL))
+    g, ps = ops._pixel_strided(x, (2, 8, 5, 6))
+    assert g is x and ps == 8
+    wide = torch.zeros(2, 24, 5, 6).contiguous(memory_format=CL)
+    g, ps = ops._pixel_strided(wide[:, 8:16], (2, 8, 5, 6))            # channel slice at a 16-byte aligned offset: read in place
+    assert g.data_ptr() == wide[:, 8:16].data_ptr() and ps == 24
+    g, ps = ops._pixel_strided(wide[:, 3:11], (2, 8, 5, 6))            # misaligned slice: copied
+    assert ps == 8 and g.is_contiguous(memory_format=CL) and g.data_ptr() != wide[:, 3:11].data_ptr()
+    g, ps = ops._pixel_strided(torch.zeros(2, 8, 5, 6), (2, 8, 5, 6))   # an NCHW gradient from outside the island: re-laid out
+    assert ps == 8 and g.is_contiguous(memory_format=CL)
+    g, st = ops._sample_strided(torch.zeros(2, 24, 5, 6)[:, 8:16], (2, 8, 5, 6))   # the NCHW twin: sample-strided slice
+    assert st == 24 * 30 or g.is_contiguous()
