@@ -81,7 +81,7 @@ def host_cores():
 
 def cpu_baseline(sample_b):
     """The oracle's train step (same op graph as the reference: 81-offset corr loop, grid_sample,
-    AvgPool SSIM) on this box's host cores: 1 untimed + 2 timed steps of `sample_b` triplets."""
+    AvgPool SSIM) on this box's host cores: 1 untimed + 3 timed steps of `sample_b` triplets."""
     from oracle import ref_cpu as R
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -93,7 +93,7 @@ def cpu_baseline(sample_b):
     x = R.synthetic_triplets(sample_b, H, W, seed=0, structured=False)
     R.train_step(model, opt, x, weights)
     t0 = time.perf_counter()
-    n = 2
+    n = 3
     for _ in range(n):
         R.train_step(model, opt, x, weights)
     dt = time.perf_counter() - t0
@@ -117,6 +117,24 @@ def cpu_baseline(sample_b):
             'kind': 'port', 'value_1thread': round(2 / dt1, 4),
             'sample': '%d timed train steps (+1 untimed) of %d synthetic 832x256 triplets (%.1f s), fp32, torch CPU '
                       'oracle on %s; value_1thread: 1 timed step of 1 triplet on one thread (%.1f s)' % (n, sample_b, dt, cpu, dt1)}
+
+
+def per_step_stats(marks, host, t_end):
+    """Spread of the timed steps.  `step_ms` = device time between consecutive per-step event records (what the GPU
+    spent on a step, including any wait for the host), `host_enqueue_ms` = host time to ENQUEUE a step (no sync inside),
+    `drain_ms` = time between the last enqueue and the closing synchronisation: when the drain is far below one step the
+    host is what paces the loop (launch-bound), when it is several steps the GPU is."""
+    import statistics as st
+    dev = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)]
+    enq = [(host[i + 1] - host[i]) * 1e3 for i in range(len(host) - 1)]
+    k = min(5, len(dev))
+
+    def summary(v):
+        s = sorted(v)
+        return {'min': round(s[0], 3), 'median': round(st.median(s), 3), 'p90': round(s[min(len(s) - 1, int(0.9 * len(s)))], 3),
+                'max': round(s[-1], 3), 'first5_mean': round(sum(v[:k]) / k, 3), 'last5_mean': round(sum(v[-k:]) / k, 3)}
+    return {'step_ms': summary(dev), 'host_enqueue_ms': summary(enq), 'drain_ms': round((t_end - host[-1]) * 1e3, 3),
+            'all_step_ms': [round(x, 2) for x in dev]}
 
 
 def sources_sha16():
@@ -168,11 +186,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
-    measured_picks = False
+    from unopticalflow_amd import tuning
     if os.environ.get('UNFLOW_MIOPEN_FIND', '1') == '1':
-        from unopticalflow_amd.tuning import enable_miopen_tuning
-        enable_miopen_tuning()                    # shipped find-db for exactly these conv shapes (tuning.py)
-        measured_picks = bool(torch.backends.cudnn.benchmark)
+        tuning.enable_miopen_tuning()             # shipped find-db for exactly these conv shapes (tuning.py)
+    measured_picks = tuning.default_channels_last()
     # channels_last conv stacks pay off with MIOpen's MEASURED solver picks (the shipped find-db: fp32 26.1 -> 25.3 ms,
     # bf16 15.9 -> 14.1 ms); with
     # its immediate-mode heuristics (another MIOpen build than the db was made with) NHWC is the slower layout (29.2 vs
@@ -203,12 +220,21 @@ def main():
     CW = ('unflow_corr_fwd', 'unflow_corr_bwd', 'unflow_warp_fwd', 'unflow_warp_bwd', 'unflow_warp_corr_fwd', 'unflow_warp_corr_bwd')
     if not args.no_kernel_timing:
         ops.kernel_timer.enable(CW, reserve=32 * args.steps)     # every cost-volume / warp launch of the timed steps: kernel-exact event pairs
+    # per-step clocks that do not perturb the loop: one event record per step on the launch stream (read after the
+    # closing barrier) and one host stamp per step (no synchronisation inside the timed region)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    host = [0.0] * (args.steps + 1)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    host[0] = t0
+    for i in range(args.steps):
         loss, _ = trainer.step(inputs)
+        marks[i + 1].record()
+        host[i + 1] = time.perf_counter()
     barrier()
     dt = time.perf_counter() - t0
+    step_stats = per_step_stats(marks, host, t0 + dt)
     ops.kernel_timer.disable()
     timed_rows = ops.kernel_timer.rows() if not args.no_kernel_timing else []      # (device is synchronised: barrier())
     if not torch.isfinite(loss):
@@ -295,6 +321,9 @@ def main():
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                        'conv_memory_format': 'channels_last' if cfg.channels_last else 'NCHW',
                        'triplets_per_s': round(pairs / 2 / dt, 2)},
+            'step_ms': step_stats['step_ms'], 'host_enqueue_ms': step_stats['host_enqueue_ms'], 'drain_ms': step_stats['drain_ms'],
+            'pairs_per_s_at_median_step': round(2 * args.batch * world / (step_stats['step_ms']['median'] * 1e-3), 2),
+            'all_step_ms': step_stats['all_step_ms'],
             'roofline': roof, 'cpu_baseline': base,
             # whole-step lower bound on the conv stacks' MFMA utilisation: conv FLOPs / (entire step time);
             # profiles/ holds the per-kernel split (convolutions alone: see DESIGN.md section 4)

@@ -244,10 +244,69 @@ def gen_module(name, B, H, W, steps, full_flows, mask_flow_scales=(), full_grads
     save(name, out)
 
 
+# ------------------------------------------------------------------ G4: KITTI flow metrics (row N1)
+def eval_inputs(seed=11, n=3, H=37, W=61):
+    """Synthetic KITTI-style ground truth at NATIVE resolution (prediction size == ground-truth size == cfg.img_hw, so the
+    reference's cv2.resize is the identity): flows with validity, non-occluded masks (a subset of valid), moving-object
+    masks, predictions = ground truth + noise with a band of gross outliers."""
+    rng = np.random.default_rng(seed)
+    gt, noc, pred, move = [], [], [], []
+    for i in range(n):
+        f = rng.standard_normal((H, W, 2)) * 12.0
+        f[: H // 3] *= 0.05                                     # small-magnitude region: the 5 % relative test decides
+        valid = (rng.random((H, W)) > 0.25).astype(np.float64)
+        nocm = valid * (rng.random((H, W)) > 0.3)
+        if i == 1:
+            nocm = valid.copy()                                 # no occluded pixel at all: the max(.., 1.0) divisor
+        p = f + rng.standard_normal((H, W, 2)) * 1.5
+        p[:, W // 2: W // 2 + 9] += 7.0                         # outliers (> 3 px)
+        m = np.zeros((H, W)); m[5:20, 10:30] = 1.0
+        gt.append(np.concatenate([f, valid[:, :, None]], 2)); noc.append(nocm); pred.append(p); move.append(m)
+    return gt, noc, pred, move
+
+
+def gen_eval():
+    """core/evaluation/evaluate_flow.py imported unmodified: calculate_error_rate (:85-90) and eval_flow_avg (:93-174).
+    Harness shims: empty ``png`` module (flowlib.py:11 imports it; read_flow_png is not called), ``cv2.resize`` that only
+    accepts the identity case.  The PNG decode and the real bilinear resize stay unpinned (no pypng / cv2 in the image)."""
+    sys.modules.setdefault('png', types.ModuleType('png'))
+    cv2 = sys.modules['cv2']
+
+    def resize(img, size, interpolation=None):
+        assert (img.shape[1], img.shape[0]) == tuple(size), 'fixture is native-resolution only'
+        return np.copy(img)
+    cv2.resize, cv2.INTER_LINEAR = resize, 1
+    # (the module file itself, not the ``core.evaluation`` package: its __init__ pulls in the depth evaluation -> skimage)
+    import importlib.util
+    sys.path.insert(0, '/root/reference/core/evaluation')                    # evaluate_flow.py:3 does ``from flowlib import ...``
+    spec = importlib.util.spec_from_file_location('evaluate_flow', '/root/reference/core/evaluation/evaluate_flow.py')
+    EF = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(EF)
+    gt, noc, pred, move = eval_inputs()
+    H, W = gt[0].shape[:2]
+    cfg = types.SimpleNamespace(img_hw=(H, W), model_dir='/nonexistent')
+    out = {'gt': np.stack(gt), 'noc': np.stack(noc), 'pred': np.stack(pred), 'move': np.stack(move)}
+    rates = []
+    for g, n_, p, m in zip(gt, noc, pred, move):
+        epe = np.sqrt(np.sum(np.square(p - g[:, :, :2]), axis=2))
+        rates.append([EF.calculate_error_rate(epe, g[:, :, :2], g[:, :, 2]), EF.calculate_error_rate(epe, g[:, :, :2], g[:, :, 2] * m),
+                      EF.calculate_error_rate(epe, g[:, :, :2], g[:, :, 2] * (1.0 - m)), EF.calculate_error_rate(epe, g[:, :, :2], n_)])
+    out['error_rates'] = np.array(rates, np.float64)
+    out['result_plain'] = np.array(EF.eval_flow_avg(gt, noc, pred, cfg))
+    out['result_moving'] = np.array(EF.eval_flow_avg(gt, noc, pred, cfg, moving_masks=move))
+    # un-rounded per-metric averages, recomputed from the reference's own formulas' pieces (the strings carry 4 decimals)
+    save('g4_eval.npz', out)
+    print(out['result_plain']); print(out['result_moving'])
+
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['eval']:
+        gen_eval()
+        sys.exit(0)
     torch.manual_seed(0)
     gen_corr()
     gen_warp()
     gen_losses()
     gen_module('g2_module_128.npz', 2, 128, 128, steps=3, full_flows=True, mask_flow_scales=(0, 1, 2, 3), full_grads=True)
     gen_module('g3_kitti_256x832.npz', 1, 256, 832, steps=1, full_flows=False, mask_flow_scales=(1, 2, 3))
+    gen_eval()

@@ -225,3 +225,87 @@ def test_single_rank_group_runs_the_collectives():
         assert tr2.grads.launched_early == 0
     finally:
         dist.destroy_process_group()
+
+
+def test_eager_step_after_a_graph_capture_packs_fresh_gradients():
+    """A hipGraph capture leaves ``remember_sources()`` behind (the graph's static gradient tensors).  A later EAGER step
+    (FlowTrainer.step falls through for a differently shaped batch) must exchange what ITS backward produced: zero() drops
+    the views of the flat buffer, the pack reads p.grad -- never the graph's tensors, which hold the previous replay's
+    gradients.  The capture is simulated on CPU (no graph needed for the bookkeeping): the 'captured' gradients are the
+    tensors of a first backward."""
+    os.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    init_distributed('gloo', force=True)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 4), torch.nn.Linear(4, 3))
+        params = list(net.parameters())
+        fg = FlatGradients(params, chunks=2, overlap=False, single_rank_collectives=True, pack=True)   # (graph mode: no hooks)
+        xa, xb = torch.randn(3, 6), torch.randn(5, 6)
+
+        fg.zero()                                           # "capture": backward assigns the graph's static tensors
+        net(xa).square().sum().backward()
+        fg.remember_sources()
+        static = [g for g in fg._sources]
+        want_a = [g.clone() for g in static]
+        fg.all_reduce_mean(from_graph=True)                 # a replay: packs from the static tensors
+        fg.check_views()
+        for p, w in zip(params, want_a):
+            assert torch.equal(p.grad, w)
+
+        fg.zero()                                           # eager step on another batch shape
+        assert all(p.grad is None for p in params)
+        net(xb).square().sum().backward()
+        want_b = [p.grad.clone() for p in params]
+        assert not any(torch.equal(a, b) for a, b in zip(want_a, want_b))
+        fg.all_reduce_mean()
+        fg.check_views()
+        for p, w in zip(params, want_b):
+            assert torch.equal(p.grad, w)                   # not the stale replay gradients, not a sum with them
+
+        for g, w in zip(static, want_a):                    # the next replay rewrites the static tensors; exchange again
+            g.copy_(2 * w)
+        fg.all_reduce_mean(from_graph=True)
+        for p, w in zip(params, want_a):
+            assert torch.equal(p.grad, 2 * w)
+        with pytest.raises(RuntimeError):
+            FlatGradients(params, chunks=2, pack=True).all_reduce_mean(from_graph=True)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_resume_across_memory_formats_relays_adam_state(tmp_path):
+    """A checkpoint written with row-major (NCHW) conv weights resumed into channels_last weights, and back: Adam's
+    moments must take the parameter's strides (the fused multi-tensor Adam walks parameter, gradient and moments by
+    memory offset), values unchanged, and training continues identically to the uninterrupted run."""
+    from unopticalflow_amd.core.networks.structures.net_utils import weights_to_channels_last
+    from unopticalflow_amd.trainer import relayout_optimizer_state
+    x = R.synthetic_triplets(1, H, W, seed=2)
+
+    def trainer_for(cl):
+        cfg, model = _make()
+        if cl:
+            weights_to_channels_last(model)
+        return FlowTrainer(cfg, model, fused_adam=False)
+
+    for src_cl, dst_cl in ((False, True), (True, False)):
+        tr = trainer_for(src_cl)
+        tr.step(x)
+        path = str(tmp_path / ('ckpt_%d.pth' % src_cl))
+        tr.save(path)
+        tr2 = trainer_for(dst_cl)
+        tr2.load(path)
+        n4 = 0
+        for p in tr2.optimizer.param_groups[0]['params']:
+            st = tr2.optimizer.state[p]
+            for k in ('exp_avg', 'exp_avg_sq'):
+                assert st[k].stride() == p.stride(), (k, tuple(p.shape), st[k].stride(), p.stride())
+            n4 += p.dim() == 4
+        assert n4 == 49
+        for (pa, sa), (pb, sb) in zip(tr.optimizer.state.items(), tr2.optimizer.state.items()):
+            assert torch.equal(sa['exp_avg'], sb['exp_avg']) and torch.equal(sa['exp_avg_sq'], sb['exp_avg_sq'])
+        l1, _ = tr.step(x)
+        l2, _ = tr2.step(x)
+        assert torch.allclose(l1, l2, rtol=1e-6)
+        for a, b in zip(tr.model.parameters(), tr2.model.parameters()):
+            assert torch.allclose(a, b, rtol=0, atol=2.5e-4)    # one more Adam step of <= lr; the two layouts take different CPU conv paths
+    relayout_optimizer_state(torch.optim.Adam([torch.nn.Parameter(torch.zeros(3))]))      # empty state: nothing to do

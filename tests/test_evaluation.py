@@ -110,3 +110,23 @@ def test_kitti_flow_task_end_to_end(tmp_path):
     res = T.test_kitti_2015(cfg, model, gt, noc, E.load_gt_mask(root, 2), num=2)
     vals = [float(t) for t in res.strip().split('\n')[1].split(',')]
     assert len(vals) == 8 and all(np.isfinite(vals))
+
+
+def test_metrics_match_the_reference_fixture(golden):
+    """The metric half of N1 pinned on the reference itself: ``tests/golden/g4_eval.npz`` holds what the reference's own
+    ``calculate_error_rate`` (evaluate_flow.py:85-90) and ``eval_flow_avg`` (:93-174) return for native-resolution synthetic
+    ground truth (prediction size == ground-truth size == cfg.img_hw, where cv2.resize is the identity; generated by
+    tests/golden/gen_golden.py from /root/reference imported unmodified).  Same numbers, same result strings.  The PNG
+    decode and the bilinear resize to another resolution stay unpinned (no pypng / cv2 in this image)."""
+    g = golden('g4_eval.npz')
+    gt, noc, pred, move = (list(g[k]) for k in ('gt', 'noc', 'pred', 'move'))
+    H, W = gt[0].shape[:2]
+    cfg = types.SimpleNamespace(img_hw=(H, W), model_dir='/nonexistent')
+    assert np.array_equal(E.resize_bilinear(pred[0], W, H), pred[0])              # the identity case is exact here too
+    for k, (gf, n_, p, m) in enumerate(zip(gt, noc, pred, move)):
+        epe = np.sqrt(np.sum(np.square(p - gf[:, :, :2]), axis=2))
+        got = [E.calculate_error_rate(epe, gf[:, :, :2], gf[:, :, 2]), E.calculate_error_rate(epe, gf[:, :, :2], gf[:, :, 2] * m),
+               E.calculate_error_rate(epe, gf[:, :, :2], gf[:, :, 2] * (1.0 - m)), E.calculate_error_rate(epe, gf[:, :, :2], n_)]
+        assert np.array_equal(np.array(got, np.float64), g['error_rates'][k])     # integer counts over integer counts: bit-equal
+    assert E.eval_flow_avg(gt, noc, pred, cfg) == str(g['result_plain'])
+    assert E.eval_flow_avg(gt, noc, pred, cfg, moving_masks=move) == str(g['result_moving'])

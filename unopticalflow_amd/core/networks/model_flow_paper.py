@@ -2,7 +2,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ... import ops
+from ... import ops, tuning
 from .structures import FeaturePyramid, PWC_tf, warp_flow
 
 
@@ -20,7 +20,7 @@ class Model_flow(nn.Module):
         (model_flow_paper.py:62-66 with num_scales=3) is not computed.
     ``cfg.align_corners`` (optional, default False) selects the grid_sample generation;
     ``cfg.precision`` (optional, 'fp32' | 'bf16') the conv-stack precision; ``cfg.channels_last`` (optional, default:
-    True for fp32) the memory format of the conv stacks' activations and weights.
+    ``tuning.default_channels_last()``) the memory format of the conv stacks' activations and weights.
     """
 
     def __init__(self, cfg):
@@ -31,9 +31,10 @@ class Model_flow(nn.Module):
         self.precision = getattr(cfg, 'precision', 'fp32')
         if self.precision not in ('fp32', 'bf16'):
             raise ValueError('precision must be fp32 or bf16, got {}'.format(self.precision))
-        # fp32 conv stacks run on channels_last tensors (NHWC: no MIOpen transposes); the bf16 option defaults to NCHW (opt in: cfg.channels_last)
+        # conv stacks on channels_last tensors (NHWC: no MIOpen transposes) when asked for, by default when MIOpen runs on the
+        # shipped find-db's measured picks (tuning.default_channels_last: the one place that decides), else NCHW
         cl = getattr(cfg, 'channels_last', None)
-        self.channels_last = (self.precision == 'fp32') if cl is None else bool(cl)
+        self.channels_last = tuning.default_channels_last() if cl is None else bool(cl)
         self.fpyramid = FeaturePyramid(channels_last=self.channels_last)
         self.pwc_model = PWC_tf(align_corners=self.align_corners, fused_warp_corr=bool(getattr(cfg, 'fused_warp_corr', False)),
                                 channels_last=self.channels_last)

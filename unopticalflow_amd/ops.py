@@ -651,6 +651,10 @@ def bias_leaky_relu_(y, bias, negative_slope=0.1, consumers=1):
     reference's conv() block (net_utils.py:7-11) in one pass; its backward also reduces the bias gradient.
     ``consumers=2`` returns the activation twice (one handle per consumer) so that the backward pass adds the
     two incoming gradients inside the kernel instead of in a separate pass."""
+    if y.dim() == 4 and y.shape[1] % 4 and _is_nhwc(y):
+        # the channels_last kernels keep a channel quad per thread; other widths (none in the flow network) take the NCHW
+        # epilogue on a re-laid-out copy instead of failing
+        y = y.contiguous()
     if consumers == 2:
         return _BiasLeakyTwo.apply(y, bias, float(negative_slope))
     return _BiasLeaky.apply(y, bias, float(negative_slope))

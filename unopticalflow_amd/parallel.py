@@ -119,14 +119,17 @@ class FlatGradients:
         """RCCL averages in the collective itself; gloo (the CPU tests) sums and the buffer is scaled afterwards."""
         return dist.ReduceOp.AVG if dist.get_backend(self.group) == 'nccl' else dist.ReduceOp.SUM
 
-    def _pack_piece(self, k):
-        """Copy the (assigned) gradients of piece k into the buffer and re-point ``p.grad`` at it."""
+    def _pack_piece(self, k, from_graph=False):
+        """Copy the (assigned) gradients of piece k into the buffer and re-point ``p.grad`` at it.  ``from_graph``: the
+        step was a hipGraph replay, whose backward wrote the graph's own static tensors (``remember_sources``); an EAGER
+        step -- also one that follows a capture, e.g. a differently shaped batch -- packs what backward assigned to
+        ``p.grad``, never the graph's buffers (they hold the previous replay's gradients)."""
         if self._packed[k]:
             return
         a, b = self._piece_params[k]
         dst, src = [], []
         for i in range(a, b):
-            g = self._sources[i] if self._sources is not None else self.params[i].grad
+            g = self._sources[i] if from_graph else self.params[i].grad
             if g is None:
                 self.views[i].zero_()                     # a parameter the loss did not reach
             elif g.data_ptr() != self.views[i].data_ptr():
@@ -137,9 +140,9 @@ class FlatGradients:
             self.params[i].grad = self.views[i]
         self._packed[k] = True
 
-    def _launch(self, k):
+    def _launch(self, k, from_graph=False):
         if self.pack:
-            self._pack_piece(k)
+            self._pack_piece(k, from_graph)
         a, b, _ = self.pieces[k]
         self._works[k] = dist.all_reduce(self.flat[a:b], op=self._averaging_op(), group=self.group, async_op=True)
 
@@ -177,15 +180,17 @@ class FlatGradients:
 
     def remember_sources(self):
         """After a hipGraph capture of forward + backward: the tensors backward assigned as gradients are the graph's own
-        static buffers, rewritten by every replay; ``pack`` copies from them from now on."""
+        static buffers, rewritten by every replay; ``all_reduce_mean(from_graph=True)`` copies from them."""
         if self.pack:
             self._sources = [p.grad for p in self.params]
 
     def zero(self):
         if self.pack:
-            if self._sources is None:                     # (under graph replay the captured backward does not read p.grad)
-                for p in self.params:
-                    p.grad = None
+            # always dropped: an eager backward must ASSIGN fresh gradients (after an exchange ``p.grad`` are views of the
+            # buffer, which still holds the last reduced values; accumulating into them would apply stale gradients).  A
+            # hipGraph replay never comes through here (its backward writes the captured tensors, not ``p.grad``).
+            for p in self.params:
+                p.grad = None
         else:
             self.flat.zero_()
         self._left = [n for _, _, n in self.pieces]
@@ -209,15 +214,21 @@ class FlatGradients:
                                    'use FlatGradients.zero() instead of optimizer.zero_grad()')
             off += p.numel()
 
-    def all_reduce_mean(self):
+    def all_reduce_mean(self, from_graph=False):
         """Average the flat gradient over all ranks (no-op for a single process).  Pieces already sent by the
-        hooks are only waited for; the rest is launched here."""
+        hooks are only waited for; the rest is launched here.  ``from_graph``: the gradients of this step are in the
+        tensors of the captured hipGraph (``remember_sources``), not in ``p.grad``."""
+        if from_graph and (not self.pack or self._sources is None):
+            raise RuntimeError('all_reduce_mean(from_graph=True) needs pack mode and remember_sources() after the capture')
         if not self._active():
+            if from_graph:                                # nothing to exchange: the optimizer reads the graph's tensors
+                for p, g in zip(self.params, self._sources):
+                    p.grad = g
             return
         world = dist.get_world_size(self.group)
         for k in range(self.chunks):
             if self._works[k] is None:
-                self._launch(k)
+                self._launch(k, from_graph)
         for w in self._works:
             w.wait()
         self._works = [None] * self.chunks

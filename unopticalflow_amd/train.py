@@ -92,6 +92,20 @@ def evaluate_during_training(cfg, model, iter_):
     return results
 
 
+def eval_barrier(timeout_s=4 * 3600):
+    """All ranks meet after rank 0's periodic evaluation.  A gloo group with its own (long) timeout carries it: the RCCL
+    group's watchdog would kill the waiting ranks."""
+    import datetime
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    g = eval_barrier.__dict__.get('group')
+    if g is None:
+        g = eval_barrier.__dict__['group'] = dist.new_group(backend='gloo', timeout=datetime.timedelta(seconds=timeout_s))
+    torch.cuda.synchronize()
+    dist.barrier(group=g)
+
+
 def train(cfg):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     ids = gpu_ids(getattr(cfg, 'gpu', '0'))
@@ -105,17 +119,14 @@ def train(cfg):
     torch.cuda.set_device(ids[local])
     dev = torch.device('cuda', ids[local])
 
-    measured_picks = False
+    from . import tuning
     if getattr(cfg, 'miopen_find', 1):
-        from .tuning import enable_miopen_tuning
-        enable_miopen_tuning()
-        measured_picks = bool(torch.backends.cudnn.benchmark)
-    if getattr(cfg, 'channels_last', None) is None:
-        # NHWC conv stacks pay off with MIOpen's measured solver picks (the shipped find-db), not with its heuristics
-        cfg.channels_last = bool(measured_picks)
-        if rank == 0 and tuple(cfg.img_hw) not in ((256, 832), (448, 1024)):
+        tuning.enable_miopen_tuning()
+        if rank == 0 and torch.backends.cudnn.benchmark and tuple(cfg.img_hw) not in ((256, 832), (448, 1024)):
             print('MIOpen find mode: the shipped find-db covers 832x256 (bs 8/GPU) and 1024x448 (bs 4/GPU); other shapes are '
                   'measured once during the first iterations (20+ minutes for a full-size shape) -- pass --miopen_find 0 to skip that.', flush=True)
+    if getattr(cfg, 'channels_last', None) is None:
+        cfg.channels_last = tuning.default_channels_last()              # NHWC only with MIOpen's measured picks
     model = get_model(cfg.mode)(cfg).to(dev)
     trainer = FlowTrainer(cfg, model, distributed=(world > 1), use_graph=bool(getattr(cfg, 'graph', 0)))
     if cfg.resume:                                                     # train.py:42-46
@@ -160,8 +171,19 @@ def train(cfg):
             rate = n_last * cfg.batch_size / dt
             print_loss(loss_pack, iter_=iter_, extra=', samples/s: {:.1f}, pairs/s: {:.1f}'.format(rate, 2 * rate))
             t_last, n_last = time.perf_counter(), 0
-        if rank == 0 and not cfg.no_test and (iter_ + 1) % cfg.test_interval == 0:     # train.py:157-162
-            evaluate_during_training(cfg, model, iter_)
+        if not cfg.no_test and (iter_ + 1) % cfg.test_interval == 0:       # train.py:157-162
+            # rank 0 evaluates (batch-1 inference shapes are not in the find-db: heuristics, no exhaustive find); the other
+            # ranks wait HERE in a barrier with a long timeout instead of in the next step's all-reduce, whose watchdog
+            # (10 min) would abort the job during a ~400-image evaluation
+            bench_mode = torch.backends.cudnn.benchmark
+            torch.backends.cudnn.benchmark = False
+            try:
+                if rank == 0:
+                    evaluate_during_training(cfg, model, iter_)
+            finally:
+                torch.backends.cudnn.benchmark = bench_mode
+                if world > 1:
+                    eval_barrier()
         if rank == 0 and (iter_ + 1) % cfg.save_interval == 0:         # train.py:153-155
             trainer.iteration = iter_
             trainer.save(os.path.join(cfg.model_dir, 'iter_{}.pth'.format(iter_)))
@@ -193,7 +215,7 @@ def main(argv=None):
     ap.add_argument('--align_corners', type=int, default=0, help='grid_sample generation: 0 torch>=1.3, 1 torch 1.2.0.')
     ap.add_argument('--num_iterations', type=int, default=None, help='override the yaml value.')
     ap.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'bf16'], help='conv-stack precision.')
-    ap.add_argument('--channels_last', type=int, default=None, help='memory format of the conv stacks (1 NHWC, 0 NCHW); default: 1 for fp32.')
+    ap.add_argument('--channels_last', type=int, default=None, help='memory format of the conv stacks (1 NHWC, 0 NCHW); default: 1 when the shipped MIOpen find-db is in use (same device and MIOpen build), else 0.')
     ap.add_argument('--miopen_find', type=int, default=1, help='1: use the shipped MIOpen find-db + benchmark mode.')
     ap.add_argument('--graph', type=int, default=0, help='1: replay the train step as a hipGraph.')
     ap.add_argument('--host_input', type=int, default=0, help='1: resize/flip/scale on the CPU workers (PIL) instead of the GPU.')

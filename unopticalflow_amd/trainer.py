@@ -102,7 +102,7 @@ class FlowTrainer:
         self._static_in.copy_(inputs)
         self._graph.replay()
         if self.distributed:
-            self.grads.all_reduce_mean()
+            self.grads.all_reduce_mean(from_graph=True)     # the replay wrote the captured gradient tensors
             self.optimizer.step()
         self.iteration += 1
         return self._static_loss, self._static_pack
@@ -135,5 +135,22 @@ class FlowTrainer:
         sd = {k[len('module.'):] if k.startswith('module.') else k: v for k, v in data['model_state_dict'].items()}
         self.model.load_state_dict(sd)
         self.optimizer.load_state_dict(data['optimizer_state_dict'])
+        relayout_optimizer_state(self.optimizer)
         self.iteration = data['iteration']
         return self.iteration
+
+
+def relayout_optimizer_state(optimizer):
+    """Give every per-parameter state tensor (Adam's exp_avg / exp_avg_sq / max_exp_avg_sq) its parameter's strides.
+    ``Optimizer.load_state_dict`` keeps the strides the moments were SAVED with; a checkpoint written by the reference,
+    by an NCHW run (--channels_last 0, --miopen_find 0, another MIOpen build) or before the conv weights went
+    channels_last then leaves row-major moments next to channels_last parameters and gradients, and the fused
+    (multi-tensor) Adam walks all four by memory offset -- it requires one layout.  Values are unchanged."""
+    for group in optimizer.param_groups:
+        for p in group['params']:
+            st = optimizer.state.get(p)
+            if not st:
+                continue
+            for k, v in st.items():
+                if torch.is_tensor(v) and v.dim() == p.dim() and v.shape == p.shape and v.stride() != p.stride():
+                    st[k] = torch.empty_like(p, dtype=v.dtype).copy_(v)      # empty_like preserves p's (dense) strides
