@@ -63,6 +63,7 @@ def parse():
     ap.add_argument('--graph', type=int, default=0, help='1: replay the step as a hipGraph (kernel timing events are then off)')
     ap.add_argument('--channels-last', type=int, default=-1, help='memory format of the conv stacks: 1 channels_last (NHWC), 0 NCHW; default: 1 when the shipped MIOpen find-db is in use, else 0 (cfg.channels_last)')
     ap.add_argument('--fused', type=int, default=0, help='1: warp + cost volume of each decoder level as one kernel (cfg.fused_warp_corr)')
+    ap.add_argument('--gc-freeze', type=int, default=1, help='0: leave Python\'s cyclic collector alone (FlowTrainer(gc_freeze_after=None)); 1: the trainer default (gc.freeze() after its second step)')
     ap.add_argument('--force-ddp', action='store_true', help='N = 1 only: run the step through the RCCL data-parallel path with a one-rank communicator')
     return ap.parse_args()
 
@@ -202,7 +203,7 @@ def main():
     torch.manual_seed(1234)                       # same random init on every rank
     model = get_model('flow')(cfg).to(dev)
     trainer = FlowTrainer(cfg, model, distributed=(world > 1 or args.force_ddp), use_graph=bool(args.graph),
-                          single_rank_collectives=args.force_ddp)
+                          single_rank_collectives=args.force_ddp, **({} if args.gc_freeze else {'gc_freeze_after': None}))
     if args.graph:
         args.no_kernel_timing = True
     gen = torch.Generator(device=dev)
@@ -224,6 +225,18 @@ def main():
     # closing barrier) and one host stamp per step (no synchronisation inside the timed region)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     host = [0.0] * (args.steps + 1)
+    import gc
+    gc_log = {'collections': [0, 0, 0], 'ms': 0.0, 'max_ms': 0.0, '_t': 0.0}
+
+    def gc_watch(phase, info):                        # how much of the timed region the cyclic collector took (host side)
+        if phase == 'start':
+            gc_log['_t'] = time.perf_counter()
+        else:
+            d = (time.perf_counter() - gc_log['_t']) * 1e3
+            gc_log['collections'][info['generation']] += 1
+            gc_log['ms'] += d
+            gc_log['max_ms'] = max(gc_log['max_ms'], d)
+    gc.callbacks.append(gc_watch)
     barrier()
     t0 = time.perf_counter()
     marks[0].record()
@@ -234,7 +247,10 @@ def main():
         host[i + 1] = time.perf_counter()
     barrier()
     dt = time.perf_counter() - t0
+    gc.callbacks.remove(gc_watch)
     step_stats = per_step_stats(marks, host, t0 + dt)
+    step_stats['host_gc'] = {'collections_gen0_1_2': gc_log['collections'], 'total_ms': round(gc_log['ms'], 2),
+                             'longest_ms': round(gc_log['max_ms'], 2), 'frozen_by_trainer': bool(trainer._gc_frozen)}
     ops.kernel_timer.disable()
     timed_rows = ops.kernel_timer.rows() if not args.no_kernel_timing else []      # (device is synchronised: barrier())
     if not torch.isfinite(loss):
@@ -323,7 +339,7 @@ def main():
                        'triplets_per_s': round(pairs / 2 / dt, 2)},
             'step_ms': step_stats['step_ms'], 'host_enqueue_ms': step_stats['host_enqueue_ms'], 'drain_ms': step_stats['drain_ms'],
             'pairs_per_s_at_median_step': round(2 * args.batch * world / (step_stats['step_ms']['median'] * 1e-3), 2),
-            'all_step_ms': step_stats['all_step_ms'],
+            'all_step_ms': step_stats['all_step_ms'], 'host_gc': step_stats['host_gc'],
             'roofline': roof, 'cpu_baseline': base,
             # whole-step lower bound on the conv stacks' MFMA utilisation: conv FLOPs / (entire step time);
             # profiles/ holds the per-kernel split (convolutions alone: see DESIGN.md section 4)

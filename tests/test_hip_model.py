@@ -98,13 +98,14 @@ def test_module_128_golden(golden, ac, cl):
             close(loss, g['total' + tag], rtol=1e-4)
             gn = float(np.sqrt(sum((p.grad.double() ** 2).sum().item() for p in model.parameters())))
             np.testing.assert_allclose(gn, float(g['grad_norm' + tag]), rtol=5e-4)
-            # per-tensor L1 norms of all 98 gradients.  Every tensor within 1e-3 of ITS OWN L1 norm plus 1e-3 of its
-            # largest element (L1 / numel <= max: the allowance of a tensor is at most 2e-3 of its norm, and this small only
-            # because rounding errors of opposite sign cancel in a sum) -- was rtol 2e-2
+            # per-tensor L1 norms of all 98 gradients.  Every tensor within 5e-4 of ITS OWN L1 norm plus 5e-4 of its
+            # largest element (L1 / numel <= max: the allowance of a tensor is at most 1e-3 of its norm) -- was rtol 2e-2
             ga = np.array([p.grad.double().abs().sum().item() for p in model.parameters()])
             gmax = np.array([p.grad.abs().max().item() for p in model.parameters()])
             ref_ga = g['grad_abs' + tag]
-            bad = np.abs(ga - ref_ga) > 1e-3 * ref_ga + 1e-3 * gmax
+            # (measured, tools/tolerance_probe.py on both memory formats and both grid_sample generations, 3 runs each:
+            # worst tensor 1.3e-4 of its L1 norm, 0.12 of a 1e-3 + 1e-3 allowance -> the bars are 5e-4 + 5e-4)
+            bad = np.abs(ga - ref_ga) > 5e-4 * ref_ga + 5e-4 * gmax
             assert not bad.any(), [(n, a, b) for (n, _), a, b, x in zip(model.named_parameters(), ga, ref_ga, bad) if x]
             if ac == 0:
                 # full gradient tensors of the first pyramid layer (end of the whole backward chain), the widest level-2
@@ -233,41 +234,66 @@ def test_sintel_1024x448_matches_oracle():
         close(pack[k], pr[k], rtol=1e-4, what=k)
 
 
+def _flow_bars(flows, ref_flows, what):
+    """bf16 flows against fp32 flows, per pyramid scale: mean end-point error within 4 % and the worst pixel within 10 % of
+    the scale's largest flow component.  Measured (tools/tolerance_probe.py, NCHW and channels_last): mean 1.4-3.0 %, worst
+    3.1-6.6 % -- an 8-bit mantissa through five coarse-to-fine levels; a wrong kernel in the bf16 path (epilogue, layout
+    glue, a dropped cast) moves a flow by its own magnitude, not by a few per cent of it."""
+    for s_, (f, r) in enumerate(zip(flows, ref_flows)):
+        f, r = f.float(), r.float()
+        scale = r.abs().max().item()
+        epe = (f - r).pow(2).sum(1).sqrt().mean().item()
+        worst = (f - r).abs().max().item()
+        assert epe <= 0.04 * scale and worst <= 0.10 * scale, (what, s_, epe / scale, worst / scale)
+
+
 def test_bf16_conv_stacks_close_to_fp32_oracle():
     """BASELINE config 3 precision: bf16 autocast on the conv stacks, fp32 corr / warp / losses.  There is no
-    bf16 reference (the reference is fp32 only): checked against the fp32 oracle at a stated loose tolerance."""
+    bf16 reference (the reference is fp32 only): checked against the fp32 ORACLE -- flows at the bars of _flow_bars, the
+    photometric / SSIM / consistency losses within 1 %, smoothness (second differences of a bf16-rounded flow come out
+    3-4 % low, consistently) within 8 % (was: a factor 1.5)."""
     from unopticalflow_amd import get_model
-    cfg = R.default_cfg(precision='bf16')
-    model = get_model('flow')(cfg).cuda()
-    model.load_state_dict(R.seeded_state_dict(model, 1234, 0.25))
     x = R.synthetic_triplets(2, 128, 128, seed=0, structured=True)
+    H = 128
     ref = R.Model_flow(R.default_cfg())
     ref.load_state_dict(R.seeded_state_dict(ref, 1234, 0.25))
-    pack = model(x.cuda())
-    loss = sum(v.mean() for v in pack.values())
-    loss.backward()
-    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
     with torch.no_grad():
         pr = ref(x)
-    for k in ('loss_pixel', 'loss_ssim', 'loss_flow_consis'):
-        close(pack[k], pr[k], rtol=5e-2, what=k)          # 8-bit mantissa through 5 coarse-to-fine levels
-    close(pack['loss_flow_smooth'], pr['loss_flow_smooth'], rtol=0.5, what='smooth')   # 2nd differences of a bf16-rounded flow
+        fr = ref.fpyramid(x[:, :, H:2 * H]), ref.fpyramid(x[:, :, 2 * H:])
+        ref_fwd = ref.pwc_model(fr[0], fr[1], [H, 128])               # centre -> right, four scales
+    for cl in (False, True):
+        cfg = R.default_cfg(precision='bf16', channels_last=cl)
+        model = get_model('flow')(cfg).cuda()
+        model.load_state_dict(R.seeded_state_dict(model, 1234, 0.25))
+        xc = x.cuda()
+        with torch.no_grad():
+            stacked = model._flows(xc[:, :, :H], xc[:, :, H:2 * H], xc[:, :, 2 * H:])
+        _flow_bars([f[2:].cpu() for f in stacked], ref_fwd, 'bf16 cl=%s' % cl)
+        pack = model(xc)
+        loss = sum(v.mean() for v in pack.values())
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+        for k in ('loss_pixel', 'loss_ssim', 'loss_flow_consis'):
+            close(pack[k], pr[k], rtol=1e-2, what=k)
+        close(pack['loss_flow_smooth'], pr['loss_flow_smooth'], rtol=8e-2, what='smooth')
 
 
 def test_bf16_step_at_kitti_size():
     """BASELINE config 3 at its real shape: one bf16 train step at 832x256, B=8 (the per-GPU batch of the 8-GPU job).
-    No bf16 reference exists; the fp32 HIP model on the same weights is the yardstick: photometric / SSIM / consistency
-    losses within 3 % per sample (8-bit mantissa through 5 coarse-to-fine levels), smoothness (second differences of a
-    bf16-rounded flow) within a factor 2, every gradient finite and the gradient norm within 25 %."""
+    No bf16 reference exists; the fp32 HIP model on the same weights is the yardstick: flows at the bars of _flow_bars,
+    photometric / SSIM / consistency losses within 1 % per sample, smoothness within 8 %, every gradient finite and the
+    gradient norm within 10 %."""
     from unopticalflow_amd import get_model
     from unopticalflow_amd.trainer import FlowTrainer
     x = R.synthetic_triplets(8, 256, 832, seed=3, structured=True).cuda()
-    packs, norms = {}, {}
+    packs, norms, flows = {}, {}, {}
     for prec in ('fp32', 'bf16', 'bf16 channels_last'):
         cfg = R.default_cfg(precision=prec.split()[0], channels_last=(True if prec != 'bf16' else False))
         model = get_model('flow')(cfg).cuda()
         model.load_state_dict(R.seeded_state_dict(model, 1234, 0.25))
         tr = FlowTrainer(cfg, model)
+        with torch.no_grad():
+            flows[prec] = [f.float().cpu() for f in model._flows(x[:, :, :256], x[:, :, 256:512], x[:, :, 512:])]
         tr.grads.zero()
         pack = model(x)
         tr.total_loss(pack).backward()
@@ -276,11 +302,13 @@ def test_bf16_step_at_kitti_size():
         packs[prec] = {k: v.detach().float().cpu() for k, v in pack.items()}
         tr.optimizer.step()
         assert all(torch.isfinite(p).all() for p in model.parameters())
+    print('gradient norms', norms)
     for prec in ('bf16', 'bf16 channels_last'):          # (NCHW and NHWC conv stacks: MIOpen picks different bf16 kernels)
+        _flow_bars(flows[prec], flows['fp32'], prec)
         for k in ('loss_pixel', 'loss_ssim', 'loss_flow_consis'):
-            close(packs[prec][k], packs['fp32'][k], rtol=3e-2, what=prec + ' ' + k)
-        close(packs[prec]['loss_flow_smooth'], packs['fp32']['loss_flow_smooth'], rtol=1.0, what=prec + ' smooth')
-        assert abs(norms[prec] - norms['fp32']) <= 0.25 * norms['fp32'], norms
+            close(packs[prec][k], packs['fp32'][k], rtol=1e-2, what=prec + ' ' + k)
+        close(packs[prec]['loss_flow_smooth'], packs['fp32']['loss_flow_smooth'], rtol=8e-2, what=prec + ' smooth')
+        assert abs(norms[prec] - norms['fp32']) <= 0.10 * norms['fp32'], norms
 
 
 # ------------------------------------------------------------------------------------ two ranks on one GPU

@@ -153,6 +153,55 @@ def corr_bwd_sweep(B=16):
         _sweep(envs, run)
 
 
+def corr_bwd_rs(B=16):
+    """Round 3: the row-streamed backward (UNFLOW_CORR_BWD=7: 16 channels per work item, 8: 8) against the group-split ring
+    kernel (default), levels 2-4, with the largest difference between their results."""
+    lib = _lib.load()
+    P = ops._ptr
+    envs = [{}] + [{'UNFLOW_CORR_BWD': v} for v in (os.environ.get('UNFLOW_RS_VARIANTS', '7,8,9,10,11').split(','))]
+    for name, (C, h, w) in list(LEVELS.items())[:3]:
+        f1 = torch.randn(B, C, h, w, device='cuda')
+        f2 = torch.randn(B, C, h, w, device='cuda')
+        g = torch.randn(B, 81, h, w, device='cuda')
+        gf1, gf2 = torch.empty_like(f1), torch.empty_like(f2)
+        bb = 4 * B * h * w * (4 * C + 81)
+        ref = {}
+
+        def run(tag):
+            gf1.fill_(float('nan')); gf2.fill_(float('nan'))
+            tb = timeit(lambda: lib.unflow_corr_bwd(P(f1), P(f2), P(g), P(gf1), P(gf2), B, C, h, w, 4, ops._stream()))
+            if not ref:
+                ref['a'], ref['b'] = gf1.clone(), gf2.clone()
+            err = max((gf1 - ref['a']).abs().max().item(), (gf2 - ref['b']).abs().max().item())
+            print('corr_bwd %s [%d,%d,%d,%d] %-40s %7.1f us (%6.0f GB/s)  max|diff vs default| %.2e (max|ref| %.2f)' % (
+                name, B, C, h, w, tag, tb, bb / tb / 1e3, err, ref['a'].abs().max().item()), flush=True)
+        _sweep(envs, run)
+
+
+def corr8_bwd_rs(B=16):
+    """d = 8 backward: row-streamed kernel (UNFLOW_CORR_BWD=7: 8 channels per item, 8: 4) against the group-split ring kernel."""
+    lib = _lib.load()
+    P = ops._ptr
+    envs = [{}, {'UNFLOW_CORR_BWD': 7}, {'UNFLOW_CORR_BWD': 8}]
+    for name, (C, h, w) in list(LEVELS.items())[:3]:
+        f1 = torch.randn(B, C, h, w, device='cuda')
+        f2 = torch.randn(B, C, h, w, device='cuda')
+        g = torch.randn(B, 289, h, w, device='cuda')
+        gf1, gf2 = torch.empty_like(f1), torch.empty_like(f2)
+        bb = 4 * B * h * w * (4 * C + 289)
+        ref = {}
+
+        def run(tag):
+            gf1.fill_(float('nan')); gf2.fill_(float('nan'))
+            tb = timeit(lambda: lib.unflow_corr_bwd(P(f1), P(f2), P(g), P(gf1), P(gf2), B, C, h, w, 8, ops._stream()))
+            if not ref:
+                ref['a'], ref['b'] = gf1.clone(), gf2.clone()
+            err = max((gf1 - ref['a']).abs().max().item(), (gf2 - ref['b']).abs().max().item())
+            print('corr_bwd d=8 %s [%d,%d,%d,%d] %-40s %7.1f us (%6.0f GB/s)  max|diff vs default| %.2e (max|ref| %.2f)' % (
+                name, B, C, h, w, tag, tb, bb / tb / 1e3, err, ref['a'].abs().max().item()), flush=True)
+        _sweep(envs, run)
+
+
 def ablate(B=16):
     """Phase ablations at level 2 (tuning library; results are wrong by construction, only the times matter)."""
     lib = _lib.load()

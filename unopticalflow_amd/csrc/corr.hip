@@ -957,6 +957,400 @@ int launch_bwd_gs(const float* f1, const float* f2, const float* g, float* gf1, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Large-map backward, "row streamed" kernel (round 3).  The group-split kernel above keeps a third of a lane's upstream
+// gradient in registers for ALL channels and pays for it with a serial gather in front of every tile (22-36 % of a
+// workgroup's life with one 768-thread workgroup per CU), a barrier per ring stage and a hand-off of partial sums.
+// Here the roles are turned around: the CHANNELS of a work item are resident -- the F halo tile of CH channels in LDS
+// (staged once by LDS-DMA), one accumulator pair per channel in registers -- and the upstream gradient STREAMS through
+// the registers one displacement row at a time (DD values x 2 pixels per lane, the next row requested while the current
+// one is being used).  A lane computes all DD x DD taps of its two pixels itself: no partial sums, no hand-off, and after
+// the one barrier behind the staging the four waves of a workgroup never meet again, so the gather of one wave, the LDS
+// reads of another and the FMAs of a third overlap, within a workgroup and across the two (R = 4, CH = 16: 72 KB) that
+// share a CU.  A work item = (tile, gradient, group of CH channels); the items that read the same gradient planes are
+// neighbours in the XCD-local order (HBM delivers the planes once, the re-reads come out of that XCD's L2).
+//   gf1[c][q] = (1/C) sum_ij g[ij][q]                         * f2[c][q + (i-R, j-R)]
+//   gf2[c][q] = (1/C) sum_ij g[(2R-i, 2R-j)][q + (i-R, j-R)]  * f1[c][q + (i-R, j-R)]
+// Both modes multiply the weight of tap (i, j) with F at q + (i-R, j-R), which the halo tile holds as an exact 0 outside the
+// image; in mode 1 the weight is read at that same position, so a weight fetched for a position outside the image (some
+// other finite gradient value, or 0 from the buffer range check) meets a 0 and needs no validity test of its own.
+// Requires W % 4 == 0 and 16-byte aligned feature tensors (LDS-DMA pieces), 32-bit buffer offsets (gs_offsets_fit).
+// ---------------------------------------------------------------------------------------------
+// Tile shapes (TYB rows of 256 / TYB lanes, 2 px per lane): 64 x 8, or 16 x 32 for widths like 13 * 2^k (208 = 13 * 16:
+// 64-wide tiles leave the fourth tile column three quarters empty, 19 % of all lanes idle).
+template <int R, int CH, int TYB_ = 8>
+struct BwdRsCfg {
+    static constexpr int DD = 2 * R + 1, TYB = TYB_, THREADS = 256, TWL = THREADS / TYB, TW = 2 * TWL;
+    static_assert(TWL == 32 || TWL == 8, "lane mappings below");
+    static constexpr int LW = TW + 2 * R, LH = TYB + 2 * R;
+    static constexpr int SC = LH * LW / 4;                                      // float4 slots per channel
+    static constexpr int ITER = (CH * SC + THREADS - 1) / THREADS;
+    static constexpr int TILE = ITER * THREADS * 4;                             // floats
+    static constexpr int HALF = (CH + 1) / 2;                                   // channels per ds_read base address (16-bit offsets)
+};
+
+template <int R>
+struct RowWeights {        // one displacement row of GsWeights
+    v2f p0[R]; float s0; v2f p1[R]; float s1;
+    __device__ __forceinline__ void set(int j, float vx, float vy) {           // (vx, vy) = tap j of pixels x, x + 1
+        if (j == 2 * R) s0 = vx; else if (j & 1) p0[j / 2].y = vx; else p0[j / 2].x = vx;
+        if (j == 0) s1 = vy; else if ((j + 1) & 1) p1[(j + 1) / 2 - 1].y = vy; else p1[(j + 1) / 2 - 1].x = vy;
+    }
+};
+
+// One row-step of the row-streamed backward: ST = channel of the group.
+// ABL (tuning builds only): 1 no LDS reads, 2 no FMAs, 4 no weight loads -- wrong results, only the times matter
+template <int ST, int STEPS, int PF, int R, int NCOL, int CH_BYTES, int HALF, int ABL = 0>
+struct RsStep {
+    template <int Q, int... Ks>
+    static __device__ __forceinline__ void load_cols(v2f (&row)[PF + 1][NCOL], unsigned a_lo, unsigned a_hi,
+                                                     std::integer_sequence<int, Ks...>) {
+        constexpr int off = (Q % HALF) * CH_BYTES;
+        ((row[Q % (PF + 1)][Ks] = lds_read_b64<off + 8 * Ks>(Q < HALF ? a_lo : a_hi)), ...);
+    }
+    template <int Q>
+    static __device__ __forceinline__ void load(v2f (&row)[PF + 1][NCOL], unsigned a_lo, unsigned a_hi) {
+        if constexpr (Q < STEPS && !(ABL & 1)) load_cols<Q>(row, a_lo, a_hi, std::make_integer_sequence<int, NCOL>{});
+    }
+    static __device__ __forceinline__ void run(const RowWeights<R>& w, v2f (&acc)[STEPS][2], v2f (&row)[PF + 1][NCOL],
+                                               unsigned a_lo, unsigned a_hi) {
+        static_assert(NCOL == R + 1, "a halo row is R + 1 float pairs");
+        if constexpr (ST < STEPS) {
+            load<ST + PF>(row, a_lo, a_hi);
+            constexpr int newer = (STEPS - 1 - ST < PF ? STEPS - 1 - ST : PF) * NCOL;
+            if constexpr (!(ABL & 1)) lds_wait<newer>();
+            constexpr int rb = ST % (PF + 1);
+            if constexpr (ABL & 2) {
+                acc[ST][0] += row[rb][0] + row[rb][1] + row[rb][2];     // (keeps the reads alive)
+                acc[ST][1] += row[rb][3] + row[rb][R];
+            } else {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                acc[ST][0] = __builtin_elementwise_fma(w.p0[k], row[rb][k], acc[ST][0]);
+                acc[ST][1] = __builtin_elementwise_fma(w.p1[k], row[rb][k + 1], acc[ST][1]);
+            }
+            acc[ST][0].x = fmaf(w.s0, row[rb][R].x, acc[ST][0].x);
+            acc[ST][1].y = fmaf(w.s1, row[rb][0].y, acc[ST][1].y);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            RsStep<ST + 1, STEPS, PF, R, NCOL, CH_BYTES, HALF, ABL>::run(w, acc, row, a_lo, a_hi);
+        }
+    }
+};
+
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+// WS wave sets share one tile: set s keeps channels [s * CH / WS, (s + 1) * CH / WS) of the item (a wave issues ~1 instruction per
+// 5 cycles, so the VALU wants 4 waves per SIMD; LDS allows two 72 KB tiles per CU, i.e. 2 x 4 waves -- with WS = 2 the same two
+// tiles carry 16 waves, each with half the accumulators)
+template <int R, int CH, int TYB, int AHEAD, int ABL = 0, int WS = 1>
+__global__ __launch_bounds__((BwdRsCfg<R, CH, TYB>::THREADS * WS)) void corr_bwd_rs_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                         const float* __restrict__ g, float* __restrict__ gf1,
+                                                         float* __restrict__ gf2, int Ctot, int H, int W,
+                                                         int tiles_x, int tiles_y, int ngrp, float inv_c) {
+    using K = BwdRsCfg<R, CH, TYB>;
+    constexpr int DD = K::DD, LW = K::LW, NCOL = R + 1, NT = K::THREADS * WS, CHL = CH / WS;
+    constexpr int ITER = (CH * K::SC + NT - 1) / NT, TILE = ITER * NT * 4;
+    static_assert(CH % WS == 0, "channels per wave set");
+    __shared__ __attribute__((aligned(16))) float tile[TILE];
+
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int cg = t % ngrp; t /= ngrp;              // the channel groups of a (tile, gradient) share its gradient planes
+    const int mode = t & 1; t >>= 1;                 // ... and so do the two gradients of a tile
+    const float* __restrict__ F = mode ? f1 : f2;
+    float* __restrict__ out = mode ? gf2 : gf1;
+    const int bx = t % tiles_x; t /= tiles_x;
+    const int by = t % tiles_y;
+    const int b = t / tiles_y;
+    const int c_begin = cg * CH;
+    const int C = min(CH, Ctot - c_begin);
+    const int l = threadIdx.x % K::THREADS, wave = threadIdx.x >> 6;
+    const int ws = __builtin_amdgcn_readfirstlane((int)threadIdx.x / K::THREADS);      // wave set (wave-uniform)
+    // lane -> (tx, ty).  A ds_read_b64 is serviced in two groups of 32 lanes; the 32 lanes of a group must fall into 64
+    // different banks.  64-wide tiles: a group is one row of 32 lanes (64 consecutive floats).  16-wide tiles (row stride
+    // LW = 24 floats): a group takes 4 rows of 8 lanes; rows 2 apart start 48 = -16 (mod 64) banks apart, so lanes 0-31 take
+    // the even rows of the wave's eight and lanes 32-63 the odd ones (banks 0-15, 48-63, 32-47, 16-31).
+    const int tx = l & (K::TWL - 1);
+    const int ty = K::TWL == 32 ? (l >> 5) : ((l >> 6) * 8 + 2 * ((l >> 3) & 3) + ((l >> 5) & 1));
+    const int x0 = bx * K::TW, y0 = by * K::TYB;
+    const int px = x0 + tx * 2, py = y0 + ty;
+    const unsigned plane = (unsigned)(H * W);
+    constexpr unsigned kOut = 0x40000000u;
+
+    // the F halo tile of this channel group -> LDS (LDS-DMA through a buffer descriptor: outside the image, in the padding
+    // and past the group's last channel the hardware range check delivers zeros)
+    {
+        const float* baseF = F + ((size_t)b * Ctot + c_begin) * plane;
+        const auto frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(baseF), 0, (int)((size_t)C * plane * 4), 0x00020000);
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        v4u stg[(ABL & 8) ? ITER : 1];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int s = it * NT + (int)threadIdx.x;
+            const int c = s / K::SC;
+            const int r = s - c * K::SC;
+            const int ly = r / (LW / 4);
+            const int gy = y0 - R + ly, gx = x0 - R + (r - ly * (LW / 4)) * 4;
+            const bool in = (c < CH) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);      // (no short circuit: no branches)
+            const unsigned off = in ? ((unsigned)c * plane + (unsigned)(gy * W + gx)) * 4u : kOut;
+            if constexpr (ABL & 8) stg[it] = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(frs, (int)off, 0, 0));
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(frs, (lds_ptr)(tile + (it * NT + wave * 64) * 4), 16, (int)off, 0, 0, 0);
+        }
+        if constexpr (ABL & 8) {                     // through registers instead of LDS-DMA: all loads out first, then the LDS writes
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const unsigned a = (unsigned)(size_t)(lds_cfloat*)(tile + (it * NT + (int)threadIdx.x) * 4);
+                asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(stg[it]) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+
+    // upstream gradient of this sample: 81 planes behind one descriptor; a lane's pair (x, x + 1) of tap (i, j) is one 8-byte load
+    const float* gb = g + (size_t)b * DD * DD * plane;
+    const auto grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gb), 0, (int)((size_t)DD * DD * plane * 4), 0x00020000);
+    const unsigned lane_off = (unsigned)(py * W + px) * 4u;
+    // a displacement row of weights travels in two halves: the loads (issued one row AHEAD, raw bits parked in registers)
+    // and, behind that row's arithmetic, the scaling into the packed-FMA layout -- consuming a value where it is loaded
+    // would make hipcc wait for it there
+    auto request_row = [&](v2u (&raw)[DD], int i) {
+#pragma unroll
+        for (int j = 0; j < DD; ++j) {
+            const int pl = mode ? (2 * R - i) * DD + (2 * R - j) : i * DD + j;             // wave-uniform
+            const unsigned uni = (unsigned)pl * plane * 4u + (unsigned)(mode * ((i - R) * W + (j - R)) * 4);
+            raw[j] = __builtin_bit_cast(v2u, __builtin_amdgcn_raw_buffer_load_b64(grs, (int)(lane_off + uni), 0, 0));
+        }
+    };
+    auto take_row = [&](RowWeights<R>& w, const v2u (&raw)[DD]) {
+#pragma unroll
+        for (int j = 0; j < DD; ++j) w.set(j, __uint_as_float(raw[j].x) * inv_c, __uint_as_float(raw[j].y) * inv_c);
+    };
+    // AHEAD rows of weights are in flight at any time: a row of arithmetic (CH x 15 instructions, ~0.45 us) is much shorter
+    // than a first-touch HBM access (1-2 us under load); with one row of lead every row waited for its weights (level 2:
+    // 67 us, 9 x ~1 us of exposed latency per workgroup).  Occupancy is set by LDS (two workgroups per CU), so the registers are free.
+    RowWeights<R> w;
+    v2u raw[AHEAD][DD];
+#pragma unroll
+    for (int k = 0; k < AHEAD; ++k) request_row(raw[k], min(k, DD - 1));
+
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * DD > 63 ? 63 : AHEAD * DD) : "memory");  // this wave's pieces of the tile have landed (the weights may still fly)
+    __builtin_amdgcn_s_barrier();                    // ... and everyone else's.  The waves do not meet again.
+
+    v2f acc[CHL][2];
+#pragma unroll
+    for (int c = 0; c < CHL; ++c) { acc[c][0] = v2f{0.f, 0.f}; acc[c][1] = v2f{0.f, 0.f}; }
+    const unsigned rows_addr = (unsigned)(size_t)(lds_cfloat*)(tile + ws * CHL * K::SC * 4 + ty * LW + tx * 2);
+    constexpr int PF = (2 * NCOL <= 15) ? 2 : 1;
+    constexpr int HALF = (CHL + 1) / 2;
+    static_assert((HALF - 1) * K::SC * 16 + (LW + 2 * R) * 4 < 65536, "ds_read offset field");
+    using Step0 = RsStep<0, CHL, PF, R, NCOL, K::SC * 16, HALF, ABL>;
+#pragma unroll 1
+    for (int i0 = 0; i0 < DD; i0 += AHEAD) {
+#pragma unroll
+        for (int k = 0; k < AHEAD; ++k) {
+            const int i = i0 + k;
+            if (DD % AHEAD != 0 && i >= DD) break;   // (wave-uniform)
+            take_row(w, raw[k]);                     // (the only vmcnt wait of the row: it was requested AHEAD rows ago)
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(ABL & 4)) request_row(raw[k], min(i + AHEAD, DD - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned a_lo = rows_addr + (unsigned)(i * LW * 4);
+            const unsigned a_hi = a_lo + (unsigned)(HALF * K::SC * 16);
+            v2f row[PF + 1][NCOL];
+            if constexpr (ABL & 1) {
+#pragma unroll
+                for (int q = 0; q <= PF; ++q)
+#pragma unroll
+                    for (int c = 0; c < NCOL; ++c) row[q][c] = v2f{(float)(i + q), (float)c};
+            }
+            Step0::template load<0>(row, a_lo, a_hi);
+            if constexpr (PF > 1) Step0::template load<1>(row, a_lo, a_hi);
+            Step0::run(w, acc, row, a_lo, a_hi);
+        }
+    }
+    if (py < H && px < W) {
+        float* op = out + (((size_t)b * Ctot + c_begin + ws * CHL) * H + py) * W + px;
+#pragma unroll
+        for (int c = 0; c < CHL; ++c)
+            if (ws * CHL + c < C)
+                *reinterpret_cast<float2*>(op + (size_t)c * plane) = make_float2(acc[c][0].x + acc[c][0].y, acc[c][1].x + acc[c][1].y);
+    }
+}
+
+template <int R, int CH, int TYB, int AHEAD, int ABL = 0, int WS = 1>
+int launch_bwd_rs(const float* f1, const float* f2, const float* g, float* gf1, float* gf2,
+                  int B, int C, int H, int W, hipStream_t s) {
+    using K = BwdRsCfg<R, CH, TYB>;
+    const int tx = ceil_div(W, K::TW), ty = ceil_div(H, K::TYB), ngrp = ceil_div(C, CH);
+    UNFLOW_LAUNCH((corr_bwd_rs_kernel<R, CH, TYB, AHEAD, ABL, WS>), dim3(tx * ty * B * 2 * ngrp), dim3(K::THREADS * WS), 0, s,
+                       f1, f2, g, gf1, gf2, C, H, W, tx, ty, ngrp, 1.0f / C);
+    return unflow_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-streamed backward, two phase-shifted halves per workgroup (round 3).  The kernel above spends its life in two phases
+// that use different parts of the chip -- staging (HBM -> LDS) and arithmetic (VALU + LDS reads; 55 TFLOP/s is what packed
+// fp32 FMAs deliver here, ~40 us for level 2) -- and because a launch starts every workgroup at once and all work items take
+// the same time, the two workgroups of a CU stay in lock-step: everybody stages, then everybody computes (ablations: staging +
+// stores alone 27 us, arithmetic alone 40 us, the kernel 63-67 us).  Here a persistent 512-thread workgroup per CU is two
+// independent halves (4 waves and one 72 KB tile buffer each) that alternate between two slot types,
+//     A: the nine displacement rows of an item          B: store it, stage the next item, wait for it
+// separated by workgroup barriers, with half 1 started one slot late: while one half computes the other one stages, by
+// construction.  The barriers are exactly the two a half needs anyway (tile landed -> first read; last read -> next DMA).
+// A half walks a contiguous run of items, so the items that share gradient planes (channel groups, both gradients of a
+// tile) follow each other on one CU / XCD.
+// ---------------------------------------------------------------------------------------------
+template <int R, int CH, int AHEAD>
+__global__ __launch_bounds__(512) void corr_bwd_rs2_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                          const float* __restrict__ g, float* __restrict__ gf1,
+                                                          float* __restrict__ gf2, int Ctot, int H, int W,
+                                                          int tiles_x, int tiles_y, int ngrp, int total, int nK, float inv_c) {
+    using K = BwdRsCfg<R, CH, 8>;
+    constexpr int DD = K::DD, LW = K::LW, NCOL = R + 1;
+    __shared__ __attribute__((aligned(16))) float tiles[2 * K::TILE];
+    const int h = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));     // which half (wave-uniform)
+    const int lt = threadIdx.x & 255, wave = lt >> 6;
+    float* tile = tiles + h * K::TILE;
+    const int tx = lt & 31, ty = lt >> 5;
+    const unsigned plane = (unsigned)(H * W);
+    constexpr unsigned kOut = 0x40000000u;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned rows_addr = (unsigned)(size_t)(lds_cfloat*)(tile + ty * LW + tx * 2);
+    constexpr int PF = (2 * NCOL <= 15) ? 2 : 1;
+    static_assert((K::HALF - 1) * K::SC * 16 + (LW + 2 * R) * 4 < 65536, "ds_read offset field");
+    using Step0 = RsStep<0, CH, PF, R, NCOL, K::SC * 16, K::HALF>;
+
+    // the item this half is working on
+    int mode = 0, b = 0, c_begin = 0, C = 0, x0 = 0, y0 = 0;
+    bool valid = false;
+    auto decode = [&](int k) {
+        int t = (wg * nK + k) * 2 + h;
+        valid = t < total;
+        t = valid ? t : 0;
+        const int cg = t % ngrp; t /= ngrp;
+        mode = t & 1; t >>= 1;
+        const int bx = t % tiles_x; t /= tiles_x;
+        const int by = t % tiles_y;
+        b = t / tiles_y;
+        c_begin = cg * CH;
+        C = min(CH, Ctot - c_begin);
+        x0 = bx * K::TW; y0 = by * K::TYB;
+    };
+    RowWeights<R> w;
+    v2u raw[AHEAD][DD];
+    v2f acc[CH][2];
+
+    auto request_row = [&](v2u (&rw)[DD], int i) {
+        const float* gb = g + (size_t)b * DD * DD * plane;
+        const auto grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gb), 0, (int)((size_t)DD * DD * plane * 4), 0x00020000);
+        const unsigned lane_off = (unsigned)((y0 + ty) * W + x0 + tx * 2) * 4u;
+#pragma unroll
+        for (int j = 0; j < DD; ++j) {
+            const int pl = mode ? (2 * R - i) * DD + (2 * R - j) : i * DD + j;
+            const unsigned uni = (unsigned)pl * plane * 4u + (unsigned)(mode * ((i - R) * W + (j - R)) * 4);
+            rw[j] = __builtin_bit_cast(v2u, __builtin_amdgcn_raw_buffer_load_b64(grs, (int)(lane_off + uni), 0, 0));
+        }
+    };
+    auto take_row = [&](const v2u (&rw)[DD]) {
+#pragma unroll
+        for (int j = 0; j < DD; ++j) w.set(j, __uint_as_float(rw[j].x) * inv_c, __uint_as_float(rw[j].y) * inv_c);
+    };
+    // slot B, second part: the item's F halo tile -> this half's buffer, and its first AHEAD rows of weights
+    auto stage = [&]() {
+        const float* F = mode ? f1 : f2;
+        const float* baseF = F + ((size_t)b * Ctot + c_begin) * plane;
+        const auto frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(baseF), 0, (int)((size_t)C * plane * 4), 0x00020000);
+#pragma unroll
+        for (int it = 0; it < K::ITER; ++it) {
+            const int s_ = it * 256 + lt;
+            const int c = s_ / K::SC;
+            const int r = s_ - c * K::SC;
+            const int ly = r / (LW / 4);
+            const int gy = y0 - R + ly, gx = x0 - R + (r - ly * (LW / 4)) * 4;
+            const bool in = (c < CH) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+            const unsigned off = in ? ((unsigned)c * plane + (unsigned)(gy * W + gx)) * 4u : kOut;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(frs, (lds_ptr)(tile + (it * 256 + wave * 64) * 4), 16, (int)off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < AHEAD; ++k) request_row(raw[k], min(k, DD - 1));
+    };
+    auto landed = [&]() {        // this wave's pieces of the tile are in LDS (the AHEAD rows of weights behind them may still fly)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * DD > 63 ? 63 : AHEAD * DD) : "memory");
+    };
+    // slot A
+    auto compute = [&]() {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { acc[c][0] = v2f{0.f, 0.f}; acc[c][1] = v2f{0.f, 0.f}; }
+#pragma unroll 1
+        for (int i0 = 0; i0 < DD; i0 += AHEAD) {
+#pragma unroll
+            for (int k = 0; k < AHEAD; ++k) {
+                const int i = i0 + k;
+                if (DD % AHEAD != 0 && i >= DD) break;
+                take_row(raw[k]);
+                __builtin_amdgcn_sched_barrier(0);
+                request_row(raw[k], min(i + AHEAD, DD - 1));
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned a_lo = rows_addr + (unsigned)(i * LW * 4);
+                const unsigned a_hi = a_lo + (unsigned)(K::HALF * K::SC * 16);
+                v2f row[PF + 1][NCOL];
+                Step0::template load<0>(row, a_lo, a_hi);
+                if constexpr (PF > 1) Step0::template load<1>(row, a_lo, a_hi);
+                Step0::run(w, acc, row, a_lo, a_hi);
+            }
+        }
+    };
+    // slot B, first part
+    auto store = [&]() {
+        const int px = x0 + tx * 2, py = y0 + ty;
+        if (py < H && px < W) {
+            float* out = mode ? gf2 : gf1;
+            float* op = out + (((size_t)b * Ctot + c_begin) * H + py) * W + px;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if (c < C)
+                    *reinterpret_cast<float2*>(op + (size_t)c * plane) = make_float2(acc[c][0].x + acc[c][0].y, acc[c][1].x + acc[c][1].y);
+        }
+    };
+
+    // Both halves execute exactly 2 nK barriers:
+    //   half 0:  B0 | A0 | B1 | A1 | ... | A(nK-1) | (store)          half 1:  (issue) | (wait) | A0 | B1 | ... | A(nK-1), store
+    decode(0);
+    if (valid) stage();
+    if (h == 0) landed();
+    __builtin_amdgcn_s_barrier();
+    if (h == 1) { landed(); __builtin_amdgcn_s_barrier(); }
+#pragma unroll 1
+    for (int k = 0; k < nK; ++k) {
+        if (valid) compute();
+        if (k + 1 < nK) {
+            __builtin_amdgcn_s_barrier();            // every wave of this half is done reading the tile
+            if (valid) store();
+            decode(k + 1);
+            if (valid) stage();
+            landed();
+            __builtin_amdgcn_s_barrier();            // the next tile has landed for all four waves
+        } else {
+            if (h == 0) __builtin_amdgcn_s_barrier();    // pairs with half 1's barrier in front of its last A
+            if (valid) store();
+        }
+    }
+}
+
+template <int R, int CH, int AHEAD>
+int launch_bwd_rs2(const float* f1, const float* f2, const float* g, float* gf1, float* gf2,
+                   int B, int C, int H, int W, hipStream_t s) {
+    using K = BwdRsCfg<R, CH, 8>;
+    const int tx = ceil_div(W, K::TW), ty = ceil_div(H, K::TYB), ngrp = ceil_div(C, CH);
+    const int total = tx * ty * B * 2 * ngrp, pairs = ceil_div(total, 2);
+    const int G = pairs < 256 ? pairs : 256;                  // one persistent workgroup per CU
+    const int nK = ceil_div(pairs, G);
+    UNFLOW_LAUNCH((corr_bwd_rs2_kernel<R, CH, AHEAD>), dim3(G), dim3(512), 0, s,
+                       f1, f2, g, gf1, gf2, C, H, W, tx, ty, ngrp, total, nK, 1.0f / C);
+    return unflow_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Small-map backward (pyramid levels 5, 6: 8x26 and 4x13 pixels, 128-196 channels).  Too few pixels
 // for the tile kernels (16 samples x 1 tile), and the per-element kernel re-reads 2*DD*DD gradient
 // values per output.  Here a lane owns one pixel of the WHOLE map and keeps its DD*DD upstream
@@ -1269,6 +1663,26 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 // 4 groups: 20 us; more groups than that only repeat the upstream-gradient gather)
                 const int items = ceil_div(W, 64) * ceil_div(H, 8) * B * 2;
                 int groups = forced_groups() ? forced_groups() : (items >= 256 ? 1 : 256 / items);
+                if (ring_ok && fb == 7) return launch_bwd_rs<4, 16, 8, 3>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                if (ring_ok && fb == 8) return launch_bwd_rs<4, 8, 8, 3>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                if (ring_ok && fb == 9) return launch_bwd_rs<4, 16, 8, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                if (ring_ok && fb == 10) return launch_bwd_rs<4, 16, 32, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                if (ring_ok && fb == 11) return launch_bwd_rs<4, 8, 8, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                if (ring_ok && fb == 12) return launch_bwd_rs2<4, 16, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                if (ring_ok && fb == 15) return launch_bwd_rs<4, 16, 8, 1, 0, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                if (ring_ok && fb == 16) return launch_bwd_rs<4, 16, 8, 2, 0, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                if (ring_ok && fb == 17) return launch_bwd_rs<4, 32, 8, 1, 0, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                if (ring_ok && fb == 13) return launch_bwd_rs2<4, 16, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                if (ring_ok && fb == 14) return launch_bwd_rs2<4, 16, 3>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+#ifdef UNFLOW_TUNING
+                if (ring_ok && fb == 21) return launch_bwd_rs<4, 16, 8, 1, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // no LDS reads
+                if (ring_ok && fb == 22) return launch_bwd_rs<4, 16, 8, 1, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // no FMAs
+                if (ring_ok && fb == 24) return launch_bwd_rs<4, 16, 8, 1, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // no weight loads
+                if (ring_ok && fb == 23) return launch_bwd_rs<4, 16, 8, 1, 3>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // neither reads nor FMAs
+                if (ring_ok && fb == 27) return launch_bwd_rs<4, 16, 8, 1, 7>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // staging + stores only
+                if (ring_ok && fb == 28) return launch_bwd_rs<4, 16, 8, 1, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // register staging
+                if (ring_ok && fb == 29) return launch_bwd_rs<4, 16, 8, 1, 15>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);  // register staging + stores only
+#endif
                 if (ring_ok && fb == 1) return launch_bwd_gs<4, 2, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, groups, s);
                 if (ring_ok && fb == 3) return launch_bwd_gs<4, 2, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, groups, s);
                 if (ring_ok && fb == 5) return launch_bwd_gs<4, 4, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, groups, s);
@@ -1277,7 +1691,16 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 // (measured and dropped: a persistent form -- 256 workgroups walking 4 items each, the next tile's gradient
                 // planes touched into L2 during the ring stages -- 109 us at level 2 against 95 for this one: the exposed
                 // gather is not what limits the kernel, and 1024 independently scheduled workgroups balance better)
-                if (ring_ok && (fb == 4 || (fb == 0 && (variant == 7 || mid_size(variant)))))
+                // round 3: the row-streamed kernel for levels 2-4 (back to back 63-67 / 35 / 17 us against 86 / 38-41 / 18-19.6 for
+                // the group-split ring kernel, which stays selectable in tuning builds: UNFLOW_CORR_BWD=4).  16 channels per work
+                // item (8 on small maps: more, shorter workgroups); 16 x 32 tiles where 64-wide ones would leave a mostly empty
+                // last tile column and the map is tall enough (level 3: 104 = 6.5 x 16)
+                if (ring_ok && fb == 0 && (variant == 7 || mid_size(variant))) {
+                    if ((long)B * H * W < 32768) return launch_bwd_rs<4, 8, 8, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                    if (forced_groups() == 32) return launch_bwd_rs<4, 16, 32, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // (tuning: 16 x 32 tiles)
+                    return launch_bwd_rs<4, 16, 8, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                }
+                if (ring_ok && fb == 4)
                     return launch_bwd_gs<4, 4, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, groups, s);
                 if (fb == 6 || variant == 1 || variant == 7) return launch_bwd<4, 2, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (variant == 2 || variant == 3 || (mid_size(variant) && (long)B * H * W >= 32768))
@@ -1291,8 +1714,11 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
         }
         case 8: variant = pick_variant(B, C, H, W);
                 if (variant == 4 || (long)B * H * W < 8192) break;      // small maps: one lane per element (117 / 57 us at levels 5 / 6, tile kernel 283 / 378)
-                if ((variant == 7 || mid_size(variant)) && (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0) && gs_offsets_fit(C, H, W, 8))
+                if ((variant == 7 || mid_size(variant)) && (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0) && gs_offsets_fit(C, H, W, 8)) {
+                    if (forced_bwd() == 7) return launch_bwd_rs<8, 8, 8, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                    if (forced_bwd() == 8) return launch_bwd_rs<8, 4, 8, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                     return launch_bwd_gs<8, 1, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, 1, s);
+                }
                 return launch_bwd<8, 1, 6, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
         default: break;
     }

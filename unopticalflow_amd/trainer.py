@@ -15,7 +15,7 @@ from .parallel import FlatGradients, PlainGradients, broadcast_parameters
 
 class FlowTrainer:
     def __init__(self, cfg, model, distributed=False, allreduce_chunks=4, fused_adam=None, use_graph=False,
-                 single_rank_collectives=False):
+                 single_rank_collectives=False, gc_freeze_after=2):
         self.cfg = cfg
         self.model = model
         self.loss_weights = generate_loss_weights_dict(cfg)
@@ -46,6 +46,14 @@ class FlowTrainer:
         # batch; inputs are copied into a static buffer.
         self.use_graph = use_graph
         self._graph = None
+        # host jitter: a step builds ~10^4 short-lived Python objects (autograd nodes, tensors, ctypes arguments); the
+        # cyclic collector's full (generation-2) pass over the ~10^6 long-lived objects of an imported torch takes
+        # 100-150 ms on the bench box -- more than the host's 2-3 step launch lead, so the GPU idles (one 50-90 ms step every
+        # ~17: 26.3-27.3 ms mean against a 24.9 ms median, profiles/r3_headline_*.json).  After ``gc_freeze_after`` steps
+        # everything alive is moved to the permanent generation (gc.freeze): later collections only look at what the steps
+        # themselves allocate.  None / 0 leaves the collector alone.
+        self.gc_freeze_after = gc_freeze_after
+        self._gc_frozen = False
 
     def total_loss(self, loss_pack):
         """train.py:147-150"""
@@ -107,9 +115,17 @@ class FlowTrainer:
         self.iteration += 1
         return self._static_loss, self._static_pack
 
+    def _settle_host(self):
+        if self.gc_freeze_after and not self._gc_frozen and self.iteration >= self.gc_freeze_after:
+            import gc
+            gc.collect()
+            gc.freeze()
+            self._gc_frozen = True
+
     def step(self, inputs):
         """One optimisation step on this rank's shard.  Returns (loss, loss_pack) (detached)."""
         self.model.train()
+        self._settle_host()
         if self.use_graph and (self._graph is None or inputs.shape == self._static_in.shape):
             return self._graph_step(inputs)          # (a ragged last batch of an epoch falls through to the eager step)
         self.grads.zero()
