@@ -98,14 +98,15 @@ def test_module_128_golden(golden, ac, cl):
             close(loss, g['total' + tag], rtol=1e-4)
             gn = float(np.sqrt(sum((p.grad.double() ** 2).sum().item() for p in model.parameters())))
             np.testing.assert_allclose(gn, float(g['grad_norm' + tag]), rtol=5e-4)
-            # per-tensor L1 norms of all 98 gradients.  Every tensor within 5e-4 of ITS OWN L1 norm plus 5e-4 of its
-            # largest element (L1 / numel <= max: the allowance of a tensor is at most 1e-3 of its norm) -- was rtol 2e-2
+            # per-tensor L1 norms of all 98 gradients: every tensor within 2e-3 of ITS OWN L1 norm plus 2e-3 of its largest
+            # element (was rtol 2e-2).  Measured (tools/tolerance_probe.py, both memory formats, both grid_sample generations):
+            # worst tensor 1.3e-4 of its norm in a warm process -- but 9.3e-4 (pwc_model.conv2_4, weight and bias alike, i.e.
+            # in the gradient that MIOpen's data-gradient convolutions hand back) in the FIRST process on a fresh box, where
+            # MIOpen's immediate mode falls back to other solvers until its kernel cache is warm; the bar covers the cold run.
             ga = np.array([p.grad.double().abs().sum().item() for p in model.parameters()])
             gmax = np.array([p.grad.abs().max().item() for p in model.parameters()])
             ref_ga = g['grad_abs' + tag]
-            # (measured, tools/tolerance_probe.py on both memory formats and both grid_sample generations, 3 runs each:
-            # worst tensor 1.3e-4 of its L1 norm, 0.12 of a 1e-3 + 1e-3 allowance -> the bars are 5e-4 + 5e-4)
-            bad = np.abs(ga - ref_ga) > 5e-4 * ref_ga + 5e-4 * gmax
+            bad = np.abs(ga - ref_ga) > 2e-3 * ref_ga + 2e-3 * gmax
             assert not bad.any(), [(n, a, b) for (n, _), a, b, x in zip(model.named_parameters(), ga, ref_ga, bad) if x]
             if ac == 0:
                 # full gradient tensors of the first pyramid layer (end of the whole backward chain), the widest level-2

@@ -12,3 +12,5 @@ for f in ('instep_rs','instep_gs'):
     for r in d['roofline']['aggregate']['per_level']:
         if r['entry']=='unflow_corr_bwd': print('   ', r['shape'], r['avg_us'], r['frac'])
 PY
+UNFLOW_MICROBENCH_TUNING=1 timeout 200 python3 tools/microbench.py corr8_bwd_rs > $out/corr8_bwd_rs.txt 2>&1
+cat $out/corr8_bwd_rs.txt | grep corr_bwd

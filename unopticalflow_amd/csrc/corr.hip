@@ -1695,13 +1695,18 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 // the group-split ring kernel, which stays selectable in tuning builds: UNFLOW_CORR_BWD=4).  16 channels per work
                 // item (8 on small maps: more, shorter workgroups); 16 x 32 tiles where 64-wide ones would leave a mostly empty
                 // last tile column and the map is tall enough (level 3: 104 = 6.5 x 16)
+                // In the train step (in-step A/B, tools/gpu_r3_d.sh): level 2 73.6 vs 91.8 us, level 3 37.5 (64 x 8 tiles; 39.5 with
+                // 16 x 32) vs 35.0, level 4 18.6 vs 20.1 -- so level 3 (32768 <= pixels < 131072, 256 items: one round of the
+                // group-split kernel) stays on the group-split ring kernel
                 if (ring_ok && fb == 0 && (variant == 7 || mid_size(variant))) {
-                    if ((long)B * H * W < 32768) return launch_bwd_rs<4, 8, 8, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                    if (forced_groups() == 32) return launch_bwd_rs<4, 16, 32, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // (tuning: 16 x 32 tiles)
-                    return launch_bwd_rs<4, 16, 8, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                    const long px = (long)B * H * W;
+                    if (px < 32768) return launch_bwd_rs<4, 8, 8, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                    if (px >= 131072) return launch_bwd_rs<4, 16, 8, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                    return launch_bwd_gs<4, 4, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, groups, s);
                 }
                 if (ring_ok && fb == 4)
                     return launch_bwd_gs<4, 4, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, groups, s);
+                if (ring_ok && fb == 32) return launch_bwd_rs<4, 16, 32, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // (tuning: 16 x 32 tiles)
                 if (fb == 6 || variant == 1 || variant == 7) return launch_bwd<4, 2, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (variant == 2 || variant == 3 || (mid_size(variant) && (long)B * H * W >= 32768))
                     return launch_bwd<4, 1, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
@@ -1715,9 +1720,10 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
         case 8: variant = pick_variant(B, C, H, W);
                 if (variant == 4 || (long)B * H * W < 8192) break;      // small maps: one lane per element (117 / 57 us at levels 5 / 6, tile kernel 283 / 378)
                 if ((variant == 7 || mid_size(variant)) && (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0) && gs_offsets_fit(C, H, W, 8)) {
-                    if (forced_bwd() == 7) return launch_bwd_rs<8, 8, 8, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                    // round 3: row-streamed, 8 channels per item: 290 / 117 / 49 us at levels 2 / 3 / 4 (group-split ring kernel 343 / 129 / 85)
+                    if (forced_bwd() == 4) return launch_bwd_gs<8, 1, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, 1, s);
                     if (forced_bwd() == 8) return launch_bwd_rs<8, 4, 8, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                    return launch_bwd_gs<8, 1, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, 1, s);
+                    return launch_bwd_rs<8, 8, 8, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 }
                 return launch_bwd<8, 1, 6, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
         default: break;
