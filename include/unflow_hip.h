@@ -75,6 +75,14 @@ int unflow_warp_fwd(const float* src, const float* flow, float* out, uint8_t* ma
 int unflow_warp_bwd(const float* src, const float* flow, const float* gout, const uint8_t* mask,
                     float* gsrc, float* gflow,
                     int B, int C, int H, int W, int align_corners, void* stream);
+/* The same backward with the source gradient computed as a GATHER (ABI 7): every workgroup owns a tile of gsrc, finds the
+ * pixels whose taps land on it through a per-tile table of tap displacements (a pre-pass; gflow's memory is its scratch until
+ * the flow gradient is written), and stores each element once -- no zero-fill, no float atomics, bitwise reproducible from
+ * run to run.  Feature maps only (mask == NULL, >= 8 channels, >= 512 pixels); other shapes take unflow_warp_bwd's path.
+ * Slower than the scatter form on MI355X (level 2: 51.6 vs 48.6 us), hence a separate entry point, not the default. */
+int unflow_warp_bwd_det(const float* src, const float* flow, const float* gout, const uint8_t* mask,
+                    float* gsrc, float* gflow,
+                    int B, int C, int H, int W, int align_corners, void* stream);
 
 /* ---- fused warp + cost volume: one decoder level of PWC_tf.forward, pwc_tf.py:121-122 (134-135, 146-147, 159-160) ----
  *   feat2_warped = self.warp(f2, flow);  cv = self.corr(f1, feat2_warped)
@@ -200,6 +208,25 @@ int unflow_bias_leaky_fwd_nhwc_bf16(uint16_t* y, const float* bias, long long P,
 int unflow_bias_leaky_bwd2_nhwc_bf16(const uint16_t* y, const uint16_t* gout, long long gout_pstride, const uint16_t* gout2,
                                      long long gout2_pstride, uint16_t* gin, float* gbias, float* partials,
                                      long long P, int C, float slope, void* stream);
+
+/* Epilogues that FILL the decoder's cat buffers (ABI 7).  The reference's decoder feeds every convolution the
+ * torch.cat of the two previous activations (pwc_tf.py:114-118: x = cat((conv0(x), x)) ... per level); here the epilogue
+ * of the convolution that produces an activation writes it straight into the channel slices of the (at most two) NHWC
+ * buffers the next convolutions read, so the cat copies do not exist:
+ *   dst1[p * dst1_pstride + c] = dst2[...] = leaky(y[p * C + c] + bias[c])     dst2 may be NULL; dst1 may be y (in place)
+ * and the backward reads the activation (for its sign) from such a slice (act, act_pstride) and its two upstream
+ * gradients from the slices of the buffers' gradients (as unflow_bias_leaky_bwd2_nhwc).  Pixel strides in elements,
+ * multiples of 4; fp32 pointers 16-byte, bf16 pointers 8-byte aligned. */
+int unflow_bias_leaky_fwd_nhwc_to(const float* y, const float* bias, long long P, int C, float slope, float* dst1,
+                                  long long dst1_pstride, float* dst2, long long dst2_pstride, void* stream);
+int unflow_bias_leaky_bwd2_nhwc_from(const float* act, long long act_pstride, const float* gout, long long gout_pstride,
+                                     const float* gout2, long long gout2_pstride, float* gin, float* gbias,
+                                     float* partials, long long P, int C, float slope, void* stream);
+int unflow_bias_leaky_fwd_nhwc_to_bf16(const uint16_t* y, const float* bias, long long P, int C, float slope, uint16_t* dst1,
+                                       long long dst1_pstride, uint16_t* dst2, long long dst2_pstride, void* stream);
+int unflow_bias_leaky_bwd2_nhwc_from_bf16(const uint16_t* act, long long act_pstride, const uint16_t* gout, long long gout_pstride,
+                                          const uint16_t* gout2, long long gout2_pstride, uint16_t* gin, float* gbias,
+                                          float* partials, long long P, int C, float slope, void* stream);
 
 /* ---- image pyramid: Model_flow.generate_img_pyramid scales 1 and 2, model_flow_paper.py:54-60 ----
  * img [planes,H,W] (planes = B*C, any leading layout) -> half [planes,H/2,W/2] (2x2 box means) and

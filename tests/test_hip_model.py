@@ -149,6 +149,32 @@ def test_model_scale_masks_bit_exact(golden, fixture, scales, acs):
                 assert np.array_equal(o != 0, ref_bits != 0) and (o[ref_bits != 0] >= 0.9999).all()
 
 
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_filled_cat_buffers_equal_the_cat_form(prec):
+    """channels_last decoder: cat inputs filled by the producing convolutions' epilogues (PWC_tf._decoder_filled, the default)
+    against the same network with torch.cat (fill_cat_buffers = False).  Same convolutions on the same values, so flows and
+    losses agree to MIOpen's run-to-run level; gradients likewise (fp32: 1e-5 of the tensor's largest gradient)."""
+    from unopticalflow_amd import get_model, generate_loss_weights_dict
+    x = R.synthetic_triplets(2, 128, 128, seed=0, structured=True).cuda()
+    outs = {}
+    for fill in (True, False):
+        cfg = R.default_cfg(precision=prec, channels_last=True)
+        model = get_model('flow')(cfg).cuda()
+        model.load_state_dict(R.seeded_state_dict(model, 1234, 0.25))
+        model.pwc_model.fill_cat_buffers = fill
+        w = generate_loss_weights_dict(cfg)
+        pack = model(x)
+        sum(w[k] * pack[k].mean() for k in pack).backward()
+        outs[fill] = ({k: v.detach().float().cpu() for k, v in pack.items()},
+                      {n: p.grad.detach().float().cpu() for n, p in model.named_parameters()})
+    tol = 1e-5 if prec == 'fp32' else 2e-2
+    for k in outs[True][0]:
+        close(outs[True][0][k], outs[False][0][k], rtol=tol, what=k)
+    for n in outs[True][1]:
+        a, b = outs[True][1][n], outs[False][1][n]
+        close(a, b, rtol=0, atol=(1e-5 if prec == 'fp32' else 5e-2) * max(b.abs().max().item(), 1e-12), what=n)
+
+
 def test_fused_warp_corr_model_matches_golden(golden):
     """cfg.fused_warp_corr: every decoder level's warp + cost volume as one kernel (N3; pwc_tf.py:121-122 ...).  Same G2
     fixture, same bars as the two-kernel path: losses 1e-4 rel, flows 1e-4 of the largest flow; the gradient norm of

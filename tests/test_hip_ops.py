@@ -259,6 +259,16 @@ def test_warp_feature_tiles_vs_oracle(ops, kind, C, h, w):
         f2 = dev(fc.detach()).requires_grad_()
         ops.warp_flow(x.detach(), f2, align_corners=ac).backward(dev(g))
         close(f2.grad, fc.grad, rtol=1e-4, atol=2e-5 * scale, what='gflow only %s' % kind)
+        # the gather form of the source gradient (unflow_warp_bwd_det: a tile of gsrc per workgroup, per-tile displacement
+        # table, no atomics): same bars, and bit-identical from run to run
+        runs = []
+        for _ in range(2):
+            x3, f3 = dev(xc.detach()).requires_grad_(), dev(fc.detach()).requires_grad_()
+            ops.warp_flow(x3, f3, align_corners=ac, deterministic=True).backward(dev(g))
+            close(x3.grad, xc.grad, rtol=1e-4, atol=2e-5, what='gather gsrc %s' % kind)
+            close(f3.grad, fc.grad, rtol=1e-4, atol=2e-5 * scale, what='gather gflow %s' % kind)
+            runs.append(x3.grad.clone())
+        assert torch.equal(runs[0], runs[1])
 
 
 @pytest.mark.parametrize('kind', ['smooth', 'mixed', 'edge', 'outside', 'noise'])
@@ -613,6 +623,51 @@ def test_bias_leaky_bf16_channels_last(ops, shape):
     assert yg.grad.dtype == torch.bfloat16 and torch.equal(yg.grad.cpu(), ref_gin)
     want = ref_gin.float().sum((0, 2, 3))
     close(bg.grad, want, rtol=1e-4, atol=1e-4 * want.abs().max().item())
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('shape', [(16, 128, 64, 208), (2, 96, 8, 26), (3, 32, 4, 13), (1, 8, 1, 1)])
+def test_bias_leaky_into_cat_buffers(ops, shape, dtype):
+    """ops.bias_leaky_relu_into: two epilogues fill ONE cat buffer (pwc_tf.py:114-118's cat((x0, x1)) without the cat), the
+    first one also in place; forward bit-equal to leaky_relu + torch.cat, backward (the gradient of the cat buffer, sliced in
+    the kernel, plus the in-place consumer's gradient) against autograd on the plain ops."""
+    N, C, H, W = shape
+    C2 = max(4, C // 2 // 4 * 4)                                 # a second, narrower activation
+    CL = torch.channels_last
+    y0, y1 = rnd(181, shape).to(dtype), rnd(182, (N, C2, H, W)).to(dtype)
+    b0, b1 = rnd(183, (C,), 0.3), rnd(184, (C2,), 0.3)
+    w_cat, w_own = rnd(185, (N, C + C2, H, W)).to(dtype), rnd(186, shape).to(dtype)
+
+    def act(y, b):                                              # fp32 math, one rounding (what the kernels do)
+        return torch.nn.functional.leaky_relu(y.float() + b.view(1, -1, 1, 1), 0.1).to(dtype)
+    ref0, ref1 = act(y0, b0), act(y1, b1)
+    ref_cat = torch.cat((ref0, ref1), 1)
+    # reference gradients: d/dy = (sum of the consumers' gradients) * slope mask, rounded once; bias = sum of the rounded values
+    g0 = (w_cat[:, :C].float() + w_own.float()) * torch.where(ref0.float() > 0, 1.0, 0.1)
+    g1 = w_cat[:, C:].float() * torch.where(ref1.float() > 0, 1.0, 0.1)
+    g0, g1 = g0.to(dtype), g1.to(dtype)
+
+    yg0 = y0.cuda().contiguous(memory_format=CL).requires_grad_()
+    yg1 = y1.cuda().contiguous(memory_format=CL).requires_grad_()
+    bg0, bg1 = b0.cuda().requires_grad_(), b1.cuda().requires_grad_()
+    buf = torch.empty((N, C + C2, H, W), dtype=dtype, device='cuda').contiguous(memory_format=CL)
+    x0, buf1, none = ops.bias_leaky_relu_into(yg0 * 1, bg0, 0.1, buf, 0, inplace=True)
+    assert none is None and buf1.data_ptr() == buf.data_ptr() and torch.equal(x0.cpu(), ref0)
+    none2, buf2, _ = ops.bias_leaky_relu_into(yg1 * 1, bg1, 0.1, buf1, C)
+    assert none2 is None and torch.equal(buf2.cpu(), ref_cat)
+    torch.autograd.backward([buf2, x0], [w_cat.cuda().contiguous(memory_format=CL), w_own.cuda().contiguous(memory_format=CL)])
+    if dtype == torch.float32:
+        close(yg0.grad, g0, rtol=1e-6, atol=1e-6); close(yg1.grad, g1, rtol=1e-6, atol=1e-6)
+    else:
+        assert torch.equal(yg0.grad.cpu(), g0) and torch.equal(yg1.grad.cpu(), g1)
+    for bg, gref in ((bg0, g0), (bg1, g1)):
+        want = gref.float().sum((0, 2, 3))
+        close(bg.grad, want, rtol=1e-4, atol=1e-4 * max(want.abs().max().item(), 1e-3))
+    # bad destinations are refused
+    with pytest.raises(RuntimeError):
+        ops.bias_leaky_relu_into(yg1 * 1, bg1, 0.1, buf.detach(), 2)                 # unaligned channel offset
+    with pytest.raises(RuntimeError):
+        ops.bias_leaky_relu_into(yg1 * 1, bg1, 0.1, buf.detach(), C + 4)             # slice runs past the buffer
 
 
 def test_conv_block_matches_reference_block(ops):

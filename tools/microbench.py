@@ -178,6 +178,32 @@ def corr_bwd_rs(B=16):
         _sweep(envs, run)
 
 
+def warp_gather(B=16):
+    """Round 3: feature-warp backward with the source gradient as a gather (default) against the scatter forms
+    (UNFLOW_WARP_GATHER=0, tuning library), through the C entry point (no autograd dispatch in the timing); the largest
+    difference between the two results."""
+    lib = _lib.load()
+    P = ops._ptr
+    for name, (C, h, w) in list(LEVELS.items())[:3]:
+        x = torch.randn(B, C, h, w, device='cuda')
+        g = torch.randn(B, C, h, w, device='cuda')
+        bb = 4 * B * h * w * (3 * C + 4)
+        for kind, fl in (('smooth', _smooth_flow(B, h, w)), ('shift+smooth', _smooth_flow(B, h, w) + 5.3), ('noise', torch.randn(B, 2, h, w, device='cuda') * 2)):
+            fl = fl.contiguous()
+            gsrc, gflow = torch.empty_like(x), torch.empty_like(fl)
+            ref = {}
+
+            def run(tag):
+                gsrc.fill_(float('nan')); gflow.fill_(float('nan'))
+                tb = timeit(lambda: lib.unflow_warp_bwd(P(x), P(fl), P(g), None, P(gsrc), P(gflow), B, C, h, w, 0, ops._stream()))
+                if not ref:
+                    ref['a'], ref['b'] = gsrc.clone(), gflow.clone()
+                err = max((gsrc - ref['a']).abs().max().item(), (gflow - ref['b']).abs().max().item())
+                print('warp_bwd %s [%d,%d,%d,%d] %-12s %-28s %7.1f us (%6.0f GB/s)  max|diff vs first| %.2e (max|ref| %.2f)' % (
+                    name, B, C, h, w, kind, tag, tb, bb / tb / 1e3, err, ref['a'].abs().max().item()), flush=True)
+            _sweep([{'UNFLOW_WARP_GATHER': 0}, {}], run)
+
+
 def corr8_bwd_rs(B=16):
     """d = 8 backward: row-streamed kernel (UNFLOW_CORR_BWD=7: 8 channels per item, 8: 4) against the group-split ring kernel."""
     lib = _lib.load()

@@ -26,6 +26,7 @@ SIGNATURES = {
     'unflow_corr_bwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'unflow_warp_fwd': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'unflow_warp_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'unflow_warp_bwd_det': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'unflow_warp_corr_supported': [_I, _I, _I, _I],
     'unflow_warp_corr_fwd': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'unflow_warp_corr_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -48,6 +49,10 @@ SIGNATURES = {
     'unflow_bias_leaky_fwd_nhwc': [_P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P],
     'unflow_bias_leaky_partials_nhwc': [ctypes.c_longlong, _I],
     'unflow_bias_leaky_bwd2_nhwc': [_P, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P],
+    'unflow_bias_leaky_fwd_nhwc_to': [_P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P],
+    'unflow_bias_leaky_bwd2_nhwc_from': [_P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P],
+    'unflow_bias_leaky_fwd_nhwc_to_bf16': [_P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P],
+    'unflow_bias_leaky_bwd2_nhwc_from_bf16': [_P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P],
     'unflow_bias_leaky_fwd_nhwc_bf16': [_P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P],
     'unflow_bias_leaky_bwd2_nhwc_bf16': [_P, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P],
     'unflow_cat_nhwc': [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P],
@@ -59,7 +64,7 @@ SIGNATURES = {
     'unflow_png_unfilter': [_P, _I, _I, _I],
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 

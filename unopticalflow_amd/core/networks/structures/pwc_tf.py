@@ -24,6 +24,9 @@ class PWC_tf(nn.Module):
         # everything outside this module stay NCHW: the decoder input is re-laid out once per level, the 2-channel
         # flows once on the way out.
         self.channels_last = bool(channels_last)
+        # channels_last only: the decoder's cat((x_k, x_k+1)) inputs are filled by the producing convolutions' epilogues
+        # (_decoder_filled) instead of being copied together by torch.cat; False keeps the cat form (tests compare the two)
+        self.fill_cat_buffers = True
         self.corr = self.corr_naive
         # True: warp + cost volume of a level as ONE kernel (ops.warp_corr; the warped features never reach HBM).
         # Measured on MI355X (profiles/r2_fused_warp_corr.txt): at parity with the two separate kernels at level 2 and
@@ -76,6 +79,8 @@ class PWC_tf(nn.Module):
         the epilogue's backward kernel."""
         c = [getattr(self, 'conv%d_%d' % (lvl, k)) for k in range(5)]
         x = self._cat(x)
+        if self._cl(x) and self.fill_cat_buffers:
+            return self._decoder_filled(lvl, c, x)
         x0, x0b = c[0](x, 2)
         x1, x1b = c[1](x0, 2)
         x2, x2b = c[2](torch.cat((x0b, x1), 1), 2)
@@ -85,6 +90,30 @@ class PWC_tf(nn.Module):
         else:
             x4 = x4b = c[4](torch.cat((x2b, x3), 1))
         return getattr(self, 'predict_flow%d' % lvl)(torch.cat((x3b, x4), 1)).float().contiguous(), x4b
+
+    def _decoder_filled(self, lvl, c, x):
+        """The same five convolutions on channels_last tensors without a single torch.cat: every conv input
+        cat((x_k, x_k+1)) (pwc_tf.py:114-118) is ONE buffer whose two channel ranges are written by the epilogues of the
+        convolutions that produce x_k and x_k+1 (ops.bias_leaky_relu_into); an activation is written to the (at most two)
+        buffers that hold it, so per activation 1 read + 2 writes replace the in-place epilogue's 1 + 1 and two cats' 2 + 2."""
+        def raw(m, t):                                   # the bias-free contraction of a conv() block
+            k = m[0]
+            return F.conv2d(t, k.weight, None, k.stride, k.padding, k.dilation, k.groups), k.bias, m[1].negative_slope
+
+        def buf(like, ch):
+            return torch.empty((like.shape[0], ch) + tuple(like.shape[2:]), dtype=like.dtype, device=like.device, memory_format=CL)
+        d0, d1, d2, d3, d4 = _DD
+        y, b, sl = raw(c[0], x)
+        x0, b01, _ = ops.bias_leaky_relu_into(y, b, sl, buf(y, d0 + d1), 0, inplace=True)        # x0: conv1's input and cat(x0, x1)
+        y, b, sl = raw(c[1], x0)
+        _, b01, b12 = ops.bias_leaky_relu_into(y, b, sl, b01, d0, buf(y, d1 + d2), 0)            # x1 -> cat(x0, x1), cat(x1, x2)
+        y, b, sl = raw(c[2], b01)
+        _, b12, b23 = ops.bias_leaky_relu_into(y, b, sl, b12, d1, buf(y, d2 + d3), 0)            # x2 -> cat(x1, x2), cat(x2, x3)
+        y, b, sl = raw(c[3], b12)
+        _, b23, b34 = ops.bias_leaky_relu_into(y, b, sl, b23, d2, buf(y, d3 + d4), 0)            # x3 -> cat(x2, x3), cat(x3, x4)
+        y, b, sl = raw(c[4], b23)
+        x4, b34, _ = ops.bias_leaky_relu_into(y, b, sl, b34, d3, inplace=(lvl == 2))             # x4 (level 2: also the context network's input)
+        return getattr(self, 'predict_flow%d' % lvl)(b34).float().contiguous(), x4
 
     def forward(self, feature_list_1, feature_list_2, img_hw):
         f1 = dict(zip(range(1, 7), feature_list_1))

@@ -110,7 +110,11 @@ __device__ __forceinline__ float4 leaky4(float4 v, float slope) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void bias_leaky_fwd_nhwc_kernel(float* __restrict__ y, const float* __restrict__ bias,
+// dst1 (and dst2 when given) receive the activation with their own pixel strides: in place (dst1 == y, stride C), and / or as
+// a channel slice of a wider NHWC tensor -- the decoder's cat((x_k, x_k+1)) buffers are filled by the epilogues of the two
+// convolutions that produce their halves, so no torch.cat copy exists (round 3).
+__global__ __launch_bounds__(256) void bias_leaky_fwd_nhwc_kernel(const float* y, const float* __restrict__ bias,
+                                                                  float* dst1, long long ps1, float* dst2, long long ps2,
                                                                   long long P, int C, int rows, float slope) {
     const int quads = C >> 2;
     const int q = threadIdx.x % quads, r = threadIdx.x / quads;
@@ -127,7 +131,9 @@ __global__ __launch_bounds__(256) void bias_leaky_fwd_nhwc_kernel(float* __restr
             if (p + (long long)u * rows < p1) {
                 float4 t = v[u];
                 t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
-                reinterpret_cast<float4*>(y + (p + (long long)u * rows) * C)[q] = leaky4(t, slope);
+                t = leaky4(t, slope);
+                reinterpret_cast<float4*>(dst1 + (p + (long long)u * rows) * ps1)[q] = t;
+                if (dst2) reinterpret_cast<float4*>(dst2 + (p + (long long)u * rows) * ps2)[q] = t;
             }
     }
 }
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(256) void bias_leaky_fwd_nhwc_kernel(float* __restr
 // tensors: pixel stride in elements.  partials[c * nblocks + block] = the workgroup's sum for channel c, rows added in
 // a fixed order (bitwise reproducible), finished by bias_grad_finalize_kernel.
 template <bool TWO>
-__global__ __launch_bounds__(256) void bias_leaky_bwd_nhwc_kernel(const float* __restrict__ y, const float* __restrict__ gout,
+__global__ __launch_bounds__(256) void bias_leaky_bwd_nhwc_kernel(const float* __restrict__ y, long long yps, const float* __restrict__ gout,
                                                                   long long gps, const float* __restrict__ gout2, long long gps2,
                                                                   float* __restrict__ gin, float* __restrict__ partials,
                                                                   long long P, int C, int rows, float slope) {
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(256) void bias_leaky_bwd_nhwc_kernel(const float* _
             for (int u = 0; u < NHWC_UNROLL; ++u) {
                 const long long pp = p + (long long)u * rows;
                 if (pp < p1) {
-                    v[u] = reinterpret_cast<const float4*>(y + pp * C)[q];
+                    v[u] = reinterpret_cast<const float4*>(y + pp * yps)[q];      // (the activation may live in a channel slice)
                     g[u] = reinterpret_cast<const float4*>(gout + pp * gps)[q];
                     if (TWO) h[u] = reinterpret_cast<const float4*>(gout2 + pp * gps2)[q];
                 }
@@ -325,13 +331,24 @@ extern "C" int unflow_bias_leaky_bwd(const float* y, const float* gout, float* g
 // channels-last twins: y / gin dense [P][C] (P = N*H*W), C a multiple of 4 and <= 1024
 static inline int nhwc_rows(int C) { const int r = 256 / (C >> 2); return r < 1 ? 1 : r; }
 
-extern "C" int unflow_bias_leaky_fwd_nhwc(float* y, const float* bias, long long P, int C, float slope, void* stream) {
-    UNFLOW_REQUIRE(y && bias && P > 0 && C >= 4 && (C & 3) == 0 && C <= 1024 && (((size_t)y | (size_t)bias) & 15) == 0);
+static int launch_fwd_nhwc(const float* y, const float* bias, long long P, int C, float slope, float* dst1, long long ps1,
+                           float* dst2, long long ps2, void* stream) {
+    UNFLOW_REQUIRE(y && bias && dst1 && P > 0 && C >= 4 && (C & 3) == 0 && C <= 1024 && (((size_t)y | (size_t)bias | (size_t)dst1) & 15) == 0);
+    UNFLOW_REQUIRE(ps1 >= C && (ps1 & 3) == 0 && (!dst2 || (ps2 >= C && (ps2 & 3) == 0 && ((size_t)dst2 & 15) == 0)));
     const long long blocks = (P + NHWC_PIX - 1) / NHWC_PIX;
     UNFLOW_REQUIRE(blocks < (1ll << 31));
-    UNFLOW_LAUNCH(bias_leaky_fwd_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, bias, P, C,
-                       nhwc_rows(C), slope);
+    UNFLOW_LAUNCH(bias_leaky_fwd_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, bias, dst1, ps1, dst2, ps2,
+                       P, C, nhwc_rows(C), slope);
     return unflow_launch_status();
+}
+
+extern "C" int unflow_bias_leaky_fwd_nhwc(float* y, const float* bias, long long P, int C, float slope, void* stream) {
+    return launch_fwd_nhwc(y, bias, P, C, slope, y, C, nullptr, 0, stream);
+}
+
+extern "C" int unflow_bias_leaky_fwd_nhwc_to(const float* y, const float* bias, long long P, int C, float slope, float* dst1,
+                                             long long dst1_pstride, float* dst2, long long dst2_pstride, void* stream) {
+    return launch_fwd_nhwc(y, bias, P, C, slope, dst1, dst1_pstride, dst2, dst2_pstride, stream);
 }
 
 extern "C" int unflow_bias_leaky_partials_nhwc(long long P, int C) {
@@ -340,10 +357,11 @@ extern "C" int unflow_bias_leaky_partials_nhwc(long long P, int C) {
     return n < (1ll << 31) ? (int)n : UNFLOW_EINVAL;
 }
 
-extern "C" int unflow_bias_leaky_bwd2_nhwc(const float* y, const float* gout, long long gout_pstride, const float* gout2,
-                                           long long gout2_pstride, float* gin, float* gbias, float* partials,
-                                           long long P, int C, float slope, void* stream) {
+static int launch_bwd_nhwc(const float* y, long long yps, const float* gout, long long gout_pstride, const float* gout2,
+                           long long gout2_pstride, float* gin, float* gbias, float* partials,
+                           long long P, int C, float slope, void* stream) {
     UNFLOW_REQUIRE(y && gout && gin && gbias && partials && P > 0 && C >= 4 && (C & 3) == 0 && C <= 1024);
+    UNFLOW_REQUIRE(yps >= C && (yps & 3) == 0);
     UNFLOW_REQUIRE(gout_pstride >= C && (gout_pstride & 3) == 0 && (((size_t)gout | (size_t)y | (size_t)gin) & 15) == 0);
     UNFLOW_REQUIRE(!gout2 || (gout2_pstride >= C && (gout2_pstride & 3) == 0 && ((size_t)gout2 & 15) == 0));
     const long long blocks = (P + NHWC_PIX - 1) / NHWC_PIX;
@@ -352,13 +370,25 @@ extern "C" int unflow_bias_leaky_bwd2_nhwc(const float* y, const float* gout, lo
     const int rows = nhwc_rows(C);
     const size_t shmem = (size_t)rows * C * sizeof(float);
     if (gout2)
-        UNFLOW_LAUNCH(bias_leaky_bwd_nhwc_kernel<true>, dim3((unsigned)blocks), dim3(256), shmem, s, y, gout, gout_pstride,
+        UNFLOW_LAUNCH(bias_leaky_bwd_nhwc_kernel<true>, dim3((unsigned)blocks), dim3(256), shmem, s, y, yps, gout, gout_pstride,
                            gout2, gout2_pstride, gin, partials, P, C, rows, slope);
     else
-        UNFLOW_LAUNCH(bias_leaky_bwd_nhwc_kernel<false>, dim3((unsigned)blocks), dim3(256), shmem, s, y, gout, gout_pstride,
+        UNFLOW_LAUNCH(bias_leaky_bwd_nhwc_kernel<false>, dim3((unsigned)blocks), dim3(256), shmem, s, y, yps, gout, gout_pstride,
                            gout2, gout2_pstride, gin, partials, P, C, rows, slope);
     UNFLOW_LAUNCH(bias_grad_finalize_kernel, dim3(C), dim3(256), 0, s, partials, (int)blocks, gbias);
     return unflow_launch_status();
+}
+
+extern "C" int unflow_bias_leaky_bwd2_nhwc(const float* y, const float* gout, long long gout_pstride, const float* gout2,
+                                           long long gout2_pstride, float* gin, float* gbias, float* partials,
+                                           long long P, int C, float slope, void* stream) {
+    return launch_bwd_nhwc(y, C, gout, gout_pstride, gout2, gout2_pstride, gin, gbias, partials, P, C, slope, stream);
+}
+
+extern "C" int unflow_bias_leaky_bwd2_nhwc_from(const float* act, long long act_pstride, const float* gout, long long gout_pstride,
+                                                const float* gout2, long long gout2_pstride, float* gin, float* gbias,
+                                                float* partials, long long P, int C, float slope, void* stream) {
+    return launch_bwd_nhwc(act, act_pstride, gout, gout_pstride, gout2, gout2_pstride, gin, gbias, partials, P, C, slope, stream);
 }
 
 extern "C" int unflow_cat_nhwc(const float* a, int Ca, const float* b, int Cb, const float* c, int Cc, float* out,

@@ -111,7 +111,8 @@ __global__ void bias_grad_finalize_bf16_kernel(const float* __restrict__ partial
 constexpr int HN_PIX = 128, HN_UNROLL = 4;
 struct alignas(8) bf4 { unsigned short v[4]; };
 
-__global__ __launch_bounds__(256) void bias_leaky_fwd_nhwc_bf16_kernel(unsigned short* __restrict__ y, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) void bias_leaky_fwd_nhwc_bf16_kernel(const unsigned short* y, const float* __restrict__ bias,
+                                                                       unsigned short* dst1, long long ps1, unsigned short* dst2, long long ps2,
                                                                        long long P, int C, int rows, float slope) {
     const int quads = C >> 2;
     const int q = threadIdx.x % quads, r = threadIdx.x / quads;
@@ -133,13 +134,14 @@ __global__ __launch_bounds__(256) void bias_leaky_fwd_nhwc_bf16_kernel(unsigned 
                     const float f = bf2f(t.v[k]) + bb[k];
                     t.v[k] = f2bf(f > 0.f ? f : f * slope);
                 }
-                reinterpret_cast<bf4*>(y + (p + (long long)u * rows) * C)[q] = t;
+                reinterpret_cast<bf4*>(dst1 + (p + (long long)u * rows) * ps1)[q] = t;
+                if (dst2) reinterpret_cast<bf4*>(dst2 + (p + (long long)u * rows) * ps2)[q] = t;
             }
     }
 }
 
 template <bool TWO>
-__global__ __launch_bounds__(256) void bias_leaky_bwd_nhwc_bf16_kernel(const unsigned short* __restrict__ y,
+__global__ __launch_bounds__(256) void bias_leaky_bwd_nhwc_bf16_kernel(const unsigned short* __restrict__ y, long long yps,
                                                                        const unsigned short* __restrict__ gout, long long gps,
                                                                        const unsigned short* __restrict__ gout2, long long gps2,
                                                                        unsigned short* __restrict__ gin, float* __restrict__ partials,
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void bias_leaky_bwd_nhwc_bf16_kernel(const uns
             for (int u = 0; u < HN_UNROLL; ++u) {
                 const long long pp = p + (long long)u * rows;
                 if (pp < p1) {
-                    v[u] = reinterpret_cast<const bf4*>(y + pp * C)[q];
+                    v[u] = reinterpret_cast<const bf4*>(y + pp * yps)[q];
                     g[u] = reinterpret_cast<const bf4*>(gout + pp * gps)[q];
                     if (TWO) h[u] = reinterpret_cast<const bf4*>(gout2 + pp * gps2)[q];
                 }
@@ -222,19 +224,31 @@ extern "C" int unflow_bias_leaky_bwd2_bf16(const uint16_t* y, const uint16_t* go
 // channels-last twins: y / gin dense [P][C] bf16 (P = N*H*W), C a multiple of 4 and <= 1024; scratch as unflow_bias_leaky_partials_nhwc
 static inline int hn_rows(int C) { const int r = 256 / (C >> 2); return r < 1 ? 1 : r; }
 
-extern "C" int unflow_bias_leaky_fwd_nhwc_bf16(uint16_t* y, const float* bias, long long P, int C, float slope, void* stream) {
-    UNFLOW_REQUIRE(y && bias && P > 0 && C >= 4 && (C & 3) == 0 && C <= 1024 && ((size_t)y & 7) == 0 && ((size_t)bias & 15) == 0);
+static int launch_fwd_nhwc_bf16(const uint16_t* y, const float* bias, long long P, int C, float slope, uint16_t* dst1, long long ps1,
+                                uint16_t* dst2, long long ps2, void* stream) {
+    UNFLOW_REQUIRE(y && bias && dst1 && P > 0 && C >= 4 && (C & 3) == 0 && C <= 1024 && (((size_t)y | (size_t)dst1) & 7) == 0 && ((size_t)bias & 15) == 0);
+    UNFLOW_REQUIRE(ps1 >= C && (ps1 & 3) == 0 && (!dst2 || (ps2 >= C && (ps2 & 3) == 0 && ((size_t)dst2 & 7) == 0)));
     const long long blocks = (P + HN_PIX - 1) / HN_PIX;
     UNFLOW_REQUIRE(blocks < (1ll << 31));
-    UNFLOW_LAUNCH(bias_leaky_fwd_nhwc_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, bias, P, C,
-                  hn_rows(C), slope);
+    UNFLOW_LAUNCH(bias_leaky_fwd_nhwc_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, bias, dst1, ps1, dst2, ps2,
+                  P, C, hn_rows(C), slope);
     return unflow_launch_status();
 }
 
-extern "C" int unflow_bias_leaky_bwd2_nhwc_bf16(const uint16_t* y, const uint16_t* gout, long long gout_pstride, const uint16_t* gout2,
-                                                long long gout2_pstride, uint16_t* gin, float* gbias, float* partials,
-                                                long long P, int C, float slope, void* stream) {
+extern "C" int unflow_bias_leaky_fwd_nhwc_bf16(uint16_t* y, const float* bias, long long P, int C, float slope, void* stream) {
+    return launch_fwd_nhwc_bf16(y, bias, P, C, slope, y, C, nullptr, 0, stream);
+}
+
+extern "C" int unflow_bias_leaky_fwd_nhwc_to_bf16(const uint16_t* y, const float* bias, long long P, int C, float slope, uint16_t* dst1,
+                                                  long long dst1_pstride, uint16_t* dst2, long long dst2_pstride, void* stream) {
+    return launch_fwd_nhwc_bf16(y, bias, P, C, slope, dst1, dst1_pstride, dst2, dst2_pstride, stream);
+}
+
+static int launch_bwd_nhwc_bf16(const uint16_t* y, long long yps, const uint16_t* gout, long long gout_pstride, const uint16_t* gout2,
+                                long long gout2_pstride, uint16_t* gin, float* gbias, float* partials,
+                                long long P, int C, float slope, void* stream) {
     UNFLOW_REQUIRE(y && gout && gin && gbias && partials && P > 0 && C >= 4 && (C & 3) == 0 && C <= 1024);
+    UNFLOW_REQUIRE(yps >= C && (yps & 3) == 0);
     UNFLOW_REQUIRE(gout_pstride >= C && (gout_pstride & 3) == 0 && (((size_t)gout | (size_t)y | (size_t)gin) & 7) == 0);
     UNFLOW_REQUIRE(!gout2 || (gout2_pstride >= C && (gout2_pstride & 3) == 0 && ((size_t)gout2 & 7) == 0));
     const long long blocks = (P + HN_PIX - 1) / HN_PIX;
@@ -243,11 +257,23 @@ extern "C" int unflow_bias_leaky_bwd2_nhwc_bf16(const uint16_t* y, const uint16_
     const int rows = hn_rows(C);
     const size_t shmem = (size_t)rows * C * sizeof(float);
     if (gout2)
-        UNFLOW_LAUNCH(bias_leaky_bwd_nhwc_bf16_kernel<true>, dim3((unsigned)blocks), dim3(256), shmem, s, y, gout, gout_pstride,
+        UNFLOW_LAUNCH(bias_leaky_bwd_nhwc_bf16_kernel<true>, dim3((unsigned)blocks), dim3(256), shmem, s, y, yps, gout, gout_pstride,
                       gout2, gout2_pstride, gin, partials, P, C, rows, slope);
     else
-        UNFLOW_LAUNCH(bias_leaky_bwd_nhwc_bf16_kernel<false>, dim3((unsigned)blocks), dim3(256), shmem, s, y, gout, gout_pstride,
+        UNFLOW_LAUNCH(bias_leaky_bwd_nhwc_bf16_kernel<false>, dim3((unsigned)blocks), dim3(256), shmem, s, y, yps, gout, gout_pstride,
                       gout2, gout2_pstride, gin, partials, P, C, rows, slope);
     UNFLOW_LAUNCH(bias_grad_finalize_bf16_kernel, dim3(C), dim3(256), 0, s, partials, (int)blocks, gbias);
     return unflow_launch_status();
+}
+
+extern "C" int unflow_bias_leaky_bwd2_nhwc_bf16(const uint16_t* y, const uint16_t* gout, long long gout_pstride, const uint16_t* gout2,
+                                                long long gout2_pstride, uint16_t* gin, float* gbias, float* partials,
+                                                long long P, int C, float slope, void* stream) {
+    return launch_bwd_nhwc_bf16(y, C, gout, gout_pstride, gout2, gout2_pstride, gin, gbias, partials, P, C, slope, stream);
+}
+
+extern "C" int unflow_bias_leaky_bwd2_nhwc_from_bf16(const uint16_t* act, long long act_pstride, const uint16_t* gout, long long gout_pstride,
+                                                     const uint16_t* gout2, long long gout2_pstride, uint16_t* gin, float* gbias,
+                                                     float* partials, long long P, int C, float slope, void* stream) {
+    return launch_bwd_nhwc_bf16(act, act_pstride, gout, gout_pstride, gout2, gout2_pstride, gin, gbias, partials, P, C, slope, stream);
 }

@@ -873,6 +873,316 @@ __global__ __launch_bounds__(256) void warp_bwd_cell_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Source gradient as a GATHER (round 3): no zero-fill, no float atomics, every element of gsrc written exactly once with a
+// plain coalesced store, bitwise reproducible.
+//
+// The kernels above own DESTINATION tiles and scatter; their windows overlap, so the overlaps meet in global float atomics on
+// a pre-zeroed gsrc (level 2: 27 MB fill + an atomic read-modify-write per window element = 1.86x the algorithmic HBM bytes).
+// Here a workgroup owns a SOURCE tile S.  Which destination pixels reach it is decided by the flow, which a workgroup cannot
+// know beyond what it reads -- so a pre-pass (warp_tile_bounds_kernel, 3 MB of flow) leaves for every destination tile the
+// range of its pixels' tap displacements  d = (x0 - x, y0 - y)  (nw tap position minus pixel position).  The owner of S scans
+// its sample's table: tile T reaches S iff  T + [dmin, dmax + 1]  meets S;  over the tiles that do, the displacements span
+// [DXmin, DXmax] x [DYmin, DYmax], and a source cell s can only be hit by the pixels  p = s + k,  k in
+// [-DXmax - 1, -DXmin] x [-DYmax - 1, -DYmin]  -- a window of (span + 2)^2 candidates that does not depend on how LARGE the
+// flow is, only on how much it varies across a few tiles (a constant flow: 2 x 2).  The gather is then dense and branch free:
+//     gsrc[c][s] = sum_k  w(s, s + k) * gout[c][s + k],   w = the bilinear weight of pixel s + k's tap that lands on s (or 0)
+// with the <= 16 weights of a cell in registers (computed once per tile from per-pixel tap records in LDS) and the gout
+// rows of  S + window  staged in LDS per chunk of channels.  Windows beyond 4 x 4 (motion boundaries with several pixels of
+// spread, noise) take a generic per-cell loop over the candidates with global reads: slow, exact, rare.
+// The flow gradient stays with the destination-tile kernel (gsrc == nullptr: no accumulation, no flush).
+// ---------------------------------------------------------------------------------------------
+struct TileBounds { int dxmin, dxmax, dymin, dymax; };     // empty: dxmin > dxmax
+
+template <int PPT>
+__global__ __launch_bounds__(256) void warp_tile_bounds_kernel(const float* __restrict__ flow, TileBounds* __restrict__ table,
+                                                               int H, int W, int ac, int TW, int TH, int tiles_x, int tiles_y) {
+    __shared__ int s_box[16];
+    int t = blockIdx.x;
+    const int bx = t % tiles_x; t /= tiles_x;
+    const int by = t % tiles_y;
+    const int b = t / tiles_y;
+    const int plane = H * W;
+    const float* fb = flow + (size_t)b * 2 * plane;
+    int x0 = kBig, x1 = -kBig, y0 = kBig, y1 = -kBig;
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        const int idx = q * 256 + (int)threadIdx.x;
+        const int ly = idx / TW, lx = idx - ly * TW;
+        const int x = bx * TW + lx, y = by * TH + ly;
+        if (ly < TH && x < W && y < H) {
+            const Taps tp = make_taps(fb[y * W + x], fb[plane + y * W + x], x, y, H, W, ac);
+            if (tp.v_nw || tp.v_ne || tp.v_sw || tp.v_se) {
+                x0 = min(x0, tp.x0 - x); x1 = max(x1, tp.x0 - x);
+                y0 = min(y0, tp.y0 - y); y1 = max(y1, tp.y0 - y);
+            }
+        }
+    }
+    x0 = wave_min_i(x0); y0 = wave_min_i(y0); x1 = wave_max_i(x1); y1 = wave_max_i(y1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_box[wave * 4 + 0] = x0; s_box[wave * 4 + 1] = y0; s_box[wave * 4 + 2] = x1; s_box[wave * 4 + 3] = y1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        TileBounds tb;
+        tb.dxmin = min(min(s_box[0], s_box[4]), min(s_box[8], s_box[12]));
+        tb.dymin = min(min(s_box[1], s_box[5]), min(s_box[9], s_box[13]));
+        tb.dxmax = max(max(s_box[2], s_box[6]), max(s_box[10], s_box[14]));
+        tb.dymax = max(max(s_box[3], s_box[7]), max(s_box[11], s_box[15]));
+        table[blockIdx.x] = tb;
+    }
+}
+
+// the weight with which pixel p (tap record: nw-tap position (x0, y0), weights with non-existent taps zeroed) lands on cell (cx, cy)
+__device__ __forceinline__ float tap_weight_on(int x0, int y0, float nw, float ne, float sw, float se, int cx, int cy) {
+    const float top = (x0 == cx) ? nw : ((x0 + 1 == cx) ? ne : 0.f);
+    const float bot = (x0 == cx) ? sw : ((x0 + 1 == cx) ? se : 0.f);
+    return (y0 == cy) ? top : ((y0 + 1 == cy) ? bot : 0.f);
+}
+
+constexpr int GK = 12;                 // largest candidate window of the LDS path: GK x GK pixels per cell
+constexpr int GN = 8;                  // contributions a cell keeps in registers (a smooth flow gives 2-6; more: that cell rescans)
+
+// one cell's gradient from scratch: every candidate straight from global memory (windows beyond GK, and the few cells of
+// the LDS path that collect more than GN contributions)
+template <int CC>
+__device__ __forceinline__ void gather_cell_global(float (&acc)[CC], const float* __restrict__ fb, const float* __restrict__ g0, int nc,
+                                                   int cx, int cy, int kx0, int ky0, int kw, int kh, int H, int W, int ac) {
+    const int plane = H * W;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) acc[c] = 0.f;
+    for (int ky = 0; ky < kh; ++ky) {
+        const int py = cy + ky0 + ky;
+        if (py < 0 || py >= H) continue;
+        for (int kx = 0; kx < kw; ++kx) {
+            const int px = cx + kx0 + kx;
+            if (px < 0 || px >= W) continue;
+            const Taps tp = make_taps(fb[py * W + px], fb[plane + py * W + px], px, py, H, W, ac);
+            const float wgt = tap_weight_on(tp.x0, tp.y0, tp.nw, tp.ne, tp.sw, tp.se, cx, cy);
+            if (wgt != 0.f) {
+#pragma unroll
+                for (int c = 0; c < CC; ++c)
+                    if (c < nc) acc[c] = fmaf(wgt, g0[(size_t)c * plane + py * W + px], acc[c]);
+            }
+        }
+    }
+}
+
+template <int PPT, int CC>
+__global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __restrict__ flow, const float* __restrict__ gout,
+                                                              const TileBounds* __restrict__ table, float* __restrict__ gsrc,
+                                                              int C, int H, int W, int ac, int TW, int TH, int tiles_x, int tiles_y,
+                                                              int cpg, int vec_ok) {
+    constexpr int DWP = 80, DHMAX = 8 + GK - 1;             // LDS row stride (64 + GK - 1 + 3 alignment columns) / rows of the staged region
+    constexpr int REGION = DHMAX * DWP;                     // floats per channel
+    constexpr int kNone = -0x7fffffff - 1;
+    __shared__ __attribute__((aligned(16))) float s_g[CC * REGION];      // tap records first (6 x REGION words), then gout chunks
+    __shared__ int s_red[16];
+    static_assert(CC >= 6, "the tap records alias the gout staging area");
+    int t = blockIdx.x;
+    const int bx = t % tiles_x; t /= tiles_x;
+    const int by = t % tiles_y;
+    const int b = t / tiles_y;
+    const int c_begin = blockIdx.y * cpg, c_end = min(C, c_begin + cpg);
+    const int plane = H * W;
+    const int sx0 = bx * TW, sy0 = by * TH;
+    const int sx1 = min(sx0 + TW, W) - 1, sy1 = min(sy0 + TH, H) - 1;
+    const float* fb = flow + (size_t)b * 2 * plane;
+    const float* gp = gout + (size_t)b * C * plane;
+    float* dp = gsrc + (size_t)b * C * plane;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    // ---- which destination tiles reach S, and with which displacements
+    int dx0 = kBig, dx1 = -kBig, dy0 = kBig, dy1 = -kBig;
+    {
+        const TileBounds* tb = table + (size_t)b * tiles_x * tiles_y;
+        for (int i = threadIdx.x; i < tiles_x * tiles_y; i += 256) {
+            const TileBounds v = tb[i];
+            const int ty = i / tiles_x, tx = i - ty * tiles_x;
+            const int tx0 = tx * TW, tx1 = min(tx0 + TW, W) - 1, ty0 = ty * TH, ty1 = min(ty0 + TH, H) - 1;
+            const bool reach = v.dxmin <= v.dxmax && tx0 + v.dxmin <= sx1 && tx1 + v.dxmax + 1 >= sx0 &&
+                               ty0 + v.dymin <= sy1 && ty1 + v.dymax + 1 >= sy0;
+            if (reach) { dx0 = min(dx0, v.dxmin); dx1 = max(dx1, v.dxmax); dy0 = min(dy0, v.dymin); dy1 = max(dy1, v.dymax); }
+        }
+        dx0 = wave_min_i(dx0); dy0 = wave_min_i(dy0); dx1 = wave_max_i(dx1); dy1 = wave_max_i(dy1);
+        if (lane == 0) { s_red[wave * 4 + 0] = dx0; s_red[wave * 4 + 1] = dy0; s_red[wave * 4 + 2] = dx1; s_red[wave * 4 + 3] = dy1; }
+        __syncthreads();
+        dx0 = min(min(s_red[0], s_red[4]), min(s_red[8], s_red[12]));
+        dy0 = min(min(s_red[1], s_red[5]), min(s_red[9], s_red[13]));
+        dx1 = max(max(s_red[2], s_red[6]), max(s_red[10], s_red[14]));
+        dy1 = max(max(s_red[3], s_red[7]), max(s_red[11], s_red[15]));
+    }
+    // this thread's cells
+    int cx[PPT], cy[PPT];
+    bool live[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        const int idx = q * 256 + (int)threadIdx.x;
+        const int ly = idx / TW, lx = idx - ly * TW;
+        cx[q] = sx0 + lx; cy[q] = sy0 + ly;
+        live[q] = ly < TH && cx[q] < W && cy[q] < H;
+    }
+    if (dx0 > dx1) {                                        // nothing lands on this tile
+#pragma unroll
+        for (int q = 0; q < PPT; ++q)
+            if (live[q])
+                for (int c = c_begin; c < c_end; ++c) dp[(size_t)c * plane + cy[q] * W + cx[q]] = 0.f;
+        return;
+    }
+    const int kx0 = -dx1 - 1, ky0 = -dy1 - 1;               // candidate p = s + (kx0 + kx, ky0 + ky)
+    const int kw = dx1 - dx0 + 2, kh = dy1 - dy0 + 2;
+
+    if (kw > GK || kh > GK || TW > 64 || TH > 8) {
+        // ---- windows beyond the LDS region: every cell from global memory
+#pragma unroll 1
+        for (int c0 = c_begin; c0 < c_end; c0 += CC) {
+            const int nc = min(CC, c_end - c0);
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                if (!live[q]) continue;
+                float acc[CC];
+                gather_cell_global<CC>(acc, fb, gp + (size_t)c0 * plane, nc, cx[q], cy[q], kx0, ky0, kw, kh, H, W, ac);
+#pragma unroll
+                for (int c = 0; c < CC; ++c)
+                    if (c < nc) dp[(size_t)(c0 + c) * plane + cy[q] * W + cx[q]] = acc[c];
+            }
+        }
+        return;
+    }
+
+    // ---- LDS path.  Region D = S + window, origin (ox, oy) (may start outside the image: those entries stay zero)
+    const int ox = sx0 + kx0, oy = sy0 + ky0;
+    const int oxa = vec_ok ? (ox & ~3) : ox;                // staged rows start 16-byte aligned
+    const int DW = (sx1 - sx0 + 1) + kw - 1 + (ox - oxa), DH = (sy1 - sy0 + 1) + kh - 1;      // <= 78, <= DHMAX
+    // tap records of D's pixels: ints x0, y0 and the four weights, region-indexed [y][x] with row stride DWP
+    int* r_x0 = reinterpret_cast<int*>(s_g);
+    int* r_y0 = r_x0 + REGION;
+    float* r_w = s_g + 2 * REGION;                          // [4][REGION]
+    for (int i = threadIdx.x; i < DH * DWP; i += 256) {
+        const int ry = i / DWP, rx = i - ry * DWP;
+        const int px = oxa + rx, py = oy + ry;
+        int x0 = -kBig, y0 = -kBig;
+        float nw = 0.f, ne = 0.f, sw = 0.f, se = 0.f;
+        if (rx < DW && px >= 0 && px < W && py >= 0 && py < H) {
+            const Taps tp = make_taps(fb[py * W + px], fb[plane + py * W + px], px, py, H, W, ac);
+            x0 = tp.x0; y0 = tp.y0; nw = tp.nw; ne = tp.ne; sw = tp.sw; se = tp.se;
+        }
+        r_x0[i] = x0; r_y0[i] = y0;
+        r_w[i] = nw; r_w[REGION + i] = ne; r_w[2 * REGION + i] = sw; r_w[3 * REGION + i] = se;
+    }
+    __syncthreads();
+    // each cell collects the pixels that land on it: (region index, weight), at most GN in registers
+    float lw[PPT][GN];
+    int li[PPT][GN];
+    bool over[PPT];                                         // more than GN contributions: this cell rescans from global memory
+    int nmax = 0;
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+#pragma unroll
+        for (int j = 0; j < GN; ++j) { lw[q][j] = 0.f; li[q][j] = 0; }
+        over[q] = false;
+        int n = 0;
+        if (live[q]) {
+            const int base = (cy[q] - sy0) * DWP + (cx[q] - sx0) + (ox - oxa);          // candidate (kx, ky) at base + ky * DWP + kx
+            for (int ky = 0; ky < kh; ++ky)
+                for (int kx = 0; kx < kw; ++kx) {
+                    const int i = base + ky * DWP + kx;
+                    const int x0 = r_x0[i], y0 = r_y0[i];
+                    if ((x0 == cx[q] || x0 + 1 == cx[q]) && (y0 == cy[q] || y0 + 1 == cy[q])) {
+                        const float wv = r_w[((y0 == cy[q] ? 0 : 2) + (x0 == cx[q] ? 0 : 1)) * REGION + i];
+                        if (wv != 0.f) {
+#pragma unroll
+                            for (int j = 0; j < GN; ++j)
+                                if (n == j) { lw[q][j] = wv; li[q][j] = i; }
+                            n++;
+                        }
+                    }
+                }
+            over[q] = n > GN;
+        }
+        nmax = max(nmax, min(n, GN));
+    }
+    nmax = wave_max_i(nmax);
+    if (lane == 0) s_red[wave] = nmax;
+    __syncthreads();                                        // (also: everyone is done with the records)
+    nmax = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+    for (int i = threadIdx.x; i < CC * REGION; i += 256) s_g[i] = 0.f;        // (entries outside the image are never staged)
+    // staging: thread t moves the 16-byte piece (region row t / (DWP/4), column t % (DWP/4)) of EVERY channel of a chunk --
+    // one constant division per tile, no per-slot index arithmetic
+    const int s_ry = (int)threadIdx.x / (DWP / 4), s_r4 = (int)threadIdx.x - s_ry * (DWP / 4);
+    int s_goff = kNone;
+    {
+        const int px = oxa + s_r4 * 4, py = oy + s_ry;
+        if (s_ry < DH && s_r4 * 4 < DW && py >= 0 && py < H && px >= 0 && px < W) s_goff = py * W + px;      // (vec: all or nothing)
+    }
+    const int s_loff = s_ry * DWP + s_r4 * 4;
+    static_assert(DHMAX * (DWP / 4) <= 512, "one or two staging pieces per thread and channel");
+    // (rows beyond 256 / (DWP/4) = 12: a second piece per thread)
+    const int s_ry2 = s_ry + 256 / (DWP / 4);
+    int s_goff2 = kNone;
+    {
+        const int t2 = (int)threadIdx.x + 256;
+        const int ry2 = t2 / (DWP / 4), r42 = t2 - ry2 * (DWP / 4);
+        const int px = oxa + r42 * 4, py = oy + ry2;
+        if (ry2 < DH && r42 * 4 < DW && py >= 0 && py < H && px >= 0 && px < W) s_goff2 = py * W + px;
+    }
+    const int s_loff2 = ((int)threadIdx.x + 256) / (DWP / 4) * DWP + (((int)threadIdx.x + 256) % (DWP / 4)) * 4;
+    (void)s_ry2;
+    __syncthreads();
+#pragma unroll 1
+    for (int c0 = c_begin; c0 < c_end; c0 += CC) {
+        const int nc = min(CC, c_end - c0);
+        const float* g0 = gp + (size_t)c0 * plane;
+        if (vec_ok) {
+            float4 v[CC];
+#pragma unroll
+            for (int c = 0; c < CC; ++c)
+                v[c] = (s_goff != kNone && c < nc) ? *reinterpret_cast<const float4*>(g0 + (size_t)c * plane + s_goff) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < CC; ++c)
+                if (s_goff != kNone) *reinterpret_cast<float4*>(s_g + c * REGION + s_loff) = v[c];
+            if (DH > 256 / (DWP / 4)) {                    // (workgroup-uniform: windows taller than 5)
+#pragma unroll
+                for (int c = 0; c < CC; ++c)
+                    v[c] = (s_goff2 != kNone && c < nc) ? *reinterpret_cast<const float4*>(g0 + (size_t)c * plane + s_goff2) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int c = 0; c < CC; ++c)
+                    if (s_goff2 != kNone) *reinterpret_cast<float4*>(s_g + c * REGION + s_loff2) = v[c];
+            }
+        } else {
+            // rows that are not 16-byte aligned (W % 4 != 0): element by element
+            for (int i = threadIdx.x; i < CC * DH * DW; i += 256) {
+                const int c = i / (DH * DW), r = i - c * (DH * DW);
+                const int ry = r / DW, rx = r - ry * DW;
+                const int px = oxa + rx, py = oy + ry;
+                if (px >= 0 && px < W && py >= 0 && py < H)
+                    s_g[c * REGION + ry * DWP + rx] = c < nc ? g0[(size_t)c * plane + py * W + px] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            float acc[CC];
+#pragma unroll
+            for (int c = 0; c < CC; ++c) acc[c] = 0.f;
+#pragma unroll
+            for (int j = 0; j < GN; ++j) {
+                if (j >= nmax) break;                       // (workgroup-uniform)
+                const float wv = lw[q][j];
+                const float* col = s_g + li[q][j];
+#pragma unroll
+                for (int c = 0; c < CC; ++c) acc[c] = fmaf(wv, col[c * REGION], acc[c]);
+            }
+            if (over[q]) gather_cell_global<CC>(acc, fb, g0, nc, cx[q], cy[q], kx0, ky0, kw, kh, H, W, ac);
+            if (live[q]) {
+#pragma unroll
+                for (int c = 0; c < CC; ++c)
+                    if (c < nc) dp[(size_t)(c0 + c) * plane + cy[q] * W + cx[q]] = acc[c];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Tile geometry for an H x W map with C channels: tiles as wide as the map allows up to 64 (52 for the 13 * 2^k wide
 // KITTI levels: no dead lanes), channel groups so that the launch has >= ~1024 workgroups.
 struct TilePlan { int TW, TH, tiles_x, tiles_y, groups, cpg; };
@@ -938,14 +1248,32 @@ extern "C" int unflow_warp_fwd(const float* src, const float* flow, float* out, 
     return unflow_launch_status();
 }
 
-extern "C" int unflow_warp_bwd(const float* src, const float* flow, const float* gout, const uint8_t* mask,
-                               float* gsrc, float* gflow, int B, int C, int H, int W, int align_corners,
-                               void* stream) {
+static int warp_bwd_impl(const float* src, const float* flow, const float* gout, const uint8_t* mask,
+                         float* gsrc, float* gflow, int B, int C, int H, int W, int align_corners,
+                         void* stream, int want_gather) {
     UNFLOW_REQUIRE(src && flow && gout && gflow && B > 0 && C > 0 && H > 0 && W > 0);
     hipStream_t s = (hipStream_t)stream;
-    if (gsrc) unflow_zero_async(gsrc, (size_t)B * C * H * W, s);
     const int ac = align_corners ? 1 : 0;
-    if (use_tiles(mask, C, H, W) && wenv("UNFLOW_WARP_TILES", 1)) {
+    const bool tiles = use_tiles(mask, C, H, W) && wenv("UNFLOW_WARP_TILES", 1);
+    // round 3: the source gradient of the feature warps as a GATHER (no zero-fill, no atomics, bitwise reproducible).  Measured
+    // against the scatter forms below (tools/microbench.py warp_gather, back to back): level 2 51.6 vs 48.6 us, level 3 37.4 vs
+    // 32.2, level 4 34.0 vs 18.6 -- three launches (bounds, gather, flow gradient) against two, and a per-tile set-up that a
+    // handful of channel chunks does not amortise -- so it is NOT the default: unflow_warp_bwd_det asks for it
+    // (UNFLOW_WARP_GATHER=1 in tuning builds).
+    const bool gather = tiles && gsrc && (want_gather || wenv("UNFLOW_WARP_GATHER", 0)) &&
+                        (size_t)B * 2 * H * W * sizeof(float) >= (size_t)B * ceil_div(W, 4) * ceil_div(H, 8) * sizeof(TileBounds);
+    if (gather) {
+        const TilePlan p = plan_tiles(B, C, H, W, 8, 8, wenv("UNFLOW_WARP_GATHER_WGS", 512));   // (the per-tile set-up -- tap records, contribution lists -- is worth ~2 chunks: few channel groups)
+        const int ntiles = p.tiles_x * p.tiles_y * B;
+        TileBounds* table = reinterpret_cast<TileBounds*>(gflow);       // gflow is scratch until its own kernel (below) writes it
+        UNFLOW_LAUNCH((warp_tile_bounds_kernel<2>), dim3(ntiles), dim3(256), 0, s, flow, table, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y);
+        const int vec_g = ((W & 3) == 0 && (((size_t)gout) & 15) == 0) ? 1 : 0;
+        UNFLOW_LAUNCH((warp_bwd_gather_kernel<2, 8>), dim3(ntiles, p.groups), dim3(256), 0, s, flow, gout, table, gsrc,
+                           C, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y, p.cpg, vec_g);
+        gsrc = nullptr;                                                  // the kernels below only owe the flow gradient
+    }
+    if (gsrc) unflow_zero_async(gsrc, (size_t)B * C * H * W, s);
+    if (tiles) {
         const int th = 8;                                       // 64x8 tiles, 2 px per lane: 152 VGPRs, 3 workgroups per CU
         const TilePlan p = plan_tiles(B, C, H, W, th, 4, wenv("UNFLOW_WARP_WGS", 512));   // level 2: 512 tiles, all channels in one workgroup
         dim3 tgrid(p.tiles_x * p.tiles_y * B, p.groups);
@@ -981,4 +1309,16 @@ extern "C" int unflow_warp_bwd(const float* src, const float* flow, const float*
     }
 #undef LAUNCH
     return unflow_launch_status();
+}
+
+extern "C" int unflow_warp_bwd(const float* src, const float* flow, const float* gout, const uint8_t* mask,
+                               float* gsrc, float* gflow, int B, int C, int H, int W, int align_corners,
+                               void* stream) {
+    return warp_bwd_impl(src, flow, gout, mask, gsrc, gflow, B, C, H, W, align_corners, stream, 0);
+}
+
+extern "C" int unflow_warp_bwd_det(const float* src, const float* flow, const float* gout, const uint8_t* mask,
+                                   float* gsrc, float* gflow, int B, int C, int H, int W, int align_corners,
+                                   void* stream) {
+    return warp_bwd_impl(src, flow, gout, mask, gsrc, gflow, B, C, H, W, align_corners, stream, 1);
 }

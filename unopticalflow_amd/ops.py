@@ -14,7 +14,7 @@ import torch
 from . import _lib
 
 __all__ = ['corr', 'warp_flow', 'warp_flow_masked', 'warp_corr', 'occ_weight', 'occ_weight_stacked', 'masked_mean', 'ssim_loss',
-           'ssim_map', 'smooth2_loss', 'consis_loss', 'bias_leaky_relu_', 'img_pyramid']
+           'ssim_map', 'smooth2_loss', 'consis_loss', 'bias_leaky_relu_', 'bias_leaky_relu_into', 'img_pyramid']
 
 
 def _ptr(t):
@@ -171,7 +171,7 @@ def corr(input1, input2, d=4):
 # ------------------------------------------------------------------------------------------
 class _Warp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, flow, use_mask, align_corners):
+    def forward(ctx, x, flow, use_mask, align_corners, deterministic=False):
         _dev(x, flow)
         x, flow = x.contiguous(), flow.contiguous()
         B, C, H, W = x.shape
@@ -183,6 +183,7 @@ class _Warp(torch.autograd.Function):
                   shape=(B, C, H, W))
         ctx.save_for_backward(x, flow, mask)
         ctx.ac = int(align_corners)
+        ctx.entry = 'unflow_warp_bwd_det' if deterministic else 'unflow_warp_bwd'
         if use_mask:
             ctx.mark_non_differentiable(mask)
             return out, mask
@@ -196,10 +197,10 @@ class _Warp(torch.autograd.Function):
         gsrc = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gflow = torch.empty_like(flow)
         with _on(x.device):
-            _call('unflow_warp_bwd', _ptr(x), _ptr(flow), _ptr(g), _ptr(mask), _ptr(gsrc), _ptr(gflow),
+            _call(ctx.entry, _ptr(x), _ptr(flow), _ptr(g), _ptr(mask), _ptr(gsrc), _ptr(gflow),
                   B, C, H, W, ctx.ac, _stream(),
                   nbytes=4 * B * H * W * ((3 * C + 4) if gsrc is not None else (2 * C + 4)), shape=(B, C, H, W))
-        return gsrc, (gflow if ctx.needs_input_grad[1] else None), None, None
+        return gsrc, (gflow if ctx.needs_input_grad[1] else None), None, None, None
 
 
 def _check_flow_shape(x, flow):
@@ -209,10 +210,11 @@ def _check_flow_shape(x, flow):
             torch.Size((B, 2, H, W)), flow.shape))
 
 
-def warp_flow(x, flow, use_mask=False, align_corners=False):
-    """warp_flow (net_utils.py:16-54): backward-warp x [B,C,H,W] by flow [B,2,H,W]."""
+def warp_flow(x, flow, use_mask=False, align_corners=False, deterministic=False):
+    """warp_flow (net_utils.py:16-54): backward-warp x [B,C,H,W] by flow [B,2,H,W].  ``deterministic``: the source gradient of a
+    feature-map warp as a gather (unflow_warp_bwd_det: no float atomics, bitwise reproducible; a few per cent to 2x slower)."""
     _check_flow_shape(x, flow)
-    out, _ = _Warp.apply(x, flow, bool(use_mask), bool(align_corners))
+    out, _ = _Warp.apply(x, flow, bool(use_mask), bool(align_corners), bool(deterministic))
     return out
 
 
@@ -658,6 +660,97 @@ def bias_leaky_relu_(y, bias, negative_slope=0.1, consumers=1):
     if consumers == 2:
         return _BiasLeakyTwo.apply(y, bias, float(negative_slope))
     return _BiasLeaky.apply(y, bias, float(negative_slope))
+
+
+class _BiasLeakyInto(torch.autograd.Function):
+    """conv() epilogue that FILLS cat buffers: ``leaky_relu(y + bias)`` of a bias-free channels_last conv output ``y`` is written
+    into the channel slice ``[off, off + C)`` of up to two wider channels_last buffers -- the inputs of the next two
+    convolutions of the decoder, which the reference builds with torch.cat (pwc_tf.py:114-118) -- and, with ``inplace``, into
+    ``y`` itself (an activation that is also consumed on its own).  Each buffer is modified in place and handed back, so
+    autograd chains the two epilogues that fill a buffer; the backward reads the activation's sign and the (at most two)
+    upstream gradients straight out of the slices (one kernel, no slice / cat / add passes)."""
+
+    @staticmethod
+    def forward(ctx, y, bias, slope, inplace, buf_a, off_a, buf_b, off_b):
+        half = y.dtype == torch.bfloat16
+        _dev(None if half else y, bias)
+        N, C, H, W = y.shape
+        if not (_is_nhwc(y) or (y.is_contiguous() and (C == 1 or H * W == 1))) or C % 4:
+            raise RuntimeError('bias_leaky_relu_into needs a dense channels_last convolution output with C % 4 == 0')
+        dests = []                                       # (tensor, pixel stride, element offset)
+        if inplace:
+            dests.append((y, C, 0))
+        for buf, off in ((buf_a, off_a), (buf_b, off_b)):
+            if buf is None:
+                continue
+            dense_cl = _is_nhwc(buf) or (buf.dim() == 4 and buf.is_contiguous() and (buf.shape[1] == 1 or H * W == 1))
+            if buf.dtype != y.dtype or buf.device != y.device or buf.shape[0] != N or tuple(buf.shape[2:]) != (H, W) or not dense_cl \
+                    or off % 4 or off < 0 or off + C > buf.shape[1]:
+                raise RuntimeError('bias_leaky_relu_into: a destination must be a dense channels_last [N, C_total, H, W] tensor of the '
+                                   "activation's dtype with a 4-aligned channel offset")
+            dests.append((buf, buf.shape[1], off))
+        if not 1 <= len(dests) <= 2:
+            raise RuntimeError('bias_leaky_relu_into writes one or two destinations, got %d' % len(dests))
+        es = y.element_size()
+        d1 = ctypes.c_void_p(dests[0][0].data_ptr() + dests[0][2] * es)
+        d2 = ctypes.c_void_p(dests[1][0].data_ptr() + dests[1][2] * es) if len(dests) > 1 else ctypes.c_void_p(0)
+        with _on(y.device):
+            _call('unflow_bias_leaky_fwd_nhwc_to_bf16' if half else 'unflow_bias_leaky_fwd_nhwc_to', _ptr(y), _ptr(bias), N * H * W, C,
+                  ctypes.c_float(slope), d1, dests[0][1], d2, dests[1][1] if len(dests) > 1 else 0, _stream(),
+                  nbytes=(1 + len(dests)) * es * N * C * H * W, shape=(N, C, H, W))
+        dirty = [t for t in ((y if inplace else None), buf_a, buf_b) if t is not None]
+        ctx.mark_dirty(*dirty)
+        # the activation (for its sign): NOT through save_for_backward -- the buffer is legitimately modified again by the
+        # epilogue that fills its other channels, which would trip the saved-tensor version check
+        ctx.act, ctx.act_ps, ctx.act_off = dests[0]
+        ctx.meta = (N, C, H, W, slope, inplace, off_a, off_b, half)
+        ctx.set_materialize_grads(False)
+        return (y if inplace else None), buf_a, buf_b
+
+    @staticmethod
+    def backward(ctx, g_y, g_a, g_b):
+        N, C, H, W, slope, inplace, off_a, off_b, half = ctx.meta
+        srcs = []                                        # (gradient tensor, channel offset)
+        if inplace and g_y is not None:
+            srcs.append((g_y, 0))
+        if g_a is not None:
+            srcs.append((g_a, off_a))
+        if g_b is not None:
+            srcs.append((g_b, off_b))
+        if not srcs:
+            return (None,) * 8
+        if len(srcs) > 2:
+            raise RuntimeError('bias_leaky_relu_into: at most two consumers per activation')
+        act = ctx.act
+        dt = act.dtype
+        es = act.element_size()
+        ptrs = []
+        for g, off in srcs:
+            if g.dtype != dt:
+                raise TypeError('gradient dtype %s does not match the activation (%s)' % (g.dtype, dt))
+            if not (_is_nhwc(g) or (g.is_contiguous() and (g.shape[1] == 1 or H * W == 1))):
+                g = g.contiguous(memory_format=torch.channels_last)
+            ptrs.append((g, ctypes.c_void_p(g.data_ptr() + off * es), g.shape[1]))
+        gin = torch.empty((N, C, H, W), dtype=dt, device=act.device, memory_format=torch.channels_last)
+        gbias = torch.empty(C, dtype=torch.float32, device=act.device)
+        P = N * H * W
+        part = torch.empty(_lib.load().unflow_bias_leaky_partials_nhwc(P, C), dtype=torch.float32, device=act.device)
+        g2 = ptrs[1] if len(ptrs) > 1 else (None, ctypes.c_void_p(0), 0)
+        with _on(act.device):
+            _call('unflow_bias_leaky_bwd2_nhwc_from_bf16' if half else 'unflow_bias_leaky_bwd2_nhwc_from',
+                  ctypes.c_void_p(act.data_ptr() + ctx.act_off * es), ctx.act_ps, ptrs[0][1], ptrs[0][2], g2[1], g2[2],
+                  _ptr(gin), _ptr(gbias), _ptr(part), P, C, ctypes.c_float(slope), _stream(),
+                  nbytes=(2 + len(ptrs)) * es * N * C * H * W, shape=(N, C, H, W))
+        ctx.act = None
+        # the buffers' incoming gradients pass through to whoever filled their other channels
+        return gin, gbias, None, None, g_a, None, g_b, None
+
+
+def bias_leaky_relu_into(y, bias, negative_slope, buf_a, off_a, buf_b=None, off_b=0, inplace=False):
+    """The conv() epilogue (net_utils.py:7-11) of a channels_last convolution output ``y``, written into ``buf_a[:, off_a:off_a+C]``
+    (and ``buf_b[:, off_b:off_b+C]``; and into ``y`` itself with ``inplace``): the way the decoder's cat((x_k, x_k+1)) inputs
+    come into being without a cat.  Returns ``(y or None, buf_a, buf_b)`` -- use the returned buffers from here on."""
+    return _BiasLeakyInto.apply(y, bias, float(negative_slope), bool(inplace), buf_a, int(off_a), buf_b, int(off_b))
 
 
 class _CatChannelsLast(torch.autograd.Function):
