@@ -268,7 +268,8 @@ def test_warp_feature_tiles_vs_oracle(ops, kind, C, h, w):
             close(x3.grad, xc.grad, rtol=1e-4, atol=2e-5, what='gather gsrc %s' % kind)
             close(f3.grad, fc.grad, rtol=1e-4, atol=2e-5 * scale, what='gather gflow %s' % kind)
             runs.append(x3.grad.clone())
-        assert torch.equal(runs[0], runs[1])
+        if C >= 8 and w >= 8 and h * w >= 512:            # (the shapes the tile kernels serve; smaller maps keep the per-tap atomics)
+            assert torch.equal(runs[0], runs[1])
 
 
 @pytest.mark.parametrize('kind', ['smooth', 'mixed', 'edge', 'outside', 'noise'])
