@@ -23,7 +23,12 @@ The single JSON line also carries
                 kind "port") timed on the host cores of this box on a bounded sample (all cores the
                 cgroup allows, plus a one-thread figure);
   conv_stack:   convolution FLOPs of the step / whole step time / dense MFMA peak of the dtype: a lower
-                bound on the conv stacks' MFMA utilisation;
+                bound on the conv stacks' MFMA utilisation; `conv_kernels_only`: the convolution kernels' own utilisation from
+                the MFMA hardware counters of a committed rocprofv3 --pmc capture (profiles/r3_conv_mfma_*.json);
+  step_ms, host_enqueue_ms, drain_ms, all_step_ms, host_gc: the spread of the timed steps -- device time between per-step
+                event records, host time to enqueue a step, how far the host was ahead at the end, and what Python's
+                cyclic collector did inside the timed region (one generation-2 pass of ~90 ms used to put a 50-90 ms step
+                into every ~17: the trainer now freezes the heap after its second step, FlowTrainer(gc_freeze_after));
   kernel_survey (N = 1 only, 3 extra untimed steps with HIP events around every C entry point): the 14 heaviest
                 entry points (losses and conv epilogues included).
 --force-ddp runs the N = 1 step through the data-parallel path on RCCL with a one-rank communicator (hooks, async
@@ -154,7 +159,7 @@ def measured_traffic(entry, shape, path=None):
     """HBM bytes per launch of (entry point, shape) from the rocprofv3 PMC passes under profiles/ (FETCH_SIZE x2 per the
     gfx950 wide-load correction + WRITE_SIZE, tools/pmc_traffic.py) -- but only if that file was measured on exactly the
     kernel sources of this build; a stale file gives (None, reason)."""
-    path = path or os.path.join(ROOT, 'profiles', 'r2_pmc_traffic.json')
+    path = path or os.path.join(ROOT, 'profiles', 'r3_pmc_traffic.json')
     if not os.path.exists(path):
         return None, 'no PMC file'
     d = json.load(open(path))
@@ -352,6 +357,14 @@ def main():
                 'frac_lower_bound': round(conv_flops[0] / (dt / args.steps) / 1e12 / MFMA_PEAK_TFLOPS[args.precision], 4)},
             'kernel_survey': survey,
         }
+        # MFMA utilisation of the convolution kernels alone, from hardware counters (a committed rocprofv3 --pmc capture of
+        # this very command: tools/gpu_r3_profile.sh -> tools/summarize_mfma.py); the live figure above divides by the whole step
+        mf = os.path.join(ROOT, 'profiles', 'r3_conv_mfma_%s.json' % args.precision)
+        if out['conv_stack'] is not None and os.path.exists(mf) and (fh, fw, args.batch) == (H, W, B_PER_GPU):
+            ck = json.load(open(mf))['conv_kernels_only']
+            out['conv_stack']['conv_kernels_only'] = {'achieved': ck['achieved_tflops'], 'frac': ck['frac_of_peak'], 'ms_per_step': ck['ms_per_step'],
+                                                      'mfma_tflop_per_step_counted': ck['mfma_tflop_per_step'],
+                                                      'source': 'profiles/%s (SQ_INSTS_VALU_MFMA_MOPS_* x 512 / kernel time, separate --pmc and --kernel-trace runs)' % os.path.basename(mf)}
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

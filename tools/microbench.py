@@ -201,7 +201,7 @@ def warp_gather(B=16):
                 err = max((gsrc - ref['a']).abs().max().item(), (gflow - ref['b']).abs().max().item())
                 print('warp_bwd %s [%d,%d,%d,%d] %-12s %-28s %7.1f us (%6.0f GB/s)  max|diff vs first| %.2e (max|ref| %.2f)' % (
                     name, B, C, h, w, kind, tag, tb, bb / tb / 1e3, err, ref['a'].abs().max().item()), flush=True)
-            _sweep([{'UNFLOW_WARP_GATHER': 0}, {}], run)
+            _sweep([{}, {"UNFLOW_WARP_GATHER": 1}], run)
 
 
 def corr8_bwd_rs(B=16):

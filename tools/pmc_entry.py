@@ -29,6 +29,8 @@ for _ in range(reps):
         lib.unflow_warp_fwd(P(f1), P(fl), P(o1), None, B, C, h, w, 0, ops._stream())
     elif entry == 'unflow_warp_bwd':
         lib.unflow_warp_bwd(P(f1), P(fl), P(f2), None, P(o1), P(gfl), B, C, h, w, 0, ops._stream())
+    elif entry == 'unflow_warp_bwd_det':
+        lib.unflow_warp_bwd_det(P(f1), P(fl), P(f2), None, P(o1), P(gfl), B, C, h, w, 0, ops._stream())
     elif entry == 'unflow_warp_corr_fwd':
         lib.unflow_warp_corr_fwd(P(f1), P(f2), P(fl), P(cv), B, C, h, w, 4, 0, ops._stream())
     else:

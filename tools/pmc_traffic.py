@@ -1,7 +1,7 @@
 """Collect HBM traffic per launch of the cost-volume / warp entry points with rocprofv3 PMC passes and write
-profiles/r2_pmc_traffic.json (read by bench.py's `roofline.traffic`, keyed by the sha256 of the kernel sources).
+profiles/r3_pmc_traffic.json (read by bench.py's `roofline.traffic`, keyed by the sha256 of the kernel sources).
 
-    python tools/pmc_traffic.py            (on the GPU box; ~3 min)
+    python tools/pmc_traffic.py [entry:level ...]           (on the GPU box; ~3 min for the default six)
 
 FETCH_SIZE and WRITE_SIZE are collected in SEPARATE passes (they do not fit one), no trace domains mixed in.  On gfx950
 FETCH_SIZE reports half the bytes of wide coalesced streams (MI355X_MICROARCH.md, HBM): x2 before adding WRITE_SIZE (KB)."""
@@ -39,7 +39,8 @@ def one_pass(entry, lvl, counter):
                 continue
             if 'at::native' in name:
                 continue
-            per_kernel.setdefault(name.split('(')[0][:70], []).append(float(r['Counter_Value']))
+            short = name.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:70]
+            per_kernel.setdefault(short, []).append(float(r['Counter_Value']))
     return per_kernel
 
 
@@ -49,7 +50,8 @@ def main():
            'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, KB per dispatch summed over the kernels '
                      'of one entry-point call; hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 wide-load correction)',
            'entries': {}}
-    for entry, lvl in ENTRIES:
+    entries = [tuple(a.split(':')) for a in sys.argv[1:]] or ENTRIES
+    for entry, lvl in entries:
         C, h, w = LEVELS[lvl]
         fetch, write = one_pass(entry, lvl, 'FETCH_SIZE'), one_pass(entry, lvl, 'WRITE_SIZE')
         f_kb = sum(sum(v) for v in fetch.values()) / REPS
@@ -60,8 +62,8 @@ def main():
                                'kernels': {k: {'fetch_kb': round(sum(v) / REPS, 1), 'write_kb': round(sum(write.get(k, [0])) / REPS, 1)}
                                            for k, v in fetch.items()}}
         print(key, res['entries'][key]['hbm_bytes_per_launch'], flush=True)
-    os.makedirs(os.path.join(ROOT, 'gpurun_out', 'r2'), exist_ok=True)
-    json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'r2', 'r2_pmc_traffic.json'), 'w'), indent=1)
+    os.makedirs(os.path.join(ROOT, 'gpurun_out', 'r3'), exist_ok=True)
+    json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'r3', 'r3_pmc_traffic.json'), 'w'), indent=1)
 
 
 if __name__ == '__main__':

@@ -29,7 +29,7 @@ class PWC_tf(nn.Module):
         self.fill_cat_buffers = True
         self.corr = self.corr_naive
         # True: warp + cost volume of a level as ONE kernel (ops.warp_corr; the warped features never reach HBM).
-        # Measured on MI355X (profiles/r2_fused_warp_corr.txt): at parity with the two separate kernels at level 2 and
+        # Measured on MI355X (profiles/r2_v1_bench_fused1.json): at parity with the two separate kernels at level 2 and
         # slower below it -- the cost-volume kernel is LDS/VALU-bound, so the warp stage adds to the bound resource --
         # hence off by default.
         self.fused_warp_corr = bool(fused_warp_corr)

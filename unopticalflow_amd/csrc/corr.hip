@@ -1458,7 +1458,7 @@ __global__ void corr_fwd_generic(const float* __restrict__ f1, const float* __re
             const float* p1 = f1 + ((size_t)b * C * H + y) * W + x;
             const float* p2 = f2 + ((size_t)b * C * H + sy) * W + sx;
             const size_t plane = (size_t)H * W;
-#pragma unroll 8
+#pragma unroll 8      // (32 in flight: 15.0 -> 18.1 us at level 5 -- the kernel is bound by its L1 traffic, not by a latency chain)
             for (int c = 0; c < C; ++c) s = fmaf(p1[c * plane], p2[c * plane], s);
         }
         cv[t] = s * inv_c;

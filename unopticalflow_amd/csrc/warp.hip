@@ -1128,19 +1128,28 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
     const int s_loff2 = ((int)threadIdx.x + 256) / (DWP / 4) * DWP + (((int)threadIdx.x + 256) % (DWP / 4)) * 4;
     (void)s_ry2;
     __syncthreads();
+    // software pipeline over the channel chunks: the NEXT chunk's pieces are requested into registers before the current
+    // chunk's gather and written to LDS after it (one HBM round trip per chunk would otherwise sit on the critical path of a
+    // workgroup that has only one or two neighbours on its CU)
+    float4 vpre[CC];
+    auto fetch = [&](int c0n) {
+        const int ncn = min(CC, c_end - c0n);
+        const float* gn = gp + (size_t)c0n * plane;
+#pragma unroll
+        for (int c = 0; c < CC; ++c)
+            vpre[c] = (s_goff != kNone && c < ncn) ? *reinterpret_cast<const float4*>(gn + (size_t)c * plane + s_goff) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    if (vec_ok) fetch(c_begin);
 #pragma unroll 1
     for (int c0 = c_begin; c0 < c_end; c0 += CC) {
         const int nc = min(CC, c_end - c0);
         const float* g0 = gp + (size_t)c0 * plane;
         if (vec_ok) {
-            float4 v[CC];
 #pragma unroll
             for (int c = 0; c < CC; ++c)
-                v[c] = (s_goff != kNone && c < nc) ? *reinterpret_cast<const float4*>(g0 + (size_t)c * plane + s_goff) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int c = 0; c < CC; ++c)
-                if (s_goff != kNone) *reinterpret_cast<float4*>(s_g + c * REGION + s_loff) = v[c];
-            if (DH > 256 / (DWP / 4)) {                    // (workgroup-uniform: windows taller than 5)
+                if (s_goff != kNone) *reinterpret_cast<float4*>(s_g + c * REGION + s_loff) = vpre[c];
+            if (DH > 256 / (DWP / 4)) {                    // (workgroup-uniform: windows taller than 5 -- a second piece, not pipelined)
+                float4 v[CC];
 #pragma unroll
                 for (int c = 0; c < CC; ++c)
                     v[c] = (s_goff2 != kNone && c < nc) ? *reinterpret_cast<const float4*>(g0 + (size_t)c * plane + s_goff2) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1159,6 +1168,8 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
             }
         }
         __syncthreads();
+        if (vec_ok && c0 + CC < c_end) fetch(c0 + CC);
+        __builtin_amdgcn_sched_barrier(0);                  // (the requests go out here, not where their values are used)
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             float acc[CC];
