@@ -979,7 +979,7 @@ int launch_bwd_gs(const float* f1, const float* f2, const float* g, float* gf1, 
 // 64-wide tiles leave the fourth tile column three quarters empty, 19 % of all lanes idle).
 template <int R, int CH, int TYB_ = 8>
 struct BwdRsCfg {
-    static constexpr int DD = 2 * R + 1, TYB = TYB_, THREADS = 256, TWL = THREADS / TYB, TW = 2 * TWL;
+    static constexpr int DD = 2 * R + 1, TYB = TYB_, THREADS = (TYB_ == 16 ? 512 : 256), TWL = THREADS / TYB, TW = 2 * TWL;     // (TYB 16: 64 x 16 tiles, 8 waves)
     static_assert(TWL == 32 || TWL == 8, "lane mappings below");
     static constexpr int LW = TW + 2 * R, LH = TYB + 2 * R;
     static constexpr int SC = LH * LW / 4;                                      // float4 slots per channel
@@ -1663,6 +1663,9 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 // 4 groups: 20 us; more groups than that only repeat the upstream-gradient gather)
                 const int items = ceil_div(W, 64) * ceil_div(H, 8) * B * 2;
                 int groups = forced_groups() ? forced_groups() : (items >= 256 ? 1 : 256 / items);
+#ifdef UNFLOW_TUNING
+                // row-streamed variants for tools/microbench.py corr_bwd_rs (UNFLOW_CORR_BWD): 7 / 9 prefetch depth 3 / 1, 8 / 11 eight channels
+                // per item, 10 16 x 32 tiles, 12-14 the two-half phase-shifted form, 15-17 wave sets sharing a tile, 21-29 phase ablations
                 if (ring_ok && fb == 7) return launch_bwd_rs<4, 16, 8, 3>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (ring_ok && fb == 8) return launch_bwd_rs<4, 8, 8, 3>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (ring_ok && fb == 9) return launch_bwd_rs<4, 16, 8, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
@@ -1673,8 +1676,8 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 if (ring_ok && fb == 16) return launch_bwd_rs<4, 16, 8, 2, 0, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (ring_ok && fb == 17) return launch_bwd_rs<4, 32, 8, 1, 0, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (ring_ok && fb == 13) return launch_bwd_rs2<4, 16, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                if (ring_ok && fb == 18) return launch_bwd_rs<4, 16, 16, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);      // 64 x 16 tiles, one 8-wave workgroup per CU
                 if (ring_ok && fb == 14) return launch_bwd_rs2<4, 16, 3>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-#ifdef UNFLOW_TUNING
                 if (ring_ok && fb == 21) return launch_bwd_rs<4, 16, 8, 1, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // no LDS reads
                 if (ring_ok && fb == 22) return launch_bwd_rs<4, 16, 8, 1, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // no FMAs
                 if (ring_ok && fb == 24) return launch_bwd_rs<4, 16, 8, 1, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // no weight loads
@@ -1695,7 +1698,7 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 // the group-split ring kernel, which stays selectable in tuning builds: UNFLOW_CORR_BWD=4).  16 channels per work
                 // item (8 on small maps: more, shorter workgroups); 16 x 32 tiles where 64-wide ones would leave a mostly empty
                 // last tile column and the map is tall enough (level 3: 104 = 6.5 x 16)
-                // In the train step (in-step A/B, tools/gpu_r3_d.sh): level 2 73.6 vs 91.8 us, level 3 37.5 (64 x 8 tiles; 39.5 with
+                // In the train step (in-step A/B, tools/gpu_r3_experiments.sh instep): level 2 73.6 vs 91.8 us, level 3 37.5 (64 x 8 tiles; 39.5 with
                 // 16 x 32) vs 35.0, level 4 18.6 vs 20.1 -- so level 3 (32768 <= pixels < 131072, 256 items: one round of the
                 // group-split kernel) stays on the group-split ring kernel
                 if (ring_ok && fb == 0 && (variant == 7 || mid_size(variant))) {
@@ -1706,7 +1709,9 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 }
                 if (ring_ok && fb == 4)
                     return launch_bwd_gs<4, 4, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, groups, s);
+#ifdef UNFLOW_TUNING
                 if (ring_ok && fb == 32) return launch_bwd_rs<4, 16, 32, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // (tuning: 16 x 32 tiles)
+#endif
                 if (fb == 6 || variant == 1 || variant == 7) return launch_bwd<4, 2, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (variant == 2 || variant == 3 || (mid_size(variant) && (long)B * H * W >= 32768))
                     return launch_bwd<4, 1, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
@@ -1721,8 +1726,10 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 if (variant == 4 || (long)B * H * W < 8192) break;      // small maps: one lane per element (117 / 57 us at levels 5 / 6, tile kernel 283 / 378)
                 if ((variant == 7 || mid_size(variant)) && (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0) && gs_offsets_fit(C, H, W, 8)) {
                     // round 3: row-streamed, 8 channels per item: 290 / 117 / 49 us at levels 2 / 3 / 4 (group-split ring kernel 343 / 129 / 85)
+#ifdef UNFLOW_TUNING
                     if (forced_bwd() == 4) return launch_bwd_gs<8, 1, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, 1, s);
                     if (forced_bwd() == 8) return launch_bwd_rs<8, 4, 8, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+#endif
                     return launch_bwd_rs<8, 8, 8, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 }
                 return launch_bwd<8, 1, 6, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
