@@ -65,7 +65,7 @@ def parse():
     ap.add_argument('--cpu-sample', type=int, default=8, help='triplets in the CPU-baseline sample step (8 = the bench batch)')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'], help='conv-stack precision (bf16: BASELINE config 3; the headline metric is fp32)')
-    ap.add_argument('--graph', type=int, default=0, help='1: replay the step as a hipGraph (kernel timing events are then off)')
+    ap.add_argument('--graph', type=int, default=-1, help='1: replay the step as a hipGraph; 0: eager; default: eager for fp32 (the headline: per-launch events inside the timed steps), replay for bf16 -- 12 ms of GPU work per step against ~14 ms of host enqueue makes the eager bf16 step host-bound (1136 vs 1377 pairs/s); under replay the roofline legs are taken in 3 eager steps after the timed region')
     ap.add_argument('--channels-last', type=int, default=-1, help='memory format of the conv stacks: 1 channels_last (NHWC), 0 NCHW; default: 1 when the shipped MIOpen find-db is in use, else 0 (cfg.channels_last)')
     ap.add_argument('--fused', type=int, default=0, help='1: warp + cost volume of each decoder level as one kernel (cfg.fused_warp_corr)')
     ap.add_argument('--fill-cat', type=int, default=1, help='0: channels_last decoder with torch.cat inputs instead of epilogue-filled cat buffers (A/B; PWC_tf.fill_cat_buffers)')
@@ -174,6 +174,8 @@ def measured_traffic(entry, shape, path=None):
 
 def main():
     args = parse()
+    if args.graph < 0:
+        args.graph = 1 if args.precision == 'bf16' else 0
     from unopticalflow_amd import get_model, _lib, ops
     from unopticalflow_amd.parallel import init_distributed
     from unopticalflow_amd.trainer import FlowTrainer
@@ -211,6 +213,7 @@ def main():
     model.pwc_model.fill_cat_buffers = bool(args.fill_cat)
     trainer = FlowTrainer(cfg, model, distributed=(world > 1 or args.force_ddp), use_graph=bool(args.graph),
                           single_rank_collectives=args.force_ddp, **({} if args.gc_freeze else {'gc_freeze_after': None}))
+    graph_timing = bool(args.graph) and not args.no_kernel_timing      # replayed timed region: the per-launch events need eager steps (after it)
     if args.graph:
         args.no_kernel_timing = True
     gen = torch.Generator(device=dev)
@@ -260,6 +263,18 @@ def main():
                              'longest_ms': round(gc_log['max_ms'], 2), 'frozen_by_trainer': bool(trainer._gc_frozen)}
     ops.kernel_timer.disable()
     timed_rows = ops.kernel_timer.rows() if not args.no_kernel_timing else []      # (device is synchronised: barrier())
+    roofline_steps = float(args.steps)
+    if graph_timing:
+        # a captured graph cannot carry the per-launch event pairs: 3 eager steps behind the replayed timed region supply them
+        trainer.use_graph = False
+        ops.kernel_timer.enable(CW, reserve=32 * 3)
+        for _ in range(3):
+            trainer.step(inputs)
+        torch.cuda.synchronize()
+        ops.kernel_timer.disable()
+        timed_rows = ops.kernel_timer.rows()
+        roofline_steps = 3.0
+        trainer.use_graph = True
     if not torch.isfinite(loss):
         raise SystemExit('non-finite loss in the timed region')
 
@@ -271,20 +286,21 @@ def main():
     # dense-contraction FLOPs of one step (forward + data-gradient + weight-gradient of every convolution),
     # counted by hooks over one extra untimed step; SURVEY 8d: 1.945 TFLOP at 832x256, B=8
     conv_flops = [0.0]
+    import torch.nn.functional as F_
+    real_conv2d = F_.conv2d
 
-    def count(mod, inp, out):
-        c = mod[0] if isinstance(mod, torch.nn.Sequential) else mod
-        out = out[0] if isinstance(out, tuple) else out      # ConvLeaky(consumers=2) returns two handles
-        f = 2.0 * out.numel() * c.in_channels * c.kernel_size[0] * c.kernel_size[1]
-        conv_flops[0] += f * (3.0 if inp[0].requires_grad else 2.0)
-    from unopticalflow_amd.core.networks.structures.net_utils import ConvLeaky
-    hooks = [m.register_forward_hook(count) for m in model.modules()
-             if isinstance(m, ConvLeaky) or (isinstance(m, torch.nn.Conv2d) and m.bias is not None and m.out_channels == 2)]
-    if not args.graph:
+    def counting_conv2d(x, w, *a, **k):                  # every convolution of the model goes through F.conv2d (ConvLeaky, the
+        out = real_conv2d(x, w, *a, **k)                 # cat-free decoder's raw contractions, the flow predictors)
+        conv_flops[0] += 2.0 * out.numel() * w.shape[1] * w.shape[2] * w.shape[3] * (3.0 if x.requires_grad else 2.0)
+        return out
+    F_.conv2d = counting_conv2d
+    was_graph, trainer.use_graph = trainer.use_graph, False          # (one eager step; a replay calls no Python)
+    try:
         trainer.step(inputs)
         torch.cuda.synchronize()
-    for h_ in hooks:
-        h_.remove()
+    finally:
+        F_.conv2d = real_conv2d
+        trainer.use_graph = was_graph
 
     survey = None
     if rank == 0 and world == 1 and not args.no_kernel_timing:
@@ -306,7 +322,7 @@ def main():
     if rank == 0:
         roof = None
         if timed_rows:
-            K = float(args.steps)
+            K = roofline_steps
 
             def entry(r):
                 return {'entry': r['entry'], 'shape': r['shape'], 'avg_us': r['avg_us'], 'launches_per_step': r['launches'] / K,
@@ -320,6 +336,7 @@ def main():
             roof = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
                     'traffic': traffic, 'traffic_source': traffic_note,
                     'kernel': '%s %s: the cost-volume / warp entry point with the largest time per step' % (top['entry'], top['shape']),
+                    'measured_in': ('3 eager steps after the timed region (the timed region replays a hipGraph)' if graph_timing else 'the timed steps'),
                     'launches': top['launches'], 'avg_us': top['avg_us'],
                     'algorithmic_bytes_per_launch': int(top['total_bytes'] / top['launches']),
                     'aggregate': {'what': 'every cost-volume and warp launch of a step (all pyramid levels, forward and backward)',
@@ -338,6 +355,7 @@ def main():
             'value': round(pairs / dt, 2), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'bf16', 'data': 'synthetic',
+            'step_mode': 'hipGraph replay' if args.graph else 'eager',
             'config': {'workload': '%dx%d triplets, bs=%d per GPU, %s, corr d=4 + warp + occlusion losses, '
                                    'fwd+bwd+Adam (BASELINE configs[%d])' % (fw, fh, args.batch, args.precision,
                                                                             (1 if args.precision == 'fp32' else 2) if (fh, fw) == (H, W) else 3),

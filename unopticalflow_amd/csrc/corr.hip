@@ -1042,13 +1042,16 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 // WS wave sets share one tile: set s keeps channels [s * CH / WS, (s + 1) * CH / WS) of the item (a wave issues ~1 instruction per
 // 5 cycles, so the VALU wants 4 waves per SIMD; LDS allows two 72 KB tiles per CU, i.e. 2 x 4 waves -- with WS = 2 the same two
 // tiles carry 16 waves, each with half the accumulators)
-template <int R, int CH, int TYB, int AHEAD, int ABL = 0, int WS = 1>
-__global__ __launch_bounds__((BwdRsCfg<R, CH, TYB>::THREADS * WS)) void corr_bwd_rs_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+// RSETS = 2 (tuning): two wave sets share one tile and split the DISPLACEMENT ROWS (set 0: rows 0-4, set 1: rows 5-8 at R = 4), each
+// streaming only its own rows of weights; set 1 hands its partial sums to set 0 through the tile's LDS once, at the end.
+template <int R, int CH, int TYB, int AHEAD, int ABL = 0, int WS = 1, int RSETS = 1>
+__global__ __launch_bounds__((BwdRsCfg<R, CH, TYB>::THREADS * WS * RSETS), (RSETS > 1 ? 4 : 1)) void corr_bwd_rs_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                          const float* __restrict__ g, float* __restrict__ gf1,
                                                          float* __restrict__ gf2, int Ctot, int H, int W,
                                                          int tiles_x, int tiles_y, int ngrp, float inv_c) {
     using K = BwdRsCfg<R, CH, TYB>;
-    constexpr int DD = K::DD, LW = K::LW, NCOL = R + 1, NT = K::THREADS * WS, CHL = CH / WS;
+    constexpr int DD = K::DD, LW = K::LW, NCOL = R + 1, NT = K::THREADS * WS * RSETS, CHL = CH / WS, RPS = (DD + RSETS - 1) / RSETS;
+    static_assert(WS == 1 || RSETS == 1, "either channel sets or row sets");
     constexpr int ITER = (CH * K::SC + NT - 1) / NT, TILE = ITER * NT * 4;
     static_assert(CH % WS == 0, "channels per wave set");
     __shared__ __attribute__((aligned(16))) float tile[TILE];
@@ -1064,7 +1067,9 @@ __global__ __launch_bounds__((BwdRsCfg<R, CH, TYB>::THREADS * WS)) void corr_bwd
     const int c_begin = cg * CH;
     const int C = min(CH, Ctot - c_begin);
     const int l = threadIdx.x % K::THREADS, wave = threadIdx.x >> 6;
-    const int ws = __builtin_amdgcn_readfirstlane((int)threadIdx.x / K::THREADS);      // wave set (wave-uniform)
+    const int set_ = __builtin_amdgcn_readfirstlane((int)threadIdx.x / K::THREADS);    // wave set (wave-uniform)
+    const int ws = RSETS > 1 ? 0 : set_, rs = RSETS > 1 ? set_ : 0;
+    const int i_begin = rs * RPS, i_end = min(DD, i_begin + RPS);
     // lane -> (tx, ty).  A ds_read_b64 is serviced in two groups of 32 lanes; the 32 lanes of a group must fall into 64
     // different banks.  64-wide tiles: a group is one row of 32 lanes (64 consecutive floats).  16-wide tiles (row stride
     // LW = 24 floats): a group takes 4 rows of 8 lanes; rows 2 apart start 48 = -16 (mod 64) banks apart, so lanes 0-31 take
@@ -1131,9 +1136,11 @@ __global__ __launch_bounds__((BwdRsCfg<R, CH, TYB>::THREADS * WS)) void corr_bwd
     RowWeights<R> w;
     v2u raw[AHEAD][DD];
 #pragma unroll
-    for (int k = 0; k < AHEAD; ++k) request_row(raw[k], min(k, DD - 1));
+    for (int k = 0; k < AHEAD; ++k) request_row(raw[k], min(i_begin + k, DD - 1));
 
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * DD > 63 ? 63 : AHEAD * DD) : "memory");  // this wave's pieces of the tile have landed (the weights may still fly)
+    // this wave's pieces of the tile have landed (the weights may still fly; the row-set variant is register-capped and may spill,
+    // and scratch traffic shares the counter: it waits for everything)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RSETS > 1 ? 0 : (AHEAD * DD > 63 ? 63 : AHEAD * DD)) : "memory");
     __builtin_amdgcn_s_barrier();                    // ... and everyone else's.  The waves do not meet again.
 
     v2f acc[CHL][2];
@@ -1145,11 +1152,11 @@ __global__ __launch_bounds__((BwdRsCfg<R, CH, TYB>::THREADS * WS)) void corr_bwd
     static_assert((HALF - 1) * K::SC * 16 + (LW + 2 * R) * 4 < 65536, "ds_read offset field");
     using Step0 = RsStep<0, CHL, PF, R, NCOL, K::SC * 16, HALF, ABL>;
 #pragma unroll 1
-    for (int i0 = 0; i0 < DD; i0 += AHEAD) {
+    for (int i0 = i_begin; i0 < i_end; i0 += AHEAD) {
 #pragma unroll
         for (int k = 0; k < AHEAD; ++k) {
             const int i = i0 + k;
-            if (DD % AHEAD != 0 && i >= DD) break;   // (wave-uniform)
+            if ((RSETS > 1 || DD % AHEAD != 0) && i >= i_end) break;   // (wave-uniform)
             take_row(w, raw[k]);                     // (the only vmcnt wait of the row: it was requested AHEAD rows ago)
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(ABL & 4)) request_row(raw[k], min(i + AHEAD, DD - 1));
@@ -1168,6 +1175,24 @@ __global__ __launch_bounds__((BwdRsCfg<R, CH, TYB>::THREADS * WS)) void corr_bwd
             Step0::run(w, acc, row, a_lo, a_hi);
         }
     }
+    if constexpr (RSETS > 1) {
+        // set 1's partial sums -> set 0, through the tile's LDS (every wave is done reading it behind the first barrier)
+        float2* slab = reinterpret_cast<float2*>(tile);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (rs == 1) {
+#pragma unroll
+            for (int c = 0; c < CHL; ++c) slab[c * K::THREADS + l] = make_float2(acc[c][0].x + acc[c][0].y, acc[c][1].x + acc[c][1].y);
+        }
+        __syncthreads();
+        if (rs != 0) return;
+#pragma unroll
+        for (int c = 0; c < CHL; ++c) {
+            const float2 o = slab[c * K::THREADS + l];
+            acc[c][0] = v2f{acc[c][0].x + acc[c][0].y + o.x, 0.f};
+            acc[c][1] = v2f{acc[c][1].x + acc[c][1].y + o.y, 0.f};
+        }
+    }
     if (py < H && px < W) {
         float* op = out + (((size_t)b * Ctot + c_begin + ws * CHL) * H + py) * W + px;
 #pragma unroll
@@ -1177,12 +1202,12 @@ __global__ __launch_bounds__((BwdRsCfg<R, CH, TYB>::THREADS * WS)) void corr_bwd
     }
 }
 
-template <int R, int CH, int TYB, int AHEAD, int ABL = 0, int WS = 1>
+template <int R, int CH, int TYB, int AHEAD, int ABL = 0, int WS = 1, int RSETS = 1>
 int launch_bwd_rs(const float* f1, const float* f2, const float* g, float* gf1, float* gf2,
                   int B, int C, int H, int W, hipStream_t s) {
     using K = BwdRsCfg<R, CH, TYB>;
     const int tx = ceil_div(W, K::TW), ty = ceil_div(H, K::TYB), ngrp = ceil_div(C, CH);
-    UNFLOW_LAUNCH((corr_bwd_rs_kernel<R, CH, TYB, AHEAD, ABL, WS>), dim3(tx * ty * B * 2 * ngrp), dim3(K::THREADS * WS), 0, s,
+    UNFLOW_LAUNCH((corr_bwd_rs_kernel<R, CH, TYB, AHEAD, ABL, WS, RSETS>), dim3(tx * ty * B * 2 * ngrp), dim3(K::THREADS * WS * RSETS), 0, s,
                        f1, f2, g, gf1, gf2, C, H, W, tx, ty, ngrp, 1.0f / C);
     return unflow_launch_status();
 }
@@ -1677,6 +1702,8 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 if (ring_ok && fb == 17) return launch_bwd_rs<4, 32, 8, 1, 0, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (ring_ok && fb == 13) return launch_bwd_rs2<4, 16, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (ring_ok && fb == 18) return launch_bwd_rs<4, 16, 16, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);      // 64 x 16 tiles, one 8-wave workgroup per CU
+                if (ring_ok && fb == 19) return launch_bwd_rs<4, 16, 8, 1, 0, 1, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // two wave sets split the displacement rows
+                if (ring_ok && fb == 20) return launch_bwd_rs<4, 16, 8, 2, 0, 1, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (ring_ok && fb == 14) return launch_bwd_rs2<4, 16, 3>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (ring_ok && fb == 21) return launch_bwd_rs<4, 16, 8, 1, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // no LDS reads
                 if (ring_ok && fb == 22) return launch_bwd_rs<4, 16, 8, 1, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // no FMAs
