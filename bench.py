@@ -10,8 +10,14 @@ warp / losses), weighted loss, backward, gradient all-reduce (N > 1, RCCL) and A
 synthetic KITTI-sized triplets [8,3,768,832] fp32 already resident in HBM (BASELINE config 2:
 832x256, bs=8 per GPU, fp32; weak scaling: the per-GPU batch is fixed).  pairs/s = 2 * triplets/s.
 
+With one process the timed steps REPLAY the step as a hipGraph (`step_mode`; ~3000 launches cost 14-24 ms of host time per step
+depending on the box against 24.3 ms of GPU work: an eager loop is host-paced on a slow host, and always in bf16); `--graph 0` runs
+them eagerly.  Several ranks run eagerly (gradient pieces leave for RCCL from hooks during backward).
+
 The single JSON line also carries
-  roofline:     HIP events around EVERY cost-volume / warp entry point inside the timed steps (on the launch stream).
+  roofline:     HIP events around EVERY cost-volume / warp entry point inside the timed steps (on the launch stream); under replay
+                (a captured graph cannot carry per-launch events) over the same number of eager steps right behind them
+                (`measured_in`).
                 The object describes the (entry point, shape) with the LARGEST time per step -- the kernel that weighs most,
                 not the one that looks best: algorithmic bytes per launch (SURVEY 8d formulas) / mean launch duration
                 against the 8 TB/s HBM peak.  `traffic` = HBM bytes per launch from the PMC passes committed under
@@ -65,7 +71,7 @@ def parse():
     ap.add_argument('--cpu-sample', type=int, default=8, help='triplets in the CPU-baseline sample step (8 = the bench batch)')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'], help='conv-stack precision (bf16: BASELINE config 3; the headline metric is fp32)')
-    ap.add_argument('--graph', type=int, default=-1, help='1: replay the step as a hipGraph; 0: eager; default: eager for fp32 (the headline: per-launch events inside the timed steps), replay for bf16 -- 12 ms of GPU work per step against ~14 ms of host enqueue makes the eager bf16 step host-bound (1136 vs 1377 pairs/s); under replay the roofline legs are taken in 3 eager steps after the timed region')
+    ap.add_argument('--graph', type=int, default=-1, help='1: replay the step as a hipGraph; 0: eager (per-launch events INSIDE the timed steps); default: replay with one process, eager with several.  Under replay the roofline legs are taken over the same number of EAGER steps (at most 20) right behind the timed region: a captured graph cannot carry per-launch event pairs')
     ap.add_argument('--channels-last', type=int, default=-1, help='memory format of the conv stacks: 1 channels_last (NHWC), 0 NCHW; default: 1 when the shipped MIOpen find-db is in use, else 0 (cfg.channels_last)')
     ap.add_argument('--fused', type=int, default=0, help='1: warp + cost volume of each decoder level as one kernel (cfg.fused_warp_corr)')
     ap.add_argument('--fill-cat', type=int, default=1, help='0: channels_last decoder with torch.cat inputs instead of epilogue-filled cat buffers (A/B; PWC_tf.fill_cat_buffers)')
@@ -175,7 +181,10 @@ def measured_traffic(entry, shape, path=None):
 def main():
     args = parse()
     if args.graph < 0:
-        args.graph = 1 if args.precision == 'bf16' else 0
+        # one process: replay (the step's ~3000 launches take 14-24 ms of host time depending on the box, against 24.3 ms (fp32) /
+        # 11.6 ms (bf16) of GPU work: the eager bf16 step is host-bound everywhere, the fp32 step on a slow host).  Several ranks:
+        # eager, where the all-reduce pieces leave from hooks during backward (under replay they could only follow the graph).
+        args.graph = 1 if int(os.environ.get('WORLD_SIZE', '1')) == 1 and not args.force_ddp else 0
     from unopticalflow_amd import get_model, _lib, ops
     from unopticalflow_amd.parallel import init_distributed
     from unopticalflow_amd.trainer import FlowTrainer
@@ -265,15 +274,17 @@ def main():
     timed_rows = ops.kernel_timer.rows() if not args.no_kernel_timing else []      # (device is synchronised: barrier())
     roofline_steps = float(args.steps)
     if graph_timing:
-        # a captured graph cannot carry the per-launch event pairs: 3 eager steps behind the replayed timed region supply them
+        # a captured graph cannot carry the per-launch event pairs: eager steps right behind the replayed timed region supply them
+        n_eager = min(args.steps, 20)
         trainer.use_graph = False
-        ops.kernel_timer.enable(CW, reserve=32 * 3)
-        for _ in range(3):
+        trainer.step(inputs)                                # (one untimed eager step: allocator / MIOpen back in eager mode)
+        ops.kernel_timer.enable(CW, reserve=32 * n_eager)
+        for _ in range(n_eager):
             trainer.step(inputs)
         torch.cuda.synchronize()
         ops.kernel_timer.disable()
         timed_rows = ops.kernel_timer.rows()
-        roofline_steps = 3.0
+        roofline_steps = float(n_eager)
         trainer.use_graph = True
     if not torch.isfinite(loss):
         raise SystemExit('non-finite loss in the timed region')
@@ -303,14 +314,16 @@ def main():
         trainer.use_graph = was_graph
 
     survey = None
-    if rank == 0 and world == 1 and not args.no_kernel_timing:
+    if rank == 0 and world == 1 and (graph_timing or not args.no_kernel_timing):
         # per-entry-point timings of ALL hand-written kernels: 3 extra (untimed) steps with an event pair attached to
         # the kernels of every C call
+        was_graph, trainer.use_graph = trainer.use_graph, False
         ops.kernel_timer.enable(True)
         for _ in range(3):
             trainer.step(inputs)
         torch.cuda.synchronize()
         ops.kernel_timer.disable()
+        trainer.use_graph = was_graph
         rows = ops.kernel_timer.rows()
         for r in rows:
             r.pop('total_us'); r.pop('total_bytes')
@@ -336,7 +349,8 @@ def main():
             roof = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
                     'traffic': traffic, 'traffic_source': traffic_note,
                     'kernel': '%s %s: the cost-volume / warp entry point with the largest time per step' % (top['entry'], top['shape']),
-                    'measured_in': ('3 eager steps after the timed region (the timed region replays a hipGraph)' if graph_timing else 'the timed steps'),
+                    'measured_in': ('%d eager steps right behind the timed region (the timed region replays a hipGraph, which cannot carry per-launch events; --graph 0 times them inside it)' % int(roofline_steps)
+                                    if graph_timing else 'the timed steps'),
                     'launches': top['launches'], 'avg_us': top['avg_us'],
                     'algorithmic_bytes_per_launch': int(top['total_bytes'] / top['launches']),
                     'aggregate': {'what': 'every cost-volume and warp launch of a step (all pyramid levels, forward and backward)',
