@@ -349,7 +349,8 @@ def test_occ_weight_and_losses_golden(ops, golden):
     fl.grad = None; fr.grad = None
     ((ls_f + ls_b) * gl).sum().backward()
     s = np.abs(g['ls_g_from_l']).max()
-    close(fl.grad, g['ls_g_from_l'], rtol=1e-3, atol=1e-4 * s); close(fr.grad, g['ls_g_from_r'], rtol=1e-3, atol=1e-4 * s)
+    # (measured, tools/probes/ssim_grad_probe.py: worst element 1.0e-6 of the largest gradient, 5e-5 relative where it matters; was 1e-3 / 1e-4)
+    close(fl.grad, g['ls_g_from_l'], rtol=1e-4, atol=5e-6 * s); close(fr.grad, g['ls_g_from_r'], rtol=1e-4, atol=5e-6 * s)
     w3 = w_f.repeat(1, 3, 1, 1)
     close(ops.ssim_map(img * w3, fr.detach() * w3), g['ssim_map'], rtol=1e-4, atol=1e-5)
 
@@ -401,7 +402,7 @@ def test_losses_vs_oracle_random(ops, hw):
     close(tot_g, tot_c, rtol=1e-5)
     (tot_g * gl_g).sum().backward()
     for a, b in ((l_g.grad, l_c.grad), (r_g.grad, r_c.grad), (ff_g.grad, ff_c.grad)):
-        close(a, b, rtol=1e-3, atol=1e-4 * b.abs().max().item())
+        close(a, b, rtol=1e-4, atol=1e-5 * b.abs().max().item())         # (SSIM part measured at 1.3e-6 of the largest gradient; was 1e-3 / 1e-4)
 
 
 def test_ssim_map_vs_oracle(ops):
