@@ -373,7 +373,7 @@ class _MaskedMean(torch.autograd.Function):
         sums = torch.empty((B, 2), dtype=torch.float32, device=dev)
         with _on(dev):
             _call('unflow_masked_mean_fwd', _ptr(diff), _ptr(w), _ptr(loss), _ptr(sums),
-                  _ptr(_partials(B, H, W, dev)), B, H, W, _stream())
+                  _ptr(_partials(B, H, W, dev)), B, H, W, _stream(), nbytes=4 * B * H * W * 2, shape=(B, 1, H, W))       # reads diff, w
         ctx.save_for_backward(w, sums)
         return loss
 
@@ -384,7 +384,7 @@ class _MaskedMean(torch.autograd.Function):
         gdiff = torch.empty_like(w)
         with _on(w.device):
             _call('unflow_masked_mean_bwd', _ptr(w), _ptr(sums), _ptr(gl.contiguous()), _ptr(gdiff), B, H, W,
-                  _stream())
+                  _stream(), nbytes=4 * B * H * W * 2, shape=(B, 1, H, W))                                              # reads w, writes gdiff
         return gdiff, None
 
 
@@ -472,7 +472,7 @@ class _Smooth2(torch.autograd.Function):
         loss = torch.empty(B, dtype=torch.float32, device=dev)
         with _on(dev):
             _call('unflow_smooth2_fwd', _ptr(flow), _ptr(img), _ptr(loss), _ptr(_partials(B, H, W, dev)),
-                  B, H, W, img.shape[0], _stream())
+                  B, H, W, img.shape[0], _stream(), nbytes=4 * H * W * (2 * B + 3 * img.shape[0]), shape=(B, 2, H, W))   # reads flow and the images once
         ctx.save_for_backward(flow, img)
         return loss
 
@@ -483,7 +483,7 @@ class _Smooth2(torch.autograd.Function):
         gflow = torch.empty_like(flow)
         with _on(flow.device):
             _call('unflow_smooth2_bwd', _ptr(flow), _ptr(img), _ptr(gl.contiguous()), _ptr(gflow), B, H, W,
-                  img.shape[0], _stream())
+                  img.shape[0], _stream(), nbytes=4 * H * W * (4 * B + 3 * img.shape[0]), shape=(B, 2, H, W))           # reads flow, images; writes gflow
         return gflow, None
 
 
@@ -502,7 +502,7 @@ class _Consis(torch.autograd.Function):
         sums = torch.empty((B, 2), dtype=torch.float32, device=dev)
         with _on(dev):
             _call('unflow_consis_fwd', _ptr(ff), _ptr(fb), _ptr(w), _ptr(loss), _ptr(sums),
-                  _ptr(_partials(B, H, W, dev)), B, H, W, _stream())
+                  _ptr(_partials(B, H, W, dev)), B, H, W, _stream(), nbytes=4 * B * H * W * 5, shape=(B, 2, H, W))       # reads both flows and the weight
         ctx.save_for_backward(ff, fb, w, sums)
         return loss
 
@@ -513,7 +513,7 @@ class _Consis(torch.autograd.Function):
         g = torch.empty_like(ff)
         with _on(ff.device):
             _call('unflow_consis_bwd', _ptr(ff), _ptr(fb), _ptr(w), _ptr(sums), _ptr(gl.contiguous()), _ptr(g),
-                  B, H, W, _stream())
+                  B, H, W, _stream(), nbytes=4 * B * H * W * 7, shape=(B, 2, H, W))                                     # + writes the flow gradient
         return g, None, None
 
 
