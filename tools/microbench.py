@@ -158,7 +158,7 @@ def corr_bwd_rs(B=16):
     kernel (default), levels 2-4, with the largest difference between their results."""
     lib = _lib.load()
     P = ops._ptr
-    envs = [{}] + [{'UNFLOW_CORR_BWD': v} for v in (os.environ.get('UNFLOW_RS_VARIANTS', '7,8,9,10,11').split(','))]
+    envs = [{}, {'UNFLOW_CORR_GROUPS': 64}] + [{'UNFLOW_CORR_BWD': v} for v in (os.environ.get('UNFLOW_RS_VARIANTS', '7,8,9,10,11').split(','))]      # (CORR_GROUPS=64: 64-wide tiles only, no mixed launch)
     for name, (C, h, w) in list(LEVELS.items())[:3]:
         f1 = torch.randn(B, C, h, w, device='cuda')
         f2 = torch.randn(B, C, h, w, device='cuda')

@@ -1045,18 +1045,17 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 // RSETS = 2 (tuning): two wave sets share one tile and split the DISPLACEMENT ROWS (set 0: rows 0-4, set 1: rows 5-8 at R = 4), each
 // streaming only its own rows of weights; set 1 hands its partial sums to set 0 through the tile's LDS once, at the end.
 template <int R, int CH, int TYB, int AHEAD, int ABL = 0, int WS = 1, int RSETS = 1>
-__global__ __launch_bounds__((BwdRsCfg<R, CH, TYB>::THREADS * WS * RSETS), (RSETS > 1 ? 4 : 1)) void corr_bwd_rs_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
-                                                         const float* __restrict__ g, float* __restrict__ gf1,
-                                                         float* __restrict__ gf2, int Ctot, int H, int W,
-                                                         int tiles_x, int tiles_y, int ngrp, float inv_c) {
+__device__ __forceinline__ void corr_bwd_rs_body(float* __restrict__ tile, int t, int x_origin,
+                                                 const float* __restrict__ f1, const float* __restrict__ f2,
+                                                 const float* __restrict__ g, float* __restrict__ gf1,
+                                                 float* __restrict__ gf2, int Ctot, int H, int W,
+                                                 int tiles_x, int tiles_y, int ngrp, float inv_c) {
     using K = BwdRsCfg<R, CH, TYB>;
     constexpr int DD = K::DD, LW = K::LW, NCOL = R + 1, NT = K::THREADS * WS * RSETS, CHL = CH / WS, RPS = (DD + RSETS - 1) / RSETS;
     static_assert(WS == 1 || RSETS == 1, "either channel sets or row sets");
-    constexpr int ITER = (CH * K::SC + NT - 1) / NT, TILE = ITER * NT * 4;
+    constexpr int ITER = (CH * K::SC + NT - 1) / NT;
     static_assert(CH % WS == 0, "channels per wave set");
-    __shared__ __attribute__((aligned(16))) float tile[TILE];
 
-    int t = xcd_remap(blockIdx.x, gridDim.x);
     const int cg = t % ngrp; t /= ngrp;              // the channel groups of a (tile, gradient) share its gradient planes
     const int mode = t & 1; t >>= 1;                 // ... and so do the two gradients of a tile
     const float* __restrict__ F = mode ? f1 : f2;
@@ -1076,7 +1075,7 @@ __global__ __launch_bounds__((BwdRsCfg<R, CH, TYB>::THREADS * WS * RSETS), (RSET
     // the even rows of the wave's eight and lanes 32-63 the odd ones (banks 0-15, 48-63, 32-47, 16-31).
     const int tx = l & (K::TWL - 1);
     const int ty = K::TWL == 32 ? (l >> 5) : ((l >> 6) * 8 + 2 * ((l >> 3) & 3) + ((l >> 5) & 1));
-    const int x0 = bx * K::TW, y0 = by * K::TYB;
+    const int x0 = x_origin + bx * K::TW, y0 = by * K::TYB;
     const int px = x0 + tx * 2, py = y0 + ty;
     const unsigned plane = (unsigned)(H * W);
     constexpr unsigned kOut = 0x40000000u;
@@ -1200,6 +1199,53 @@ __global__ __launch_bounds__((BwdRsCfg<R, CH, TYB>::THREADS * WS * RSETS), (RSET
             if (ws * CHL + c < C)
                 *reinterpret_cast<float2*>(op + (size_t)c * plane) = make_float2(acc[c][0].x + acc[c][0].y, acc[c][1].x + acc[c][1].y);
     }
+}
+
+template <int R, int CH, int TYB, int AHEAD, int ABL = 0, int WS = 1, int RSETS = 1>
+__global__ __launch_bounds__((BwdRsCfg<R, CH, TYB>::THREADS * WS * RSETS), (RSETS > 1 ? 4 : 1)) void corr_bwd_rs_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                         const float* __restrict__ g, float* __restrict__ gf1,
+                                                         float* __restrict__ gf2, int Ctot, int H, int W,
+                                                         int tiles_x, int tiles_y, int ngrp, float inv_c) {
+    using K = BwdRsCfg<R, CH, TYB>;
+    constexpr int NT = K::THREADS * WS * RSETS, ITER = (CH * K::SC + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) float tile[ITER * NT * 4];
+    corr_bwd_rs_body<R, CH, TYB, AHEAD, ABL, WS, RSETS>(tile, xcd_remap(blockIdx.x, gridDim.x), 0, f1, f2, g, gf1, gf2, Ctot, H, W,
+                                                        tiles_x, tiles_y, ngrp, inv_c);
+}
+
+// Mixed tile shapes in one launch: 64x8 tiles over the whole 64-pixel columns of the map and 16x32 tiles over a last column of
+// <= 16 pixels (208 = 3 x 64 + 16: with 64-wide tiles only, the fourth tile column runs three quarters empty -- 19 % of all
+// lanes idle, and the arithmetic of this kernel is what bounds it).  Both shapes cover 512 pixels with 256 lanes, so the items
+// take the same time; the narrow ones are spread evenly through the (XCD-local) item order.
+template <int R, int CH, int AHEAD>
+__global__ __launch_bounds__(256) void corr_bwd_rs_mixed_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                                const float* __restrict__ g, float* __restrict__ gf1,
+                                                                float* __restrict__ gf2, int Ctot, int H, int W,
+                                                                int wide_tiles_x, int wide_tiles_y, int narrow_tiles_y, int n_narrow, int stride,
+                                                                int ngrp, float inv_c) {
+    using KW = BwdRsCfg<R, CH, 8>;
+    using KN = BwdRsCfg<R, CH, 32>;
+    constexpr int TILE_W = ((CH * KW::SC + 255) / 256) * 256 * 4, TILE_N = ((CH * KN::SC + 255) / 256) * 256 * 4;
+    __shared__ __attribute__((aligned(16))) float tile[TILE_W > TILE_N ? TILE_W : TILE_N];
+    const int u = xcd_remap(blockIdx.x, gridDim.x);
+    const int nb = min(n_narrow, (u + 1) / stride);                 // narrow items at positions stride - 1, 2 stride - 1, ... up to and including u
+    const bool narrow = (u % stride == stride - 1) && (u / stride < n_narrow);      // (workgroup-uniform)
+    if (narrow)
+        corr_bwd_rs_body<R, CH, 32, AHEAD>(tile, nb - 1, wide_tiles_x * 64, f1, f2, g, gf1, gf2, Ctot, H, W, 1, narrow_tiles_y, ngrp, inv_c);
+    else
+        corr_bwd_rs_body<R, CH, 8, AHEAD>(tile, u - nb, 0, f1, f2, g, gf1, gf2, Ctot, H, W, wide_tiles_x, wide_tiles_y, ngrp, inv_c);
+}
+
+template <int R, int CH, int AHEAD>
+int launch_bwd_rs_mixed(const float* f1, const float* f2, const float* g, float* gf1, float* gf2,
+                        int B, int C, int H, int W, hipStream_t s) {
+    const int ngrp = ceil_div(C, CH);
+    const int wide_x = W / 64, wide_y = ceil_div(H, 8), narrow_y = ceil_div(H, 32);
+    const int n_wide = wide_x * wide_y * B * 2 * ngrp, n_narrow = narrow_y * B * 2 * ngrp;
+    const int total = n_wide + n_narrow, stride = total / n_narrow;
+    UNFLOW_LAUNCH((corr_bwd_rs_mixed_kernel<R, CH, AHEAD>), dim3(total), dim3(256), 0, s,
+                       f1, f2, g, gf1, gf2, C, H, W, wide_x, wide_y, narrow_y, n_narrow, stride, ngrp, 1.0f / C);
+    return unflow_launch_status();
 }
 
 template <int R, int CH, int TYB, int AHEAD, int ABL = 0, int WS = 1, int RSETS = 1>
@@ -1731,7 +1777,13 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 if (ring_ok && fb == 0 && (variant == 7 || mid_size(variant))) {
                     const long px = (long)B * H * W;
                     if (px < 32768) return launch_bwd_rs<4, 8, 8, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                    if (px >= 131072) return launch_bwd_rs<4, 16, 8, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                    if (px >= 131072) {
+                        // a last tile column of <= 16 pixels (208 = 3 x 64 + 16) as 16 x 32 tiles in the same launch
+                        const int rem = W % 64;
+                        if (forced_groups() != 64 && rem > 0 && rem <= 16 && W >= 64 && H >= 32)
+                            return launch_bwd_rs_mixed<4, 16, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                        return launch_bwd_rs<4, 16, 8, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                    }
                     return launch_bwd_gs<4, 4, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, groups, s);
                 }
                 if (ring_ok && fb == 4)
