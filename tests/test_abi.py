@@ -88,7 +88,7 @@ def test_dma_ring_kernels_do_not_spill():
     assert len(names) == len(scratch) and names
     checked = 0
     for n, s in zip(names, scratch):
-        if 'ring_kernel' in n or 'gs_kernel' in n or 'rs_kernel' in n or 'rs2_kernel' in n or 'rs_mixed_kernel' in n:      # (row-streamed backward: counted vmcnt behind its LDS-DMA too)
+        if 'ring_kernel' in n or 'ring_mixed_kernel' in n or 'gs_kernel' in n or 'rs_kernel' in n or 'rs2_kernel' in n or 'rs_mixed_kernel' in n:      # (row-streamed backward: counted vmcnt behind its LDS-DMA too)
             assert s == 0, (n, s)
             checked += 1
     assert checked >= 3      # ring<9 rows>, ring<3 rows>, group-split backward

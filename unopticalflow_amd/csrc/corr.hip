@@ -296,11 +296,12 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_kernel(const float* __restric
 // order is XCD-aware so the halos shared by neighbouring tiles are served by one XCD's L2.
 // Requires W % 4 == 0.
 // ---------------------------------------------------------------------------------------------
-template <int R, int CC, int DG>
+template <int R, int CC, int DG, int TYB_ = 8>
 struct RingCfg {
     static constexpr int DD = 2 * R + 1;
     static constexpr int NG = (DD + DG - 1) / DG;
-    static constexpr int TW = 64, TYB = 8, NS = 4;
+    static constexpr int TYB = TYB_, TWL = 256 / TYB, TW = 2 * TWL, NS = 4;     // 64 x 8 tiles, or 16 x 32 (TYB 32: the narrow last column of a map)
+    static_assert(TWL == 32 || TWL == 8, "lane mappings of the kernel");
     static constexpr int LW = TW + 2 * R, LH = TYB + DG - 1;
     // float4 slots per channel: the f2 halo tile (padded to whole 64-slot pieces, so that every wave-instruction of the
     // DMA reads ONE tensor and can go through that tensor's buffer descriptor), then the f1 tile
@@ -380,25 +381,27 @@ struct FwdSlots {
     }
 };
 
-template <int R, int CC, int DG>
-__global__ __launch_bounds__(256, (RingCfg<R, CC, DG>::WAVES)) void corr_fwd_ring_kernel(
+template <int R, int CC, int DG, int TYB>
+__device__ __forceinline__ void corr_fwd_ring_body(float* __restrict__ ring, int t, int x_origin,
     const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ cv, int C, int H, int W,
     int tiles_x, int tiles_y, float inv_c, int dbg, unsigned long long* stamps) {
-    using K = RingCfg<R, CC, DG>;
+    using K = RingCfg<R, CC, DG, TYB>;
     constexpr int DD = K::DD, LW = K::LW, NROW = 2 + 2 * R;
-    __shared__ __attribute__((aligned(16))) float ring[K::NS * K::STAGE];
     // stamp segments: 0 set-up + prologue DMA issue | 1 vmcnt wait + barrier | 2 DMA issue | 3 row pipeline | 4 store issue
     STAMP_DECL();
 
-    const int total = gridDim.x;
-    int t = xcd_remap(blockIdx.x, total);
     const int bx = t % tiles_x; t /= tiles_x;
     const int by = t % tiles_y;
     const int b = t / tiles_y;
     const int i0 = blockIdx.y * DG;                          // first displacement row of this workgroup
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    // lane -> (tx, ty): 64-wide tiles: a row of 32 lanes per 32-lane LDS group; 16-wide tiles (row stride 24 floats): four rows of
+    // 8 lanes per group, the even rows of a wave's eight in lanes 0-31 and the odd ones in lanes 32-63 (conflict-free banks,
+    // as in the row-streamed backward)
+    const int l_ = (int)threadIdx.x;
+    const int tx = l_ & (K::TWL - 1);
+    const int ty = K::TWL == 32 ? (l_ >> 5) : ((l_ >> 6) * 8 + 2 * ((l_ >> 3) & 3) + ((l_ >> 5) & 1));
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: the DMA descriptor choice is scalar
-    const int x0 = bx * K::TW, y0 = by * K::TYB;
+    const int x0 = x_origin + bx * K::TW, y0 = by * K::TYB;
     const int px = x0 + tx * 2, py = y0 + ty;
     const size_t plane = (size_t)H * W;
     const int nchunk = (C + CC - 1) / CC;
@@ -469,6 +472,44 @@ __global__ __launch_bounds__(256, (RingCfg<R, CC, DG>::WAVES)) void corr_fwd_rin
     }
     STAMP(4);
     STAMP_WRITE(stamps, blockIdx.y == 0 ? (int)blockIdx.x * 3 + (wave < 3 ? wave : 2) : 1 << 30, (threadIdx.x & 63) == 0 && wave < 3);
+}
+
+template <int R, int CC, int DG>
+__global__ __launch_bounds__(256, (RingCfg<R, CC, DG>::WAVES)) void corr_fwd_ring_kernel(
+    const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ cv, int C, int H, int W,
+    int tiles_x, int tiles_y, float inv_c, int dbg, unsigned long long* stamps) {
+    using K = RingCfg<R, CC, DG>;
+    __shared__ __attribute__((aligned(16))) float ring[K::NS * K::STAGE];
+    corr_fwd_ring_body<R, CC, DG, 8>(ring, xcd_remap(blockIdx.x, gridDim.x), 0, f1, f2, cv, C, H, W, tiles_x, tiles_y, inv_c, dbg, stamps);
+}
+
+// 64x8 tiles over the full 64-pixel columns and 16x32 tiles over a last column of <= 16 pixels, in one launch (the forward twin of
+// corr_bwd_rs_mixed_kernel: 208 = 3 x 64 + 16 leaves 19 % of the lanes of 64-wide tiles idle)
+template <int R, int CC, int DG>
+__global__ __launch_bounds__(256, (RingCfg<R, CC, DG>::WAVES)) void corr_fwd_ring_mixed_kernel(
+    const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ cv, int C, int H, int W,
+    int wide_tiles_x, int wide_tiles_y, int narrow_tiles_y, int n_narrow, int stride, float inv_c) {
+    using KW = RingCfg<R, CC, DG, 8>;
+    using KN = RingCfg<R, CC, DG, 32>;
+    __shared__ __attribute__((aligned(16))) float ring[KW::NS * (KW::STAGE > KN::STAGE ? KW::STAGE : KN::STAGE)];
+    const int u = xcd_remap(blockIdx.x, gridDim.x);
+    const int nb = min(n_narrow, (u + 1) / stride);
+    const bool narrow = (u % stride == stride - 1) && (u / stride < n_narrow);      // (workgroup-uniform)
+    if (narrow)
+        corr_fwd_ring_body<R, CC, DG, 32>(ring, nb - 1, wide_tiles_x * 64, f1, f2, cv, C, H, W, 1, narrow_tiles_y, inv_c, 0, nullptr);
+    else
+        corr_fwd_ring_body<R, CC, DG, 8>(ring, u - nb, 0, f1, f2, cv, C, H, W, wide_tiles_x, wide_tiles_y, inv_c, 0, nullptr);
+}
+
+template <int R, int CC, int DG>
+int launch_fwd_ring_mixed(const float* f1, const float* f2, float* cv, int B, int C, int H, int W, hipStream_t s) {
+    static_assert(RingCfg<R, CC, DG>::NG == 1, "all displacement rows in one workgroup");
+    const int wide_x = W / 64, wide_y = ceil_div(H, 8), narrow_y = ceil_div(H, 32);
+    const int n_wide = wide_x * wide_y * B, n_narrow = narrow_y * B;
+    const int total = n_wide + n_narrow, stride = total / n_narrow;
+    UNFLOW_LAUNCH((corr_fwd_ring_mixed_kernel<R, CC, DG>), dim3(total), dim3(256), 0, s, f1, f2, cv, C, H, W,
+                       wide_x, wide_y, narrow_y, n_narrow, stride, 1.0f / C);
+    return unflow_launch_status();
 }
 
 template <int R, int CC, int DG>
@@ -1213,16 +1254,16 @@ __global__ __launch_bounds__((BwdRsCfg<R, CH, TYB>::THREADS * WS * RSETS), (RSET
                                                         tiles_x, tiles_y, ngrp, inv_c);
 }
 
-// Mixed tile shapes in one launch: 64x8 tiles over the whole 64-pixel columns of the map and 16x32 tiles over a last column of
-// <= 16 pixels (208 = 3 x 64 + 16: with 64-wide tiles only, the fourth tile column runs three quarters empty -- 19 % of all
+// Mixed tile shapes in one launch: 64x8 tiles over the whole 64-pixel columns of the map and 16x32 tiles over the remaining
+// <= 48 pixels, in columns of 16 (208 = 3 x 64 + 16: with 64-wide tiles only, the fourth tile column runs three quarters empty -- 19 % of all
 // lanes idle, and the arithmetic of this kernel is what bounds it).  Both shapes cover 512 pixels with 256 lanes, so the items
 // take the same time; the narrow ones are spread evenly through the (XCD-local) item order.
 template <int R, int CH, int AHEAD>
 __global__ __launch_bounds__(256) void corr_bwd_rs_mixed_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                                 const float* __restrict__ g, float* __restrict__ gf1,
                                                                 float* __restrict__ gf2, int Ctot, int H, int W,
-                                                                int wide_tiles_x, int wide_tiles_y, int narrow_tiles_y, int n_narrow, int stride,
-                                                                int ngrp, float inv_c) {
+                                                                int wide_tiles_x, int wide_tiles_y, int narrow_tiles_x, int narrow_tiles_y,
+                                                                int n_narrow, int stride, int ngrp, float inv_c) {
     using KW = BwdRsCfg<R, CH, 8>;
     using KN = BwdRsCfg<R, CH, 32>;
     constexpr int TILE_W = ((CH * KW::SC + 255) / 256) * 256 * 4, TILE_N = ((CH * KN::SC + 255) / 256) * 256 * 4;
@@ -1231,7 +1272,7 @@ __global__ __launch_bounds__(256) void corr_bwd_rs_mixed_kernel(const float* __r
     const int nb = min(n_narrow, (u + 1) / stride);                 // narrow items at positions stride - 1, 2 stride - 1, ... up to and including u
     const bool narrow = (u % stride == stride - 1) && (u / stride < n_narrow);      // (workgroup-uniform)
     if (narrow)
-        corr_bwd_rs_body<R, CH, 32, AHEAD>(tile, nb - 1, wide_tiles_x * 64, f1, f2, g, gf1, gf2, Ctot, H, W, 1, narrow_tiles_y, ngrp, inv_c);
+        corr_bwd_rs_body<R, CH, 32, AHEAD>(tile, nb - 1, wide_tiles_x * 64, f1, f2, g, gf1, gf2, Ctot, H, W, narrow_tiles_x, narrow_tiles_y, ngrp, inv_c);
     else
         corr_bwd_rs_body<R, CH, 8, AHEAD>(tile, u - nb, 0, f1, f2, g, gf1, gf2, Ctot, H, W, wide_tiles_x, wide_tiles_y, ngrp, inv_c);
 }
@@ -1240,11 +1281,11 @@ template <int R, int CH, int AHEAD>
 int launch_bwd_rs_mixed(const float* f1, const float* f2, const float* g, float* gf1, float* gf2,
                         int B, int C, int H, int W, hipStream_t s) {
     const int ngrp = ceil_div(C, CH);
-    const int wide_x = W / 64, wide_y = ceil_div(H, 8), narrow_y = ceil_div(H, 32);
-    const int n_wide = wide_x * wide_y * B * 2 * ngrp, n_narrow = narrow_y * B * 2 * ngrp;
+    const int wide_x = W / 64, wide_y = ceil_div(H, 8), narrow_x = ceil_div(W % 64, 16), narrow_y = ceil_div(H, 32);
+    const int n_wide = wide_x * wide_y * B * 2 * ngrp, n_narrow = narrow_x * narrow_y * B * 2 * ngrp;
     const int total = n_wide + n_narrow, stride = total / n_narrow;
     UNFLOW_LAUNCH((corr_bwd_rs_mixed_kernel<R, CH, AHEAD>), dim3(total), dim3(256), 0, s,
-                       f1, f2, g, gf1, gf2, C, H, W, wide_x, wide_y, narrow_y, n_narrow, stride, ngrp, 1.0f / C);
+                       f1, f2, g, gf1, gf2, C, H, W, wide_x, wide_y, narrow_x, narrow_y, n_narrow, stride, ngrp, 1.0f / C);
     return unflow_launch_status();
 }
 
@@ -1687,7 +1728,15 @@ extern "C" int unflow_corr_fwd(const float* f1, const float* f2, float* cv, int 
                 if (variant == 1) return launch_fwd<4, 2, 9, 8>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 2) return launch_fwd<4, 1, 9, 8>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 3) return launch_fwd<4, 1, 3, 8>(f1, f2, cv, B, C, H, W, s);
-                if (variant == 7 && ring_ok) return launch_fwd_ring<4, 2, 9>(f1, f2, cv, B, C, H, W, s);
+                if (variant == 7 && ring_ok) {
+#ifdef UNFLOW_TUNING
+                    // (208 = 3 x 64 + 16: the remainder column as 16 x 32 tiles in the same launch, as the backward does -- measured for
+                    // the forward, whose time is stores and DMA rather than arithmetic: 37.6 vs 36.4 us back to back, 34.7 vs 32.7 in the
+                    // step: not taken; UNFLOW_CORR_SPLIT=65 selects it in tuning builds)
+                    if (forced_split() == 65 && W % 64 > 0 && W % 64 <= 16 && W >= 64 && H >= 32) return launch_fwd_ring_mixed<4, 2, 9>(f1, f2, cv, B, C, H, W, s);
+#endif
+                    return launch_fwd_ring<4, 2, 9>(f1, f2, cv, B, C, H, W, s);
+                }
                 if (variant == 9 && ring_ok) return launch_fwd_ring<4, 2, 3>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 12 && ring_ok) return launch_fwd_ringp<4, 2, 3, 2>(f1, f2, cv, B, C, H, W, s);
                 if (variant == 13 && ring_ok) return launch_fwd_ringp<4, 2, 3, 4>(f1, f2, cv, B, C, H, W, s);
@@ -1747,6 +1796,7 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 if (ring_ok && fb == 16) return launch_bwd_rs<4, 16, 8, 2, 0, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (ring_ok && fb == 17) return launch_bwd_rs<4, 32, 8, 1, 0, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (ring_ok && fb == 13) return launch_bwd_rs2<4, 16, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                if (ring_ok && fb == 33 && W % 64 > 0 && W % 64 <= 48 && W >= 64 && H >= 32) return launch_bwd_rs_mixed<4, 16, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (ring_ok && fb == 18) return launch_bwd_rs<4, 16, 16, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);      // 64 x 16 tiles, one 8-wave workgroup per CU
                 if (ring_ok && fb == 19) return launch_bwd_rs<4, 16, 8, 1, 0, 1, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // two wave sets split the displacement rows
                 if (ring_ok && fb == 20) return launch_bwd_rs<4, 16, 8, 2, 0, 1, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
@@ -1778,7 +1828,9 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                     const long px = (long)B * H * W;
                     if (px < 32768) return launch_bwd_rs<4, 8, 8, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                     if (px >= 131072) {
-                        // a last tile column of <= 16 pixels (208 = 3 x 64 + 16) as 16 x 32 tiles in the same launch
+                        // a remainder of <= 16 pixels beside the 64-pixel columns (208 = 3 x 64 + 16) as 16 x 32 tiles in the same launch:
+                        // 65.9 -> 59.3 us back to back, 74-75 -> 69.2 us in the step.  (Wider remainders -- two or three 16-pixel columns,
+                        // UNFLOW_CORR_BWD=33 in tuning builds -- measured at level 3, 104 = 64 + 40: 37.8 vs 33.3 us, no gain.)
                         const int rem = W % 64;
                         if (forced_groups() != 64 && rem > 0 && rem <= 16 && W >= 64 && H >= 32)
                             return launch_bwd_rs_mixed<4, 16, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
