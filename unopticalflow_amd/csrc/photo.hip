@@ -7,6 +7,7 @@
 // partial per workgroup -> fixed-order finalize (bitwise reproducible, no float atomics).
 // Built with -ffp-contract=off: the elementwise algebra follows the reference op by op.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -183,6 +184,65 @@ __global__ void smooth2_finalize_kernel(const float* __restrict__ partials, int 
     if (threadIdx.x == 0) {
         const float nx = 2.0f * (float)H * (float)(W - 2), ny = 2.0f * (float)(H - 2) * (float)W;
         loss[b] = (s0 / nx + s1 / ny) / 2.0f;     // empty means (W<3 or H<3) are NaN, as in torch
+    }
+}
+
+// Backward through LDS tiles (round 3).  With S_x[c][q] = wx(q) * sgn(dx2_c(q)) (q = where a second difference starts) the gradient is
+//   g_c[p] = kx * (S_x[c][p-2] - 2 S_x[c][p-1] + S_x[c][p]) + ky * (the same down the column),
+// so every S -- one exp, six image and six flow loads -- is worth computing ONCE per position instead of once per pixel that uses it
+// (three times in each direction in the per-pixel form below: 36.5 us for 75 MB at scale 0).  A 256-thread workgroup owns 64 x 8
+// pixels: S_x on 8 x 66 positions, S_y on 10 x 64, as float2 (both flow channels) in LDS.
+constexpr int SM_TW = 64, SM_TH = 8;
+__global__ __launch_bounds__(256) void smooth2_bwd_tile_kernel(const float* __restrict__ flow, const float* __restrict__ img,
+                                                               const float* __restrict__ gloss, float* __restrict__ gflow,
+                                                               int H, int W, int img_b) {
+    constexpr int NX = SM_TH * (SM_TW + 2), NY = (SM_TH + 2) * SM_TW;
+    __shared__ float2 s_x[NX], s_y[NY];
+    const int b = blockIdx.z, x0 = blockIdx.x * SM_TW, y0 = blockIdx.y * SM_TH;
+    const int HW = H * W;
+    const float* f = flow + (size_t)b * 2 * HW;
+    const float* im = img + (size_t)(b % img_b) * 3 * HW;
+    for (int i = threadIdx.x; i < NX + NY; i += 256) {
+        float2 v = make_float2(0.f, 0.f);
+        if (i < NX) {
+            const int r = i / (SM_TW + 2), c = i - r * (SM_TW + 2);
+            const int y = y0 + r, x = x0 - 2 + c;                    // dx2 starting at x, weight w_x[x+1]
+            if (y < H && x >= 0 && x + 2 < W) {
+                const int q = y * W + x;
+                const float w = edge_w(im, HW, q + 1, q + 2);
+                const float a0 = f[q] / 20.0f, m0 = f[q + 1] / 20.0f, z0 = f[q + 2] / 20.0f;
+                const float a1 = f[HW + q] / 20.0f, m1 = f[HW + q + 1] / 20.0f, z1 = f[HW + q + 2] / 20.0f;
+                v = make_float2(w * sgn((z0 - m0) - (m0 - a0)), w * sgn((z1 - m1) - (m1 - a1)));
+            }
+            s_x[i] = v;
+        } else {
+            const int j = i - NX;
+            const int r = j / SM_TW, c = j - r * SM_TW;
+            const int y = y0 - 2 + r, x = x0 + c;
+            if (x < W && y >= 0 && y + 2 < H) {
+                const int q = y * W + x;
+                const float w = edge_w(im, HW, q + W, q + 2 * W);
+                const float a0 = f[q] / 20.0f, m0 = f[q + W] / 20.0f, z0 = f[q + 2 * W] / 20.0f;
+                const float a1 = f[HW + q] / 20.0f, m1 = f[HW + q + W] / 20.0f, z1 = f[HW + q + 2 * W] / 20.0f;
+                v = make_float2(w * sgn((z0 - m0) - (m0 - a0)), w * sgn((z1 - m1) - (m1 - a1)));
+            }
+            s_y[j] = v;
+        }
+    }
+    __syncthreads();
+    const float kx = gloss[b] / (2.0f * (2.0f * (float)H * (float)(W - 2))) / 20.0f;
+    const float ky = gloss[b] / (2.0f * (2.0f * (float)(H - 2) * (float)W)) / 20.0f;
+#pragma unroll
+    for (int k = 0; k < SM_TW * SM_TH / 256; ++k) {
+        const int idx = k * 256 + (int)threadIdx.x;
+        const int r = idx / SM_TW, c = idx - r * SM_TW;
+        const int y = y0 + r, x = x0 + c;
+        if (x >= W || y >= H) continue;
+        const float2 xa = s_x[r * (SM_TW + 2) + c], xb = s_x[r * (SM_TW + 2) + c + 1], xc = s_x[r * (SM_TW + 2) + c + 2];      // starts x-2, x-1, x
+        const float2 ya = s_y[r * SM_TW + c], yb = s_y[(r + 1) * SM_TW + c], yc = s_y[(r + 2) * SM_TW + c];                    // starts y-2, y-1, y
+        const size_t o = (size_t)b * 2 * HW + (size_t)y * W + x;
+        gflow[o] = kx * ((xa.x - 2.f * xb.x) + xc.x) + ky * ((ya.x - 2.f * yb.x) + yc.x);
+        gflow[o + HW] = kx * ((xa.y - 2.f * xb.y) + xc.y) + ky * ((ya.y - 2.f * yb.y) + yc.y);
     }
 }
 
@@ -424,6 +484,16 @@ extern "C" int unflow_smooth2_bwd(const float* flow, const float* img, const flo
                                   int B, int H, int W, int img_batch, void* stream) {
     UNFLOW_REQUIRE(flow && img && gloss && gflow && B > 0 && H > 0 && W > 0 && img_batch > 0 && B % img_batch == 0);
     hipStream_t s = (hipStream_t)stream;
+#ifdef UNFLOW_TUNING
+    const bool per_pixel = getenv("UNFLOW_SMOOTH_OLD") != nullptr;      // A/B against the per-pixel form (tools/probes/loss_kernel_times.py)
+#else
+    const bool per_pixel = false;
+#endif
+    if (!per_pixel && B <= 65535 && H >= 3 && W >= 3) {
+        UNFLOW_LAUNCH(smooth2_bwd_tile_kernel, dim3(ceil_div(W, SM_TW), ceil_div(H, SM_TH), B), dim3(256), 0, s, flow, img, gloss, gflow,
+                           H, W, img_batch);
+        return unflow_launch_status();
+    }
     UNFLOW_LAUNCH(smooth2_bwd_kernel, dim3(flat_blocks((size_t)B * H * W)), dim3(256), 0, s, flow, img, gloss,
                        gflow, B, H, W, img_batch);
     return unflow_launch_status();
