@@ -180,6 +180,7 @@ def measured_traffic(entry, shape, path=None):
 
 def main():
     args = parse()
+    auto_graph = args.graph < 0
     if args.graph < 0:
         # one process: replay (the step's ~3000 launches take 14-24 ms of host time depending on the box, against 24.3 ms (fp32) /
         # 11.6 ms (bf16) of GPU work: the eager bf16 step is host-bound everywhere, the fp32 step on a slow host).  Several ranks:
@@ -222,6 +223,7 @@ def main():
     model.pwc_model.fill_cat_buffers = bool(args.fill_cat)
     trainer = FlowTrainer(cfg, model, distributed=(world > 1 or args.force_ddp), use_graph=bool(args.graph),
                           single_rank_collectives=args.force_ddp, **({} if args.gc_freeze else {'gc_freeze_after': None}))
+    user_no_timing = args.no_kernel_timing
     graph_timing = bool(args.graph) and not args.no_kernel_timing      # replayed timed region: the per-launch events need eager steps (after it)
     if args.graph:
         args.no_kernel_timing = True
@@ -235,7 +237,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    warm = args.warmup
+    if args.graph and auto_graph and warm > 0:
+        # the DEFAULT replay mode must not cost a run: if the capture fails on this box (it builds inside the first step), say so
+        # and fall back to the eager step on a fresh model / trainer -- an explicit --graph 1 fails loudly instead
+        try:
+            trainer.step(inputs)
+            torch.cuda.synchronize()
+            warm -= 1
+        except Exception as e:                              # noqa: BLE001
+            sys.stderr.write('bench.py: hipGraph capture failed (%s: %s); continuing with eager steps\n' % (type(e).__name__, e))
+            args.graph, graph_timing, args.no_kernel_timing = 0, False, user_no_timing
+            torch.manual_seed(1234)
+            model = get_model('flow')(cfg).to(dev)
+            model.pwc_model.fill_cat_buffers = bool(args.fill_cat)
+            trainer = FlowTrainer(cfg, model, distributed=(world > 1 or args.force_ddp), use_graph=False,
+                                  single_rank_collectives=args.force_ddp, **({} if args.gc_freeze else {'gc_freeze_after': None}))
+    for _ in range(warm):
         trainer.step(inputs)
     CW = ('unflow_corr_fwd', 'unflow_corr_bwd', 'unflow_warp_fwd', 'unflow_warp_bwd', 'unflow_warp_corr_fwd', 'unflow_warp_corr_bwd')
     if not args.no_kernel_timing:
