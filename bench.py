@@ -74,6 +74,7 @@ def parse():
     ap.add_argument('--graph', type=int, default=-1, help='1: replay the step as a hipGraph; 0: eager (per-launch events INSIDE the timed steps); default: replay with one process, eager with several.  Under replay the roofline legs are taken over the same number of EAGER steps (at most 20) right behind the timed region: a captured graph cannot carry per-launch event pairs')
     ap.add_argument('--channels-last', type=int, default=-1, help='memory format of the conv stacks: 1 channels_last (NHWC), 0 NCHW; default: 1 when the shipped MIOpen find-db is in use, else 0 (cfg.channels_last)')
     ap.add_argument('--fused', type=int, default=0, help='1: warp + cost volume of each decoder level as one kernel (cfg.fused_warp_corr)')
+    ap.add_argument('--fused-upsample', type=int, default=1, help='0: F.interpolate + multiply for the flow up-sampling instead of unflow_upsample_scaled_* (A/B; PWC_tf.fused_upsample)')
     ap.add_argument('--fill-cat', type=int, default=1, help='0: channels_last decoder with torch.cat inputs instead of epilogue-filled cat buffers (A/B; PWC_tf.fill_cat_buffers)')
     ap.add_argument('--gc-freeze', type=int, default=1, help='0: leave Python\'s cyclic collector alone (FlowTrainer(gc_freeze_after=None)); 1: the trainer default (gc.freeze() after its second step)')
     ap.add_argument('--force-ddp', action='store_true', help='N = 1 only: run the step through the RCCL data-parallel path with a one-rank communicator')
@@ -221,6 +222,7 @@ def main():
     torch.manual_seed(1234)                       # same random init on every rank
     model = get_model('flow')(cfg).to(dev)
     model.pwc_model.fill_cat_buffers = bool(args.fill_cat)
+    model.pwc_model.fused_upsample = bool(args.fused_upsample)
     trainer = FlowTrainer(cfg, model, distributed=(world > 1 or args.force_ddp), use_graph=bool(args.graph),
                           single_rank_collectives=args.force_ddp, **({} if args.gc_freeze else {'gc_freeze_after': None}))
     user_no_timing = args.no_kernel_timing
@@ -251,6 +253,7 @@ def main():
             torch.manual_seed(1234)
             model = get_model('flow')(cfg).to(dev)
             model.pwc_model.fill_cat_buffers = bool(args.fill_cat)
+            model.pwc_model.fused_upsample = bool(args.fused_upsample)
             trainer = FlowTrainer(cfg, model, distributed=(world > 1 or args.force_ddp), use_graph=False,
                                   single_rank_collectives=args.force_ddp, **({} if args.gc_freeze else {'gc_freeze_after': None}))
     for _ in range(warm):

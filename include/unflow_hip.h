@@ -228,6 +228,13 @@ int unflow_bias_leaky_bwd2_nhwc_from_bf16(const uint16_t* act, long long act_pst
                                           const uint16_t* gout2, long long gout2_pstride, uint16_t* gin, float* gbias,
                                           float* partials, long long P, int C, float slope, void* stream);
 
+/* ---- flow up-sampling of the decoder (ABI 8): out = mul * F.interpolate(x, bilinear, align_corners=False) for an integer
+ * up-sampling factor per axis (Ho % Hi == 0, Wo % Wi == 0) -- pwc_tf.py:119,131,144,156 (factor 2, mul 2.0) and :174-177
+ * (F.interpolate(flow * 4.0, size): the factor 4.0 commutes exactly).  x [planes,Hi,Wi] -> out [planes,Ho,Wo]; the backward is
+ * a gather over the output pixels that read an input pixel (fixed order, bitwise reproducible). */
+int unflow_upsample_scaled_fwd(const float* x, float* out, int planes, int Hi, int Wi, int Ho, int Wo, float mul, void* stream);
+int unflow_upsample_scaled_bwd(const float* gout, float* gin, int planes, int Hi, int Wi, int Ho, int Wo, float mul, void* stream);
+
 /* ---- image pyramid: Model_flow.generate_img_pyramid scales 1 and 2, model_flow_paper.py:54-60 ----
  * img [planes,H,W] (planes = B*C, any leading layout) -> half [planes,H/2,W/2] (2x2 box means) and
  * quarter [planes,H/4,W/4] (4x4 box means of img).  H, W multiples of 4. */

@@ -152,7 +152,7 @@ def test_model_scale_masks_bit_exact(golden, fixture, scales, acs):
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 def test_filled_cat_buffers_equal_the_cat_form(prec):
     """channels_last decoder: cat inputs filled by the producing convolutions' epilogues (PWC_tf._decoder_filled, the default)
-    against the same network with torch.cat (fill_cat_buffers = False).  Same convolutions on the same values, so flows and
+    against the same network with torch.cat (fill_cat_buffers = False) and torch's flow up-sampling.  Same convolutions on the same values, so flows and
     losses agree to 1e-5 (fp32) / 1e-3 (bf16); gradients to the run-to-run level of the convolutions (see below)."""
     from unopticalflow_amd import get_model, generate_loss_weights_dict
     x = R.synthetic_triplets(2, 128, 128, seed=0, structured=True).cuda()
@@ -162,6 +162,7 @@ def test_filled_cat_buffers_equal_the_cat_form(prec):
         model = get_model('flow')(cfg).cuda()
         model.load_state_dict(R.seeded_state_dict(model, 1234, 0.25))
         model.pwc_model.fill_cat_buffers = fill
+        model.pwc_model.fused_upsample = fill            # (False: F.interpolate + multiply, pwc_tf.py:119-177, instead of unflow_upsample_scaled_*)
         w = generate_loss_weights_dict(cfg)
         pack = model(x)
         sum(w[k] * pack[k].mean() for k in pack).backward()

@@ -700,6 +700,37 @@ def test_img_pyramid_vs_oracle(ops, shape):
     close(quarter, ref[2], rtol=0, atol=3e-7)
 
 
+@pytest.mark.parametrize('shape,size,mul', [((16, 2, 4, 13), (8, 26), 2.0), ((16, 2, 32, 104), (64, 208), 2.0), ((16, 2, 64, 208), (256, 832), 4.0),
+                                            ((16, 2, 8, 26), (32, 104), 4.0), ((3, 2, 5, 7), (15, 7), 2.0), ((2, 3, 6, 9), (6, 9), 4.0),
+                                            ((1, 2, 1, 1), (2, 2), 2.0), ((2, 2, 7, 4), (7, 24), 1.0)])
+def test_upsample_scaled_vs_torch(ops, shape, size, mul):
+    """The decoder's flow up-sampling (pwc_tf.py:119-177) as one kernel each way against the ops the reference (and the oracle,
+    ref_cpu.py:274,285) runs on the CPU: F.interpolate(bilinear, align_corners=False) and the scalar multiply.  Same taps and
+    weights; fp32 contraction order may differ by an ulp or two of the result (bar: 1e-6 relative to the largest value).  The
+    gather backward is bitwise reproducible."""
+    import torch.nn.functional as F
+    x = rnd(71, shape, scale=3.0)
+    g = rnd(72, shape[:2] + size)
+    xr = x.clone().requires_grad_(True)
+    if mul == 4.0:
+        ref = F.interpolate(xr * 4.0, list(size), mode='bilinear')
+    else:
+        ref = F.interpolate(xr, list(size), mode='bilinear') * mul
+    ref.backward(g)
+    xg = x.cuda().requires_grad_(True)
+    out = ops.upsample_bilinear_scaled(xg, size, mul)
+    out.backward(g.cuda())
+    close(out, ref, rtol=0, atol=1e-6 * ref.abs().max().item(), what='forward')
+    close(xg.grad, xr.grad, rtol=0, atol=2e-6 * xr.grad.abs().max().item(), what='backward')
+    first = xg.grad.clone()
+    xg.grad = None
+    ops.upsample_bilinear_scaled(xg, size, mul).backward(g.cuda())
+    assert torch.equal(first, xg.grad)
+    if shape[2] > 1:                                     # (a 1-row map up-samples to any height)
+        with pytest.raises(ValueError):
+            ops.upsample_bilinear_scaled(xg, (size[0] + 1, size[1]), mul)
+
+
 def test_kernel_exact_timing_slots(ops):
     """bench.py's roofline legs: a timed C call carries an event pair on its kernels (unflow_timing_begin /
     hipExtLaunchKernelGGL).  The slot's time is positive, not longer than a hipEventRecord bracket around the same call,

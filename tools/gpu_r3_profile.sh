@@ -10,7 +10,7 @@ what=${@:-fp32 bf16 traffic corr8}
 for w in $what; do
   case $w in
     fp32|bf16)
-      extra=""; [ $w = bf16 ] && extra="--precision bf16 --graph 0"      # (eager: a --pmc pass over hipGraph replays left the GPU unresponsive once)
+      extra="--graph 0"; [ $w = bf16 ] && extra="--precision bf16 --graph 0"      # (eager: a --pmc pass over hipGraph replays left the GPU unresponsive once)
       OUT=$GRAFT_REPO_ROOT/gpurun_out/r3/prof_$w; mkdir -p $OUT
       ( cd /tmp && export TMPDIR=/tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing $extra > $OUT/run.log 2>&1 )
       T=$(ls $OUT/*/*kernel_trace.csv | head -1)

@@ -49,6 +49,8 @@ SIGNATURES = {
     'unflow_bias_leaky_fwd_nhwc': [_P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P],
     'unflow_bias_leaky_partials_nhwc': [ctypes.c_longlong, _I],
     'unflow_bias_leaky_bwd2_nhwc': [_P, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P],
+    'unflow_upsample_scaled_fwd': [_P, _P, _I, _I, _I, _I, _I, ctypes.c_float, _P],
+    'unflow_upsample_scaled_bwd': [_P, _P, _I, _I, _I, _I, _I, ctypes.c_float, _P],
     'unflow_bias_leaky_fwd_nhwc_to': [_P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P],
     'unflow_bias_leaky_bwd2_nhwc_from': [_P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P],
     'unflow_bias_leaky_fwd_nhwc_to_bf16': [_P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P],
@@ -64,7 +66,7 @@ SIGNATURES = {
     'unflow_png_unfilter': [_P, _I, _I, _I],
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lib = None
 
 

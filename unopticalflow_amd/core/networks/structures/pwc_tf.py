@@ -27,6 +27,7 @@ class PWC_tf(nn.Module):
         # channels_last only: the decoder's cat((x_k, x_k+1)) inputs are filled by the producing convolutions' epilogues
         # (_decoder_filled) instead of being copied together by torch.cat; False keeps the cat form (tests compare the two)
         self.fill_cat_buffers = True
+        self.fused_upsample = True        # flow up-sampling + its scale factor as one kernel each way (ops.upsample_bilinear_scaled)
         self.corr = self.corr_naive
         # True: warp + cost volume of a level as ONE kernel (ops.warp_corr; the warped features never reach HBM).
         # Measured on MI355X (profiles/r2_v1_bench_fused1.json): at parity with the two separate kernels at level 2 and
@@ -60,6 +61,14 @@ class PWC_tf(nn.Module):
             # autocast then casts the NHWC tensor)
             return ops.cat_channels_last([p.float() for p in parts])
         return parts[0] if len(parts) == 1 else torch.cat(parts, 1)
+
+    def _up(self, flow, size, mul):
+        """mul * bilinear up-sampling of a flow: one HIP kernel each way for the integer factors of the pyramid (ops.upsample_bilinear_scaled),
+        the torch ops otherwise (CPU tensors, other ratios)."""
+        h, w = flow.shape[2], flow.shape[3]
+        if self.fused_upsample and flow.is_cuda and flow.dtype == torch.float32 and size[0] % h == 0 and size[1] % w == 0 and size[0] >= h and size[1] >= w:
+            return ops.upsample_bilinear_scaled(flow, size, mul)
+        return F.interpolate(flow * mul, list(size), mode='bilinear') if mul == 4.0 else F.interpolate(flow, list(size), mode='bilinear') * mul
 
     def predict_flow(self, in_planes):
         return nn.Conv2d(in_planes, 2, kernel_size=3, stride=1, padding=1, bias=True)
@@ -121,7 +130,7 @@ class PWC_tf(nn.Module):
         flow, _ = self._decoder(6, (self.corr(f1[6], f2[6]),))
         level_flow = {}
         for lvl in (5, 4, 3, 2):
-            up = F.interpolate(flow, scale_factor=2.0, mode='bilinear') * 2.0
+            up = self._up(flow, (2 * flow.shape[2], 2 * flow.shape[3]), 2.0)         # F.interpolate(flow, scale_factor=2.0, 'bilinear') * 2.0 (pwc_tf.py:119)
             if self.fused_warp_corr and self.corr == self.corr_naive:      # (a user-supplied self.corr keeps the two-op path)
                 cv = ops.warp_corr(f1[lvl].float(), f2[lvl].float(), up.float(), 4, self.align_corners)
             else:
@@ -133,5 +142,5 @@ class PWC_tf(nn.Module):
         x = self.dc_conv4(self.dc_conv3(self.dc_conv2(self.dc_conv1(torch.cat([fl2, x4], 1)))))
         level_flow[2] = level_flow[2] + self.dc_conv7(self.dc_conv6(self.dc_conv5(x))).float().contiguous()
         img_h, img_w = img_hw[0], img_hw[1]
-        return [F.interpolate(level_flow[lvl] * 4.0, [img_h // (1 << k), img_w // (1 << k)], mode='bilinear')
-                for k, lvl in enumerate((2, 3, 4, 5))]
+        # F.interpolate(flow * 4.0, size, 'bilinear') (pwc_tf.py:174-177): the factor 4.0 commutes with the interpolation exactly
+        return [self._up(level_flow[lvl], (img_h // (1 << k), img_w // (1 << k)), 4.0) for k, lvl in enumerate((2, 3, 4, 5))]

@@ -415,6 +415,90 @@ extern "C" int unflow_split_nhwc(const float* in, float* a, int Ca, float* b, in
     return unflow_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Flow up-sampling of the decoder (pwc_tf.py:119,131,144,156: F.interpolate(flow, scale_factor=2, bilinear) * 2.0; :174-177:
+// F.interpolate(flow * 4.0, size) -- the scale factor 4 commutes with the interpolation exactly, a power of two) as ONE kernel
+// each way instead of interpolate + multiply (+ their two backward kernels): ATen's up-sampling spends 13-15 us per launch on
+// these 2-channel maps and its backward scatters with atomics.  Same arithmetic as ATen's upsample_bilinear2d with
+// align_corners = False:  src = max((dst + 0.5) * (in / out) - 0.5, 0), i0 = floor(src), i1 = i0 + (i0 < in - 1), l1 = src - i0,
+// out = l0y * (l0x * a + l1x * b) + l1y * (l0x * c + l1x * d), then * mul.  The backward is a gather (every input pixel sums the
+// output pixels that read it, in a fixed order): bitwise reproducible.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void up_src(int dst, float ratio, int in, int& i0, int& i1, float& l0, float& l1) {
+    float src = ((float)dst + 0.5f) * ratio - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;                                     // src >= 0: truncation = floor
+    i0 = min(i0, in - 1);
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.0f - l1;
+}
+
+__global__ __launch_bounds__(256) void upsample_scaled_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                                  int Hi, int Wi, int Ho, int Wo, float ry, float rx, float mul) {
+    const int p = blockIdx.y;
+    const float* xp = x + (size_t)p * Hi * Wi;
+    float* op = out + (size_t)p * Ho * Wo;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < Ho * Wo; t += gridDim.x * 256) {
+        const int oy = t / Wo, ox = t - oy * Wo;
+        int y0, y1, x0, x1; float a0, a1, b0, b1;
+        up_src(oy, ry, Hi, y0, y1, a0, a1);
+        up_src(ox, rx, Wi, x0, x1, b0, b1);
+        const float v = a0 * (b0 * xp[y0 * Wi + x0] + b1 * xp[y0 * Wi + x1]) + a1 * (b0 * xp[y1 * Wi + x0] + b1 * xp[y1 * Wi + x1]);
+        op[t] = v * mul;
+    }
+}
+
+// gin[y][x] = mul * sum over the output pixels whose taps include (y, x); the candidate rows / columns of an input pixel are
+// [F y - F/2 - 1, F y + 3F/2] for an up-sampling factor F = out / in (one spare on each side; the clamped first and last rows fall inside)
+__global__ __launch_bounds__(256) void upsample_scaled_bwd_kernel(const float* __restrict__ g, float* __restrict__ gin,
+                                                                  int Hi, int Wi, int Ho, int Wo, float ry, float rx, float mul, int Fy, int Fx) {
+    const int p = blockIdx.y;
+    const float* gp = g + (size_t)p * Ho * Wo;
+    float* ip = gin + (size_t)p * Hi * Wi;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < Hi * Wi; t += gridDim.x * 256) {
+        const int y = t / Wi, x = t - y * Wi;
+        const int oy_lo = max(0, Fy * y - Fy / 2 - 1), oy_hi = min(Ho - 1, Fy * y + (3 * Fy) / 2);
+        const int ox_lo = max(0, Fx * x - Fx / 2 - 1), ox_hi = min(Wo - 1, Fx * x + (3 * Fx) / 2);
+        float acc = 0.f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            int y0, y1; float a0, a1;
+            up_src(oy, ry, Hi, y0, y1, a0, a1);
+            const float wy = (y0 == y ? a0 : 0.f) + (y1 == y ? a1 : 0.f);
+            if (wy == 0.f) continue;
+            float row = 0.f;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                int x0, x1; float b0, b1;
+                up_src(ox, rx, Wi, x0, x1, b0, b1);
+                const float wx = (x0 == x ? b0 : 0.f) + (x1 == x ? b1 : 0.f);
+                row = fmaf(wx, gp[oy * Wo + ox], row);
+            }
+            acc = fmaf(wy, row, acc);
+        }
+        ip[t] = acc * mul;
+    }
+}
+
+static int upsample_args_ok(const void* a, const void* b, int planes, int Hi, int Wi, int Ho, int Wo) {
+    return a && b && planes > 0 && planes <= 65535 && Hi > 0 && Wi > 0 && Ho >= Hi && Wo >= Wi && Ho % Hi == 0 && Wo % Wi == 0;
+}
+
+extern "C" int unflow_upsample_scaled_fwd(const float* x, float* out, int planes, int Hi, int Wi, int Ho, int Wo, float mul, void* stream) {
+    UNFLOW_REQUIRE(upsample_args_ok(x, out, planes, Hi, Wi, Ho, Wo));
+    const int blocks = ceil_div(Ho * Wo, 256) < 1024 ? ceil_div(Ho * Wo, 256) : 1024;
+    UNFLOW_LAUNCH(upsample_scaled_fwd_kernel, dim3(blocks, planes), dim3(256), 0, (hipStream_t)stream, x, out, Hi, Wi, Ho, Wo,
+                       (float)Hi / (float)Ho, (float)Wi / (float)Wo, mul);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_upsample_scaled_bwd(const float* gout, float* gin, int planes, int Hi, int Wi, int Ho, int Wo, float mul, void* stream) {
+    UNFLOW_REQUIRE(upsample_args_ok(gout, gin, planes, Hi, Wi, Ho, Wo));
+    const int blocks = ceil_div(Hi * Wi, 256) < 1024 ? ceil_div(Hi * Wi, 256) : 1024;
+    UNFLOW_LAUNCH(upsample_scaled_bwd_kernel, dim3(blocks, planes), dim3(256), 0, (hipStream_t)stream, gout, gin, Hi, Wi, Ho, Wo,
+                       (float)Hi / (float)Ho, (float)Wi / (float)Wo, mul, Ho / Hi, Wo / Wi);
+    return unflow_launch_status();
+}
+
 extern "C" int unflow_img_pyramid(const float* img, float* half, float* quarter, int planes, int H, int W,
                                   void* stream) {
     UNFLOW_REQUIRE(img && half && quarter && planes > 0 && H > 0 && W > 0 && (H & 3) == 0 && (W & 3) == 0);

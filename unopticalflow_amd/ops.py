@@ -14,7 +14,7 @@ import torch
 from . import _lib
 
 __all__ = ['corr', 'warp_flow', 'warp_flow_masked', 'warp_corr', 'occ_weight', 'occ_weight_stacked', 'masked_mean', 'ssim_loss',
-           'ssim_map', 'smooth2_loss', 'consis_loss', 'bias_leaky_relu_', 'bias_leaky_relu_into', 'img_pyramid']
+           'ssim_map', 'smooth2_loss', 'consis_loss', 'bias_leaky_relu_', 'bias_leaky_relu_into', 'upsample_bilinear_scaled', 'img_pyramid']
 
 
 def _ptr(t):
@@ -827,6 +827,39 @@ def to_nchw(x):
         return x.contiguous()
     _dev(x)
     return _ToNCHW.apply(x)
+
+
+class _UpsampleScaled(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, mul):
+        dev = _dev(x)
+        x = x.contiguous()
+        B, C, Hi, Wi = x.shape
+        out = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=dev)
+        with _on(dev):
+            _call('unflow_upsample_scaled_fwd', _ptr(x), _ptr(out), B * C, Hi, Wi, Ho, Wo, ctypes.c_float(mul), _stream(),
+                  nbytes=4 * B * C * (Hi * Wi + Ho * Wo), shape=(B, C, Ho, Wo))
+        ctx.meta = (B, C, Hi, Wi, Ho, Wo, mul)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, Hi, Wi, Ho, Wo, mul = ctx.meta
+        g = g.contiguous()
+        gin = torch.empty((B, C, Hi, Wi), dtype=torch.float32, device=g.device)
+        with _on(g.device):
+            _call('unflow_upsample_scaled_bwd', _ptr(g), _ptr(gin), B * C, Hi, Wi, Ho, Wo, ctypes.c_float(mul), _stream(),
+                  nbytes=4 * B * C * (Hi * Wi + Ho * Wo), shape=(B, C, Ho, Wo))
+        return gin, None, None, None
+
+
+def upsample_bilinear_scaled(x, size, mul=1.0):
+    """``mul * F.interpolate(x, size, mode='bilinear', align_corners=False)`` for integer up-sampling factors, one kernel each way
+    (the decoder's flow up-sampling, pwc_tf.py:119-177: ``interpolate(flow, scale_factor=2) * 2.0`` and ``interpolate(flow * 4.0, size)``)."""
+    Ho, Wo = int(size[0]), int(size[1])
+    if x.dim() != 4 or Ho % x.shape[2] or Wo % x.shape[3] or Ho < x.shape[2] or Wo < x.shape[3]:
+        raise ValueError('upsample_bilinear_scaled: integer up-sampling factors only, got %s -> %s' % (tuple(x.shape[2:]), (Ho, Wo)))
+    return _UpsampleScaled.apply(x, Ho, Wo, float(mul))
 
 
 def img_pyramid(img):
