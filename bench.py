@@ -73,6 +73,7 @@ def parse():
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'], help='conv-stack precision (bf16: BASELINE config 3; the headline metric is fp32)')
     ap.add_argument('--graph', type=int, default=-1, help='1: replay the step as a hipGraph; 0: eager (per-launch events INSIDE the timed steps); default: replay with one process, eager with several.  Under replay the roofline legs are taken over the same number of EAGER steps (at most 20) right behind the timed region: a captured graph cannot carry per-launch event pairs')
     ap.add_argument('--channels-last', type=int, default=-1, help='memory format of the conv stacks: 1 channels_last (NHWC), 0 NCHW; default: 1 when the shipped MIOpen find-db is in use, else 0 (cfg.channels_last)')
+    ap.add_argument('--weight-shadows', type=int, default=1, help='bf16 only; 0: autocast casts every convolution weight per call instead of one multi-tensor cast per pass (A/B; cfg.weight_shadows)')
     ap.add_argument('--fused', type=int, default=0, help='1: warp + cost volume of each decoder level as one kernel (cfg.fused_warp_corr)')
     ap.add_argument('--fused-upsample', type=int, default=1, help='0: F.interpolate + multiply for the flow up-sampling instead of unflow_upsample_scaled_* (A/B; PWC_tf.fused_upsample)')
     ap.add_argument('--fill-cat', type=int, default=1, help='0: channels_last decoder with torch.cat inputs instead of epilogue-filled cat buffers (A/B; PWC_tf.fill_cat_buffers)')
@@ -217,7 +218,7 @@ def main():
     cl = measured_picks if args.channels_last < 0 else bool(args.channels_last)
     cfg = types.SimpleNamespace(mode='flow', dataset='kitti_depth', num_scales=3, h_flow_consist_alpha=3.0,
                                 h_flow_consist_beta=0.05, w_ssim=0.85, w_flow_smooth=10.0, w_flow_consis=0.01,
-                                lr=1e-4, align_corners=False, precision=args.precision, fused_warp_corr=bool(args.fused),
+                                lr=1e-4, align_corners=False, precision=args.precision, weight_shadows=bool(args.weight_shadows), fused_warp_corr=bool(args.fused),
                                 channels_last=cl)
     torch.manual_seed(1234)                       # same random init on every rank
     model = get_model('flow')(cfg).to(dev)

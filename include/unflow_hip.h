@@ -193,6 +193,11 @@ int unflow_bias_leaky_bwd2_nhwc(const float* y, const float* gout, long long gou
 int unflow_cat_nhwc(const float* a, int Ca, const float* b, int Cb, const float* c, int Cc, float* out,
                     int B, int HW, void* stream);
 int unflow_split_nhwc(const float* in, float* a, int Ca, float* b, int Cb, float* c, int Cc, int B, int HW, void* stream);
+/* (ABI 8) the same two with the NHWC side in bf16 (raw uint16_t; the bf16 conv-stack option): the NCHW planes stay fp32, one
+ * round-to-nearest-even per element into the NHWC tensor, exact widening out of it. */
+int unflow_cat_nhwc_bf16(const float* a, int Ca, const float* b, int Cb, const float* c, int Cc, uint16_t* out,
+                         int B, int HW, void* stream);
+int unflow_split_nhwc_bf16(const uint16_t* in, float* a, int Ca, float* b, int Cb, float* c, int Cc, int B, int HW, void* stream);
 
 /* bf16 activations (the bf16 conv-stack option: torch.autocast around the reference's conv() blocks): y, gout,
  * gout2, gin are bf16 (raw uint16_t), bias / gbias / partials fp32; arithmetic in fp32, one round-to-nearest-even

@@ -582,6 +582,35 @@ def test_cat_channels_last_and_back(ops, shape, chans):
     assert torch.equal(y.grad.cpu(), go)
 
 
+@pytest.mark.parametrize('shape,chans', [((16, 64, 208), (81, 32, 2)), ((16, 4, 13), (81,)), ((3, 7, 9), (5, 3)), ((2, 8, 26), (81, 128, 2))])
+def test_cat_channels_last_bf16_side(ops, shape, chans):
+    """bf16 conv-stack option: the same glue with the NHWC side in bf16 and the NCHW planes fp32 -- the cat rounds once
+    (round-to-nearest-even: the values torch.cat(...).bfloat16() holds, what autocast hands the convolution), the way back
+    widens exactly.  Bit-equal."""
+    B, H, W = shape
+    CL = torch.channels_last
+    xs = [rnd(190 + k, (B, c, H, W)) for k, c in enumerate(chans)]
+    gs = [x.cuda().requires_grad_(k != 1) for k, x in enumerate(xs)]
+    out = ops.cat_channels_last(gs, torch.bfloat16)
+    ref = torch.cat(xs, 1).to(torch.bfloat16)
+    assert out.dtype == torch.bfloat16 and out.is_contiguous(memory_format=CL) and torch.equal(out.cpu(), ref)
+    go = rnd(195, tuple(ref.shape)).to(torch.bfloat16)
+    out.backward(go.cuda().contiguous(memory_format=CL))
+    o = 0
+    for k, c in enumerate(chans):
+        if k == 1:
+            assert gs[k].grad is None
+        else:
+            assert gs[k].grad.dtype == torch.float32 and gs[k].grad.is_contiguous() and torch.equal(gs[k].grad.cpu(), go[:, o:o + c].float())
+        o += c
+    y = ref.cuda().contiguous(memory_format=CL).requires_grad_()                       # a bf16 NHWC activation (pyramid feature)
+    z = ops.to_nchw(y * 1.0)
+    assert z.dtype == torch.float32 and z.is_contiguous() and torch.equal(z.cpu(), ref.float())
+    g32 = rnd(196, tuple(ref.shape))
+    z.backward(g32.cuda())
+    assert y.grad.dtype == torch.bfloat16 and torch.equal(y.grad.cpu(), g32.to(torch.bfloat16))
+
+
 @pytest.mark.parametrize('shape', [(16, 128, 64, 208), (2, 5, 7, 9), (3, 8, 4, 4), (2, 16, 8, 26)])
 def test_bias_leaky_bf16(ops, shape):
     """bf16 conv-stack option: same epilogue on bf16 activations -- fp32 arithmetic, one rounding per element."""

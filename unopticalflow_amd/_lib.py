@@ -59,6 +59,8 @@ SIGNATURES = {
     'unflow_bias_leaky_bwd2_nhwc_bf16': [_P, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P],
     'unflow_cat_nhwc': [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P],
     'unflow_split_nhwc': [_P, _P, _I, _P, _I, _P, _I, _I, _I, _P],
+    'unflow_cat_nhwc_bf16': [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P],
+    'unflow_split_nhwc_bf16': [_P, _P, _I, _P, _I, _P, _I, _I, _I, _P],
     'unflow_bias_leaky_fwd_bf16': [_P, _P, _I, _I, _I, _I, ctypes.c_float, _P],
     'unflow_bias_leaky_bwd2_bf16': [_P, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, _P],
     'unflow_img_pyramid': [_P, _P, _P, _I, _I, _I, _P],

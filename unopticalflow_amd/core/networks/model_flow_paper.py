@@ -1,9 +1,12 @@
+import contextlib
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops, tuning
 from .structures import FeaturePyramid, PWC_tf, warp_flow
+from .structures.net_utils import WeightShadows
 
 
 class Model_flow(nn.Module):
@@ -35,6 +38,8 @@ class Model_flow(nn.Module):
         # shipped find-db's measured picks (tuning.default_channels_last: the one place that decides), else NCHW
         cl = getattr(cfg, 'channels_last', None)
         self.channels_last = tuning.default_channels_last() if cl is None else bool(cl)
+        # bf16 option: one multi-tensor cast of all convolution weights per pass (False: autocast's per-call casts; tests compare)
+        self.weight_shadows = bool(getattr(cfg, 'weight_shadows', True))
         self.fpyramid = FeaturePyramid(channels_last=self.channels_last)
         self.pwc_model = PWC_tf(align_corners=self.align_corners, fused_warp_corr=bool(getattr(cfg, 'fused_warp_corr', False)),
                                 channels_last=self.channels_last)
@@ -142,8 +147,17 @@ class Model_flow(nn.Module):
             feature_list_2 = [f[B:] for f in feats]
             return self.pwc_model(feature_list_1, feature_list_2, img_hw)[0].float()
 
+    @contextlib.contextmanager
     def _autocast(self):
-        return torch.autocast('cuda', dtype=torch.bfloat16, enabled=(self.precision == 'bf16'))
+        """The conv stacks' precision for one network pass: nothing for fp32; for bf16 the autocast region plus one bf16 copy of
+        every convolution weight for the whole pass (net_utils.WeightShadows) instead of autocast's cast per call."""
+        if self.precision != 'bf16':
+            yield
+            return
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            on_gpu = self.weight_shadows and next(self.fpyramid.parameters()).is_cuda
+            with WeightShadows((self.fpyramid, self.pwc_model), enabled=on_gpu):
+                yield
 
     def _flows(self, imgl, img, imgr, frames=None):
         """Both directed flow pyramids with one 3B pyramid pass and one 2B decoder pass.  ``frames`` is the

@@ -5,6 +5,76 @@ import torch.nn.functional as F
 from .... import ops
 
 
+def conv_weight(c):
+    """The weight a convolution module contracts with in this forward: its parameter, or -- bf16 conv-stack option -- the
+    bf16 copy ``WeightShadows`` made for the whole network in one launch."""
+    w = c.__dict__.get('_w_half')
+    return c.weight if w is None else w
+
+
+class _CastAll(torch.autograd.Function):
+    """bf16 copies of a list of fp32 parameters by ONE multi-tensor kernel (torch._foreach_copy_), and their bf16 gradients
+    widened back to fp32 the same way.  Autocast does the same arithmetic per convolution call: one cast launch per weight
+    forward and one per weight gradient backward, ~100 launches of 4-5 us per step."""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        outs = [torch.empty_like(w, dtype=torch.bfloat16) for w in ws]          # (empty_like keeps the channels_last strides)
+        torch._foreach_copy_(outs, [w.detach() for w in ws])
+        ctx.like = [(w.shape, w.stride()) for w in ws]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        outs, src, dst = [], [], []
+        for g, (shape, stride) in zip(gs, ctx.like):
+            if g is None:
+                outs.append(None)
+                continue
+            o = torch.empty_strided(shape, stride, dtype=torch.float32, device=g.device)
+            if g.stride() != stride:                    # (the multi-tensor kernel walks both sides by offset)
+                g = torch.empty_strided(shape, stride, dtype=g.dtype, device=g.device).copy_(g)
+            outs.append(o); src.append(g); dst.append(o)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        return tuple(outs)
+
+
+class WeightShadows:
+    """Context manager around a network pass of the bf16 option: every convolution weight (and the bias of the plain
+    Conv2d heads, which autocast would cast per call too) of ``modules`` gets its bf16 copy for the pass; ``conv_weight`` /
+    ``HeadConv2d`` pick it up.  Gradients reach the fp32 parameters through ``_CastAll.backward``."""
+
+    def __init__(self, modules, enabled=True):
+        self.convs = [m for mod in modules for m in mod.modules() if isinstance(m, nn.Conv2d)] if enabled else []
+
+    def __enter__(self):
+        if not self.convs:
+            return self
+        heads = [m for m in self.convs if isinstance(m, HeadConv2d) and m.bias is not None]
+        halves = _CastAll.apply(*([m.weight for m in self.convs] + [m.bias for m in heads]))
+        for m, w in zip(self.convs, halves):
+            m.__dict__['_w_half'] = w
+        for m, b in zip(heads, halves[len(self.convs):]):
+            m.__dict__['_b_half'] = b
+        return self
+
+    def __exit__(self, *exc):
+        for m in self.convs:
+            m.__dict__.pop('_w_half', None)
+            m.__dict__.pop('_b_half', None)
+        return False
+
+
+class HeadConv2d(nn.Conv2d):
+    """nn.Conv2d (the reference's predict_flow heads, pwc_tf.py:93-94: bias inside the convolution, no activation) that
+    contracts with the pass's bf16 shadows when there are any; same parameters, same state-dict keys."""
+
+    def forward(self, x):
+        b = self.__dict__.get('_b_half')
+        return self._conv_forward(x, conv_weight(self), self.bias if b is None else b)
+
+
 class ConvLeaky(nn.Sequential):
     """The reference's conv() block, Sequential(Conv2d(bias=True), LeakyReLU(0.1)): same children, same
     ``<name>.0.weight`` / ``<name>.0.bias`` state-dict keys.  On a HIP tensor the forward runs the
@@ -15,7 +85,7 @@ class ConvLeaky(nn.Sequential):
         """``consumers=2``: returns (y, y) -- two handles of the same activation, one per consumer, so the two
         gradients meet inside the epilogue's backward kernel (ops.bias_leaky_relu_)."""
         c = self[0]
-        y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
+        y = F.conv2d(x, conv_weight(c), None, c.stride, c.padding, c.dilation, c.groups)
         # fp32, or bf16 under the autocast of cfg.precision == 'bf16' (bias stays fp32): the same fused epilogue
         return ops.bias_leaky_relu_(y, c.bias, self[1].negative_slope, consumers)
 

@@ -3,7 +3,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .... import ops
-from .net_utils import conv, warp_flow, weights_to_channels_last, CL
+from .net_utils import conv, conv_weight, HeadConv2d, warp_flow, weights_to_channels_last, CL
 
 _DD = (128, 128, 96, 64, 32)                       # decoder widths (reference pwc_tf.py:25)
 _FEAT = {6: 0, 5: 128, 4: 96, 3: 64, 2: 32}        # channels of the pyramid level fed to each decoder
@@ -57,9 +57,10 @@ class PWC_tf(nn.Module):
         """The decoder input torch.cat(parts, 1) (pwc_tf.py:113): written directly in channels_last order when the conv
         stack runs in it (one kernel instead of a cat and a re-layout)."""
         if self._cl(parts[0]):
-            # (bf16 option: the pyramid features are bf16; the cat is fp32 like torch.cat's type promotion, the convolution's
-            # autocast then casts the NHWC tensor)
-            return ops.cat_channels_last([p.float() for p in parts])
+            # (bf16 option: the cat of the fp32 parts is rounded to bf16 in the same pass -- the values autocast would hand the
+            # convolution after torch.cat's fp32 result)
+            half = parts[0].is_cuda and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+            return ops.cat_channels_last([p.float() for p in parts], torch.bfloat16 if half else torch.float32)
         return parts[0] if len(parts) == 1 else torch.cat(parts, 1)
 
     def _up(self, flow, size, mul):
@@ -71,7 +72,7 @@ class PWC_tf(nn.Module):
         return F.interpolate(flow * mul, list(size), mode='bilinear') if mul == 4.0 else F.interpolate(flow, list(size), mode='bilinear') * mul
 
     def predict_flow(self, in_planes):
-        return nn.Conv2d(in_planes, 2, kernel_size=3, stride=1, padding=1, bias=True)
+        return HeadConv2d(in_planes, 2, kernel_size=3, stride=1, padding=1, bias=True)
 
     def warp(self, x, flow):
         return warp_flow(x.float(), flow.float(), use_mask=False, align_corners=self.align_corners)
@@ -107,7 +108,7 @@ class PWC_tf(nn.Module):
         buffers that hold it, so per activation 1 read + 2 writes replace the in-place epilogue's 1 + 1 and two cats' 2 + 2."""
         def raw(m, t):                                   # the bias-free contraction of a conv() block
             k = m[0]
-            return F.conv2d(t, k.weight, None, k.stride, k.padding, k.dilation, k.groups), k.bias, m[1].negative_slope
+            return F.conv2d(t, conv_weight(k), None, k.stride, k.padding, k.dilation, k.groups), k.bias, m[1].negative_slope
 
         def buf(like, ch):
             return torch.empty((like.shape[0], ch) + tuple(like.shape[2:]), dtype=like.dtype, device=like.device, memory_format=CL)

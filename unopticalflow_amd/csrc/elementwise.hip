@@ -10,6 +10,7 @@
 //
 // Layout NCHW fp32; lanes along the contiguous H*W axis, 16 bytes per lane when H*W % 4 == 0.
 #include "common.h"
+#include <stdint.h>
 
 namespace {
 
@@ -205,7 +206,20 @@ __device__ __forceinline__ const float* plane_of(const Planes3& src, int b, int 
     return (k == 0 ? src.p[0] : k == 1 ? src.p[1] : src.p[2]) + ((size_t)b * (k == 0 ? src.c[0] : k == 1 ? src.c[1] : src.c[2]) + cc) * HW;
 }
 
-__global__ __launch_bounds__(256) void cat_nhwc_fwd_kernel(Planes3 src, float* __restrict__ dst, int HW, int C) {
+// T: the element type of the NHWC side -- float, or unsigned short = bf16 bits for the bf16 conv-stack option (the NCHW planes
+// stay fp32: what the cost volume / warp kernels read and write), one round-to-nearest-even per element on the way in
+__device__ __forceinline__ float nhwc_load(const float* p) { return *p; }
+__device__ __forceinline__ float nhwc_load(const unsigned short* p) { return __uint_as_float((unsigned)*p << 16); }
+__device__ __forceinline__ void nhwc_store(float* p, float v) { *p = v; }
+__device__ __forceinline__ void nhwc_store(unsigned short* p, float v) {
+    unsigned u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) { *p = 0x7fc0; return; }      // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    *p = (unsigned short)(u >> 16);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cat_nhwc_fwd_kernel(Planes3 src, T* __restrict__ dst, int HW, int C) {
     extern __shared__ float tile[];                   // [C][LG_LD]
     const int b = blockIdx.y, p0 = blockIdx.x * LG_PIX, npx = min(LG_PIX, HW - p0);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -223,25 +237,26 @@ __global__ __launch_bounds__(256) void cat_nhwc_fwd_kernel(Planes3 src, float* _
         }
     }
     __syncthreads();
-    float* d = dst + ((size_t)b * HW + p0) * C;
+    T* d = dst + ((size_t)b * HW + p0) * C;
     const int n = npx * C;
     for (int e = threadIdx.x; e < n; e += 256) {
         const int px = e / C, c = e - px * C;
-        d[e] = tile[c * LG_LD + px];
+        nhwc_store(d + e, tile[c * LG_LD + px]);
     }
 }
 
 // the inverse: NHWC [B][HW][C] -> up to three NCHW tensors (destinations with a null pointer are skipped)
-__global__ __launch_bounds__(256) void split_nhwc_kernel(const float* __restrict__ srcp, PlanesOut3 dst, int HW, int C) {
+template <typename T>
+__global__ __launch_bounds__(256) void split_nhwc_kernel(const T* __restrict__ srcp, PlanesOut3 dst, int HW, int C) {
     extern __shared__ float tile[];
     const int b = blockIdx.y, p0 = blockIdx.x * LG_PIX, npx = min(LG_PIX, HW - p0);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const float* s = srcp + ((size_t)b * HW + p0) * C;
+    const T* s = srcp + ((size_t)b * HW + p0) * C;
     const int n = npx * C;
     for (int e0 = threadIdx.x; e0 < n; e0 += 256 * LG_UNROLL) {
         float v[LG_UNROLL];
 #pragma unroll
-        for (int u = 0; u < LG_UNROLL; ++u) v[u] = (e0 + 256 * u < n) ? s[e0 + 256 * u] : 0.f;
+        for (int u = 0; u < LG_UNROLL; ++u) v[u] = (e0 + 256 * u < n) ? nhwc_load(s + e0 + 256 * u) : 0.f;
 #pragma unroll
         for (int u = 0; u < LG_UNROLL; ++u) {
             const int e = e0 + 256 * u;
@@ -391,28 +406,48 @@ extern "C" int unflow_bias_leaky_bwd2_nhwc_from(const float* act, long long act_
     return launch_bwd_nhwc(act, act_pstride, gout, gout_pstride, gout2, gout2_pstride, gin, gbias, partials, P, C, slope, stream);
 }
 
-extern "C" int unflow_cat_nhwc(const float* a, int Ca, const float* b, int Cb, const float* c, int Cc, float* out,
-                               int B, int HW, void* stream) {
+template <typename T>
+static int launch_cat_nhwc(const float* a, int Ca, const float* b, int Cb, const float* c, int Cc, T* out, int B, int HW, void* stream) {
     UNFLOW_REQUIRE(a && out && Ca > 0 && Cb >= 0 && Cc >= 0 && (Cb == 0 || b) && (Cc == 0 || c) && (Cb > 0 || Cc == 0) &&
                    B > 0 && B <= 65535 && HW > 0);
     const int C = Ca + Cb + Cc;
     const size_t shmem = (size_t)C * LG_LD * sizeof(float);
     UNFLOW_REQUIRE(shmem <= 160 * 1024);
     Planes3 src = {{a, b, c}, {Ca, Cb, Cc}};
-    if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)cat_nhwc_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    UNFLOW_LAUNCH(cat_nhwc_fwd_kernel, dim3(ceil_div(HW, LG_PIX), B), dim3(256), shmem, (hipStream_t)stream, src, out, HW, C);
+    if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)cat_nhwc_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    UNFLOW_LAUNCH(cat_nhwc_fwd_kernel<T>, dim3(ceil_div(HW, LG_PIX), B), dim3(256), shmem, (hipStream_t)stream, src, out, HW, C);
     return unflow_launch_status();
 }
 
-extern "C" int unflow_split_nhwc(const float* in, float* a, int Ca, float* b, int Cb, float* c, int Cc, int B, int HW, void* stream) {
+template <typename T>
+static int launch_split_nhwc(const T* in, float* a, int Ca, float* b, int Cb, float* c, int Cc, int B, int HW, void* stream) {
     UNFLOW_REQUIRE(in && Ca > 0 && Cb >= 0 && Cc >= 0 && (Cb > 0 || Cc == 0) && B > 0 && B <= 65535 && HW > 0);
     const int C = Ca + Cb + Cc;
     const size_t shmem = (size_t)C * LG_LD * sizeof(float);
     UNFLOW_REQUIRE(shmem <= 160 * 1024);
     PlanesOut3 dst = {{a, b, c}, {Ca, Cb, Cc}};
-    if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)split_nhwc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    UNFLOW_LAUNCH(split_nhwc_kernel, dim3(ceil_div(HW, LG_PIX), B), dim3(256), shmem, (hipStream_t)stream, in, dst, HW, C);
+    if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)split_nhwc_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    UNFLOW_LAUNCH(split_nhwc_kernel<T>, dim3(ceil_div(HW, LG_PIX), B), dim3(256), shmem, (hipStream_t)stream, in, dst, HW, C);
     return unflow_launch_status();
+}
+
+extern "C" int unflow_cat_nhwc(const float* a, int Ca, const float* b, int Cb, const float* c, int Cc, float* out,
+                               int B, int HW, void* stream) {
+    return launch_cat_nhwc<float>(a, Ca, b, Cb, c, Cc, out, B, HW, stream);
+}
+
+extern "C" int unflow_split_nhwc(const float* in, float* a, int Ca, float* b, int Cb, float* c, int Cc, int B, int HW, void* stream) {
+    return launch_split_nhwc<float>(in, a, Ca, b, Cb, c, Cc, B, HW, stream);
+}
+
+// bf16 conv-stack option: the NHWC side in bf16 (what the convolutions read and write under autocast), the NCHW planes fp32
+extern "C" int unflow_cat_nhwc_bf16(const float* a, int Ca, const float* b, int Cb, const float* c, int Cc, uint16_t* out,
+                                    int B, int HW, void* stream) {
+    return launch_cat_nhwc<unsigned short>(a, Ca, b, Cb, c, Cc, out, B, HW, stream);
+}
+
+extern "C" int unflow_split_nhwc_bf16(const uint16_t* in, float* a, int Ca, float* b, int Cb, float* c, int Cc, int B, int HW, void* stream) {
+    return launch_split_nhwc<unsigned short>(in, a, Ca, b, Cb, c, Cc, B, HW, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -754,78 +754,88 @@ def bias_leaky_relu_into(y, bias, negative_slope, buf_a, off_a, buf_b=None, off_
 
 
 class _CatChannelsLast(torch.autograd.Function):
-    """cat(tensors, 1) of up to three NCHW tensors, produced directly in channels_last order; backward hands each input
-    its NCHW gradient (one kernel each way)."""
+    """cat(tensors, 1) of up to three fp32 NCHW tensors, produced directly in channels_last order (fp32, or bf16 for the bf16
+    conv-stack option); backward hands each input its fp32 NCHW gradient (one kernel each way)."""
 
     @staticmethod
-    def forward(ctx, *ts):
+    def forward(ctx, half, *ts):
         dev = _dev(*ts)
         ts = [t.contiguous() for t in ts]
         B, _, H, W = ts[0].shape
         cs = [t.shape[1] for t in ts] + [0] * (3 - len(ts))
-        out = torch.empty((B, sum(cs), H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        out = torch.empty((B, sum(cs), H, W), dtype=torch.bfloat16 if half else torch.float32, device=dev, memory_format=torch.channels_last)
         ps = [_ptr(t) for t in ts] + [None] * (3 - len(ts))
         with _on(dev):
-            _call('unflow_cat_nhwc', ps[0], cs[0], ps[1], cs[1], ps[2], cs[2], _ptr(out), B, H * W, _stream(),
-                  nbytes=8 * out.numel(), shape=tuple(out.shape))
+            _call('unflow_cat_nhwc_bf16' if half else 'unflow_cat_nhwc', ps[0], cs[0], ps[1], cs[1], ps[2], cs[2], _ptr(out), B, H * W, _stream(),
+                  nbytes=(6 if half else 8) * out.numel(), shape=tuple(out.shape))
         ctx.cs = cs
         ctx.n = len(ts)
+        ctx.half = half
         return out
 
     @staticmethod
     def backward(ctx, g):
         B, C, H, W = g.shape
-        if not g.is_contiguous(memory_format=torch.channels_last):
-            g = g.contiguous(memory_format=torch.channels_last)
-        need = [ctx.needs_input_grad[k] for k in range(ctx.n)] + [False] * (3 - ctx.n)
+        want = torch.bfloat16 if ctx.half else torch.float32
+        if g.dtype != want or not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.to(want).contiguous(memory_format=torch.channels_last)
+        need = [ctx.needs_input_grad[k + 1] for k in range(ctx.n)] + [False] * (3 - ctx.n)
         outs = [torch.empty((B, ctx.cs[k], H, W), dtype=torch.float32, device=g.device) if need[k] else None for k in range(3)]
         if any(need):
             with _on(g.device):
-                _call('unflow_split_nhwc', _ptr(g), _ptr(outs[0]), ctx.cs[0], _ptr(outs[1]), ctx.cs[1], _ptr(outs[2]), ctx.cs[2],
-                      B, H * W, _stream(), nbytes=8 * g.numel(), shape=(B, C, H, W))
-        return tuple(outs[:ctx.n])
+                _call('unflow_split_nhwc_bf16' if ctx.half else 'unflow_split_nhwc', _ptr(g), _ptr(outs[0]), ctx.cs[0], _ptr(outs[1]), ctx.cs[1],
+                      _ptr(outs[2]), ctx.cs[2], B, H * W, _stream(), nbytes=(6 if ctx.half else 8) * g.numel(), shape=(B, C, H, W))
+        return (None,) + tuple(outs[:ctx.n])
 
 
 class _ToNCHW(torch.autograd.Function):
-    """A channels_last activation as a plain NCHW tensor (and its gradient back into channels_last)."""
+    """A channels_last activation (fp32 or bf16) as a plain fp32 NCHW tensor (and its gradient back into channels_last, in the
+    activation's dtype)."""
 
     @staticmethod
     def forward(ctx, x):
         B, C, H, W = x.shape
+        ctx.half = x.dtype == torch.bfloat16
         out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
         with _on(x.device):
-            _call('unflow_split_nhwc', _ptr(x), _ptr(out), C, None, 0, None, 0, B, H * W, _stream(),
-                  nbytes=8 * x.numel(), shape=(B, C, H, W))
+            _call('unflow_split_nhwc_bf16' if ctx.half else 'unflow_split_nhwc', _ptr(x), _ptr(out), C, None, 0, None, 0, B, H * W, _stream(),
+                  nbytes=(6 if ctx.half else 8) * x.numel(), shape=(B, C, H, W))
         return out
 
     @staticmethod
     def backward(ctx, g):
         B, C, H, W = g.shape
-        g = g.contiguous()
-        out = torch.empty((B, C, H, W), dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
+        g = g.float().contiguous()
+        out = torch.empty((B, C, H, W), dtype=torch.bfloat16 if ctx.half else torch.float32, device=g.device, memory_format=torch.channels_last)
         with _on(g.device):
-            _call('unflow_cat_nhwc', _ptr(g), C, None, 0, None, 0, _ptr(out), B, H * W, _stream(),
-                  nbytes=8 * g.numel(), shape=(B, C, H, W))
+            _call('unflow_cat_nhwc_bf16' if ctx.half else 'unflow_cat_nhwc', _ptr(g), C, None, 0, None, 0, _ptr(out), B, H * W, _stream(),
+                  nbytes=(6 if ctx.half else 8) * g.numel(), shape=(B, C, H, W))
         return out
 
 
-def cat_channels_last(tensors):
+def cat_channels_last(tensors, dtype=torch.float32):
     """``torch.cat(tensors, 1).contiguous(memory_format=torch.channels_last)`` for up to three fp32 NCHW tensors in ONE
-    pass (the decoder input of pwc_tf.py:113 at the border of the channels_last conv stack)."""
+    pass (the decoder input of pwc_tf.py:113 at the border of the channels_last conv stack).  ``dtype=torch.bfloat16``: the
+    result rounded to bf16 in the same pass (what autocast would make of it in front of a convolution)."""
     tensors = tuple(tensors)
     if not 1 <= len(tensors) <= 3:
         raise ValueError('cat_channels_last takes 1 to 3 tensors, got %d' % len(tensors))
     if any(t.dtype != torch.float32 or t.dim() != 4 or t.shape[0] != tensors[0].shape[0] or t.shape[2:] != tensors[0].shape[2:]
            for t in tensors):
         raise ValueError('cat_channels_last: fp32 [B, C_k, H, W] tensors with equal B, H, W expected')
-    return _CatChannelsLast.apply(*tensors)
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError('cat_channels_last: fp32 or bf16 output, got %s' % dtype)
+    return _CatChannelsLast.apply(dtype == torch.bfloat16, *tensors)
 
 
 def to_nchw(x):
-    """A dense channels_last fp32 activation as a contiguous NCHW tensor (one transposing kernel each way)."""
-    if x.dtype != torch.float32 or not _is_nhwc(x):
+    """A dense channels_last fp32 or bf16 activation as a contiguous fp32 NCHW tensor (one transposing kernel each way)."""
+    if x.dtype not in (torch.float32, torch.bfloat16) or not _is_nhwc(x):
         return x.contiguous()
-    _dev(x)
+    if x.dtype == torch.float32:
+        _dev(x)
+    elif not x.is_cuda:
+        raise RuntimeError('unopticalflow_amd ops run on an MI355X (HIP) device only; got a %s tensor. There is no CPU fallback.' % x.device)
     return _ToNCHW.apply(x)
 
 
