@@ -233,6 +233,19 @@ int unflow_bias_leaky_bwd2_nhwc_from_bf16(const uint16_t* act, long long act_pst
                                           const uint16_t* gout2, long long gout2_pstride, uint16_t* gin, float* gbias,
                                           float* partials, long long P, int C, float slope, void* stream);
 
+/* ---- loss bookkeeping (ABI 8).  Model_flow.forward sums every per-sample loss over the scales (`loss = 0; loss += term(scale)`,
+ * model_flow_paper.py:92-99,140-148,171-177,183-195) and adds the two directions (:226-233); train.py:147-150 weights the four batch
+ * means.  One launch each way per stage, same association of the fp32 additions.
+ *   terms   HOST array of 4 * n_scales device pointers, [loss][scale]; losses 0..2 (pixel, ssim, smooth) are [2B] vectors
+ *           (bwd half | fwd half), loss 3 (consis) is [B];  outs / gouts: HOST arrays of 4 device pointers, [B] each (a NULL
+ *           gradient pointer counts as zeros);  gin: 7 * B floats = [3][2B] then [B] -- the gradient of every scale's term of
+ *           a loss is the same vector.
+ *   unflow_weighted_mean_sum_*: loss = sum_k weights[k] * mean_b(terms[k][b]), K <= 8; weights is a HOST array. */
+int unflow_loss_combine_fwd(const float* const* terms, int n_scales, int B, float* const* outs, void* stream);
+int unflow_loss_combine_bwd(const float* const* gouts, int B, float* gin, void* stream);
+int unflow_weighted_mean_sum_fwd(const float* const* terms, const float* weights, int K, int B, float* loss, void* stream);
+int unflow_weighted_mean_sum_bwd(const float* gloss, const float* weights, int K, int B, float* const* grads, void* stream);
+
 /* ---- flow up-sampling of the decoder (ABI 8): out = mul * F.interpolate(x, bilinear, align_corners=False) for an integer
  * up-sampling factor per axis (Ho % Hi == 0, Wo % Wi == 0) -- pwc_tf.py:119,131,144,156 (factor 2, mul 2.0) and :174-177
  * (F.interpolate(flow * 4.0, size): the factor 4.0 commutes exactly).  x [planes,Hi,Wi] -> out [planes,Ho,Wo]; the backward is

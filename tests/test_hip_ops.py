@@ -760,6 +760,48 @@ def test_upsample_scaled_vs_torch(ops, shape, size, mul):
             ops.upsample_bilinear_scaled(xg, (size[0] + 1, size[1]), mul)
 
 
+@pytest.mark.parametrize('B,n', [(16, 3), (1, 1), (5, 4), (70, 2)])
+def test_loss_bookkeeping_vs_torch(ops, B, n):
+    """Model_flow.forward's sums over scales and directions (model_flow_paper.py:224-235) and the step's weighted batch means
+    (train.py:147-150) as one launch each way: the same fp32 additions in the same association -> the loss pack is bit-equal to
+    the eager form, and so are the gradients (each term's gradient is the loss gradient itself); the weighted mean to 1e-6
+    (the batch sum is a tree here, a loop in ATen)."""
+    terms = [[rnd(300 + 10 * k + s, (B if k == 3 else 2 * B,), uniform=True) for s in range(n)] for k in range(4)]
+    gout = [rnd(350 + k, (B,)) for k in range(4)]
+    ref_in = [[t.clone().requires_grad_(True) for t in ts] for ts in terms]
+    ref = []
+    for k in range(4):
+        acc = 0
+        for t in ref_in[k]:
+            acc = acc + t
+        ref.append(acc[B:] + acc[:B] if k < 3 else acc)
+    torch.autograd.backward(ref, gout)
+    dev_in = [[t.cuda().requires_grad_(True) for t in ts] for ts in terms]
+    out = ops.loss_combine(*dev_in)
+    torch.autograd.backward(list(out), [g.cuda() for g in gout])
+    for k in range(4):
+        assert out[k].shape == (B,) and torch.equal(out[k].cpu(), ref[k]), k
+        for a, b in zip(dev_in[k], ref_in[k]):
+            assert torch.equal(a.grad.cpu(), b.grad), k
+    only = [[t.cuda().requires_grad_(True) for t in ts] for ts in terms]             # a loss nobody differentiates: zero gradient
+    o = ops.loss_combine(*only)
+    (o[0].sum() + o[3].sum()).backward()
+    assert all(float(t.grad.abs().max()) == 0.0 for t in only[1] + only[2]) and torch.equal(only[0][0].grad.cpu(), torch.ones(2 * B))
+
+    w = [0.15, 0.85, 10.0, 0.01]
+    vr = [t.detach().clone().requires_grad_(True) for t in ref]
+    want = sum(wk * t.mean() for wk, t in zip(w, vr))
+    want.backward()
+    vd = [t.detach().cuda().requires_grad_(True) for t in ref]
+    got = ops.weighted_mean_sum(vd, w)
+    got.backward()
+    close(got, want, rtol=1e-6, atol=0)
+    for a, b in zip(vd, vr):
+        close(a.grad, b.grad, rtol=1e-6, atol=0)
+    with pytest.raises(ValueError):
+        ops.loss_combine(dev_in[0], dev_in[1], dev_in[2], dev_in[0])
+
+
 def test_kernel_exact_timing_slots(ops):
     """bench.py's roofline legs: a timed C call carries an event pair on its kernels (unflow_timing_begin /
     hipExtLaunchKernelGGL).  The slot's time is positive, not longer than a hipEventRecord bracket around the same call,

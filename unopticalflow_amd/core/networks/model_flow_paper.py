@@ -40,6 +40,7 @@ class Model_flow(nn.Module):
         self.channels_last = tuning.default_channels_last() if cl is None else bool(cl)
         # bf16 option: one multi-tensor cast of all convolution weights per pass (False: autocast's per-call casts; tests compare)
         self.weight_shadows = bool(getattr(cfg, 'weight_shadows', True))
+        self.fused_loss_sums = True      # the sums over scales and directions of forward() as one launch each way (False: eager adds; tests compare)
         self.fpyramid = FeaturePyramid(channels_last=self.channels_last)
         self.pwc_model = PWC_tf(align_corners=self.align_corners, fused_warp_corr=bool(getattr(cfg, 'fused_warp_corr', False)),
                                 channels_last=self.channels_last)
@@ -213,16 +214,19 @@ class Model_flow(nn.Module):
         # compute_diff_weight :224-225, compute_loss_with_mask x2 :226-227, compute_loss_ssim x2 :229-230,
         # compute_loss_flow_smooth x2 :232-233, compute_loss_flow_consis :235.  Sums over scales first, then fwd + bwd,
         # exactly the reference's association.
-        pixel = ssim = smooth = consis = 0
+        pixel, ssim, smooth, consis = [], [], [], []
         for s in range(n):
             diff, wgt = ops.occ_weight_stacked(img_pyramid[s], warped[s])       # (diff_bwd | diff_fwd), (weight_bwd | weight_fwd)
-            pixel = pixel + ops.masked_mean(diff, wgt)
-            ssim = ssim + ops.ssim_loss(img_pyramid[s], warped[s], wgt)
-            smooth = smooth + ops.smooth2_loss(flows_lr[s], img_pyramid[s])
-            consis = consis + ops.consis_loss(optical_flows_fwd[s], optical_flows_bwd[s], wgt[B:])
-        loss_pack['loss_pixel'] = pixel[B:] + pixel[:B]                         # fwd + bwd (:226-227)
-        loss_pack['loss_ssim'] = ssim[B:] + ssim[:B]
-        loss_pack['loss_flow_smooth'] = smooth[B:] + smooth[:B]
-        loss_pack['loss_flow_consis'] = consis
+            pixel.append(ops.masked_mean(diff, wgt))
+            ssim.append(ops.ssim_loss(img_pyramid[s], warped[s], wgt))
+            smooth.append(ops.smooth2_loss(flows_lr[s], img_pyramid[s]))
+            consis.append(ops.consis_loss(optical_flows_fwd[s], optical_flows_bwd[s], wgt[B:]))
+        if self.fused_loss_sums and n <= 4:
+            # `loss = 0; loss += term(scale)` per loss, then fwd + bwd (:226-233), as one launch each way (ops.loss_combine)
+            packed = ops.loss_combine(pixel, ssim, smooth, consis)
+        else:
+            packed = [sum(t[1:], t[0]) for t in (pixel, ssim, smooth, consis)]
+            packed = [t[B:] + t[:B] for t in packed[:3]] + packed[3:]           # fwd + bwd (:226-227)
+        loss_pack['loss_pixel'], loss_pack['loss_ssim'], loss_pack['loss_flow_smooth'], loss_pack['loss_flow_consis'] = packed
 
         return loss_pack

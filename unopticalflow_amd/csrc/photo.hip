@@ -346,6 +346,65 @@ __global__ void consis_bwd_kernel(const float* __restrict__ ff, const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Loss bookkeeping of Model_flow.forward (model_flow_paper.py:224-235) and of the step (train.py:147-150).  Every term is a
+// [B]- or [2B]-vector per scale; summing them over scales, adding the two directions and weighting the four batch means are
+// ~50 launches of 4-5 us in eager ops (adds, slices and their zero-fill + copy + add backward, means, scalar multiplies).
+// Here: one launch each way for each of the two stages, same association of the fp32 additions as the reference.
+// ---------------------------------------------------------------------------------------------
+constexpr int LOSS_MAX_SCALES = 4;
+struct LossTerms { const float* t[4][LOSS_MAX_SCALES]; };     // [pixel, ssim, smooth: (bwd | fwd) [2B]; consis: [B]][scale]
+struct LossOuts { float* o[4]; };
+struct LossGrads { const float* g[4]; };
+
+__global__ void loss_combine_fwd_kernel(LossTerms in, LossOuts out, int n, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float bwd = 0.f, fwd = 0.f;                     // loss = 0; loss = loss + term(scale) (:92-99 ...): 0 + x is exact
+        for (int s = 0; s < n; ++s) { bwd += in.t[k][s][b]; fwd += in.t[k][s][B + b]; }
+        out.o[k][b] = fwd + bwd;                        // loss_with_mask(fwd) + loss_with_mask(bwd) (:226-233)
+    }
+    float c = 0.f;
+    for (int s = 0; s < n; ++s) c += in.t[3][s][b];
+    out.o[3][b] = c;
+}
+
+// d(out_k[b]) / d(term_k[s][b]) = d / d(term_k[s][B + b]) = 1 for every scale: one (bwd | fwd) gradient vector per loss serves all scales
+__global__ void loss_combine_bwd_kernel(LossGrads g, float* __restrict__ gin, int B) {      // gin: [3][2B] then [B]
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v = g.g[k] ? g.g[k][b] : 0.f;
+        gin[k * 2 * B + b] = v;
+        gin[k * 2 * B + B + b] = v;
+    }
+    gin[6 * B + b] = g.g[3] ? g.g[3][b] : 0.f;
+}
+
+struct MeanTerms { const float* t[8]; float w[8]; };
+struct MeanGrads { float* g[8]; float w[8]; };
+
+// loss = sum_k w_k * mean_b(t_k[b]) (train.py:147-150), keys in order; one workgroup, lanes along the batch
+__global__ __launch_bounds__(256) void weighted_mean_sum_fwd_kernel(MeanTerms in, int K, int B, float* __restrict__ loss) {
+    __shared__ float red[4];
+    float total = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float s = sum_partials(in.t[k], B, 1, 0, red);
+        total += in.w[k] * (s / (float)B);
+    }
+    if (threadIdx.x == 0) *loss = total;
+}
+
+__global__ void weighted_mean_sum_bwd_kernel(MeanGrads out, int K, int B, const float* __restrict__ gloss) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float g = *gloss / (float)B;
+    for (int k = 0; k < K; ++k) out.g[k][b] = out.w[k] * g;
+}
+
 inline int flat_blocks(size_t n) {
     size_t b = (n + 255) / 256;
     return (int)(b < 8192 ? (b ? b : 1) : 8192);
@@ -355,7 +414,7 @@ inline int flat_blocks(size_t n) {
 
 int unflow_ssim_blocks(int H, int W);   // ssim.hip
 
-extern "C" int unflow_abi_version(void) { return 8; }   // 2: + unflow_warp_corr_*; 3: img_batch on the 2B loss entries; 4: + *_nhwc epilogues; 5: + unflow_timing_*; 6: + *_nhwc_bf16 epilogues; 7: + *_nhwc_to / *_nhwc_from (epilogues that fill cat buffers), unflow_warp_bwd_det; 8: + unflow_upsample_scaled_*
+extern "C" int unflow_abi_version(void) { return 8; }   // 2: + unflow_warp_corr_*; 3: img_batch on the 2B loss entries; 4: + *_nhwc epilogues; 5: + unflow_timing_*; 6: + *_nhwc_bf16 epilogues; 7: + *_nhwc_to / *_nhwc_from (epilogues that fill cat buffers), unflow_warp_bwd_det; 8: + unflow_upsample_scaled_*, *_nhwc_bf16 glue, unflow_loss_combine_*, unflow_weighted_mean_sum_*
 
 // ---- kernel-exact timing slots (see UNFLOW_LAUNCH in common.h) ----
 #include <mutex>
@@ -422,6 +481,47 @@ extern "C" int unflow_timing_reset(void) {
     std::lock_guard<std::mutex> lock(g_timing_mutex);
     g_timing_next = 0;                               // slot ids start over; the event pairs are kept for re-use
     return 0;
+}
+
+// terms: HOST array of 4 * n_scales device pointers, [loss][scale]: pixel, ssim, smooth ([2B] each: bwd half | fwd half), consis ([B]);
+// outs: HOST array of 4 device pointers, [B] each
+extern "C" int unflow_loss_combine_fwd(const float* const* terms, int n_scales, int B, float* const* outs, void* stream) {
+    UNFLOW_REQUIRE(terms && outs && n_scales > 0 && n_scales <= LOSS_MAX_SCALES && B > 0);
+    LossTerms in = {};
+    LossOuts out;
+    for (int k = 0; k < 4; ++k) {
+        UNFLOW_REQUIRE(outs[k]);
+        out.o[k] = outs[k];
+        for (int s = 0; s < n_scales; ++s) { UNFLOW_REQUIRE(terms[k * n_scales + s]); in.t[k][s] = terms[k * n_scales + s]; }
+    }
+    UNFLOW_LAUNCH(loss_combine_fwd_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, in, out, n_scales, B);
+    return unflow_launch_status();
+}
+
+// gouts: HOST array of 4 device pointers ([B] each; NULL = no gradient for that loss); gin: [3][2B] followed by [B] (7 * B floats)
+extern "C" int unflow_loss_combine_bwd(const float* const* gouts, int B, float* gin, void* stream) {
+    UNFLOW_REQUIRE(gouts && gin && B > 0);
+    LossGrads g;
+    for (int k = 0; k < 4; ++k) g.g[k] = gouts[k];
+    UNFLOW_LAUNCH(loss_combine_bwd_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, g, gin, B);
+    return unflow_launch_status();
+}
+
+// terms / grads: HOST arrays of K device pointers ([B] each), weights: HOST array of K floats; loss, gloss: one device float
+extern "C" int unflow_weighted_mean_sum_fwd(const float* const* terms, const float* weights, int K, int B, float* loss, void* stream) {
+    UNFLOW_REQUIRE(terms && weights && loss && K > 0 && K <= 8 && B > 0);
+    MeanTerms in = {};
+    for (int k = 0; k < K; ++k) { UNFLOW_REQUIRE(terms[k]); in.t[k] = terms[k]; in.w[k] = weights[k]; }
+    UNFLOW_LAUNCH(weighted_mean_sum_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in, K, B, loss);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_weighted_mean_sum_bwd(const float* gloss, const float* weights, int K, int B, float* const* grads, void* stream) {
+    UNFLOW_REQUIRE(gloss && weights && grads && K > 0 && K <= 8 && B > 0);
+    MeanGrads out = {};
+    for (int k = 0; k < K; ++k) { UNFLOW_REQUIRE(grads[k]); out.g[k] = grads[k]; out.w[k] = weights[k]; }
+    UNFLOW_LAUNCH(weighted_mean_sum_bwd_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, out, K, B, gloss);
+    return unflow_launch_status();
 }
 
 extern "C" int unflow_partials_per_sample(int H, int W) {

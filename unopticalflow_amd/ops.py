@@ -14,7 +14,7 @@ import torch
 from . import _lib
 
 __all__ = ['corr', 'warp_flow', 'warp_flow_masked', 'warp_corr', 'occ_weight', 'occ_weight_stacked', 'masked_mean', 'ssim_loss',
-           'ssim_map', 'smooth2_loss', 'consis_loss', 'bias_leaky_relu_', 'bias_leaky_relu_into', 'upsample_bilinear_scaled', 'img_pyramid']
+           'ssim_map', 'smooth2_loss', 'consis_loss', 'bias_leaky_relu_', 'bias_leaky_relu_into', 'upsample_bilinear_scaled', 'loss_combine', 'weighted_mean_sum', 'img_pyramid']
 
 
 def _ptr(t):
@@ -520,6 +520,83 @@ class _Consis(torch.autograd.Function):
 def consis_loss(fwd_flow, bwd_flow, w_fwd):
     """One scale of compute_loss_flow_consis (model_flow_paper.py:183-193) -> [B]; grad to fwd_flow."""
     return _Consis.apply(fwd_flow, bwd_flow.detach(), w_fwd.detach())
+
+
+def _ptr_array(tensors):
+    """A host array of device pointers (NULL for None) for the entry points that take a list of vectors."""
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+class _LossCombine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, n, B, *terms):
+        dev = _dev(*terms)
+        terms = [t.contiguous() for t in terms]
+        outs = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(4)]
+        with _on(dev):
+            _call('unflow_loss_combine_fwd', _ptr_array(terms), n, B, _ptr_array(outs), _stream())
+        ctx.meta = (n, B)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n, B = ctx.meta
+        dev = next(g.device for g in gs if g is not None)
+        gs = [None if g is None else g.float().contiguous() for g in gs]
+        gin = torch.empty(7 * B, dtype=torch.float32, device=dev)
+        with _on(dev):
+            _call('unflow_loss_combine_bwd', _ptr_array(gs), B, _ptr(gin), _stream())
+        per_loss = [gin[2 * B * k:2 * B * (k + 1)] for k in range(3)] + [gin[6 * B:]]
+        return (None, None) + tuple(per_loss[k] for k in range(4) for _ in range(n))      # the same vector for every scale of a loss
+
+
+def loss_combine(pixel, ssim, smooth, consis):
+    """The loss bookkeeping of Model_flow.forward (model_flow_paper.py:224-235) in one launch each way: ``pixel``, ``ssim``,
+    ``smooth`` are lists over scales of [2B] vectors (bwd half | fwd half), ``consis`` a list of [B] vectors; returns the four
+    [B] tensors of the loss pack -- per loss the terms summed over the scales (in order, from 0), then fwd + bwd."""
+    n = len(pixel)
+    if not (n == len(ssim) == len(smooth) == len(consis)) or not 1 <= n <= 4:
+        raise ValueError('loss_combine: one term per scale and loss, 1 to 4 scales')
+    B = consis[0].shape[0]
+    for t in list(pixel) + list(ssim) + list(smooth):
+        if t.shape != (2 * B,):
+            raise ValueError('loss_combine: [2B] vectors expected, got %s for B = %d' % (tuple(t.shape), B))
+    for t in consis:
+        if t.shape != (B,):
+            raise ValueError('loss_combine: [B] consistency terms expected, got %s' % (tuple(t.shape),))
+    return _LossCombine.apply(n, B, *pixel, *ssim, *smooth, *consis)
+
+
+class _WeightedMeanSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        dev = _dev(*terms)
+        terms = [t.contiguous() for t in terms]
+        K, B = len(terms), terms[0].shape[0]
+        w = (ctypes.c_float * K)(*weights)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        with _on(dev):
+            _call('unflow_weighted_mean_sum_fwd', _ptr_array(terms), w, K, B, _ptr(loss), _stream())
+        ctx.meta = (tuple(weights), K, B)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        weights, K, B = ctx.meta
+        g = g.float().contiguous()
+        grads = [torch.empty(B, dtype=torch.float32, device=g.device) for _ in range(K)]
+        with _on(g.device):
+            _call('unflow_weighted_mean_sum_bwd', _ptr(g), (ctypes.c_float * K)(*weights), K, B, _ptr_array(grads), _stream())
+        return (None,) + tuple(grads)
+
+
+def weighted_mean_sum(terms, weights):
+    """``sum_k weights[k] * terms[k].mean()`` (train.py:147-150) for up to 8 [B] vectors in one launch each way."""
+    terms = list(terms)
+    weights = [float(w) for w in weights]
+    if not 1 <= len(terms) <= 8 or len(weights) != len(terms) or any(t.dim() != 1 or t.shape != terms[0].shape for t in terms):
+        raise ValueError('weighted_mean_sum: 1 to 8 vectors of one length, one weight each')
+    return _WeightedMeanSum.apply(weights, *terms)
 
 
 # ------------------------------------------------------------------------------------------
