@@ -233,6 +233,17 @@ int unflow_bias_leaky_bwd2_nhwc_from_bf16(const uint16_t* act, long long act_pst
                                           const uint16_t* gout2, long long gout2_pstride, uint16_t* gin, float* gbias,
                                           float* partials, long long P, int C, float slope, void* stream);
 
+/* ---- flow heads (ABI 8): predict_flow (pwc_tf.py:93-94, Conv2d(c, 2, 3, bias=True), no activation) and the residual that follows
+ * it (`flow = predict_flow(x) + up_flow`, :130,143,155,167; `flow2 + dc_conv7(x)`, :171) at the border of the channels_last conv
+ * stack.  y [N*HW][2]: the bias-free convolution output (NHWC; fp32, or bf16 as raw uint16_t); res (may be NULL), out, g: fp32
+ * NCHW [N][2][HW];  out = y + bias (+ res).  Backward: gy = g re-laid out (rounded once for bf16), gbias[2] = sum g (fixed
+ * summation order); the residual's gradient is g itself.  partials: unflow_flow_head_partials() floats of scratch. */
+int unflow_flow_head_partials(void);
+int unflow_flow_head_fwd(const float* y, const float* bias, const float* res, float* out, int N, int HW, void* stream);
+int unflow_flow_head_fwd_bf16(const uint16_t* y, const float* bias, const float* res, float* out, int N, int HW, void* stream);
+int unflow_flow_head_bwd(const float* g, float* gy, float* gbias, float* partials, int N, int HW, void* stream);
+int unflow_flow_head_bwd_bf16(const float* g, uint16_t* gy, float* gbias, float* partials, int N, int HW, void* stream);
+
 /* ---- loss bookkeeping (ABI 8).  Model_flow.forward sums every per-sample loss over the scales (`loss = 0; loss += term(scale)`,
  * model_flow_paper.py:92-99,140-148,171-177,183-195) and adds the two directions (:226-233); train.py:147-150 weights the four batch
  * means.  One launch each way per stage, same association of the fp32 additions.

@@ -162,6 +162,9 @@ def test_filled_cat_buffers_equal_the_cat_form(prec):
         model = get_model('flow')(cfg).cuda()
         model.load_state_dict(R.seeded_state_dict(model, 1234, 0.25))
         model.pwc_model.fill_cat_buffers = fill
+        # (False: conv(bias).float().contiguous() + up, pwc_tf.py:93-94,130, instead of ops.flow_head -- the same fp32 additions; under
+        # bf16 autocast ATen adds the bias in bf16, another arithmetic than the fused head's fp32 add, so it is not toggled there)
+        model.pwc_model.fused_head = fill or prec == 'bf16'
         model.pwc_model.fused_upsample = fill            # (False: F.interpolate + multiply, pwc_tf.py:119-177, instead of unflow_upsample_scaled_*)
         w = generate_loss_weights_dict(cfg)
         pack = model(x)

@@ -760,6 +760,40 @@ def test_upsample_scaled_vs_torch(ops, shape, size, mul):
             ops.upsample_bilinear_scaled(xg, (size[0] + 1, size[1]), mul)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('shape,with_res', [((32, 2, 64, 208), True), ((32, 2, 4, 13), False), ((3, 2, 7, 9), True), ((1, 2, 1, 1), True),
+                                            ((2, 2, 300, 700), True)])
+def test_flow_head_vs_torch(ops, shape, with_res, dtype):
+    """predict_flow's bias, the NHWC -> NCHW hand-off and the residual (pwc_tf.py:93-94,130,171) in one pass: the same fp32
+    additions in the same order as conv(bias) ... .float().contiguous() + up, so bit-equal; backward: the gradient re-laid out
+    (rounded once for a bf16 stack), the bias gradient (1e-5: a tree sum here), the residual's gradient = the gradient."""
+    CL = torch.channels_last
+    y = rnd(400, shape, 2.0).to(dtype)
+    bias = rnd(401, (2,), 0.5)
+    res = rnd(402, shape) if with_res else None
+    g = rnd(403, shape)
+    ref = y.float() + bias.view(1, 2, 1, 1)
+    if with_res:
+        ref = ref + res
+    yd = y.cuda().contiguous(memory_format=CL).requires_grad_(True)
+    bd = bias.cuda().requires_grad_(True)
+    rd = res.cuda().requires_grad_(True) if with_res else None
+    out = ops.flow_head(yd, bd, rd)
+    assert out.dtype == torch.float32 and out.is_contiguous() and torch.equal(out.cpu(), ref)
+    out.backward(g.cuda())
+    assert yd.grad.dtype == dtype and torch.equal(yd.grad.cpu(), g.to(dtype))
+    want = g.sum((0, 2, 3))
+    close(bd.grad, want, rtol=1e-5, atol=1e-5 * g.abs().sum().item() / 2)
+    if with_res:
+        assert torch.equal(rd.grad.cpu(), g)
+    first = bd.grad.clone()
+    bd.grad = None
+    ops.flow_head(yd, bd, rd).backward(g.cuda())
+    assert torch.equal(first, bd.grad)                          # fixed summation order
+    with pytest.raises(ValueError):
+        ops.flow_head(torch.zeros(1, 3, 4, 4, device='cuda'), bd)
+
+
 @pytest.mark.parametrize('B,n', [(16, 3), (1, 1), (5, 4), (70, 2)])
 def test_loss_bookkeeping_vs_torch(ops, B, n):
     """Model_flow.forward's sums over scales and directions (model_flow_paper.py:224-235) and the step's weighted batch means

@@ -27,6 +27,7 @@ class PWC_tf(nn.Module):
         # channels_last only: the decoder's cat((x_k, x_k+1)) inputs are filled by the producing convolutions' epilogues
         # (_decoder_filled) instead of being copied together by torch.cat; False keeps the cat form (tests compare the two)
         self.fill_cat_buffers = True
+        self.fused_head = True            # flow heads: bias + NHWC -> NCHW + residual as one kernel each way (ops.flow_head)
         self.fused_upsample = True        # flow up-sampling + its scale factor as one kernel each way (ops.upsample_bilinear_scaled)
         self.corr = self.corr_naive
         # True: warp + cost volume of a level as ONE kernel (ops.warp_corr; the warped features never reach HBM).
@@ -71,6 +72,15 @@ class PWC_tf(nn.Module):
             return ops.upsample_bilinear_scaled(flow, size, mul)
         return F.interpolate(flow * mul, list(size), mode='bilinear') if mul == 4.0 else F.interpolate(flow, list(size), mode='bilinear') * mul
 
+    def _head(self, m, x, residual=None):
+        """``predict_flow(x) [+ residual]`` (pwc_tf.py:118,130,143,155,167,171) as the fp32 NCHW flow.  On a channels_last stack: the
+        bias-free contraction, then bias, re-layout and residual in ONE pass (ops.flow_head) instead of ATen's bias add, copy and add."""
+        if self.fused_head and self._cl(x):
+            y = F.conv2d(x, conv_weight(m), None, m.stride, m.padding, m.dilation, m.groups)
+            return ops.flow_head(y, m.bias, residual)
+        flow = m(x).float().contiguous()
+        return flow if residual is None else flow + residual
+
     def predict_flow(self, in_planes):
         return HeadConv2d(in_planes, 2, kernel_size=3, stride=1, padding=1, bias=True)
 
@@ -82,7 +92,7 @@ class PWC_tf(nn.Module):
         bf16 features of an autocast run are widened first)."""
         return ops.corr(input1.float(), input2.float(), d)
 
-    def _decoder(self, lvl, x):
+    def _decoder(self, lvl, x, residual=None):
         """``x``: the tuple of tensors the reference concatenates into the decoder input.
         reference pwc_tf.py:113-118 (and the same six lines per level).  Every activation feeds two
         consumers; it is taken as two handles (ConvLeaky(consumers=2)) so the gradients are summed inside
@@ -90,7 +100,7 @@ class PWC_tf(nn.Module):
         c = [getattr(self, 'conv%d_%d' % (lvl, k)) for k in range(5)]
         x = self._cat(x)
         if self._cl(x) and self.fill_cat_buffers:
-            return self._decoder_filled(lvl, c, x)
+            return self._decoder_filled(lvl, c, x, residual)
         x0, x0b = c[0](x, 2)
         x1, x1b = c[1](x0, 2)
         x2, x2b = c[2](torch.cat((x0b, x1), 1), 2)
@@ -99,9 +109,9 @@ class PWC_tf(nn.Module):
             x4, x4b = c[4](torch.cat((x2b, x3), 1), 2)
         else:
             x4 = x4b = c[4](torch.cat((x2b, x3), 1))
-        return getattr(self, 'predict_flow%d' % lvl)(torch.cat((x3b, x4), 1)).float().contiguous(), x4b
+        return self._head(getattr(self, 'predict_flow%d' % lvl), torch.cat((x3b, x4), 1), residual), x4b
 
-    def _decoder_filled(self, lvl, c, x):
+    def _decoder_filled(self, lvl, c, x, residual=None):
         """The same five convolutions on channels_last tensors without a single torch.cat: every conv input
         cat((x_k, x_k+1)) (pwc_tf.py:114-118) is ONE buffer whose two channel ranges are written by the epilogues of the
         convolutions that produce x_k and x_k+1 (ops.bias_leaky_relu_into); an activation is written to the (at most two)
@@ -123,7 +133,7 @@ class PWC_tf(nn.Module):
         _, b23, b34 = ops.bias_leaky_relu_into(y, b, sl, b23, d2, buf(y, d3 + d4), 0)            # x3 -> cat(x2, x3), cat(x3, x4)
         y, b, sl = raw(c[4], b23)
         x4, b34, _ = ops.bias_leaky_relu_into(y, b, sl, b34, d3, inplace=(lvl == 2))             # x4 (level 2: also the context network's input)
-        return getattr(self, 'predict_flow%d' % lvl)(b34).float().contiguous(), x4
+        return self._head(getattr(self, 'predict_flow%d' % lvl), b34, residual), x4
 
     def forward(self, feature_list_1, feature_list_2, img_hw):
         f1 = dict(zip(range(1, 7), feature_list_1))
@@ -136,12 +146,11 @@ class PWC_tf(nn.Module):
                 cv = ops.warp_corr(f1[lvl].float(), f2[lvl].float(), up.float(), 4, self.align_corners)
             else:
                 cv = self.corr(f1[lvl], self.warp(f2[lvl], up))
-            flow, x4 = self._decoder(lvl, (cv, f1[lvl], up))
-            flow = flow + up
+            flow, x4 = self._decoder(lvl, (cv, f1[lvl], up), up)             # flow = predict_flow(x) + up_flow (pwc_tf.py:130,143,155,167)
             level_flow[lvl] = flow
         fl2 = level_flow[2].contiguous(memory_format=CL) if self._cl(x4) else level_flow[2]
         x = self.dc_conv4(self.dc_conv3(self.dc_conv2(self.dc_conv1(torch.cat([fl2, x4], 1)))))
-        level_flow[2] = level_flow[2] + self.dc_conv7(self.dc_conv6(self.dc_conv5(x))).float().contiguous()
+        level_flow[2] = self._head(self.dc_conv7, self.dc_conv6(self.dc_conv5(x)), level_flow[2])      # flow2 + dc_conv7(...) (pwc_tf.py:171)
         img_h, img_w = img_hw[0], img_hw[1]
         # F.interpolate(flow * 4.0, size, 'bilinear') (pwc_tf.py:174-177): the factor 4.0 commutes with the interpolation exactly
         return [self._up(level_flow[lvl], (img_h // (1 << k), img_w // (1 << k)), 4.0) for k, lvl in enumerate((2, 3, 4, 5))]

@@ -514,6 +514,50 @@ __global__ __launch_bounds__(256) void upsample_scaled_bwd_kernel(const float* _
     }
 }
 
+// Up-sampling factor F = 2 or 4 on both axes (every call of the decoder): the taps of an input pixel are the 2F x 2F outputs
+// oy = F y - F/2 + i, ox = F x - F/2 + j with the closed-form weights  w(i) = (i + 0.5) / F  for i < F (the pixel is the lower /
+// right tap i1 of those outputs)  and  1 - (i - F + 0.5) / F  for i >= F (it is their tap i0) -- exact in fp32 for a power of two,
+// the values up_src() computes.  At the borders both taps of an output fall on the same pixel (src clamped to 0 / i1 clamped to
+// in - 1) and the weight is l0 + l1 = 1.  No per-candidate source arithmetic: 2F x 2F loads and FMAs per input pixel.
+template <int F>
+__device__ __forceinline__ void up_tap_weights(int v, int n_in, float (&w)[2 * F], int (&o)[2 * F]) {
+    const int n_out = F * n_in;
+#pragma unroll
+    for (int i = 0; i < 2 * F; ++i) {
+        const int q = F * v - F / 2 + i;
+        float t = i < F ? ((float)i + 0.5f) / (float)F : 1.0f - ((float)(i - F) + 0.5f) / (float)F;
+        if ((v == 0 && i < F) || (v == n_in - 1 && i >= F)) t = 1.0f;
+        const bool in = q >= 0 && q < n_out;
+        w[i] = in ? t : 0.f;
+        o[i] = in ? q : 0;
+    }
+}
+
+template <int F>
+__global__ __launch_bounds__(256) void upsample_scaled_bwd_pow2_kernel(const float* __restrict__ g, float* __restrict__ gin,
+                                                                       int Hi, int Wi, float mul) {
+    const int p = blockIdx.y, Wo = F * Wi;
+    const float* gp = g + (size_t)p * (F * Hi) * Wo;
+    float* ip = gin + (size_t)p * Hi * Wi;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < Hi * Wi; t += gridDim.x * 256) {
+        const int y = t / Wi, x = t - y * Wi;
+        float wy[2 * F], wx[2 * F];
+        int oy[2 * F], ox[2 * F];
+        up_tap_weights<F>(y, Hi, wy, oy);
+        up_tap_weights<F>(x, Wi, wx, ox);
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2 * F; ++i) {
+            const float* row = gp + (size_t)oy[i] * Wo;
+            float r = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2 * F; ++j) r = fmaf(wx[j], row[ox[j]], r);
+            acc = fmaf(wy[i], r, acc);
+        }
+        ip[t] = acc * mul;
+    }
+}
+
 static int upsample_args_ok(const void* a, const void* b, int planes, int Hi, int Wi, int Ho, int Wo) {
     return a && b && planes > 0 && planes <= 65535 && Hi > 0 && Wi > 0 && Ho >= Hi && Wo >= Wi && Ho % Hi == 0 && Wo % Wi == 0;
 }
@@ -529,9 +573,103 @@ extern "C" int unflow_upsample_scaled_fwd(const float* x, float* out, int planes
 extern "C" int unflow_upsample_scaled_bwd(const float* gout, float* gin, int planes, int Hi, int Wi, int Ho, int Wo, float mul, void* stream) {
     UNFLOW_REQUIRE(upsample_args_ok(gout, gin, planes, Hi, Wi, Ho, Wo));
     const int blocks = ceil_div(Hi * Wi, 256) < 1024 ? ceil_div(Hi * Wi, 256) : 1024;
+    if (Ho == 2 * Hi && Wo == 2 * Wi) {
+        UNFLOW_LAUNCH(upsample_scaled_bwd_pow2_kernel<2>, dim3(blocks, planes), dim3(256), 0, (hipStream_t)stream, gout, gin, Hi, Wi, mul);
+        return unflow_launch_status();
+    }
+    if (Ho == 4 * Hi && Wo == 4 * Wi) {
+        UNFLOW_LAUNCH(upsample_scaled_bwd_pow2_kernel<4>, dim3(blocks, planes), dim3(256), 0, (hipStream_t)stream, gout, gin, Hi, Wi, mul);
+        return unflow_launch_status();
+    }
     UNFLOW_LAUNCH(upsample_scaled_bwd_kernel, dim3(blocks, planes), dim3(256), 0, (hipStream_t)stream, gout, gin, Hi, Wi, Ho, Wo,
                        (float)Hi / (float)Ho, (float)Wi / (float)Wo, mul, Ho / Hi, Wo / Wi);
     return unflow_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// The flow heads (pwc_tf.py:93-94 predict_flow: Conv2d(c, 2, 3, bias=True), no activation; :118,130,143,155,167,171
+// `flow = predict_flow(x) [+ up_flow]`) at the border of the channels_last conv stack: the bias-free convolution output y
+// [P][2] (NHWC, fp32 or bf16) becomes the fp32 NCHW flow  out[b][c][hw] = y[p][c] + bias[c] (+ res[b][c][hw])  in one pass --
+// instead of ATen's bias add, re-layout copy and residual add -- and the way back  gy[p][c] = g[b][c][hw],
+// gbias[c] = sum g  (partials[block][2], rows summed in a fixed order) replaces a re-layout copy and a 10 us reduction.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void flow_head_fwd_kernel(const T* __restrict__ y, const float* __restrict__ bias,
+                                                            const float* __restrict__ res, float* __restrict__ out, int HW, long long P) {
+    const float b0 = bias[0], b1 = bias[1];
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long long)gridDim.x * 256) {
+        const long long n = p / HW;
+        const int hw = (int)(p - n * HW);
+        float v0 = nhwc_load(y + 2 * p) + b0, v1 = nhwc_load(y + 2 * p + 1) + b1;
+        const size_t o = (size_t)n * 2 * HW + hw;
+        if (res) { v0 += res[o]; v1 += res[o + HW]; }
+        out[o] = v0;
+        out[o + HW] = v1;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void flow_head_bwd_kernel(const float* __restrict__ g, T* __restrict__ gy, float* __restrict__ partials,
+                                                            int HW, long long P) {
+    __shared__ float red[2][4];
+    float s0 = 0.f, s1 = 0.f;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long long)gridDim.x * 256) {
+        const long long n = p / HW;
+        const int hw = (int)(p - n * HW);
+        const size_t o = (size_t)n * 2 * HW + hw;
+        const float g0 = g[o], g1 = g[o + HW];
+        nhwc_store(gy + 2 * p, g0);
+        nhwc_store(gy + 2 * p + 1, g1);
+        s0 += g0; s1 += g1;
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wid] = s0; red[1][wid] = s1; }
+    __syncthreads();
+    if (threadIdx.x < 2) partials[blockIdx.x * 2 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+__global__ __launch_bounds__(256) void flow_head_bias_finalize_kernel(const float* __restrict__ partials, int nblk, float* __restrict__ gbias) {
+    __shared__ float red[4];
+    const float s0 = sum_partials(partials, nblk, 2, 0, red);
+    const float s1 = sum_partials(partials, nblk, 2, 1, red);
+    if (threadIdx.x == 0) { gbias[0] = s0; gbias[1] = s1; }
+}
+
+constexpr int FLOW_HEAD_MAX_BLOCKS = 512;
+
+template <typename T>
+static int launch_flow_head_fwd(const T* y, const float* bias, const float* res, float* out, int N, int HW, void* stream) {
+    UNFLOW_REQUIRE(y && bias && out && N > 0 && HW > 0);
+    const long long P = (long long)N * HW;
+    const int blocks = (int)((P + 255) / 256 < 2048 ? (P + 255) / 256 : 2048);
+    UNFLOW_LAUNCH(flow_head_fwd_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, bias, res, out, HW, P);
+    return unflow_launch_status();
+}
+
+template <typename T>
+static int launch_flow_head_bwd(const float* g, T* gy, float* gbias, float* partials, int N, int HW, void* stream) {
+    UNFLOW_REQUIRE(g && gy && gbias && partials && N > 0 && HW > 0);
+    const long long P = (long long)N * HW;
+    const int blocks = (int)((P + 255) / 256 < FLOW_HEAD_MAX_BLOCKS ? (P + 255) / 256 : FLOW_HEAD_MAX_BLOCKS);
+    UNFLOW_LAUNCH(flow_head_bwd_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, gy, partials, HW, P);
+    UNFLOW_LAUNCH(flow_head_bias_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, blocks, gbias);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_flow_head_partials(void) { return 2 * FLOW_HEAD_MAX_BLOCKS; }
+
+extern "C" int unflow_flow_head_fwd(const float* y, const float* bias, const float* res, float* out, int N, int HW, void* stream) {
+    return launch_flow_head_fwd<float>(y, bias, res, out, N, HW, stream);
+}
+extern "C" int unflow_flow_head_fwd_bf16(const uint16_t* y, const float* bias, const float* res, float* out, int N, int HW, void* stream) {
+    return launch_flow_head_fwd<unsigned short>(y, bias, res, out, N, HW, stream);
+}
+extern "C" int unflow_flow_head_bwd(const float* g, float* gy, float* gbias, float* partials, int N, int HW, void* stream) {
+    return launch_flow_head_bwd<float>(g, gy, gbias, partials, N, HW, stream);
+}
+extern "C" int unflow_flow_head_bwd_bf16(const float* g, uint16_t* gy, float* gbias, float* partials, int N, int HW, void* stream) {
+    return launch_flow_head_bwd<unsigned short>(g, gy, gbias, partials, N, HW, stream);
 }
 
 extern "C" int unflow_img_pyramid(const float* img, float* half, float* quarter, int planes, int H, int W,

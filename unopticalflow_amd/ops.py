@@ -14,7 +14,7 @@ import torch
 from . import _lib
 
 __all__ = ['corr', 'warp_flow', 'warp_flow_masked', 'warp_corr', 'occ_weight', 'occ_weight_stacked', 'masked_mean', 'ssim_loss',
-           'ssim_map', 'smooth2_loss', 'consis_loss', 'bias_leaky_relu_', 'bias_leaky_relu_into', 'upsample_bilinear_scaled', 'loss_combine', 'weighted_mean_sum', 'img_pyramid']
+           'ssim_map', 'smooth2_loss', 'consis_loss', 'bias_leaky_relu_', 'bias_leaky_relu_into', 'upsample_bilinear_scaled', 'loss_combine', 'weighted_mean_sum', 'flow_head', 'img_pyramid']
 
 
 def _ptr(t):
@@ -182,6 +182,7 @@ class _Warp(torch.autograd.Function):
                   int(align_corners), _stream(), nbytes=B * H * W * (8 * C + 8 + (1 if use_mask else 0)),
                   shape=(B, C, H, W))
         ctx.save_for_backward(x, flow, mask)
+        ctx.set_materialize_grads(False)             # (no zero-filled "gradient" for the mask: a fill launch per warp otherwise)
         ctx.ac = int(align_corners)
         ctx.entry = 'unflow_warp_bwd_det' if deterministic else 'unflow_warp_bwd'
         if use_mask:
@@ -193,6 +194,8 @@ class _Warp(torch.autograd.Function):
     def backward(ctx, g, _gmask):
         x, flow, mask = ctx.saved_tensors
         B, C, H, W = x.shape
+        if g is None:
+            return None, None, None, None, None
         g = g.contiguous()
         gsrc = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gflow = torch.empty_like(flow)
@@ -295,6 +298,7 @@ class _OccWeight(torch.autograd.Function):
                   _ptr(w_bwd), _ptr(w_fwd), _ptr(v_bwd), _ptr(v_fwd), B, H, W, _stream(),
                   nbytes=B * H * W * (4 * 13 + 2), shape=(B, 3, H, W))
         ctx.save_for_backward(img, from_l, from_r)
+        ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(w_bwd, w_fwd, v_bwd, v_fwd)     # weight is .data (:122)
         return diff_l, diff_r, w_bwd, w_fwd, v_bwd, v_fwd
 
@@ -334,6 +338,7 @@ class _OccWeight2(torch.autograd.Function):
                   _ptr(wgt[:B]), _ptr(wgt[B:]), _ptr(None), _ptr(None), B, H, W, _stream(),
                   nbytes=B * H * W * 4 * 13, shape=(B, 3, H, W))
         ctx.save_for_backward(img, warped)
+        ctx.set_materialize_grads(False)                             # (no zero-filled [2B,1,H,W] "gradient" for the weights)
         ctx.mark_non_differentiable(wgt)                             # weight is .data (model_flow_paper.py:122)
         return diff, wgt
 
@@ -914,6 +919,47 @@ def to_nchw(x):
     elif not x.is_cuda:
         raise RuntimeError('unopticalflow_amd ops run on an MI355X (HIP) device only; got a %s tensor. There is no CPU fallback.' % x.device)
     return _ToNCHW.apply(x)
+
+
+class _FlowHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, bias, res):
+        half = y.dtype == torch.bfloat16
+        dev = _dev(bias, res) if half else _dev(y, bias, res)
+        N, C, H, W = y.shape
+        res = None if res is None else res.contiguous()
+        out = torch.empty((N, 2, H, W), dtype=torch.float32, device=dev)
+        with _on(dev):
+            _call('unflow_flow_head_fwd_bf16' if half else 'unflow_flow_head_fwd', _ptr(y), _ptr(bias), _ptr(res), _ptr(out), N, H * W, _stream(),
+                  nbytes=N * H * W * 2 * ((2 if half else 4) + 4 + (4 if res is not None else 0)), shape=(N, 2, H, W))
+        ctx.half = half
+        ctx.has_res = res is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, _, H, W = g.shape
+        g = g.contiguous()
+        gy = torch.empty((N, 2, H, W), dtype=torch.bfloat16 if ctx.half else torch.float32, device=g.device, memory_format=torch.channels_last)
+        gbias = torch.empty(2, dtype=torch.float32, device=g.device)
+        lib = _lib.load()
+        partials = torch.empty(lib.unflow_flow_head_partials(), dtype=torch.float32, device=g.device)
+        with _on(g.device):
+            _call('unflow_flow_head_bwd_bf16' if ctx.half else 'unflow_flow_head_bwd', _ptr(g), _ptr(gy), _ptr(gbias), _ptr(partials), N, H * W,
+                  _stream(), nbytes=N * H * W * 2 * ((2 if ctx.half else 4) + 4), shape=(N, 2, H, W))
+        return gy, gbias, (g if ctx.has_res else None)
+
+
+def flow_head(y, bias, residual=None):
+    """``(y + bias.view(1, 2, 1, 1)).float().contiguous() [+ residual]`` for the bias-free output ``y`` [N,2,H,W] (channels_last, fp32
+    or bf16) of a predict_flow convolution (pwc_tf.py:93-94,118,130,...): the fp32 NCHW flow in one pass each way."""
+    if y.dim() != 4 or y.shape[1] != 2 or y.dtype not in (torch.float32, torch.bfloat16) or not y.is_cuda:
+        raise ValueError('flow_head: a [N,2,H,W] fp32 / bf16 HIP tensor expected, got %s %s' % (tuple(y.shape), y.dtype))
+    if not y.is_contiguous(memory_format=torch.channels_last):
+        y = y.contiguous(memory_format=torch.channels_last)
+    if residual is not None and tuple(residual.shape) != tuple(y.shape):
+        raise ValueError('flow_head: residual %s against %s' % (tuple(residual.shape), tuple(y.shape)))
+    return _FlowHead.apply(y, bias, residual)
 
 
 class _UpsampleScaled(torch.autograd.Function):
