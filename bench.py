@@ -75,6 +75,7 @@ def parse():
     ap.add_argument('--channels-last', type=int, default=-1, help='memory format of the conv stacks: 1 channels_last (NHWC), 0 NCHW; default: 1 when the shipped MIOpen find-db is in use, else 0 (cfg.channels_last)')
     ap.add_argument('--weight-shadows', type=int, default=1, help='bf16 only; 0: autocast casts every convolution weight per call instead of one multi-tensor cast per pass (A/B; cfg.weight_shadows)')
     ap.add_argument('--fused', type=int, default=0, help='1: warp + cost volume of each decoder level as one kernel (cfg.fused_warp_corr)')
+    ap.add_argument('--dup-centre', type=int, default=1, help='0: torch.cat((c, c)) of the centre features instead of the hand-off that writes them twice (A/B; Model_flow.dup_centre)')
     ap.add_argument('--fused-head', type=int, default=1, help='0: ATen bias add, re-layout copy and residual add behind the flow heads instead of unflow_flow_head_* (A/B; PWC_tf.fused_head)')
     ap.add_argument('--fused-loss-sums', type=int, default=1, help='0: eager adds / means for the loss bookkeeping instead of unflow_loss_combine_* and unflow_weighted_mean_sum_* (A/B)')
     ap.add_argument('--fused-upsample', type=int, default=1, help='0: F.interpolate + multiply for the flow up-sampling instead of unflow_upsample_scaled_* (A/B; PWC_tf.fused_upsample)')
@@ -228,6 +229,7 @@ def main():
     model.pwc_model.fused_upsample = bool(args.fused_upsample)
     model.pwc_model.fused_head = bool(args.fused_head)
     model.fused_loss_sums = bool(args.fused_loss_sums)
+    model.dup_centre = bool(args.dup_centre)
     trainer = FlowTrainer(cfg, model, distributed=(world > 1 or args.force_ddp), use_graph=bool(args.graph),
                           single_rank_collectives=args.force_ddp, **({} if args.gc_freeze else {'gc_freeze_after': None}))
     trainer.fused_total_loss = bool(args.fused_loss_sums)
@@ -262,6 +264,7 @@ def main():
             model.pwc_model.fused_upsample = bool(args.fused_upsample)
             model.pwc_model.fused_head = bool(args.fused_head)
             model.fused_loss_sums = bool(args.fused_loss_sums)
+            model.dup_centre = bool(args.dup_centre)
             trainer = FlowTrainer(cfg, model, distributed=(world > 1 or args.force_ddp), use_graph=False,
                                   single_rank_collectives=args.force_ddp, **({} if args.gc_freeze else {'gc_freeze_after': None}))
             trainer.fused_total_loss = bool(args.fused_loss_sums)

@@ -233,6 +233,15 @@ int unflow_bias_leaky_bwd2_nhwc_from_bf16(const uint16_t* act, long long act_pst
                                           const uint16_t* gout2, long long gout2_pstride, uint16_t* gin, float* gbias,
                                           float* partials, long long P, int C, float slope, void* stream);
 
+/* (ABI 8) The pyramid hand-off with the last `dup` samples written twice: in [Bin][HW][C] (NHWC; fp32 / bf16) -> out fp32 NCHW
+ * [Bin + dup][C][HW], samples Bin .. Bin + dup - 1 = samples Bin - dup .. Bin - 1 (the centre frame's features are the first input of
+ * both decoder directions: no torch.cat((c, c))); and the gradient's way back, g fp32 NCHW [Bout + dup][C][HW] -> out NHWC
+ * [Bout][HW][C] with g[Bout + i] added to sample Bout - dup + i. */
+int unflow_to_nchw_dup(const float* in, float* out, int C, int Bin, int dup, int HW, void* stream);
+int unflow_to_nchw_dup_bf16(const uint16_t* in, float* out, int C, int Bin, int dup, int HW, void* stream);
+int unflow_to_nhwc_fold(const float* g, float* out, int C, int Bout, int dup, int HW, void* stream);
+int unflow_to_nhwc_fold_bf16(const float* g, uint16_t* out, int C, int Bout, int dup, int HW, void* stream);
+
 /* ---- flow heads (ABI 8): predict_flow (pwc_tf.py:93-94, Conv2d(c, 2, 3, bias=True), no activation) and the residual that follows
  * it (`flow = predict_flow(x) + up_flow`, :130,143,155,167; `flow2 + dc_conv7(x)`, :171) at the border of the channels_last conv
  * stack.  y [N*HW][2]: the bias-free convolution output (NHWC; fp32, or bf16 as raw uint16_t); res (may be NULL), out, g: fp32

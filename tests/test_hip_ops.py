@@ -580,6 +580,15 @@ def test_cat_channels_last_and_back(ops, shape, chans):
     assert z.is_contiguous() and torch.equal(z.cpu(), ref)
     z.backward(go.cuda())
     assert torch.equal(y.grad.cpu(), go)
+    for d in (1, B):                                  # the hand-off that writes its last d samples twice (no torch.cat((c, c)))
+        y = ref.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+        z = ops.to_nchw(y * 1.0, dup_tail=d)
+        assert z.is_contiguous() and torch.equal(z.cpu(), torch.cat((ref, ref[B - d:]), 0))
+        gd = rnd(96 + d, (B + d,) + tuple(ref.shape[1:]))
+        z.backward(gd.cuda())
+        want = gd[:B].clone()
+        want[B - d:] += gd[B:]
+        assert torch.equal(y.grad.cpu(), want)
 
 
 @pytest.mark.parametrize('shape,chans', [((16, 64, 208), (81, 32, 2)), ((16, 4, 13), (81,)), ((3, 7, 9), (5, 3)), ((2, 8, 26), (81, 128, 2))])
@@ -609,6 +618,14 @@ def test_cat_channels_last_bf16_side(ops, shape, chans):
     g32 = rnd(196, tuple(ref.shape))
     z.backward(g32.cuda())
     assert y.grad.dtype == torch.bfloat16 and torch.equal(y.grad.cpu(), g32.to(torch.bfloat16))
+    y = ref.cuda().contiguous(memory_format=CL).requires_grad_()
+    z = ops.to_nchw(y * 1.0, dup_tail=1)
+    assert torch.equal(z.cpu(), torch.cat((ref, ref[B - 1:]), 0).float())
+    gd = rnd(197, (B + 1,) + tuple(ref.shape[1:]))
+    z.backward(gd.cuda())
+    want = gd[:B].clone()
+    want[B - 1:] += gd[B:]
+    assert torch.equal(y.grad.cpu(), want.to(torch.bfloat16))              # one rounding, after the fp32 sum
 
 
 @pytest.mark.parametrize('shape', [(16, 128, 64, 208), (2, 5, 7, 9), (3, 8, 4, 4), (2, 16, 8, 26)])

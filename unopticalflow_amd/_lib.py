@@ -49,6 +49,10 @@ SIGNATURES = {
     'unflow_bias_leaky_fwd_nhwc': [_P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P],
     'unflow_bias_leaky_partials_nhwc': [ctypes.c_longlong, _I],
     'unflow_bias_leaky_bwd2_nhwc': [_P, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P, _P, ctypes.c_longlong, _I, ctypes.c_float, _P],
+    'unflow_to_nchw_dup': [_P, _P, _I, _I, _I, _I, _P],
+    'unflow_to_nchw_dup_bf16': [_P, _P, _I, _I, _I, _I, _P],
+    'unflow_to_nhwc_fold': [_P, _P, _I, _I, _I, _I, _P],
+    'unflow_to_nhwc_fold_bf16': [_P, _P, _I, _I, _I, _I, _P],
     'unflow_flow_head_partials': [],
     'unflow_flow_head_fwd': [_P, _P, _P, _P, _I, _I, _P],
     'unflow_flow_head_fwd_bf16': [_P, _P, _P, _P, _I, _I, _P],

@@ -40,6 +40,7 @@ class Model_flow(nn.Module):
         self.channels_last = tuning.default_channels_last() if cl is None else bool(cl)
         # bf16 option: one multi-tensor cast of all convolution weights per pass (False: autocast's per-call casts; tests compare)
         self.weight_shadows = bool(getattr(cfg, 'weight_shadows', True))
+        self.dup_centre = True           # the pyramid hand-off writes the centre features twice (False: torch.cat((c, c)); A/B)
         self.fused_loss_sums = True      # the sums over scales and directions of forward() as one launch each way (False: eager adds; tests compare)
         self.fpyramid = FeaturePyramid(channels_last=self.channels_last)
         self.pwc_model = PWC_tf(align_corners=self.align_corners, fused_warp_corr=bool(getattr(cfg, 'fused_warp_corr', False)),
@@ -168,12 +169,19 @@ class Model_flow(nn.Module):
         if frames is None:
             frames = torch.cat((imgl, imgr, img), 0)
         with self._autocast():
-            feats = self.fpyramid(frames)                                    # [3B, ...] per level
+            # [4B, ...] per level: (left | right | centre | centre) -- the hand-off out of the conv stack writes the centre features
+            # twice (FeaturePyramid dup_tail), so both decoder inputs are views and the two gradients of the centre features meet
+            # in the hand-off's backward kernel
+            feats = self.fpyramid(frames, dup_tail=B if self.dup_centre else 0)
             # the decoder never reads pyramid level 1 (pwc_tf.py:108-179 uses c12..c16 / c22..c26): nothing built for it.
-            # split (not slices): its backward is one cat, a slice's is a zero-fill + copy + add of the whole 3B map
-            parts = [f.split((2 * B, B)) for f in feats[1:]]                 # (left | right), centre
+            # split (not slices): its backward is one cat, a slice's is a zero-fill + copy + add of the whole map
+            if self.dup_centre:
+                parts = [f.split((2 * B, 2 * B)) for f in feats[1:]]         # (left | right), (centre | centre)
+            else:
+                parts = [f.split((2 * B, B)) for f in feats[1:]]
+                parts = [(lr, torch.cat((c, c), 0)) for lr, c in parts]
             feat_lr = [None] + [lr for lr, _ in parts]
-            feat_c2 = [None] + [torch.cat((c, c), 0) for _, c in parts]
+            feat_c2 = [None] + [c2 for _, c2 in parts]
             flows = self.pwc_model(feat_c2, feat_lr, [img_h, img_w])         # [2B, 2, h, w] per scale
         return [f.float() for f in flows]
 

@@ -25,7 +25,9 @@ class FeaturePyramid(nn.Module):
         if self.channels_last:
             weights_to_channels_last(self)
 
-    def forward(self, img):
+    def forward(self, img, dup_tail=0):
+        """``dup_tail`` = d: every returned level (but the unused first) carries d extra samples, copies of its last d -- the train
+        step's (left | right | centre) batch comes back as (left | right | centre | centre), both decoder inputs as views."""
         cl = self.channels_last and img.is_cuda and img.dtype == torch.float32      # (under bf16 autocast the convs then produce bf16 NHWC)
         outs, t, last = [], (img.contiguous(memory_format=CL) if cl else img), len(_CHANNELS) - 1
         for lvl in range(len(_CHANNELS)):
@@ -35,5 +37,9 @@ class FeaturePyramid(nn.Module):
             else:
                 t = out = getattr(self, 'conv%d' % (2 * lvl + 2))(t)
             # level 1 is never read by the decoder (pwc_tf.py:108-179): it stays as it is
-            outs.append(ops.to_nchw(out) if (cl and lvl > 0) else out)
+            if cl and lvl > 0:
+                out = ops.to_nchw(out, dup_tail)
+            elif dup_tail and lvl > 0:
+                out = torch.cat((out, out[out.shape[0] - dup_tail:]), 0)
+            outs.append(out)
         return tuple(outs)

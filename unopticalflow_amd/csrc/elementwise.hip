@@ -218,8 +218,10 @@ __device__ __forceinline__ void nhwc_store(unsigned short* p, float v) {
     *p = (unsigned short)(u >> 16);
 }
 
+// fold > 0 (one source tensor): the last ``fold`` samples of the output also receive the source samples ``fold`` further on --
+// the gradient of a hand-off that duplicated its last samples (split_nhwc_kernel with Bin < gridDim.y)
 template <typename T>
-__global__ __launch_bounds__(256) void cat_nhwc_fwd_kernel(Planes3 src, T* __restrict__ dst, int HW, int C) {
+__global__ __launch_bounds__(256) void cat_nhwc_fwd_kernel(Planes3 src, T* __restrict__ dst, int HW, int C, int fold) {
     extern __shared__ float tile[];                   // [C][LG_LD]
     const int b = blockIdx.y, p0 = blockIdx.x * LG_PIX, npx = min(LG_PIX, HW - p0);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -229,6 +231,7 @@ __global__ __launch_bounds__(256) void cat_nhwc_fwd_kernel(Planes3 src, T* __res
         for (int u = 0; u < LG_UNROLL; ++u) {
             const int c = c0 + 4 * u;
             v[u] = (c < C && lane < npx) ? plane_of(src, b, c, HW)[p0 + lane] : 0.f;
+            if (fold > 0 && b >= (int)gridDim.y - fold && c < C && lane < npx) v[u] += plane_of(src, b + fold, c, HW)[p0 + lane];
         }
 #pragma unroll
         for (int u = 0; u < LG_UNROLL; ++u) {
@@ -246,12 +249,15 @@ __global__ __launch_bounds__(256) void cat_nhwc_fwd_kernel(Planes3 src, T* __res
 }
 
 // the inverse: NHWC [B][HW][C] -> up to three NCHW tensors (destinations with a null pointer are skipped)
+// Bin < gridDim.y: output samples beyond Bin repeat the LAST gridDim.y - Bin source samples (the centre frame's features feed both
+// decoder directions, model_flow_paper.py:198-201 run twice -> one hand-off writes them twice instead of a torch.cat((c, c)))
 template <typename T>
-__global__ __launch_bounds__(256) void split_nhwc_kernel(const T* __restrict__ srcp, PlanesOut3 dst, int HW, int C) {
+__global__ __launch_bounds__(256) void split_nhwc_kernel(const T* __restrict__ srcp, PlanesOut3 dst, int HW, int C, int Bin) {
     extern __shared__ float tile[];
     const int b = blockIdx.y, p0 = blockIdx.x * LG_PIX, npx = min(LG_PIX, HW - p0);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const T* s = srcp + ((size_t)b * HW + p0) * C;
+    const int sb = b < Bin ? b : b - ((int)gridDim.y - Bin);
+    const T* s = srcp + ((size_t)sb * HW + p0) * C;
     const int n = npx * C;
     for (int e0 = threadIdx.x; e0 < n; e0 += 256 * LG_UNROLL) {
         float v[LG_UNROLL];
@@ -407,27 +413,28 @@ extern "C" int unflow_bias_leaky_bwd2_nhwc_from(const float* act, long long act_
 }
 
 template <typename T>
-static int launch_cat_nhwc(const float* a, int Ca, const float* b, int Cb, const float* c, int Cc, T* out, int B, int HW, void* stream) {
+static int launch_cat_nhwc(const float* a, int Ca, const float* b, int Cb, const float* c, int Cc, T* out, int B, int HW, void* stream,
+                           int fold = 0) {
     UNFLOW_REQUIRE(a && out && Ca > 0 && Cb >= 0 && Cc >= 0 && (Cb == 0 || b) && (Cc == 0 || c) && (Cb > 0 || Cc == 0) &&
-                   B > 0 && B <= 65535 && HW > 0);
+                   B > 0 && B <= 65535 && HW > 0 && fold >= 0 && fold <= B && (fold == 0 || Cb == 0));
     const int C = Ca + Cb + Cc;
     const size_t shmem = (size_t)C * LG_LD * sizeof(float);
     UNFLOW_REQUIRE(shmem <= 160 * 1024);
     Planes3 src = {{a, b, c}, {Ca, Cb, Cc}};
     if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)cat_nhwc_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    UNFLOW_LAUNCH(cat_nhwc_fwd_kernel<T>, dim3(ceil_div(HW, LG_PIX), B), dim3(256), shmem, (hipStream_t)stream, src, out, HW, C);
+    UNFLOW_LAUNCH(cat_nhwc_fwd_kernel<T>, dim3(ceil_div(HW, LG_PIX), B), dim3(256), shmem, (hipStream_t)stream, src, out, HW, C, fold);
     return unflow_launch_status();
 }
 
 template <typename T>
-static int launch_split_nhwc(const T* in, float* a, int Ca, float* b, int Cb, float* c, int Cc, int B, int HW, void* stream) {
-    UNFLOW_REQUIRE(in && Ca > 0 && Cb >= 0 && Cc >= 0 && (Cb > 0 || Cc == 0) && B > 0 && B <= 65535 && HW > 0);
+static int launch_split_nhwc(const T* in, float* a, int Ca, float* b, int Cb, float* c, int Cc, int B, int HW, void* stream, int dup = 0) {
+    UNFLOW_REQUIRE(in && Ca > 0 && Cb >= 0 && Cc >= 0 && (Cb > 0 || Cc == 0) && B > 0 && B <= 65535 && HW > 0 && dup >= 0 && dup < B);
     const int C = Ca + Cb + Cc;
     const size_t shmem = (size_t)C * LG_LD * sizeof(float);
     UNFLOW_REQUIRE(shmem <= 160 * 1024);
     PlanesOut3 dst = {{a, b, c}, {Ca, Cb, Cc}};
     if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)split_nhwc_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    UNFLOW_LAUNCH(split_nhwc_kernel<T>, dim3(ceil_div(HW, LG_PIX), B), dim3(256), shmem, (hipStream_t)stream, in, dst, HW, C);
+    UNFLOW_LAUNCH(split_nhwc_kernel<T>, dim3(ceil_div(HW, LG_PIX), B), dim3(256), shmem, (hipStream_t)stream, in, dst, HW, C, B - dup);
     return unflow_launch_status();
 }
 
@@ -438,6 +445,23 @@ extern "C" int unflow_cat_nhwc(const float* a, int Ca, const float* b, int Cb, c
 
 extern "C" int unflow_split_nhwc(const float* in, float* a, int Ca, float* b, int Cb, float* c, int Cc, int B, int HW, void* stream) {
     return launch_split_nhwc<float>(in, a, Ca, b, Cb, c, Cc, B, HW, stream);
+}
+
+// NHWC [Bin][HW][C] -> NCHW [Bin + dup][C][HW] whose last dup samples repeat samples Bin - dup .. Bin - 1, and the gradient's way back:
+// NCHW [Bout + dup][C][HW] -> NHWC [Bout][HW][C] with the repeated samples' gradients added to their originals
+extern "C" int unflow_to_nchw_dup(const float* in, float* out, int C, int Bin, int dup, int HW, void* stream) {
+    UNFLOW_REQUIRE(dup >= 0 && dup <= Bin);
+    return launch_split_nhwc<float>(in, out, C, nullptr, 0, nullptr, 0, Bin + dup, HW, stream, dup);
+}
+extern "C" int unflow_to_nchw_dup_bf16(const uint16_t* in, float* out, int C, int Bin, int dup, int HW, void* stream) {
+    UNFLOW_REQUIRE(dup >= 0 && dup <= Bin);
+    return launch_split_nhwc<unsigned short>(in, out, C, nullptr, 0, nullptr, 0, Bin + dup, HW, stream, dup);
+}
+extern "C" int unflow_to_nhwc_fold(const float* g, float* out, int C, int Bout, int dup, int HW, void* stream) {
+    return launch_cat_nhwc<float>(g, C, nullptr, 0, nullptr, 0, out, Bout, HW, stream, dup);
+}
+extern "C" int unflow_to_nhwc_fold_bf16(const float* g, uint16_t* out, int C, int Bout, int dup, int HW, void* stream) {
+    return launch_cat_nhwc<unsigned short>(g, C, nullptr, 0, nullptr, 0, out, Bout, HW, stream, dup);
 }
 
 // bf16 conv-stack option: the NHWC side in bf16 (what the convolutions read and write under autocast), the NCHW planes fp32

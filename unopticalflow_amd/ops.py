@@ -872,27 +872,30 @@ class _CatChannelsLast(torch.autograd.Function):
 
 class _ToNCHW(torch.autograd.Function):
     """A channels_last activation (fp32 or bf16) as a plain fp32 NCHW tensor (and its gradient back into channels_last, in the
-    activation's dtype)."""
+    activation's dtype).  ``dup`` > 0: the last ``dup`` samples are written twice (output batch B + dup) and their two gradients
+    meet in the backward kernel."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, dup):
         B, C, H, W = x.shape
         ctx.half = x.dtype == torch.bfloat16
-        out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+        ctx.dup = dup
+        out = torch.empty((B + dup, C, H, W), dtype=torch.float32, device=x.device)
         with _on(x.device):
-            _call('unflow_split_nhwc_bf16' if ctx.half else 'unflow_split_nhwc', _ptr(x), _ptr(out), C, None, 0, None, 0, B, H * W, _stream(),
-                  nbytes=(6 if ctx.half else 8) * x.numel(), shape=(B, C, H, W))
+            _call('unflow_to_nchw_dup_bf16' if ctx.half else 'unflow_to_nchw_dup', _ptr(x), _ptr(out), C, B, dup, H * W, _stream(),
+                  nbytes=(2 if ctx.half else 4) * x.numel() + 4 * out.numel(), shape=(B + dup, C, H, W))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        B, C, H, W = g.shape
+        Bd, C, H, W = g.shape
+        B = Bd - ctx.dup
         g = g.float().contiguous()
         out = torch.empty((B, C, H, W), dtype=torch.bfloat16 if ctx.half else torch.float32, device=g.device, memory_format=torch.channels_last)
         with _on(g.device):
-            _call('unflow_cat_nhwc_bf16' if ctx.half else 'unflow_cat_nhwc', _ptr(g), C, None, 0, None, 0, _ptr(out), B, H * W, _stream(),
-                  nbytes=(6 if ctx.half else 8) * g.numel(), shape=(B, C, H, W))
-        return out
+            _call('unflow_to_nhwc_fold_bf16' if ctx.half else 'unflow_to_nhwc_fold', _ptr(g), _ptr(out), C, B, ctx.dup, H * W, _stream(),
+                  nbytes=4 * g.numel() + (2 if ctx.half else 4) * out.numel(), shape=(B, C, H, W))
+        return out, None
 
 
 def cat_channels_last(tensors, dtype=torch.float32):
@@ -910,15 +913,21 @@ def cat_channels_last(tensors, dtype=torch.float32):
     return _CatChannelsLast.apply(dtype == torch.bfloat16, *tensors)
 
 
-def to_nchw(x):
-    """A dense channels_last fp32 or bf16 activation as a contiguous fp32 NCHW tensor (one transposing kernel each way)."""
+def to_nchw(x, dup_tail=0):
+    """A dense channels_last fp32 or bf16 activation as a contiguous fp32 NCHW tensor (one transposing kernel each way).
+    ``dup_tail`` = d > 0: the result has d more samples, copies of the last d (``torch.cat((y, y[-d:]))`` without the cat: the centre
+    frame's pyramid features feed both decoder directions)."""
+    dup_tail = int(dup_tail)
+    if not 0 <= dup_tail <= x.shape[0]:
+        raise ValueError('to_nchw: dup_tail %d for a batch of %d' % (dup_tail, x.shape[0]))
     if x.dtype not in (torch.float32, torch.bfloat16) or not _is_nhwc(x):
-        return x.contiguous()
+        x = x.contiguous()
+        return torch.cat((x, x[x.shape[0] - dup_tail:]), 0) if dup_tail else x
     if x.dtype == torch.float32:
         _dev(x)
     elif not x.is_cuda:
         raise RuntimeError('unopticalflow_amd ops run on an MI355X (HIP) device only; got a %s tensor. There is no CPU fallback.' % x.device)
-    return _ToNCHW.apply(x)
+    return _ToNCHW.apply(x, dup_tail)
 
 
 class _FlowHead(torch.autograd.Function):
