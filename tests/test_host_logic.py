@@ -1,0 +1,114 @@
+"""CPU tests of the host-side logic around the HIP operators (no kernel runs here): the bf16 option's weight shadows, the argument
+checks the operators make before they touch a device, the torch forms the model falls back to off the GPU."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from unopticalflow_amd import ops
+from unopticalflow_amd.core.networks.structures import PWC_tf
+from unopticalflow_amd.core.networks.structures.net_utils import HeadConv2d, WeightShadows, conv, conv_weight, weights_to_channels_last
+
+
+def test_weight_shadows_cast_once_and_route_gradients():
+    """net_utils.WeightShadows: inside the context every convolution contracts with a bf16 copy of its weight (heads also of their
+    bias) made by ONE autograd node; outside nothing is left on the modules; the fp32 parameters get fp32 gradients in their own
+    (channels_last) layout, equal to what per-call casts (autocast's arithmetic) give."""
+    torch.manual_seed(0)
+    net = nn.Sequential(conv(3, 8), conv(8, 8), HeadConv2d(8, 2, 3, padding=1))
+    weights_to_channels_last(net)
+    x = torch.randn(2, 3, 9, 7).bfloat16()
+
+    def run(shadows):
+        for p in net.parameters():
+            p.grad = None
+        if shadows:
+            with WeightShadows((net,)):
+                assert all(conv_weight(m).dtype == torch.bfloat16 for m in net.modules() if isinstance(m, nn.Conv2d))
+                nodes = {conv_weight(m).grad_fn for m in net.modules() if isinstance(m, nn.Conv2d)}
+                assert len(nodes) == 1                                  # one cast node for all weights
+                t = x
+                for blk in net[:2]:
+                    c = blk[0]
+                    t = F.leaky_relu(F.conv2d(t, conv_weight(c), c.bias.bfloat16(), padding=1), 0.1)
+                y = net[2](t)
+        else:
+            t = x
+            for blk in net[:2]:
+                c = blk[0]
+                t = F.leaky_relu(F.conv2d(t, c.weight.bfloat16(), c.bias.bfloat16(), padding=1), 0.1)
+            y = F.conv2d(t, net[2].weight.bfloat16(), net[2].bias.bfloat16(), padding=1)
+        y.float().square().sum().backward()
+        return y.detach().float(), [p.grad.clone() for p in net.parameters()]
+
+    ya, ga = run(True)
+    assert not any('_w_half' in m.__dict__ or '_b_half' in m.__dict__ for m in net.modules())
+    yb, gb = run(False)
+    assert torch.equal(ya, yb)
+    for p, a, b in zip(net.parameters(), ga, gb):
+        assert a.dtype == torch.float32 and a.stride() == p.stride()
+        assert torch.equal(a, b)
+    with WeightShadows((net,), enabled=False):
+        assert conv_weight(net[0][0]) is net[0][0].weight
+
+
+def test_flow_heads_keep_the_reference_checkpoint_keys():
+    """HeadConv2d replaces nn.Conv2d for predict_flow{6..2} / dc_conv7 (pwc_tf.py:93-94): same parameters, same state-dict keys, and
+    without shadows the same forward."""
+    pw = PWC_tf()
+    keys = set(pw.state_dict().keys())
+    for lvl in (6, 5, 4, 3, 2):
+        assert {'predict_flow%d.weight' % lvl, 'predict_flow%d.bias' % lvl} <= keys
+    assert {'dc_conv7.weight', 'dc_conv7.bias'} <= keys
+    m = pw.predict_flow6
+    x = torch.randn(1, m.in_channels, 4, 5)
+    assert torch.equal(m(x), F.conv2d(x, m.weight, m.bias, padding=1))
+    up = torch.randn(1, 2, 4, 5)
+    assert torch.equal(pw._head(m, x, up), F.conv2d(x, m.weight, m.bias, padding=1) + up)      # the torch form off the GPU
+
+
+def test_flow_upsampling_falls_back_to_interpolate_off_the_gpu():
+    pw = PWC_tf()
+    flow = torch.randn(2, 2, 4, 13)
+    assert torch.equal(pw._up(flow, (8, 26), 2.0), F.interpolate(flow, scale_factor=2.0, mode='bilinear') * 2.0)      # pwc_tf.py:119
+    assert torch.equal(pw._up(flow, (16, 52), 4.0), F.interpolate(flow * 4.0, [16, 52], mode='bilinear'))             # pwc_tf.py:174
+
+
+def test_operator_argument_checks_come_before_the_device():
+    """Shape errors are ValueErrors whatever the device; a well-formed CPU call is refused loudly (no CPU fallback)."""
+    x = torch.randn(1, 2, 4, 6)
+    with pytest.raises(ValueError):
+        ops.upsample_bilinear_scaled(x, (6, 12), 2.0)                   # 6 is not a multiple of 4
+    with pytest.raises(ValueError):
+        ops.upsample_bilinear_scaled(x, (2, 6), 1.0)                    # down-sampling
+    with pytest.raises(RuntimeError, match='MI355X'):
+        ops.upsample_bilinear_scaled(x, (8, 12), 2.0)
+    B = 3
+    two, one = [torch.rand(2 * B)] * 2, [torch.rand(B)] * 2
+    with pytest.raises(ValueError):
+        ops.loss_combine(two, two, two, two)                            # consistency terms are [B]
+    with pytest.raises(ValueError):
+        ops.loss_combine(two, two, two[:1], one)                        # one term per scale and loss
+    with pytest.raises(RuntimeError, match='MI355X'):
+        ops.loss_combine(two, two, two, one)
+    with pytest.raises(ValueError):
+        ops.weighted_mean_sum(one, [1.0])
+    with pytest.raises(RuntimeError, match='MI355X'):
+        ops.weighted_mean_sum(one, [1.0, 2.0])
+    with pytest.raises(ValueError):
+        ops.flow_head(torch.zeros(1, 3, 4, 4), torch.zeros(2))
+    with pytest.raises(ValueError):
+        ops.to_nchw(torch.zeros(2, 4, 3, 3), dup_tail=3)
+    y = torch.arange(2 * 4 * 3 * 3, dtype=torch.float32).view(2, 4, 3, 3)
+    assert torch.equal(ops.to_nchw(y, dup_tail=1), torch.cat((y, y[1:]), 0))    # plain NCHW input: nothing to re-lay out
+
+
+def test_total_loss_off_the_gpu_is_the_reference_formula():
+    """FlowTrainer.total_loss (train.py:147-150): sum_k w_k * mean(loss_k); the fused operator is only taken for HIP tensors."""
+    import types
+    from unopticalflow_amd.trainer import FlowTrainer
+    cfg = types.SimpleNamespace(w_ssim=0.85, w_flow_smooth=10.0, w_flow_consis=0.01, lr=1e-4)
+    tr = FlowTrainer(cfg, nn.Linear(2, 2), fused_adam=False)
+    pack = {'loss_pixel': torch.rand(4), 'loss_ssim': torch.rand(4), 'loss_flow_smooth': torch.rand(4), 'loss_flow_consis': torch.rand(4)}
+    want = 0.15 * pack['loss_pixel'].mean() + 0.85 * pack['loss_ssim'].mean() + 10.0 * pack['loss_flow_smooth'].mean() + 0.01 * pack['loss_flow_consis'].mean()
+    torch.testing.assert_close(tr.total_loss(pack), want, rtol=1e-6, atol=0)
