@@ -430,10 +430,21 @@ def main():
             out['conv_stack']['conv_kernels_only'] = {'achieved': ck['achieved_tflops'], 'frac': ck['frac_of_peak'], 'ms_per_step': ck['ms_per_step'],
                                                       'mfma_tflop_per_step_counted': ck['mfma_tflop_per_step'],
                                                       'source': 'profiles/%s (SQ_INSTS_VALU_MFMA_MOPS_* x 512 / kernel time, separate --pmc and --kernel-trace runs)' % os.path.basename(mf)}
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        # RCCL writes a version banner to the C stdout stream (fully buffered when stdout is a file or a pipe: it would land behind
+        # the JSON at exit); drain it first so that the JSON is the LAST line of stdout, after the process group is gone
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(line, flush=True)
 
 
 if __name__ == '__main__':
