@@ -50,6 +50,12 @@ def test_weight_shadows_cast_once_and_route_gradients():
         assert torch.equal(a, b)
     with WeightShadows((net,), enabled=False):
         assert conv_weight(net[0][0]) is net[0][0].weight
+    for p in net.parameters():
+        p.grad = None
+    with WeightShadows((net,)):                     # a shadow nobody reads (the head's bias when ops.flow_head adds it in fp32): no gradient, no error
+        h = net[2]
+        F.conv2d(x[:, :1].repeat(1, 8, 1, 1), conv_weight(h), None, padding=1).float().sum().backward()
+    assert h.weight.grad is not None and h.bias.grad is None and net[0][0].weight.grad is None
 
 
 def test_flow_heads_keep_the_reference_checkpoint_keys():

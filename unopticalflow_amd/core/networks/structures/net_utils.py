@@ -21,6 +21,7 @@ class _CastAll(torch.autograd.Function):
     def forward(ctx, *ws):
         outs = [torch.empty_like(w, dtype=torch.bfloat16) for w in ws]          # (empty_like keeps the channels_last strides)
         torch._foreach_copy_(outs, [w.detach() for w in ws])
+        ctx.set_materialize_grads(False)        # a shadow nobody used (a head's bias when ops.flow_head adds it in fp32) has no gradient: no zero-fill + add
         ctx.like = [(w.shape, w.stride()) for w in ws]
         return tuple(outs)
 
