@@ -10,6 +10,10 @@
 #   instep        bench.py on the tuning library: row-streamed (default) vs group-split (UNFLOW_CORR_BWD=4) inside the train step
 #   cat           bench.py with / without the epilogue-filled cat buffers (--fill-cat), fp32 and bf16
 #   warp_gather   the gather-form warp backward (unflow_warp_bwd_det) vs the scatter forms, per level and flow kind
+#   glue SWITCH   same-box A/B of one of the glue-launch fusions of DESIGN section 3 item 32 / 33: the parity tests that cover it, then the
+#                 driver-style bench line with the switch on and off, hipGraph replay and eager.  SWITCH = fused-upsample | fused-loss-sums |
+#                 fused-head | dup-centre | weight-shadows (the last one on --precision bf16)
+#   aten          tools/probes/aten_sources.py: the ATen / runtime kernels of an eager step by launching op and autograd node (fp32, bf16)
 #   entry E L     rocprofv3 kernel trace of one C entry point at one level (tools/pmc_entry.py): per-kernel averages
 out=gpurun_out/r3
 mkdir -p $out
@@ -43,6 +47,20 @@ for f in ('instep_rs','instep_gs'):
 import json; d=json.loads(open('$out/cat_fill${f}_$prec.json').read().strip().splitlines()[-1]); print('$prec fill-cat $f', d['value'], d['ms_per_step'], d['step_ms']['median'])"
     done; done ;;
   warp_gather) UNFLOW_MICROBENCH_TUNING=1 timeout 300 python3 tools/microbench.py warp_gather 2>&1 | tee $out/warp_gather.txt | grep warp_bwd ;;
+  glue)
+    sw=${1:-fused-head}; extra=""; [ $sw = weight-shadows ] && extra="--precision bf16"
+    python3 -m pytest tests/test_hip_ops.py -q -m gpu -k "upsample or flow_head or loss_bookkeeping or cat_channels_last" 2>&1 | tail -3
+    python3 -m pytest tests/test_hip_model.py -q -m gpu -k "golden or filled or shadows" 2>&1 | tail -3
+    for g in -1 0; do for v in 1 0; do
+      python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline $extra --graph $g --$sw $v > $out/glue_${sw}${v}_graph$g.json 2> $out/glue_${sw}${v}_graph$g.err
+    done; done
+    python3 -c "
+import json,glob
+for f in sorted(glob.glob('$out/glue_${sw}*.json')):
+    d=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split('/')[-1], d['value'], d['ms_per_step'], d['step_ms']['median'], d['step_mode'])" ;;
+  aten)
+    python3 tools/probes/aten_sources.py > $out/aten_sources_fp32.txt 2>&1; python3 tools/probes/aten_sources.py bf16 > $out/aten_sources_bf16.txt 2>&1
+    grep total $out/aten_sources_fp32.txt $out/aten_sources_bf16.txt ;;
   entry)
     e=${1:-unflow_warp_bwd_det}; l=${2:-L2}; d=$GRAFT_REPO_ROOT/$out/prof_entry_${e}_$l; mkdir -p $d
     ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $GRAFT_REPO_ROOT/tools/pmc_entry.py $e $l 10 > $d/run.log 2>&1 )
