@@ -73,7 +73,9 @@ def test_flow_heads_keep_the_reference_checkpoint_keys():
     assert torch.equal(pw._head(m, x, up), F.conv2d(x, m.weight, m.bias, padding=1) + up)      # the torch form off the GPU
 
 
-def test_flow_upsampling_falls_back_to_interpolate_off_the_gpu():
+def test_flow_upsampling_torch_form_is_the_reference_expression():
+    """PWC_tf._up on tensors the HIP kernel does not take (here: host tensors of the module-level tests) is literally the reference's
+    expression; Model_flow as a whole has no CPU path (its cost volume / warp / loss operators refuse host tensors)."""
     pw = PWC_tf()
     flow = torch.randn(2, 2, 4, 13)
     assert torch.equal(pw._up(flow, (8, 26), 2.0), F.interpolate(flow, scale_factor=2.0, mode='bilinear') * 2.0)      # pwc_tf.py:119

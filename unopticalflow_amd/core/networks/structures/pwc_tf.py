@@ -66,7 +66,8 @@ class PWC_tf(nn.Module):
 
     def _up(self, flow, size, mul):
         """mul * bilinear up-sampling of a flow: one HIP kernel each way for the integer factors of the pyramid (ops.upsample_bilinear_scaled),
-        the torch ops otherwise (CPU tensors, other ratios)."""
+        the reference's torch expression for what the kernel does not take (a non-integer ratio; host tensors in module-level tests --
+        the model as a whole has no CPU path: its cost volume, warp and loss operators refuse host tensors)."""
         h, w = flow.shape[2], flow.shape[3]
         if self.fused_upsample and flow.is_cuda and flow.dtype == torch.float32 and size[0] % h == 0 and size[1] % w == 0 and size[0] >= h and size[1] >= w:
             return ops.upsample_bilinear_scaled(flow, size, mul)
