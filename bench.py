@@ -10,9 +10,11 @@ warp / losses), weighted loss, backward, gradient all-reduce (N > 1, RCCL) and A
 synthetic KITTI-sized triplets [8,3,768,832] fp32 already resident in HBM (BASELINE config 2:
 832x256, bs=8 per GPU, fp32; weak scaling: the per-GPU batch is fixed).  pairs/s = 2 * triplets/s.
 
-With one process the timed steps REPLAY the step as a hipGraph (`step_mode`; ~3000 launches cost 14-24 ms of host time per step
-depending on the box against 24.3 ms of GPU work: an eager loop is host-paced on a slow host, and always in bf16); `--graph 0` runs
-them eagerly.  Several ranks run eagerly (gradient pieces leave for RCCL from hooks during backward).
+`python bench.py --gpus N` starts its N ranks itself when no launcher did (unopticalflow_amd/launch.py; the parent makes no GPU
+call).  The timed steps REPLAY the step as a hipGraph (`step_mode`; ~3000 launches cost 14-24 ms of host time per step
+depending on the box against 24.3 ms of GPU work: an eager loop is host-paced on a slow host, and always in bf16) -- with several
+ranks as graph(forward + backward + gradient pack) -> one RCCL all-reduce -> graph(Adam); `--graph 0` runs the steps eagerly
+(several ranks: gradient pieces leave for RCCL from hooks during backward).
 
 The single JSON line also carries
   roofline:     HIP events around EVERY cost-volume / warp entry point inside the timed steps (on the launch stream); under replay
@@ -51,6 +53,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+def self_launch_if_needed():
+    """``python bench.py --gpus N`` (N > 1) with no launcher in front: start the N ranks ourselves (the reference takes its GPU
+    list on one command line, train.py:208-214).  Runs BEFORE torch is imported: the parent never initialises HIP, it relays
+    rank 0's JSON line as its own last stdout line and exits with the worst child code.  UNFLOW_BENCH_ONE_GPU=1 (rehearsal on a
+    one-GPU box) goes the same way."""
+    n, argv = 1, sys.argv[1:]
+    for i, a in enumerate(argv):
+        if a == '--gpus' and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith('--gpus='):
+            n = int(a.split('=', 1)[1])
+    if n <= 1 or 'WORLD_SIZE' in os.environ:
+        return
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_unflow_launch', os.path.join(ROOT, 'unopticalflow_amd', 'launch.py'))
+    launch = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(launch)                              # (by path: importing the package would import torch)
+    sys.exit(launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], n))
+
+
+if __name__ == '__main__':
+    self_launch_if_needed()
+
 import torch                                                     # noqa: E402
 import torch.distributed as dist                                 # noqa: E402
 
@@ -71,7 +97,7 @@ def parse():
     ap.add_argument('--cpu-sample', type=int, default=8, help='triplets in the CPU-baseline sample step (8 = the bench batch)')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'], help='conv-stack precision (bf16: BASELINE config 3; the headline metric is fp32)')
-    ap.add_argument('--graph', type=int, default=-1, help='1: replay the step as a hipGraph; 0: eager (per-launch events INSIDE the timed steps); default: replay with one process, eager with several.  Under replay the roofline legs are taken over the same number of EAGER steps (at most 20) right behind the timed region: a captured graph cannot carry per-launch event pairs')
+    ap.add_argument('--graph', type=int, default=-1, help='1: replay the step as a hipGraph; 0: eager (per-launch events INSIDE the timed steps); default: replay.  Under replay the roofline legs are taken over the same number of EAGER steps (at most 20) right behind the timed region: a captured graph cannot carry per-launch event pairs')
     ap.add_argument('--channels-last', type=int, default=-1, help='memory format of the conv stacks: 1 channels_last (NHWC), 0 NCHW; default: 1 when the shipped MIOpen find-db is in use, else 0 (cfg.channels_last)')
     ap.add_argument('--weight-shadows', type=int, default=1, help='bf16 only; 0: autocast casts every convolution weight per call instead of one multi-tensor cast per pass (A/B; cfg.weight_shadows)')
     ap.add_argument('--fused', type=int, default=0, help='1: warp + cost volume of each decoder level as one kernel (cfg.fused_warp_corr)')
@@ -80,7 +106,7 @@ def parse():
     ap.add_argument('--fused-loss-sums', type=int, default=1, help='0: eager adds / means for the loss bookkeeping instead of unflow_loss_combine_* and unflow_weighted_mean_sum_* (A/B)')
     ap.add_argument('--fused-upsample', type=int, default=1, help='0: F.interpolate + multiply for the flow up-sampling instead of unflow_upsample_scaled_* (A/B; PWC_tf.fused_upsample)')
     ap.add_argument('--fill-cat', type=int, default=1, help='0: channels_last decoder with torch.cat inputs instead of epilogue-filled cat buffers (A/B; PWC_tf.fill_cat_buffers)')
-    ap.add_argument('--gc-freeze', type=int, default=1, help='0: leave Python\'s cyclic collector alone (FlowTrainer(gc_freeze_after=None)); 1: the trainer default (gc.freeze() after its second step)')
+    ap.add_argument('--gc-freeze', type=int, default=1, help='0: leave Python\'s cyclic collector alone; 1: FlowTrainer(gc_freeze_after=2), what train.py asks for too (gc.freeze() after the second step, once per process)')
     ap.add_argument('--force-ddp', action='store_true', help='N = 1 only: run the step through the RCCL data-parallel path with a one-rank communicator')
     return ap.parse_args()
 
@@ -187,10 +213,13 @@ def main():
     args = parse()
     auto_graph = args.graph < 0
     if args.graph < 0:
-        # one process: replay (the step's ~3000 launches take 14-24 ms of host time depending on the box, against 24.3 ms (fp32) /
-        # 11.6 ms (bf16) of GPU work: the eager bf16 step is host-bound everywhere, the fp32 step on a slow host).  Several ranks:
-        # eager, where the all-reduce pieces leave from hooks during backward (under replay they could only follow the graph).
-        args.graph = 1 if int(os.environ.get('WORLD_SIZE', '1')) == 1 and not args.force_ddp else 0
+        # replay, with one process and with several.  The step's ~3000 launches take 14-24 ms of host time depending on the box,
+        # against 24 ms (fp32) / 11 ms (bf16) of GPU work: the eager bf16 step is host-bound everywhere, the fp32 step on a slow or
+        # contended host -- and with N ranks the slowest host paces all of them.  Replayed, a rank enqueues an input copy, two graph
+        # launches and ONE 20.5 MB all-reduce per step (FlowTrainer._build_graph); the exchange is not overlapped with backward
+        # (~0.3 ms exposed of a 24 ms step) but no rank ever waits for a Python interpreter.  --graph 0: eager launches, gradient
+        # pieces all-reduced from hooks during backward.  A/B incl. a contended host: profiles/r4_multirank_step_mode.md
+        args.graph = 1
     from unopticalflow_amd import get_model, _lib, ops
     from unopticalflow_amd.parallel import init_distributed
     from unopticalflow_amd.trainer import FlowTrainer
@@ -231,7 +260,7 @@ def main():
     model.fused_loss_sums = bool(args.fused_loss_sums)
     model.dup_centre = bool(args.dup_centre)
     trainer = FlowTrainer(cfg, model, distributed=(world > 1 or args.force_ddp), use_graph=bool(args.graph),
-                          single_rank_collectives=args.force_ddp, **({} if args.gc_freeze else {'gc_freeze_after': None}))
+                          single_rank_collectives=args.force_ddp, gc_freeze_after=2 if args.gc_freeze else None)
     trainer.fused_total_loss = bool(args.fused_loss_sums)
     user_no_timing = args.no_kernel_timing
     graph_timing = bool(args.graph) and not args.no_kernel_timing      # replayed timed region: the per-launch events need eager steps (after it)
@@ -266,7 +295,7 @@ def main():
             model.fused_loss_sums = bool(args.fused_loss_sums)
             model.dup_centre = bool(args.dup_centre)
             trainer = FlowTrainer(cfg, model, distributed=(world > 1 or args.force_ddp), use_graph=False,
-                                  single_rank_collectives=args.force_ddp, **({} if args.gc_freeze else {'gc_freeze_after': None}))
+                                  single_rank_collectives=args.force_ddp, gc_freeze_after=2 if args.gc_freeze else None)
             trainer.fused_total_loss = bool(args.fused_loss_sums)
     for _ in range(warm):
         trainer.step(inputs)
@@ -323,8 +352,18 @@ def main():
         raise SystemExit('non-finite loss in the timed region')
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    rank_spread = None
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # how the ranks differ: the slowest rank's host is what an eager job is paced by
+        mine = torch.tensor([step_stats['step_ms']['median'], step_stats['step_ms']['max'], step_stats['host_enqueue_ms']['median'],
+                             step_stats['host_enqueue_ms']['max'], step_stats['drain_ms']], device=dev, dtype=torch.float64)
+        hi, lo = mine.clone(), mine.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        names = ('step_ms_median', 'step_ms_max', 'host_enqueue_ms_median', 'host_enqueue_ms_max', 'drain_ms')
+        rank_spread = {'max_over_ranks': {n: round(v, 3) for n, v in zip(names, hi.tolist())},
+                       'min_over_ranks': {n: round(v, 3) for n, v in zip(names, lo.tolist())}}
     dt = t.item()
 
     # dense-contraction FLOPs of one step (forward + data-gradient + weight-gradient of every convolution),
@@ -402,7 +441,9 @@ def main():
             'value': round(pairs / dt, 2), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'bf16', 'data': 'synthetic',
-            'step_mode': 'hipGraph replay' if args.graph else 'eager',
+            'step_mode': (('hipGraph replay: graph(forward + backward + gradient pack), one all-reduce of the flat gradient, graph(Adam)'
+                           if (world > 1 or args.force_ddp) else 'hipGraph replay') if args.graph else
+                          ('eager, gradient pieces all-reduced from hooks during backward' if (world > 1 or args.force_ddp) else 'eager')),
             'config': {'workload': '%dx%d triplets, bs=%d per GPU, %s, corr d=4 + warp + occlusion losses, '
                                    'fwd+bwd+Adam (BASELINE configs[%d])' % (fw, fh, args.batch, args.precision,
                                                                             (1 if args.precision == 'fp32' else 2) if (fh, fw) == (H, W) else 3),
@@ -411,7 +452,7 @@ def main():
                        'triplets_per_s': round(pairs / 2 / dt, 2)},
             'step_ms': step_stats['step_ms'], 'host_enqueue_ms': step_stats['host_enqueue_ms'], 'drain_ms': step_stats['drain_ms'],
             'pairs_per_s_at_median_step': round(2 * args.batch * world / (step_stats['step_ms']['median'] * 1e-3), 2),
-            'all_step_ms': step_stats['all_step_ms'], 'host_gc': step_stats['host_gc'],
+            'all_step_ms': step_stats['all_step_ms'], 'host_gc': step_stats['host_gc'], 'rank_spread': rank_spread,
             'roofline': roof, 'cpu_baseline': base,
             # whole-step lower bound on the conv stacks' MFMA utilisation: conv FLOPs / (entire step time);
             # profiles/ holds the per-kernel split (convolutions alone: see DESIGN.md section 4)

@@ -17,7 +17,7 @@ algorithm of the reference files (paths relative to the upstream repo):
   train.py:33-39,137-152                          one optimisation step
 
 Parity pin: ``tests/golden/*.npz`` were produced by importing the reference
-itself in the build container (``tools/gen_golden.py``); ``tests/test_oracle_*``
+itself in the build container (``tests/golden/gen_golden.py``); ``tests/test_oracle_*``
 checks every function here against them.  The arithmetic bottoms out in
 PyTorch ATen (pinned upstream at torch==1.2.0, here torch 2.10): the
 ``align_corners`` switch reproduces both generations of ``grid_sample``

@@ -121,9 +121,7 @@ def test_host_library_has_no_hip_dependency():
     assert rows[1, 1:].tolist() == [6, 7, 8]
 
 
-def test_c_program_links_against_the_abi(tmp_path):
-    """tools/capi_bench.cpp uses include/unflow_hip.h from plain C++ (no torch, no Python): it must compile and
-    link against the in-tree library (it is only run on the GPU box)."""
+def _build_capi_bench(tmp_path):
     import subprocess
     import __graft_entry__ as ge
     ge.build()
@@ -134,6 +132,55 @@ def test_c_program_links_against_the_abi(tmp_path):
                         '-Wl,-rpath,' + os.path.join(ROOT, 'unopticalflow_amd'), '-o', exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert os.path.exists(exe)
+    return exe
+
+
+def test_c_program_links_against_the_abi(tmp_path):
+    """tools/capi_bench.cpp uses include/unflow_hip.h from plain C++ (no torch, no Python): it must compile and
+    link against the in-tree library (it is RUN by test_c_program_runs_and_matches_the_oracle on the GPU box)."""
+    _build_capi_bench(tmp_path)
+
+
+def test_one_abi_version_number():
+    """include/unflow_hip.h's UNFLOW_ABI_VERSION is what the library returns (csrc/photo.hip returns the macro), what the Python
+    binding expects (_lib.ABI_VERSION is read from the header) and what the C program compares with."""
+    from unopticalflow_amd import _lib
+    assert _lib.ABI_VERSION == _lib.header_abi_version() >= 8
+    assert 'return UNFLOW_ABI_VERSION;' in open(os.path.join(ROOT, 'unopticalflow_amd', 'csrc', 'photo.hip')).read()
+    assert 'unflow_abi_version() != UNFLOW_ABI_VERSION' in open(os.path.join(ROOT, 'tools', 'capi_bench.cpp')).read()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.unflow_abi_version.restype = ctypes.c_int
+    assert lib.unflow_abi_version() == _lib.ABI_VERSION          # (a host function: callable without a GPU)
+
+
+@pytest.mark.gpu
+def test_c_program_runs_and_matches_the_oracle(tmp_path):
+    """The Python-free user of the boundary ("standalone bench/rocprof harness without Python"), RUN as a fresh child
+    process: cost volume forward + backward through the C ABI on its deterministic input, compared with the CPU oracle's
+    corr_naive (pwc_tf.py:97-106) and its autograd."""
+    import re
+    import subprocess
+    import numpy as np
+    from oracle import ref_cpu as R
+    exe = _build_capi_bench(tmp_path)
+    B, C, H, W, d = 2, 12, 24, 68, 4
+    r = subprocess.run([exe] + [str(v) for v in (B, C, H, W, d, 2)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    got = {m.group(1): [float(x) for x in m.group(2).split()] for m in re.finditer(r'^(\w+) = (.*)$', r.stdout, re.M)}
+    D = 2 * d + 1
+    nf, nc = B * C * H * W, B * D * D * H * W
+    i = np.arange(max(nf, nc) + 8, dtype=np.uint64)
+    v = ((i * np.uint64(2654435761)) % np.uint64(2001)).astype(np.float32) / np.float32(1000.0) - np.float32(1.0)
+    f1 = torch.from_numpy(v[:nf].reshape(B, C, H, W).copy()).requires_grad_()
+    f2 = torch.from_numpy(v[7:7 + nf].reshape(B, C, H, W).copy()).requires_grad_()
+    g = torch.from_numpy(v[3:3 + nc].reshape(B, D * D, H, W).copy())
+    cv = R.corr_naive(f1, f2, d)
+    cv.backward(g)
+    centre = cv[0, d * D + d, H // 2, :4].detach().numpy()
+    np.testing.assert_allclose(got['cv_centre'], centre, rtol=1e-5, atol=1e-6)
+    for name, t in (('sum_abs_cv', cv.detach()), ('sum_abs_gf1', f1.grad), ('sum_abs_gf2', f2.grad)):
+        np.testing.assert_allclose(got[name][0], t.double().abs().sum().item(), rtol=1e-5, err_msg=name)
+    assert 'GB/s algorithmic' in r.stdout
 
 
 def test_miopen_tuning_paths(monkeypatch):

@@ -78,3 +78,24 @@ def test_train_resume_and_test_cli(tmp_path, host_input, capsys):
         assert res is not None
     finally:
         os.chdir(cwd)
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher in front (the driver's command form; the reference takes its GPU list on one
+    command line, train.py:208-214): the parent starts two fresh ranks, relays rank 0's JSON as its last stdout line, exits 0.
+    Rehearsal on this one-GPU box: both ranks share device 0 over gloo (UNFLOW_BENCH_ONE_GPU=1) -- the numbers mean nothing,
+    the plumbing (self-launch, replayed step with one all-reduce, barriers, MAX over ranks, rank spread) is the real one."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UNFLOW_BENCH_ONE_GPU='1', UNFLOW_MIOPEN_FIND='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2',
+                        '--hw', '64', '128', '--batch', '2', '--no-cpu-baseline'], env=env, cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['steps'] == 3 and line['value'] > 0 and line['config']['parallelism'] == 'dp2'
+    assert line['step_mode'].startswith('hipGraph replay') and line['rank_spread']['max_over_ranks']['step_ms_median'] > 0

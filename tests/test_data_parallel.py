@@ -83,6 +83,50 @@ def test_two_ranks_match_single_process(tmp_path, steps):
         np.testing.assert_allclose(a.numpy(), b.detach().numpy(), rtol=1e-4, atol=2e-5)  # Adam: |update| <= lr = 1e-4
 
 
+def _worker_flat(rank, world, port, steps, out_path):
+    """The replayed multi-rank step's exchange without the graphs (they need a GPU): backward assigns, ``pack_all`` copies
+    every piece into the flat buffer (what graph A ends with), ONE ``all_reduce_flat``, Adam on the buffer's views (graph B)."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    init_distributed('gloo')
+    cfg, model = _make(seed_params=1234 if rank == 0 else 999)
+    trainer = FlowTrainer(cfg, model, distributed=True, fused_adam=False, use_graph=True)   # graph mode: no hooks
+    assert not trainer.grads.overlap and not trainer.grads._hooks
+    x = R.synthetic_triplets(2 * world, H, W, seed=5, structured=True)
+    mine = shard_batch(x, rank, world)
+    for _ in range(steps):
+        trainer.grads.zero()
+        loss_pack = trainer.model(mine)
+        trainer.total_loss(loss_pack).backward()
+        assert trainer.grads.launched_early == 0
+        trainer.grads.pack_all()
+        trainer.grads.check_views()
+        trainer.grads.all_reduce_flat()
+        trainer.optimizer.step()
+    if rank == 0:
+        torch.save({'grad': trainer.grads.vector(), 'params': [p.detach().clone() for p in model.parameters()]}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_flat_exchange_matches_single_process(tmp_path):
+    world, steps = 2, 2
+    out = str(tmp_path / 'rank0.pt')
+    mp.spawn(_worker_flat, args=(world, _free_port(), steps, out), nprocs=world, join=True)
+    got = torch.load(out)
+    torch.set_num_threads(4)
+    cfg, model = _make()
+    trainer = FlowTrainer(cfg, model, distributed=False, fused_adam=False)
+    x = R.synthetic_triplets(2 * world, H, W, seed=5, structured=True)
+    for _ in range(steps):
+        trainer.step(x)
+    g_ref = trainer.grads.vector()
+    np.testing.assert_allclose(got['grad'].numpy(), g_ref.numpy(), rtol=1e-4, atol=1e-5 * g_ref.abs().max().item())
+    for a, b in zip(got['params'], model.parameters()):
+        np.testing.assert_allclose(a.numpy(), b.detach().numpy(), rtol=1e-4, atol=2e-5)
+
+
 def test_flat_gradients_alias_and_zero():
     cfg, model = _make()
     fg = FlatGradients(model.parameters())

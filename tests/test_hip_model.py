@@ -441,6 +441,97 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
         # a gradient that is numerically zero takes either sign, so two runs can differ by 4 * lr there
 
 
+def _gpu_rank_graph(rank, world, port, out_path):
+    import os
+    import torch.distributed as dist
+    os.environ.update(RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from unopticalflow_amd import get_model
+    from unopticalflow_amd.parallel import init_distributed, shard_batch
+    from unopticalflow_amd.trainer import FlowTrainer
+    init_distributed('gloo')
+    torch.cuda.set_device(0)
+    cfg = R.default_cfg()
+    torch.manual_seed(7 + rank)
+    model = get_model('flow')(cfg).cuda()
+    if rank == 0:
+        model.load_state_dict(R.seeded_state_dict(R.Model_flow(cfg), 1234, 0.25))
+    trainer = FlowTrainer(cfg, model, distributed=True, use_graph=True)
+    assert not trainer.grads.overlap
+    x = R.synthetic_triplets(2 * world, 64, 128, seed=5, structured=True).cuda()
+    mine = shard_batch(x, rank, world)
+    losses = []
+    for it in range(3):
+        loss, _ = trainer.step(mine)                          # graph A, one all-reduce of the flat buffer, graph B
+        losses.append(float(loss))
+        if it == 0:
+            first = trainer.grads.vector()                    # p.grad are the flat buffer's views since the capture
+    assert trainer._graph is not None and trainer._graph_opt is not None and trainer.iteration == 3
+    other = R.synthetic_triplets(1, 64, 128, seed=9, structured=True).cuda()
+    trainer.step(other)                                       # another batch shape: the eager step, pieces exchanged the old way
+    trainer.step(mine)                                        # and back to the replay
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+    if rank == 0:
+        torch.save({'grad': first.cpu(), 'losses': losses, 'params3': None}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_replayed_step_matches_single_process(tmp_path):
+    """The multi-rank DEFAULT step mode (bench.py, train.py): graph(forward + backward + gradient pack) -> one all-reduce of
+    the flat buffer -> graph(Adam), two ranks sharing the GPU over gloo == one eager process on the global batch.  The local
+    loss of rank 0 differs from the global one, so gradients (first step) are what is compared; then an eager step on another
+    batch shape and a replay after it must still run."""
+    import socket
+    import torch.multiprocessing as mp
+    from unopticalflow_amd import get_model
+    from unopticalflow_amd.trainer import FlowTrainer
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / 'rank0.pt')
+    mp.start_processes(_gpu_rank_graph, args=(2, port, out), nprocs=2, join=True, start_method='spawn')
+    got = torch.load(out)
+    cfg = R.default_cfg()
+    model = get_model('flow')(cfg).cuda()
+    model.load_state_dict(R.seeded_state_dict(R.Model_flow(cfg), 1234, 0.25))
+    trainer = FlowTrainer(cfg, model, distributed=False)
+    x = R.synthetic_triplets(4, 64, 128, seed=5, structured=True).cuda()
+    trainer.step(x)
+    g_ref = trainer.grads.vector().cpu()
+    np.testing.assert_allclose(got['grad'].numpy(), g_ref.numpy(), rtol=2e-3, atol=2e-4 * g_ref.abs().max().item())
+    assert all(np.isfinite(got['losses']))
+
+
+def test_graph_capture_keeps_a_loaded_adam_state(tmp_path):
+    """Resume under replay: the capture's three warm-up iterations must give back the optimizer state a checkpoint put there
+    (train.py:42-46), not zero it -- step counter, moments and the next update equal the eager continuation."""
+    from unopticalflow_amd import get_model
+    from unopticalflow_amd.trainer import FlowTrainer
+    cfg = R.default_cfg()
+    sd = R.seeded_state_dict(R.Model_flow(cfg), 1234, 0.25)
+    x = R.synthetic_triplets(2, 64, 128, seed=3, structured=True).cuda()
+
+    def fresh(graph):
+        model = get_model('flow')(cfg).cuda()
+        model.load_state_dict(sd)
+        return FlowTrainer(cfg, model, use_graph=graph)
+    a = fresh(False)
+    a.step(x); a.step(x)
+    path = str(tmp_path / 'two_steps.pth')
+    a.save(path)
+    a.step(x)                                                        # the eager continuation
+    b = fresh(True)
+    assert b.load(path, map_location='cuda') == 2
+    b.step(x)
+    torch.cuda.synchronize()
+    pa, pb = a.optimizer.param_groups[0]['params'], b.optimizer.param_groups[0]['params']
+    for qa, qb in zip(pa, pb):
+        sa, sb = a.optimizer.state[qa], b.optimizer.state[qb]
+        assert float(sb['step']) == 3.0 == float(sa['step'])
+        scale = sa['exp_avg'].abs().max().item() + 1e-12
+        np.testing.assert_allclose(sb['exp_avg'].cpu().numpy(), sa['exp_avg'].cpu().numpy(), rtol=1e-2, atol=2e-3 * scale)
+        np.testing.assert_allclose(qb.detach().cpu().numpy(), qa.detach().cpu().numpy(), rtol=0, atol=2.5e-4)   # one step of <= lr; sign flips where the gradient is ~0
+
+
 def _rccl_single_rank(rank, port, out_path):
     import os
     import torch.distributed as dist

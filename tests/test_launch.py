@@ -1,0 +1,55 @@
+"""unopticalflow_amd.launch: one command line starts one process per GPU (the reference's `--gpu 0,1,.. --multi_gpu` form,
+train.py:208-214) -- CPU checks of the launcher itself; the GPU rehearsal of `python bench.py --gpus 2` is in test_cli.py."""
+import io
+import os
+import sys
+import textwrap
+import time
+
+from unopticalflow_amd.launch import launched_by_torchrun, rank_env, spawn_ranks
+
+WORKER = textwrap.dedent('''
+    import os, sys, time
+    r, w = os.environ['RANK'], os.environ['WORLD_SIZE']
+    assert os.environ['LOCAL_RANK'] == r and os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0
+    assert os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    print('rank %s of %s' % (r, w), flush=True)
+    if len(sys.argv) > 1 and r == sys.argv[1]:
+        sys.exit(3)
+    time.sleep(float(sys.argv[2]) if len(sys.argv) > 2 else 0.0)
+    print('{"rank": %s}' % r, flush=True)
+''')
+
+
+def test_ranks_get_their_environment_and_rank0_owns_stdout(tmp_path):
+    f = tmp_path / 'w.py'
+    f.write_text(WORKER)
+    out, err = io.StringIO(), io.StringIO()
+    assert spawn_ranks([sys.executable, str(f)], 3, out=out, err=err) == 0
+    assert out.getvalue().splitlines() == ['rank 0 of 3', '{"rank": 0}']          # rank 0's last line stays the last line
+    assert sorted(l for l in err.getvalue().splitlines() if l.startswith('{')) == ['{"rank": 1}', '{"rank": 2}']
+
+
+def test_a_failed_rank_ends_the_job_with_its_code(tmp_path):
+    f = tmp_path / 'w.py'
+    f.write_text(WORKER)
+    out, err = io.StringIO(), io.StringIO()
+    t0 = time.monotonic()
+    rc = spawn_ranks([sys.executable, str(f), '1', '60'], 3, out=out, err=err)      # rank 1 exits 3, the others would sleep 60 s
+    assert rc == 3 and time.monotonic() - t0 < 20
+    assert 'rank 1 exited with code 3' in err.getvalue() and '{"rank": 0}' not in out.getvalue()
+
+
+def test_rank_env_and_detection():
+    e = rank_env(2, 4, 1234, base={'PATH': os.environ.get('PATH', '')})
+    assert (e['RANK'], e['LOCAL_RANK'], e['WORLD_SIZE'], e['MASTER_PORT']) == ('2', '2', '4', '1234')
+    assert int(e['OMP_NUM_THREADS']) >= 1
+    assert launched_by_torchrun(e) and not launched_by_torchrun({'PATH': ''})
+    assert rank_env(0, 2, 1, base={'OMP_NUM_THREADS': '7'})['OMP_NUM_THREADS'] == '7'
+
+
+def test_bench_parent_does_not_import_torch_before_launching():
+    """`python bench.py --gpus N` decides to self-launch before `import torch` (the parent must never initialise HIP)."""
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py')).read()
+    assert src.index('self_launch_if_needed()\n\nimport torch') > 0
+    assert src.index('def self_launch_if_needed') < src.index('\nimport torch')

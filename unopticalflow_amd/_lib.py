@@ -81,12 +81,26 @@ SIGNATURES = {
     'unflow_png_unfilter': [_P, _I, _I, _I],
 }
 
-ABI_VERSION = 8
-_lib = None
+HEADER_PATH = os.path.join(os.path.dirname(PKG), 'include', 'unflow_hip.h')
+
+
+def header_abi_version(path=HEADER_PATH):
+    """``#define UNFLOW_ABI_VERSION n`` of include/unflow_hip.h -- ONE number for the library (built from that header), a C
+    user and this binding."""
+    import re
+    with open(path) as f:
+        m = re.search(r'^#define\s+UNFLOW_ABI_VERSION\s+(\d+)\s*$', f.read(), re.M)
+    if m is None:
+        raise UnflowLibraryError('%s does not define UNFLOW_ABI_VERSION' % path)
+    return int(m.group(1))
 
 
 class UnflowLibraryError(RuntimeError):
     pass
+
+
+ABI_VERSION = header_abi_version()
+_lib = None
 
 
 def load():

@@ -414,7 +414,7 @@ inline int flat_blocks(size_t n) {
 
 int unflow_ssim_blocks(int H, int W);   // ssim.hip
 
-extern "C" int unflow_abi_version(void) { return 8; }   // 2: + unflow_warp_corr_*; 3: img_batch on the 2B loss entries; 4: + *_nhwc epilogues; 5: + unflow_timing_*; 6: + *_nhwc_bf16 epilogues; 7: + *_nhwc_to / *_nhwc_from (epilogues that fill cat buffers), unflow_warp_bwd_det; 8: + unflow_upsample_scaled_*, *_nhwc_bf16 glue, unflow_loss_combine_*, unflow_weighted_mean_sum_*, unflow_flow_head_*
+extern "C" int unflow_abi_version(void) { return UNFLOW_ABI_VERSION; }   // 2: + unflow_warp_corr_*; 3: img_batch on the 2B loss entries; 4: + *_nhwc epilogues; 5: + unflow_timing_*; 6: + *_nhwc_bf16 epilogues; 7: + *_nhwc_to / *_nhwc_from (epilogues that fill cat buffers), unflow_warp_bwd_det; 8: + unflow_upsample_scaled_*, *_nhwc_bf16 glue, unflow_loss_combine_*, unflow_weighted_mean_sum_*, unflow_flow_head_*
 
 // ---- kernel-exact timing slots (see UNFLOW_LAUNCH in common.h) ----
 #include <mutex>

@@ -1,0 +1,104 @@
+"""Start one process per GPU from a single command line.
+
+The reference takes its GPU list on ONE command (``python train.py --gpu 0,1,2,3 --multi_gpu``, train.py:36-37,208-214:
+single-process DataParallel).  Here the data-parallel job is one process per GPU over RCCL; ``spawn_ranks`` is what lets
+``python bench.py --gpus N`` and ``python -m unopticalflow_amd.train --gpu 0,..,N-1 --multi_gpu`` keep that one-command form
+without ``torch.distributed.run`` in front: the parent starts N FRESH children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+their environment), relays rank 0's stdout as its own and returns the worst exit code.
+
+The parent never touches the GPU: this module imports nothing but the standard library, and a caller must invoke it
+before it initialises HIP (a process that has initialised the GPU must not exec or fork workers that use it).
+"""
+import os
+import signal
+import socket
+import subprocess
+import sys
+import threading
+import time
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launched_by_torchrun(env=None):
+    """True inside a process that a launcher (torch.distributed.run or ``spawn_ranks``) has already given a rank."""
+    env = os.environ if env is None else env
+    return 'RANK' in env and 'WORLD_SIZE' in env
+
+
+def rank_env(rank, world, port, base=None):
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')            # the host driver only does dmabuf IPC (RCCL needs it)
+    if 'OMP_NUM_THREADS' not in env:                              # as torch.distributed.run: do not let N ranks each spin up every core
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        env['OMP_NUM_THREADS'] = str(max(1, cores // world))
+    return env
+
+
+def spawn_ranks(argv, world, poll_s=0.2, grace_s=10.0, out=None, err=None):
+    """Run ``argv`` (a full command, e.g. ``[sys.executable, 'bench.py', '--gpus', '8']``) as ``world`` ranks.
+
+    Rank 0's stdout is forwarded line by line to ``out`` (default: this process's stdout) -- a rank-0 program that prints its
+    result last keeps it last; the other ranks' stdout goes to ``err`` (stderr), every rank's stderr is inherited.  When a rank
+    fails, the others (which would wait for it in a collective until the watchdog fires) are terminated by PID.  Returns 0 when
+    every rank succeeded, else the exit code of the rank that failed first (128 + signal for a killed rank)."""
+    if world < 1:
+        raise ValueError('world must be >= 1')
+    out = sys.stdout if out is None else out
+    err = sys.stderr if err is None else err
+    port = free_port()
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen(list(argv), env=rank_env(r, world, port), stdout=subprocess.PIPE,
+                                      stderr=None, text=True, bufsize=1))
+
+    def pump(p, sink):
+        for line in p.stdout:
+            sink.write(line)
+            sink.flush()
+    threads = [threading.Thread(target=pump, args=(p, out if r == 0 else err), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+    failed, first_bad = None, 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad and failed is None:
+                failed, first_bad = time.monotonic(), (128 - bad[0] if bad[0] < 0 else bad[0])
+                for p in procs:                                   # exact PIDs of our own children, never a pattern
+                    if p.poll() is None:
+                        p.send_signal(signal.SIGTERM)
+            if all(c is not None for c in codes):
+                break
+            if failed is not None and time.monotonic() - failed > grace_s:
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+            time.sleep(poll_s)
+    except KeyboardInterrupt:
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signal.SIGTERM)
+        raise
+    for t in threads:
+        t.join(timeout=5.0)
+    worst = 0
+    for r, p in enumerate(procs):
+        c = p.returncode
+        c = 128 - c if c < 0 else c
+        if c != 0:
+            err.write('launch: rank %d exited with code %d\n' % (r, c))
+        worst = max(worst, c)
+    return first_bad or worst                                     # the rank that failed first, not the SIGTERM we answered with

@@ -178,6 +178,25 @@ class FlatGradients:
                 self.launched_early += 1
         self._hooks = [p.register_post_accumulate_grad_hook(hook) for p in self.params]
 
+    def pack_all(self):
+        """Copy every piece's (assigned) gradients into the buffer and point ``p.grad`` at its views -- what the trainer puts at
+        the END of a captured forward + backward graph: a replay then leaves the whole gradient in ``flat``, ready for ONE
+        collective (``all_reduce_flat``), and the optimizer graph that follows reads the views."""
+        if not self.pack:
+            return
+        for k in range(self.chunks):
+            self._pack_piece(k)
+
+    def all_reduce_flat(self):
+        """Average the whole buffer over the ranks with a single collective (the replayed step: nothing to overlap with, so
+        one 20.5 MB message instead of four pieces).  On RCCL the call is enqueued on the communicator's stream and the
+        current stream waits for it -- the host does not."""
+        if not self._active():
+            return
+        dist.all_reduce(self.flat, op=self._averaging_op(), group=self.group)
+        if self._averaging_op() != dist.ReduceOp.AVG and dist.get_world_size(self.group) > 1:
+            self.flat.mul_(1.0 / dist.get_world_size(self.group))
+
     def remember_sources(self):
         """After a hipGraph capture of forward + backward: the tensors backward assigned as gradients are the graph's own
         static buffers, rewritten by every replay; ``all_reduce_mean(from_graph=True)`` copies from them."""

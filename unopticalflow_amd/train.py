@@ -2,8 +2,9 @@
 
     python -m unopticalflow_amd.train -c unopticalflow_amd/config/kitti.yaml --gpu 0 --mode flow \
         --prepared_save_dir data_s1 --model_dir models [--synthetic]
+    python -m unopticalflow_amd.train -c ... --gpu 0,1,2,3,4,5,6,7 --multi_gpu          # starts its 8 ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        -m unopticalflow_amd.train -c ... --gpu 0,1,2,3,4,5,6,7 --multi_gpu
+        -m unopticalflow_amd.train -c ... --gpu 0,1,2,3,4,5,6,7 --multi_gpu              # (or behind a launcher)
 
 Same flags and yaml keys as the reference.  ``--multi_gpu`` keeps its meaning -- the global batch is
 batch_size x num_gpus and num_iterations / num_gpus (train.py:211-213) -- but runs one process per
@@ -92,18 +93,24 @@ def evaluate_during_training(cfg, model, iter_):
     return results
 
 
-def eval_barrier(timeout_s=4 * 3600):
-    """All ranks meet after rank 0's periodic evaluation.  A gloo group with its own (long) timeout carries it: the RCCL
-    group's watchdog would kill the waiting ranks."""
+def make_eval_group(timeout_s=4 * 3600):
+    """A gloo group with its own (long) timeout for the barrier behind rank 0's periodic evaluation: the RCCL group's
+    watchdog (10 min) would kill the waiting ranks.  Created ONCE at start-up, while every rank is present -- group
+    construction is itself a rendezvous, and doing it lazily would have ranks 1..N enter it minutes before rank 0."""
     import datetime
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return None
+    return dist.new_group(backend='gloo', timeout=datetime.timedelta(seconds=timeout_s))
+
+
+def eval_barrier(group):
+    """All ranks meet after rank 0's periodic evaluation (``group`` from ``make_eval_group``; None: one process)."""
+    import torch.distributed as dist
+    if group is None:
         return
-    g = eval_barrier.__dict__.get('group')
-    if g is None:
-        g = eval_barrier.__dict__['group'] = dist.new_group(backend='gloo', timeout=datetime.timedelta(seconds=timeout_s))
     torch.cuda.synchronize()
-    dist.barrier(group=g)
+    dist.barrier(group=group)
 
 
 def train(cfg):
@@ -118,6 +125,7 @@ def train(cfg):
     rank, local_rank, world = init_distributed('nccl', device_index=ids[local])
     torch.cuda.set_device(ids[local])
     dev = torch.device('cuda', ids[local])
+    eval_group = make_eval_group() if not getattr(cfg, 'no_test', False) else None
 
     from . import tuning
     if getattr(cfg, 'miopen_find', 1):
@@ -128,7 +136,7 @@ def train(cfg):
     if getattr(cfg, 'channels_last', None) is None:
         cfg.channels_last = tuning.default_channels_last()              # NHWC only with MIOpen's measured picks
     model = get_model(cfg.mode)(cfg).to(dev)
-    trainer = FlowTrainer(cfg, model, distributed=(world > 1), use_graph=bool(getattr(cfg, 'graph', 0)))
+    trainer = FlowTrainer(cfg, model, distributed=(world > 1), use_graph=bool(getattr(cfg, 'graph', 1)), gc_freeze_after=2)
     if cfg.resume:                                                     # train.py:42-46
         name = 'iter_{}.pth'.format(cfg.iter_start) if cfg.iter_start > 0 else 'last.pth'
         cfg.iter_start = trainer.load(os.path.join(cfg.model_dir, name), map_location=dev)
@@ -182,8 +190,7 @@ def train(cfg):
                     evaluate_during_training(cfg, model, iter_)
             finally:
                 torch.backends.cudnn.benchmark = bench_mode
-                if world > 1:
-                    eval_barrier()
+                eval_barrier(eval_group)
         if rank == 0 and (iter_ + 1) % cfg.save_interval == 0:         # train.py:153-155
             trainer.iteration = iter_
             trainer.save(os.path.join(cfg.model_dir, 'iter_{}.pth'.format(iter_)))
@@ -217,7 +224,9 @@ def main(argv=None):
     ap.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'bf16'], help='conv-stack precision.')
     ap.add_argument('--channels_last', type=int, default=None, help='memory format of the conv stacks (1 NHWC, 0 NCHW); default: 1 when the shipped MIOpen find-db is in use (same device and MIOpen build), else 0.')
     ap.add_argument('--miopen_find', type=int, default=1, help='1: use the shipped MIOpen find-db + benchmark mode.')
-    ap.add_argument('--graph', type=int, default=0, help='1: replay the train step as a hipGraph.')
+    ap.add_argument('--graph', type=int, default=1, help='1 (default): replay the train step as a hipGraph -- one process: forward + backward + Adam in one graph; '
+                    'several ranks: forward + backward, one all-reduce, Adam graph (the host enqueues 4 things per step instead of ~3000); '
+                    '0: eager launches, gradient pieces all-reduced from hooks during backward.')
     ap.add_argument('--host_input', type=int, default=0, help='1: resize/flip/scale on the CPU workers (PIL) instead of the GPU.')
     args = ap.parse_args(argv)
     if args.config_file is None:
@@ -226,6 +235,16 @@ def main(argv=None):
         raise ValueError('config file not found.')
     if args.depth_pretrained_model:
         raise ValueError('--depth_pretrained_model belongs to the depth stage, which this package does not cover')
+    num_gpus = len(str(args.gpu).split(','))
+    if (args.multi_gpu and num_gpus <= 1) or ((not args.multi_gpu) and num_gpus > 1):
+        raise ValueError('Error! the number of gpus used in the --gpu argument does not match the argument --multi_gpu.')
+    from .launch import launched_by_torchrun, spawn_ranks
+    if args.multi_gpu and not launched_by_torchrun():
+        # the reference's one-command form (train.py:208-214): start one process per listed GPU ourselves.  This parent has
+        # imported torch but made no GPU call; the children are fresh interpreters, rank r drives the r-th id of --gpu.
+        import sys
+        cmd = [sys.executable, '-m', 'unopticalflow_amd.train'] + (list(argv) if argv is not None else sys.argv[1:])
+        raise SystemExit(spawn_ranks(cmd, num_gpus))
     if args.model_dir is None:
         args.model_dir = os.path.join('models', os.path.splitext(os.path.split(args.config_file)[1])[0])
     args.model_dir = os.path.join(os.getcwd(), args.model_dir, args.mode)
@@ -241,15 +260,11 @@ def main(argv=None):
         if attr == 'num_iterations' and val is None:
             continue
         cfg[attr] = val
-    num_gpus = len(str(args.gpu).split(','))
-    if (args.multi_gpu and num_gpus <= 1) or ((not args.multi_gpu) and num_gpus > 1):
-        raise ValueError('Error! the number of gpus used in the --gpu argument does not match the argument --multi_gpu.')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.multi_gpu:
         if world != num_gpus:
-            raise ValueError('--multi_gpu with {} gpus needs {} processes: launch with '
-                             'python -m torch.distributed.run --nproc-per-node {} -m unopticalflow_amd.train ...'
-                             .format(num_gpus, num_gpus, num_gpus))
+            raise ValueError('--multi_gpu with {} gpus but the launcher started {} process(es): drop the launcher (this '
+                             'command starts its own ranks) or use --nproc-per-node {}'.format(num_gpus, world, num_gpus))
         cfg['batch_size'] = cfg['batch_size'] * num_gpus               # train.py:211-213
         if num_iter_override is None:
             cfg['num_iterations'] = int(cfg['num_iterations'] / num_gpus)

@@ -12,10 +12,12 @@ import torch
 from .core.config import generate_loss_weights_dict
 from .parallel import FlatGradients, PlainGradients, broadcast_parameters
 
+_PROCESS_GC_FROZEN = False
+
 
 class FlowTrainer:
     def __init__(self, cfg, model, distributed=False, allreduce_chunks=4, fused_adam=None, use_graph=False,
-                 single_rank_collectives=False, gc_freeze_after=2):
+                 single_rank_collectives=False, gc_freeze_after=None):
         self.cfg = cfg
         self.model = model
         self.loss_weights = generate_loss_weights_dict(cfg)
@@ -37,7 +39,7 @@ class FlowTrainer:
             fused_adam = params[0].is_cuda
         if fused_adam:
             kw['fused'] = True
-        if use_graph:
+        if use_graph and params[0].is_cuda:
             kw['capturable'] = True                    # step counters live on the device
         self.optimizer = torch.optim.Adam([{'params': params, 'lr': cfg.lr}], **kw)
         self.iteration = 0
@@ -49,12 +51,14 @@ class FlowTrainer:
         # host jitter: a step builds ~10^4 short-lived Python objects (autograd nodes, tensors, ctypes arguments); the
         # cyclic collector's full (generation-2) pass over the ~10^6 long-lived objects of an imported torch takes
         # 100-150 ms on the bench box -- more than the host's 2-3 step launch lead, so the GPU idles (one 50-90 ms step every
-        # ~17: 26.3-27.3 ms mean against a 24.9 ms median, profiles/r3_headline_*.json).  After ``gc_freeze_after`` steps
-        # everything alive is moved to the permanent generation (gc.freeze): later collections only look at what the steps
-        # themselves allocate.  None / 0 leaves the collector alone.
+        # ~17: 26.3-27.3 ms mean against a 24.9 ms median, profiles/r3_headline_*.json).  With ``gc_freeze_after=N`` everything
+        # alive after N steps is moved to the permanent generation (gc.freeze): later collections only look at what the steps
+        # themselves allocate.  It is PROCESS-GLOBAL, so it is opt-in (train.py and bench.py ask for it, a library user's
+        # process is left alone), done at most once per process, and ``close()`` undoes it.
         self.gc_freeze_after = gc_freeze_after
         self.fused_total_loss = True
         self._gc_frozen = False
+        self._steps_here = 0                           # steps THIS object ran (a resumed run starts at iteration >> 2)
 
     def total_loss(self, loss_pack):
         """train.py:147-150; on the GPU one launch each way (ops.weighted_mean_sum) instead of a mean, a multiply and an add per key"""
@@ -77,38 +81,49 @@ class FlowTrainer:
         return loss, loss_pack
 
     def _build_graph(self, inputs):
-        """Capture forward + loss + backward (+ Adam) once.  The three warm-up iterations PyTorch needs before a capture
-        (MIOpen picks its solvers, Adam creates its state) run on the first batch too, but must not count as training:
-        parameters and optimizer state are restored afterwards (Adam's step counters included), so the replayed
-        trajectory is the eager one."""
+        """Capture the step once.  One process: forward + loss + backward + Adam in one graph.  Several ranks: graph A =
+        forward + loss + backward + the copy of every gradient into the flat buffer, then ONE all-reduce of that buffer
+        outside any graph, then graph B = Adam on the buffer's views -- per step the host enqueues an input copy, two graph
+        launches and one collective, whatever the ~3000 kernel launches inside would have cost it.
+        The three warm-up iterations PyTorch needs before a capture (MIOpen picks its solvers, Adam creates its state) run on
+        the first batch too, but must not count as training: parameters and optimizer state are restored afterwards (Adam's
+        step counters included; a state loaded from a checkpoint is put back, a fresh one zeroed), so the replayed trajectory
+        is the eager one.  The warm-up exchanges nothing (its updates are discarded on every rank alike)."""
         self._static_in = inputs.clone()
         saved_model = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        saved_opt = {id(v): v.detach().clone() for st in self.optimizer.state.values() for v in st.values() if torch.is_tensor(v)}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                  # warm-up off the capture
             for it in range(3):
                 self._eager_fwd_bwd(self._static_in)
-                if not self.distributed:
-                    self.optimizer.step()
+                self.optimizer.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         with torch.no_grad():
             for k, v in self.model.state_dict().items():
                 v.copy_(saved_model[k])
-            if not self.distributed:                   # zero Adam's moments and counters in place (the graph keeps these tensors)
-                for st in self.optimizer.state.values():
-                    for v in st.values():
-                        if torch.is_tensor(v):
+            for st in self.optimizer.state.values():   # in place: the graphs keep these tensors
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        if id(v) in saved_opt:
+                            v.copy_(saved_opt[id(v)])
+                        else:
                             v.zero_()
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             loss, pack = self._eager_fwd_bwd(self._static_in)
-            if not self.distributed:                   # with several ranks the all-reduce stays outside the graph
+            if self.distributed:
+                self.grads.pack_all()                  # the replay leaves the gradient in the flat buffer; p.grad -> its views
+            else:
                 self.optimizer.step()
             self._static_loss = loss.detach()
             self._static_pack = {k: v.detach() for k, v in pack.items()}
+        self._graph_opt = None
         if self.distributed:
-            self.grads.remember_sources()              # replays rewrite these tensors; the exchange copies from them
+            self._graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_opt):
+                self.optimizer.step()
 
     def _graph_step(self, inputs):
         if self._graph is None:
@@ -116,17 +131,30 @@ class FlowTrainer:
         self._static_in.copy_(inputs)
         self._graph.replay()
         if self.distributed:
-            self.grads.all_reduce_mean(from_graph=True)     # the replay wrote the captured gradient tensors
-            self.optimizer.step()
+            self.grads.all_reduce_flat()
+            self._graph_opt.replay()
         self.iteration += 1
         return self._static_loss, self._static_pack
 
     def _settle_host(self):
-        if self.gc_freeze_after and not self._gc_frozen and self.iteration >= self.gc_freeze_after:
-            import gc
-            gc.collect()
-            gc.freeze()
+        global _PROCESS_GC_FROZEN
+        if self.gc_freeze_after and not self._gc_frozen and self._steps_here >= self.gc_freeze_after:
             self._gc_frozen = True
+            if not _PROCESS_GC_FROZEN:                 # once per process, whichever trainer gets there first
+                import gc
+                gc.collect()
+                gc.freeze()
+                _PROCESS_GC_FROZEN = True
+        self._steps_here += 1
+
+    def close(self):
+        """Undo the process-global side effect of ``gc_freeze_after`` (the frozen objects become collectable again)."""
+        global _PROCESS_GC_FROZEN
+        if self._gc_frozen and _PROCESS_GC_FROZEN:
+            import gc
+            gc.unfreeze()
+            _PROCESS_GC_FROZEN = False
+        self._gc_frozen = False
 
     def step(self, inputs):
         """One optimisation step on this rank's shard.  Returns (loss, loss_pack) (detached)."""
