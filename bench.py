@@ -26,7 +26,8 @@ The single JSON line also carries
                 profiles/ -- only when that file was measured on the very kernel sources of this build (sha256 of
                 csrc/*.hip recorded next to it), else null.  `aggregate` = all cost-volume + warp launches of a step as
                 one figure (north_star: "achieved HBM GB/s for corr/warp") with the per-level table; `best` = the entry
-                with the highest fraction, for reference;
+                with the highest fraction, for reference; `losses` = the same aggregate + per-entry table for the loss kernels
+                (SSIM window reduction, occlusion weights, masked L1, smoothness, consistency);
   cpu_baseline: the CPU oracle (oracle/ref_cpu.py, the restatement of the reference's op graph,
                 kind "port") timed on the host cores of this box on a bounded sample (all cores the
                 cgroup allows, plus a one-thread figure);
@@ -192,12 +193,36 @@ def sources_sha16():
     return h.hexdigest()[:16]
 
 
+def host_sources_sha16():
+    """sha256 (first 16 hex digits) over the Python sources that decide WHICH convolutions a step runs (the package, not tools)."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, 'unopticalflow_amd')
+    for d, _, files in sorted(os.walk(base)):
+        for name in sorted(files):
+            if name.endswith('.py'):
+                h.update(os.path.relpath(os.path.join(d, name), base).encode()); h.update(open(os.path.join(d, name), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def latest_profile(pattern):
+    """profiles/r<N>_<pattern> of the highest round present (this round's capture when there is one, else the last one)."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_' + pattern)):
+        m = re.match(r'r(\d+)_', os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return best[1] if best else None
+
+
 def measured_traffic(entry, shape, path=None):
     """HBM bytes per launch of (entry point, shape) from the rocprofv3 PMC passes under profiles/ (FETCH_SIZE x2 per the
     gfx950 wide-load correction + WRITE_SIZE, tools/pmc_traffic.py) -- but only if that file was measured on exactly the
     kernel sources of this build; a stale file gives (None, reason)."""
-    path = path or os.path.join(ROOT, 'profiles', 'r3_pmc_traffic.json')
-    if not os.path.exists(path):
+    path = path or latest_profile('pmc_traffic.json')
+    if path is None or not os.path.exists(path):
         return None, 'no PMC file'
     d = json.load(open(path))
     if d.get('sources_sha16') != sources_sha16():
@@ -299,9 +324,14 @@ def main():
             trainer.fused_total_loss = bool(args.fused_loss_sums)
     for _ in range(warm):
         trainer.step(inputs)
-    CW = ('unflow_corr_fwd', 'unflow_corr_bwd', 'unflow_warp_fwd', 'unflow_warp_bwd', 'unflow_warp_corr_fwd', 'unflow_warp_corr_bwd')
+    CW = ('unflow_corr_fwd', 'unflow_corr_bwd', 'unflow_warp_fwd', 'unflow_warp_bwd', 'unflow_warp_bwd_det', 'unflow_warp_corr_fwd', 'unflow_warp_corr_bwd')
+    # the second timed set: the occlusion-aware loss kernels (north_star names the SSIM window reduction and the occlusion-mask
+    # ops next to corr / warp) -> roofline.losses
+    LOSSES = ('unflow_ssim_loss_fwd', 'unflow_ssim_loss_bwd', 'unflow_occ_weight_fwd', 'unflow_absdiff_bwd', 'unflow_masked_mean_fwd',
+              'unflow_masked_mean_bwd', 'unflow_smooth2_fwd', 'unflow_smooth2_bwd', 'unflow_consis_fwd', 'unflow_consis_bwd')
+    TIMED = CW + LOSSES
     if not args.no_kernel_timing:
-        ops.kernel_timer.enable(CW, reserve=32 * args.steps)     # every cost-volume / warp launch of the timed steps: kernel-exact event pairs
+        ops.kernel_timer.enable(TIMED, reserve=96 * args.steps)     # every such launch of the timed steps: kernel-exact event pairs
     # per-step clocks that do not perturb the loop: one event record per step on the launch stream (read after the
     # closing barrier) and one host stamp per step (no synchronisation inside the timed region)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -340,7 +370,7 @@ def main():
         n_eager = min(args.steps, 20)
         trainer.use_graph = False
         trainer.step(inputs)                                # (one untimed eager step: allocator / MIOpen back in eager mode)
-        ops.kernel_timer.enable(CW, reserve=32 * n_eager)
+        ops.kernel_timer.enable(TIMED, reserve=96 * n_eager)
         for _ in range(n_eager):
             trainer.step(inputs)
         torch.cuda.synchronize()
@@ -413,6 +443,8 @@ def main():
                 return {'entry': r['entry'], 'shape': r['shape'], 'avg_us': r['avg_us'], 'launches_per_step': r['launches'] / K,
                         'us_per_step': round(r['total_us'] / K, 2), 'algorithmic_bytes_per_launch': int(r['total_bytes'] / r['launches']),
                         'algorithmic_GBps': r['algorithmic_GBps'], 'frac': round((r['algorithmic_GBps'] or 0.0) / HBM_PEAK_GBS, 4)}
+            loss_rows = [r for r in timed_rows if r['entry'] in LOSSES]
+            timed_rows = [r for r in timed_rows if r['entry'] in CW]
             top = timed_rows[0]                      # rows() sorts by total time: the heaviest (entry point, shape)
             best = max(timed_rows, key=lambda r: r['algorithmic_GBps'] or 0.0)
             tot_us, tot_b = sum(r['total_us'] for r in timed_rows) / K, sum(r['total_bytes'] for r in timed_rows) / K
@@ -432,6 +464,15 @@ def main():
                                   'launches_per_step': sum(r['launches'] for r in timed_rows) / K,
                                   'per_level': [entry(r) for r in timed_rows]},
                     'best': entry(best)}
+            if loss_rows:
+                l_us, l_b = sum(r['total_us'] for r in loss_rows) / K, sum(r['total_bytes'] for r in loss_rows) / K
+                roof['losses'] = {'what': 'every occlusion-weight / masked-L1 / SSIM / smoothness / consistency launch of a step (three scales, both '
+                                          'directions batched as 2B), forward and backward; bound: hbm',
+                                  'algorithmic_bytes_per_step': int(l_b), 'us_per_step': round(l_us, 1),
+                                  'achieved': round(l_b / l_us / 1e3, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                  'frac': round(l_b / l_us / 1e3 / HBM_PEAK_GBS, 4),
+                                  'launches_per_step': sum(r['launches'] for r in loss_rows) / K,
+                                  'per_entry': [entry(r) for r in loss_rows]}
         base = None
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_baseline(args.cpu_sample)
@@ -465,12 +506,15 @@ def main():
         }
         # MFMA utilisation of the convolution kernels alone, from hardware counters (a committed rocprofv3 --pmc capture of
         # this very command: tools/gpu_r3_profile.sh -> tools/summarize_mfma.py); the live figure above divides by the whole step
-        mf = os.path.join(ROOT, 'profiles', 'r3_conv_mfma_%s.json' % args.precision)
-        if out['conv_stack'] is not None and os.path.exists(mf) and (fh, fw, args.batch) == (H, W, B_PER_GPU):
-            ck = json.load(open(mf))['conv_kernels_only']
+        mf = latest_profile('conv_mfma_%s.json' % args.precision)
+        if out['conv_stack'] is not None and mf is not None and (fh, fw, args.batch) == (H, W, B_PER_GPU):
+            mfd = json.load(open(mf))
+            ck = mfd['conv_kernels_only']
+            same = mfd.get('sources_sha16') == sources_sha16() and mfd.get('host_sources_sha16') == host_sources_sha16()
             out['conv_stack']['conv_kernels_only'] = {'achieved': ck['achieved_tflops'], 'frac': ck['frac_of_peak'], 'ms_per_step': ck['ms_per_step'],
                                                       'mfma_tflop_per_step_counted': ck['mfma_tflop_per_step'],
-                                                      'source': 'profiles/%s (SQ_INSTS_VALU_MFMA_MOPS_* x 512 / kernel time, separate --pmc and --kernel-trace runs)' % os.path.basename(mf)}
+                                                      'measured_on_these_sources': same,      # False: a capture of an earlier source state, kept for reference
+                                                      'source': 'profiles/%s (SQ_INSTS_VALU_MFMA_MOPS_* x 512 / kernel time, separate --pmc and --kernel-trace runs; NOT measured in this run)' % os.path.basename(mf)}
         line = json.dumps(out)
     else:
         line = None

@@ -244,38 +244,69 @@ def test_fused_warp_corr_model_matches_golden(golden):
     np.testing.assert_allclose(gn, float(g['grad_norm_ac0']), rtol=5e-4)
 
 
+def _grad_bars(model, ref_abs, ref_norm, what):
+    """The 128x128 bars (test_module_128_golden) at any size: gradient norm within 5e-4, every tensor's L1 norm within 2e-3 of
+    itself plus 2e-3 of the tensor's largest element."""
+    gn = float(np.sqrt(sum((p.grad.double() ** 2).sum().item() for p in model.parameters())))
+    np.testing.assert_allclose(gn, float(ref_norm), rtol=5e-4, err_msg=what + ' gradient norm')
+    ga = np.array([p.grad.double().abs().sum().item() for p in model.parameters()])
+    gmax = np.array([p.grad.abs().max().item() for p in model.parameters()])
+    bad = np.abs(ga - ref_abs) > 2e-3 * ref_abs + 2e-3 * gmax
+    assert not bad.any(), (what, [(n, a, b) for (n, _), a, b, x in zip(model.named_parameters(), ga, ref_abs, bad) if x])
+
+
 @CL_CASES
 def test_kitti_256x832_golden(golden, cl):
-    """832x256 (KITTI size), B=1: loss pack and inference flow against the reference fixture."""
+    """832x256 (KITTI size), B=1 against the reference fixture: loss pack and inference flow, then the BACKWARD at the headline
+    resolution -- gradient norm, the L1 norm of each of the 98 gradients, and the parameters after one Adam step
+    (train.py:139-152), in both memory formats of the conv stacks."""
+    from unopticalflow_amd import generate_loss_weights_dict
     g = golden('g3_kitti_256x832.npz')
     cfg, model = _build(0, float(g['flow_gain']), cl)
+    weights = generate_loss_weights_dict(cfg)
     x = R.synthetic_triplets(1, 256, 832, seed=0, structured=True).cuda()
     with torch.no_grad():
-        pack = model(x)
-        for k in pack:
-            close(pack[k], g[k + '_ac0'], rtol=1e-4, what=k)
         inf = model.inference_flow(x[:, :, 256:512], x[:, :, 512:])
         ref = g['inference_flow_ac0']
         close(inf[:, :, ::8, ::8], ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+    opt = torch.optim.Adam([{'params': [p for p in model.parameters() if p.requires_grad], 'lr': cfg.lr}])
+    opt.zero_grad()
+    pack = model(x)
+    for k in pack:
+        close(pack[k], g[k + '_ac0'], rtol=1e-4, what=k)
+    loss = sum(weights[k] * pack[k].mean() for k in pack)
+    close(loss, g['total_ac0'], rtol=1e-4)
+    loss.backward()
+    _grad_bars(model, g['grad_abs_ac0'], g['grad_norm_ac0'], '832x256 B=1')
+    opt.step()
+    pa = np.array([p.detach().double().abs().sum().item() for p in model.parameters()])
+    np.testing.assert_allclose(pa, g['param_abs_step1_ac0'], rtol=5e-4)       # |Adam update| <= lr per element
 
 
 @CL_CASES
 def test_batch8_matches_oracle_and_is_sample_independent(cl):
     """BASELINE config 2 shape (B=8, 832x256): losses of sample b do not depend on its batch mates
-    (the 3B / 2B batching inside Model_flow is exact per sample), and one sample equals the oracle."""
+    (the 3B / 2B batching inside Model_flow is exact per sample), one sample equals the oracle -- forward AND backward: the
+    gradient of sample 5's weighted loss, taken through the B=8 launch, against the oracle's backward of that triplet alone."""
+    from unopticalflow_amd import generate_loss_weights_dict
     cfg, model = _build(cl=cl)
+    weights = generate_loss_weights_dict(cfg)
     x = R.synthetic_triplets(8, 256, 832, seed=3, structured=True)
     with torch.no_grad():
-        pack8 = model(x.cuda())
         pack1 = model(x[5:6].cuda())
+    pack8 = model(x.cuda())
     for k in pack8:
         close(pack8[k][5:6], pack1[k].cpu(), rtol=2e-5, what=k)
+    sum(weights[k] * pack8[k][5] for k in pack8).backward()           # one sample's contribution to the batch-mean loss (x B)
     ref = R.Model_flow(R.default_cfg())
     ref.load_state_dict(R.seeded_state_dict(ref, 1234, 0.25))
-    with torch.no_grad():
-        pr = ref(x[5:6])
+    pr = ref(x[5:6])
     for k in pr:
-        close(pack1[k], pr[k], rtol=1e-4, what=k)
+        close(pack1[k], pr[k].detach(), rtol=1e-4, what=k)
+    sum(weights[k] * pr[k][0] for k in pr).backward()
+    ref_abs = np.array([p.grad.double().abs().sum().item() for p in ref.parameters()])
+    ref_norm = np.sqrt(sum((p.grad.double() ** 2).sum().item() for p in ref.parameters()))
+    _grad_bars(model, ref_abs, ref_norm, 'sample 5 of 8')
 
 
 def test_rejects_cpu_tensors():
@@ -291,16 +322,24 @@ def test_input_size_must_be_multiple_of_64():
 
 
 def test_sintel_1024x448_matches_oracle():
-    """BASELINE config 4 resolution (Sintel 1024x448, large-map tiles): one sample vs the CPU oracle."""
+    """BASELINE config 4 (Sintel 1024x448, bs = 4 per GPU: the large-map tiles of every kernel at the batch the configuration
+    names): the loss pack of all four samples and the backward of the batch-mean loss against the CPU oracle."""
+    from unopticalflow_amd import generate_loss_weights_dict
     cfg, model = _build()
-    x = R.synthetic_triplets(1, 448, 1024, seed=4, structured=True)
+    weights = generate_loss_weights_dict(cfg)
+    x = R.synthetic_triplets(4, 448, 1024, seed=4, structured=True)
     ref = R.Model_flow(R.default_cfg())
     ref.load_state_dict(R.seeded_state_dict(ref, 1234, 0.25))
-    with torch.no_grad():
-        pack = model(x.cuda())
-        pr = ref(x)
+    torch.set_num_threads(max(1, len(__import__('os').sched_getaffinity(0))))
+    pack = model(x.cuda())
+    pr = ref(x)
     for k in pr:
-        close(pack[k], pr[k], rtol=1e-4, what=k)
+        close(pack[k], pr[k].detach(), rtol=1e-4, what=k)
+    sum(weights[k] * pack[k].mean() for k in pack).backward()
+    sum(weights[k] * pr[k].mean() for k in pr).backward()
+    ref_abs = np.array([p.grad.double().abs().sum().item() for p in ref.parameters()])
+    ref_norm = np.sqrt(sum((p.grad.double() ** 2).sum().item() for p in ref.parameters()))
+    _grad_bars(model, ref_abs, ref_norm, '1024x448 B=4')
 
 
 def _flow_bars(flows, ref_flows, what):

@@ -120,3 +120,17 @@ def test_total_loss_off_the_gpu_is_the_reference_formula():
     pack = {'loss_pixel': torch.rand(4), 'loss_ssim': torch.rand(4), 'loss_flow_smooth': torch.rand(4), 'loss_flow_consis': torch.rand(4)}
     want = 0.15 * pack['loss_pixel'].mean() + 0.85 * pack['loss_ssim'].mean() + 10.0 * pack['loss_flow_smooth'].mean() + 0.01 * pack['loss_flow_consis'].mean()
     torch.testing.assert_close(tr.total_loss(pack), want, rtol=1e-6, atol=0)
+
+
+def test_weight_shadow_groups_split_the_cast_nodes():
+    """WeightShadows(groups=k): k cast nodes over consecutive convolutions, so the eager data-parallel step's all-reduce pieces do
+    not all wait for the end of backward; same values and gradients as one node."""
+    torch.manual_seed(0)
+    net = nn.Sequential(conv(3, 4), conv(4, 4), conv(4, 4), HeadConv2d(4, 2, 3, padding=1))
+    with WeightShadows((net,), groups=3):
+        nodes = [conv_weight(m).grad_fn for m in net.modules() if isinstance(m, nn.Conv2d)]
+        assert len(set(nodes)) == 3 and nodes[0] is not nodes[-1]
+        assert net[3].__dict__['_b_half'].dtype == torch.bfloat16
+    with WeightShadows((net,), groups=99):
+        assert len({conv_weight(m).grad_fn for m in net.modules() if isinstance(m, nn.Conv2d)}) == 4
+    assert not any('_w_half' in m.__dict__ for m in net.modules())

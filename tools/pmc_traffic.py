@@ -1,5 +1,5 @@
 """Collect HBM traffic per launch of the cost-volume / warp entry points with rocprofv3 PMC passes and write
-profiles/r3_pmc_traffic.json (read by bench.py's `roofline.traffic`, keyed by the sha256 of the kernel sources).
+profiles/r4_pmc_traffic.json (via gpurun_out/r4/; read by bench.py's `roofline.traffic`, keyed by the sha256 of the kernel sources).
 
     python tools/pmc_traffic.py [entry:level ...]           (on the GPU box; ~3 min for the default six)
 
@@ -62,8 +62,8 @@ def main():
                                'kernels': {k: {'fetch_kb': round(sum(v) / REPS, 1), 'write_kb': round(sum(write.get(k, [0])) / REPS, 1)}
                                            for k, v in fetch.items()}}
         print(key, res['entries'][key]['hbm_bytes_per_launch'], flush=True)
-    os.makedirs(os.path.join(ROOT, 'gpurun_out', 'r3'), exist_ok=True)
-    json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'r3', 'r3_pmc_traffic.json'), 'w'), indent=1)
+    os.makedirs(os.path.join(ROOT, 'gpurun_out', 'r4'), exist_ok=True)
+    json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'r4', 'r4_pmc_traffic.json'), 'w'), indent=1)
 
 
 if __name__ == '__main__':

@@ -48,7 +48,10 @@ def main():
             fam[f][c] += sum(x for _, x in v[-n:])
         fam[f]['ns'] += dur[k]
         fam[f]['dispatches'] += n
-    res = {'steps': steps, 'peak_tflops': peak, 'families': {}}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import host_sources_sha16, sources_sha16          # the capture is valid for exactly these sources (bench.py checks)
+    res = {'steps': steps, 'peak_tflops': peak, 'sources_sha16': sources_sha16(), 'host_sources_sha16': host_sources_sha16(), 'families': {}}
     tot = collections.defaultdict(float)
     for f, v in sorted(fam.items(), key=lambda kv: -kv[1]['ns']):
         mops = v.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0.0) + v.get('SQ_INSTS_VALU_MFMA_MOPS_BF16', 0.0)

@@ -40,6 +40,7 @@ class Model_flow(nn.Module):
         self.channels_last = tuning.default_channels_last() if cl is None else bool(cl)
         # bf16 option: one multi-tensor cast of all convolution weights per pass (False: autocast's per-call casts; tests compare)
         self.weight_shadows = bool(getattr(cfg, 'weight_shadows', True))
+        self.weight_shadow_groups = int(getattr(cfg, 'weight_shadow_groups', 1))     # cast nodes of the bf16 option (net_utils.WeightShadows)
         self.dup_centre = True           # the pyramid hand-off writes the centre features twice (False: torch.cat((c, c)); A/B)
         self.fused_loss_sums = True      # the sums over scales and directions of forward() as one launch each way (False: eager adds; tests compare)
         self.fpyramid = FeaturePyramid(channels_last=self.channels_last)
@@ -158,7 +159,7 @@ class Model_flow(nn.Module):
             return
         with torch.autocast('cuda', dtype=torch.bfloat16):
             on_gpu = self.weight_shadows and next(self.fpyramid.parameters()).is_cuda
-            with WeightShadows((self.fpyramid, self.pwc_model), enabled=on_gpu):
+            with WeightShadows((self.fpyramid, self.pwc_model), enabled=on_gpu, groups=self.weight_shadow_groups):
                 yield
 
     def _flows(self, imgl, img, imgr, frames=None):

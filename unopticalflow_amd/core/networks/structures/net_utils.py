@@ -46,18 +46,26 @@ class WeightShadows:
     Conv2d heads, which autocast would cast per call too) of ``modules`` gets its bf16 copy for the pass; ``conv_weight`` /
     ``HeadConv2d`` pick it up.  Gradients reach the fp32 parameters through ``_CastAll.backward``."""
 
-    def __init__(self, modules, enabled=True):
+    def __init__(self, modules, enabled=True, groups=1):
+        """``groups``: number of cast nodes the weights are spread over, consecutive in registration order.  One node hands
+        EVERY weight gradient to its parameter at the very end of backward; with the eager data-parallel step, whose all-reduce
+        pieces leave from hooks the moment their last gradient exists, that would serialise the whole exchange behind
+        backward -- the trainer asks for one node per piece then (FlowTrainer: ``model.weight_shadow_groups``)."""
         self.convs = [m for mod in modules for m in mod.modules() if isinstance(m, nn.Conv2d)] if enabled else []
+        self.groups = max(1, min(int(groups), len(self.convs))) if self.convs else 1
 
     def __enter__(self):
         if not self.convs:
             return self
-        heads = [m for m in self.convs if isinstance(m, HeadConv2d) and m.bias is not None]
-        halves = _CastAll.apply(*([m.weight for m in self.convs] + [m.bias for m in heads]))
-        for m, w in zip(self.convs, halves):
-            m.__dict__['_w_half'] = w
-        for m, b in zip(heads, halves[len(self.convs):]):
-            m.__dict__['_b_half'] = b
+        n = len(self.convs)
+        for g in range(self.groups):
+            part = self.convs[g * n // self.groups:(g + 1) * n // self.groups]
+            heads = [m for m in part if isinstance(m, HeadConv2d) and m.bias is not None]
+            halves = _CastAll.apply(*([m.weight for m in part] + [m.bias for m in heads]))
+            for m, w in zip(part, halves):
+                m.__dict__['_w_half'] = w
+            for m, b in zip(heads, halves[len(part):]):
+                m.__dict__['_b_half'] = b
         return self
 
     def __exit__(self, *exc):

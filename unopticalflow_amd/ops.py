@@ -783,8 +783,10 @@ class _BiasLeakyInto(torch.autograd.Function):
         dirty = [t for t in ((y if inplace else None), buf_a, buf_b) if t is not None]
         ctx.mark_dirty(*dirty)
         # the activation (for its sign): NOT through save_for_backward -- the buffer is legitimately modified again by the
-        # epilogue that fills its other channels, which would trip the saved-tensor version check
-        ctx.act, ctx.act_ps, ctx.act_off = dests[0]
+        # epilogue that fills its other channels, which would trip the saved-tensor version check.  A DETACHED alias: the buffer
+        # is also an output of this node (mark_dirty), so keeping the tensor itself would close the cycle ctx -> tensor ->
+        # grad_fn -> ctx, which only backward breaks (a grad-enabled forward without backward would pin every cat buffer).
+        ctx.act, ctx.act_ps, ctx.act_off = dests[0][0].detach(), dests[0][1], dests[0][2]
         ctx.meta = (N, C, H, W, slope, inplace, off_a, off_b, half)
         ctx.set_materialize_grads(False)
         return (y if inplace else None), buf_a, buf_b

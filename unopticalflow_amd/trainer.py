@@ -31,6 +31,10 @@ class FlowTrainer:
         if distributed:
             self.grads = FlatGradients(params, chunks=allreduce_chunks, overlap=not use_graph,
                                        single_rank_collectives=single_rank_collectives, pack=True)
+            if self.grads.overlap and hasattr(model, 'weight_shadow_groups'):
+                # bf16 option: one weight-cast node per all-reduce piece, so that a piece's gradients exist (and its hook fires)
+                # when backward has passed ITS layers, not at the very end of backward (net_utils.WeightShadows)
+                model.weight_shadow_groups = max(model.weight_shadow_groups, 2 * self.grads.chunks)
         else:
             self.grads = PlainGradients(params)
         self.distributed = distributed
