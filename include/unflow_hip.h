@@ -36,7 +36,7 @@ extern "C" {
 /* ABI version of this header (bumped on any signature change).  The library returns the value it was BUILT with; a C user
  * compares `unflow_abi_version() == UNFLOW_ABI_VERSION` (tools/capi_bench.cpp), the Python binding reads this very line
  * (unopticalflow_amd/_lib.py). */
-#define UNFLOW_ABI_VERSION 8
+#define UNFLOW_ABI_VERSION 9
 int unflow_abi_version(void);
 
 /* ---- kernel-exact timing (bench.py's roofline legs; nothing in the reference corresponds) ----
@@ -255,6 +255,22 @@ int unflow_flow_head_fwd(const float* y, const float* bias, const float* res, fl
 int unflow_flow_head_fwd_bf16(const uint16_t* y, const float* bias, const float* res, float* out, int N, int HW, void* stream);
 int unflow_flow_head_bwd(const float* g, float* gy, float* gbias, float* partials, int N, int HW, void* stream);
 int unflow_flow_head_bwd_bf16(const float* g, uint16_t* gy, float* gbias, float* partials, int N, int HW, void* stream);
+
+/* ---- deferred bias-gradient reduction (ABI 9).  Every backward entry point above that takes `gbias` (unflow_bias_leaky_bwd*,
+ * unflow_flow_head_bwd*) finishes with a small second-stage launch that adds its per-workgroup partial sums into gbias in a
+ * fixed order.  A backward pass of the flow network (43 conv() blocks net_utils.py:7-11 + the predict_flow heads
+ * pwc_tf.py:93-94) paid 49 of those launches, ~5 us each.  Since ABI 9, gbias == NULL makes such an entry point stop after
+ * its first stage (the partial sums stay in `partials`, which the caller keeps alive), and ONE call of this function
+ * finishes all pending reductions with one launch (per 56 jobs), each channel summed in exactly the order the entry point's
+ * own second stage uses -- the same bits.
+ *   partials[j], gbias[j]   device pointers of job j (HOST arrays of njobs entries)
+ *   n[j]                    partial sums per channel: N * ceil(H*W / 4096) for the NCHW entries (unflow_bias_leaky_partials / C),
+ *                           ceil(P / 128) for the NHWC ones (unflow_bias_leaky_partials_nhwc / C), ceil(N*HW / 256) capped at 512
+ *                           for a flow head
+ *   C[j]                    channels (2 for a flow head)
+ *   mode[j]                 0: fp32 conv epilogue (NCHW or NHWC), 1: bf16 conv epilogue, 2: flow head */
+int unflow_bias_grad_finalize_batch(const void* const* partials, void* const* gbias, const int* n, const int* C,
+                                    const int* mode, int njobs, void* stream);
 
 /* ---- loss bookkeeping (ABI 8).  Model_flow.forward sums every per-sample loss over the scales (`loss = 0; loss += term(scale)`,
  * model_flow_paper.py:92-99,140-148,171-177,183-195) and adds the two directions (:226-233); train.py:147-150 weights the four batch

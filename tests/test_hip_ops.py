@@ -811,6 +811,63 @@ def test_flow_head_vs_torch(ops, shape, with_res, dtype):
         ops.flow_head(torch.zeros(1, 3, 4, 4, device='cuda'), bd)
 
 
+def test_deferred_bias_gradients_are_the_same_bits(ops):
+    """ABI 9: the second stage of every bias-gradient reduction of a backward pass as ONE launch at its end
+    (ops.deferred_bias_grads, unflow_bias_grad_finalize_batch) -- fp32 / bf16 conv epilogues in both layouts, the cat-filling
+    epilogue and the flow heads in one graph, 60 jobs (two batches), against the per-node second stages: identical bits."""
+    CL = torch.channels_last
+    torch.manual_seed(5)
+
+    def run(deferred):
+        ops.deferred_bias_grads.enabled = deferred
+        biases, total = [], 0
+        try:
+            for rep in range(10):
+                for kind in range(6):
+                    gen = torch.Generator().manual_seed(1000 + 10 * rep + kind)
+                    if kind == 0:                           # NCHW fp32
+                        y = torch.randn(3, 20, 9 + rep, 11, generator=gen).cuda().requires_grad_()
+                        b = torch.randn(20, generator=gen).cuda().requires_grad_()
+                        out = ops.bias_leaky_relu_(y * 1.0, b, 0.1)
+                    elif kind == 1:                         # NHWC fp32
+                        y = torch.randn(4, 32, 16, 13 + rep, generator=gen).cuda().contiguous(memory_format=CL).requires_grad_()
+                        b = torch.randn(32, generator=gen).cuda().requires_grad_()
+                        out = ops.bias_leaky_relu_(y * 1.0, b, 0.1)
+                    elif kind == 2:                         # NHWC bf16
+                        y = torch.randn(2, 16, 33, 17, generator=gen).cuda().bfloat16().contiguous(memory_format=CL).requires_grad_()
+                        b = torch.randn(16, generator=gen).cuda().requires_grad_()
+                        out = ops.bias_leaky_relu_(y * 1.0, b, 0.1).float()
+                    elif kind == 3:                         # NCHW bf16
+                        y = torch.randn(2, 6, 21, 30, generator=gen).cuda().bfloat16().requires_grad_()
+                        b = torch.randn(6, generator=gen).cuda().requires_grad_()
+                        out = ops.bias_leaky_relu_(y * 1.0, b, 0.1).float()
+                    elif kind == 4:                         # cat-filling epilogue
+                        y = torch.randn(2, 8, 12, 20, generator=gen).cuda().contiguous(memory_format=CL).requires_grad_()
+                        b = torch.randn(8, generator=gen).cuda().requires_grad_()
+                        buf = torch.zeros(2, 24, 12, 20, device='cuda').contiguous(memory_format=CL)
+                        _, buf, _ = ops.bias_leaky_relu_into(y * 1.0, b, 0.1, buf, 8)
+                        out = buf[:, 8:16]
+                    else:                                   # flow head
+                        y = torch.randn(5, 2, 40, 52, generator=gen).cuda().contiguous(memory_format=CL).requires_grad_()
+                        b = torch.randn(2, generator=gen).cuda().requires_grad_()
+                        out = ops.flow_head(y, b, None)
+                    total = total + (out * torch.randn(out.shape, generator=gen).cuda()).sum()
+                    biases.append(b)
+            assert not ops.deferred_bias_grads.jobs
+            total.backward()
+            assert not ops.deferred_bias_grads.jobs and not ops.deferred_bias_grads.queued      # flushed by the engine's final callback
+            torch.cuda.synchronize()
+            return [b.grad.clone() for b in biases]
+        finally:
+            ops.deferred_bias_grads.enabled = True
+    a, b = run(True), run(False)
+    assert len(a) == 60
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert torch.equal(u, v), (i, (u - v).abs().max().item())
+    # outside a backward pass (a direct call of an autograd.Function's backward, no engine) nothing is deferred
+    assert not ops._in_backward()
+
+
 @pytest.mark.parametrize('B,n', [(16, 3), (1, 1), (5, 4), (70, 2)])
 def test_loss_bookkeeping_vs_torch(ops, B, n):
     """Model_flow.forward's sums over scales and directions (model_flow_paper.py:224-235) and the step's weighted batch means

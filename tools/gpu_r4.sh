@@ -1,0 +1,79 @@
+#!/bin/bash
+# Round-4 GPU recipes.  One or more recipes per call:   gpurun -- bash tools/gpu_r4.sh <recipe> [<recipe> ...]
+# Outputs under gpurun_out/r4/ (copy what is to be judged into profiles/r4_*).
+#   suite      the whole -m gpu suite (no -x: every failure is listed) + smoke()
+#   headline   the driver's exact bench command, twice
+#   ranks      `python3 bench.py --gpus 2` with NO launcher in front, two ranks sharing the GPU over gloo (UNFLOW_BENCH_ONE_GPU=1)
+#   stepmode   multi-rank step mode A/B on the one-rank RCCL rehearsal (--force-ddp): hipGraph replay + one all-reduce + Adam graph
+#              against eager + hooks, fp32 and bf16, on an idle host and confined to ONE core next to a busy-loop neighbour
+#   finddb     tools/probes/finddb_run_to_run.py: what two forms of the network differ by under MIOpen's measured picks
+#   losses     tools/probes/loss_kernel_times.py + microbench losses
+#   capi       build tools/capi_bench and run it under rocprofv3 --kernel-trace --stats (Python-free cost-volume capture)
+#   profile    rocprofv3 kernel trace of bench.py reduced to the timed steps (+ MFMA counters): fp32
+#   traffic    tools/pmc_traffic.py (HBM bytes per launch, separate --pmc passes)
+cd $GRAFT_REPO_ROOT
+out=gpurun_out/r4
+mkdir -p $out
+line() { python3 - "$@" <<'PY'
+import json, sys
+for f in sys.argv[1:]:
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+    except Exception as e:
+        print(f, 'NO JSON', e); continue
+    r = d.get('roofline') or {}
+    print(f.split('/')[-1], d['value'], 'pairs/s', d['ms_per_step'], 'ms', '| median', d['step_ms']['median'], 'max', d['step_ms']['max'],
+          '| enqueue', d['host_enqueue_ms']['median'], '| drain', d['drain_ms'], '|', d['step_mode'][:40],
+          '| roof', r.get('avg_us'), r.get('frac'), 'agg', (r.get('aggregate') or {}).get('us_per_step'), (r.get('aggregate') or {}).get('frac'),
+          'losses', (r.get('losses') or {}).get('us_per_step'), (r.get('losses') or {}).get('frac'))
+PY
+}
+for r in "$@"; do
+case $r in
+  suite)
+    python3 -m pytest tests -m gpu -q -p no:cacheprovider > $out/suite.log 2>&1; echo "suite rc=$?"; tail -15 $out/suite.log
+    python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
+  headline)
+    for i in a b; do python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_n1_$i.json 2> $out/bench_n1_$i.err; done
+    line $out/bench_n1_a.json $out/bench_n1_b.json ;;
+  ranks)
+    UNFLOW_BENCH_ONE_GPU=1 python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_2ranks_onegpu.json 2> $out/bench_2ranks_onegpu.err
+    echo "ranks rc=$?"; line $out/bench_2ranks_onegpu.json; tail -3 $out/bench_2ranks_onegpu.err ;;
+  stepmode)
+    for prec in fp32 bf16; do for g in 1 0; do
+      python3 bench.py --force-ddp --graph $g --precision $prec --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing > $out/stepmode_${prec}_graph${g}_idle.json 2> $out/stepmode.err
+      # contended: this process on core 0 only, next to a busy loop on the same core
+      taskset -c 0 python3 -c "while True: pass" & busy=$!
+      taskset -c 0 python3 bench.py --force-ddp --graph $g --precision $prec --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing > $out/stepmode_${prec}_graph${g}_contended.json 2>> $out/stepmode.err
+      kill $busy; wait $busy 2>/dev/null
+    done; done
+    line $out/stepmode_*.json ;;
+  finddb) timeout 900 python3 tools/probes/finddb_run_to_run.py > $out/finddb_run_to_run.json 2> $out/finddb.err; cat $out/finddb_run_to_run.json | python3 -m json.tool ;;
+  losses) timeout 300 python3 tools/probes/loss_kernel_times.py 2>&1 | tee $out/loss_kernel_times.txt | tail -30 ;;
+  capi)
+    /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 tools/capi_bench.cpp -Iinclude -Lunopticalflow_amd -lunflow_hip -Wl,-rpath,$GRAFT_REPO_ROOT/unopticalflow_amd -o $out/capi_bench || exit 1
+    ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof_capi -- $GRAFT_REPO_ROOT/$out/capi_bench 16 32 64 208 4 50 > $GRAFT_REPO_ROOT/$out/capi_bench.txt 2>&1 )
+    cat $out/capi_bench.txt | tail -8; S=$(ls $out/prof_capi/*/*kernel_stats.csv | head -1); cp $S $out/capi_corr_kernel_stats.csv; head -5 $S; rm -f $out/prof_capi/*/*kernel_trace.csv ;;
+  profile)
+    w=fp32; extra="--graph 0"
+    OUT=$GRAFT_REPO_ROOT/$out/prof_$w; mkdir -p $OUT
+    ( cd /tmp && export TMPDIR=/tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing $extra > $OUT/run.log 2>&1 )
+    T=$(ls $OUT/*/*kernel_trace.csv | head -1)
+    python3 tools/summarize_trace.py $T $OUT/timed_region_stats.csv --steps 9 | head -3
+    rm -f $T
+    M=$GRAFT_REPO_ROOT/$out/mfma_$w; mkdir -p $M
+    ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $M -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing $extra > $M/run.log 2>&1 )
+    CC=$(ls $M/*/*counter_collection.csv | head -1)
+    python3 tools/summarize_mfma.py $CC $OUT/timed_region_stats.csv $out/r4_conv_mfma_$w.json --steps 9 --peak 157.3 && rm -f $CC ;;
+  traffic) python3 tools/pmc_traffic.py 2>&1 | tail -8 ;;
+  ssim_variants)
+    # variant builds of the library (made on the build host: UNFLOW_TUNING_TAG=<tag> UNFLOW_TUNING_EXTRA_FLAGS="-D..." python -m
+    # unopticalflow_amd.build --tuning), each timed by the loss-kernel probe; the shipped library first
+    python3 -m pytest tests/test_hip_ops.py -q -m gpu -k "ssim or losses or reductions" -p no:cacheprovider 2>&1 | tail -3
+    echo "== shipped"; timeout 200 python3 tools/probes/loss_kernel_times.py 2>&1 | grep -E "ssim" | tee $out/ssim_shipped.txt
+    for lib in unopticalflow_amd/libunflow_hip_tuning_*.so; do
+      echo "== $lib"; UNFLOW_LIB_PATH=$GRAFT_REPO_ROOT/$lib timeout 200 python3 tools/probes/loss_kernel_times.py 2>&1 | grep -E "ssim" | tee $out/ssim_$(basename $lib .so).txt
+    done ;;
+  *) echo "unknown recipe $r" ;;
+esac
+done

@@ -7,7 +7,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from unopticalflow_amd import ops, _lib  # noqa: E402
-if os.environ.get('UNFLOW_MICROBENCH_TUNING') == '1':
+if os.environ.get('UNFLOW_LIB_PATH'):                      # a variant build (python -m unopticalflow_amd.build --tuning with UNFLOW_TUNING_TAG)
+    _lib.LIB_PATH = os.environ['UNFLOW_LIB_PATH']
+elif os.environ.get('UNFLOW_MICROBENCH_TUNING') == '1':
     from unopticalflow_amd import build as _b
     _lib.LIB_PATH = _b.LIB_TUNING
 
@@ -18,7 +20,7 @@ for s in range(3):
     warped = torch.rand(16, 3, H, W, device='cuda', requires_grad=True)
     flow = (torch.randn(16, 2, H, W, device='cuda') * 3).requires_grad_()
     ops.kernel_timer.enable(True)
-    for _ in range(12):
+    for _ in range(int(os.environ.get('UNFLOW_PROBE_ITERS', '12'))):
         diff, wgt = ops.occ_weight_stacked(img, warped)
         loss = ops.masked_mean(diff, wgt).sum() + ops.ssim_loss(img, warped, wgt).sum() + ops.smooth2_loss(flow, img).sum() + \
             ops.consis_loss(flow[8:], flow[:8], wgt[8:]).sum()

@@ -56,6 +56,10 @@ def build(force=False, verbose=True, tuning=False):
     lib = LIB_TUNING if tuning else LIB
     extra = ('-DUNFLOW_TUNING',) + tuple(os.environ.get('UNFLOW_TUNING_EXTRA_FLAGS', '').split()) if tuning else ()
     objdir = os.path.join(PKG, '_obj_tuning' if tuning else '_obj')
+    tag = os.environ.get('UNFLOW_TUNING_TAG', '') if tuning else ''
+    if tag:                                              # several variant builds side by side (tools/gpu_r4.sh ssim_variants)
+        lib = lib[:-3] + '_' + tag + '.so'
+        objdir += '_' + tag
     os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     hdrs = _headers()

@@ -96,6 +96,37 @@ __global__ void bias_grad_finalize_kernel(const float* __restrict__ partials, in
     if (threadIdx.x == 0) gbias[c] = s;
 }
 
+// The second stage of MANY bias-gradient reductions in one launch (ABI 9).  A backward pass of the flow network runs 43 conv
+// epilogues + 6 flow heads, each of which used to end in its own ~5 us finalize launch (218 us per step, profiles/r3); with
+// gbias == NULL the backward entry points leave their per-workgroup partial sums behind and the host hands all of them to
+// this kernel at the end of the pass.  A block = one channel of one job, summed exactly as the job's own finalize kernel
+// would have (mode 0: sum_partials over partials[c][n]; 1: the bf16 epilogues' block_sum_256 order; 2: a flow head's
+// partials[n][2]) -- bitwise the same gradients.
+struct BiasJob { const float* partials; float* gbias; int n, C, mode, pad; };
+constexpr int BIAS_JOBS = 56;
+struct BiasBatch { BiasJob job[BIAS_JOBS]; int first[BIAS_JOBS + 1]; };
+
+__global__ __launch_bounds__(256) void bias_grad_finalize_batch_kernel(BiasBatch b, int njobs) {
+    __shared__ float red[4];
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= b.first[j + 1]) ++j;
+    const int c = (int)blockIdx.x - b.first[j];
+    const float* p = b.job[j].partials;
+    const int n = b.job[j].n, mode = b.job[j].mode;
+    float s;
+    if (mode == 0) {
+        s = sum_partials(p + (size_t)c * n, n, 1, 0, red);
+    } else if (mode == 1) {
+        float acc[1] = {0.f};
+        for (int i = threadIdx.x; i < n; i += 256) acc[0] += p[(size_t)c * n + i];
+        block_sum_256<1>(acc, red);
+        s = acc[0];
+    } else {
+        s = sum_partials(p, n, 2, c, red);
+    }
+    if (threadIdx.x == 0) b.job[j].gbias[c] = s;
+}
+
 
 // ---- channels-last (NHWC) twins: the conv stacks run in channels_last (MIOpen's implicit-GEMM solvers are NHWC
 // kernels; on NCHW tensors each of them is wrapped in batched_transpose launches, 2.2 ms of a 26 ms step), so their
@@ -326,7 +357,7 @@ extern "C" int unflow_bias_leaky_partials(int N, int C, int H, int W) {
 extern "C" int unflow_bias_leaky_bwd2(const float* y, const float* gout, long long gout_stride, const float* gout2,
                                       long long gout2_stride, float* gin, float* gbias, float* partials,
                                       int N, int C, int H, int W, float slope, void* stream) {
-    UNFLOW_REQUIRE(y && gout && gin && gbias && partials && N > 0 && C > 0 && H > 0 && W > 0 && N <= 65535 && C <= 65535);
+    UNFLOW_REQUIRE(y && gout && gin && partials && N > 0 && C > 0 && H > 0 && W > 0 && N <= 65535 && C <= 65535);
     const int HW = H * W, nchunk = ceil_div(HW, EW_TILE);
     UNFLOW_REQUIRE(gout_stride >= (long long)C * HW && (!gout2 || gout2_stride >= (long long)C * HW));
     if ((HW & 3) == 0)      // the 16-byte path needs every sample block on a 16-byte boundary
@@ -339,7 +370,7 @@ extern "C" int unflow_bias_leaky_bwd2(const float* y, const float* gout, long lo
     else
         UNFLOW_LAUNCH(bias_leaky_bwd_kernel<false>, dim3(nchunk, C, N), dim3(256), 0, s, y, gout, gout_stride, gout2,
                            gout2_stride, gin, partials, C, HW, slope);
-    UNFLOW_LAUNCH(bias_grad_finalize_kernel, dim3(C), dim3(256), 0, s, partials, N * nchunk, gbias);
+    if (gbias) UNFLOW_LAUNCH(bias_grad_finalize_kernel, dim3(C), dim3(256), 0, s, partials, N * nchunk, gbias);     // (NULL: deferred, unflow_bias_grad_finalize_batch)
     return unflow_launch_status();
 }
 
@@ -381,7 +412,7 @@ extern "C" int unflow_bias_leaky_partials_nhwc(long long P, int C) {
 static int launch_bwd_nhwc(const float* y, long long yps, const float* gout, long long gout_pstride, const float* gout2,
                            long long gout2_pstride, float* gin, float* gbias, float* partials,
                            long long P, int C, float slope, void* stream) {
-    UNFLOW_REQUIRE(y && gout && gin && gbias && partials && P > 0 && C >= 4 && (C & 3) == 0 && C <= 1024);
+    UNFLOW_REQUIRE(y && gout && gin && partials && P > 0 && C >= 4 && (C & 3) == 0 && C <= 1024);
     UNFLOW_REQUIRE(yps >= C && (yps & 3) == 0);
     UNFLOW_REQUIRE(gout_pstride >= C && (gout_pstride & 3) == 0 && (((size_t)gout | (size_t)y | (size_t)gin) & 15) == 0);
     UNFLOW_REQUIRE(!gout2 || (gout2_pstride >= C && (gout2_pstride & 3) == 0 && ((size_t)gout2 & 15) == 0));
@@ -396,7 +427,7 @@ static int launch_bwd_nhwc(const float* y, long long yps, const float* gout, lon
     else
         UNFLOW_LAUNCH(bias_leaky_bwd_nhwc_kernel<false>, dim3((unsigned)blocks), dim3(256), shmem, s, y, yps, gout, gout_pstride,
                            gout2, gout2_pstride, gin, partials, P, C, rows, slope);
-    UNFLOW_LAUNCH(bias_grad_finalize_kernel, dim3(C), dim3(256), 0, s, partials, (int)blocks, gbias);
+    if (gbias) UNFLOW_LAUNCH(bias_grad_finalize_kernel, dim3(C), dim3(256), 0, s, partials, (int)blocks, gbias);
     return unflow_launch_status();
 }
 
@@ -673,11 +704,11 @@ static int launch_flow_head_fwd(const T* y, const float* bias, const float* res,
 
 template <typename T>
 static int launch_flow_head_bwd(const float* g, T* gy, float* gbias, float* partials, int N, int HW, void* stream) {
-    UNFLOW_REQUIRE(g && gy && gbias && partials && N > 0 && HW > 0);
+    UNFLOW_REQUIRE(g && gy && partials && N > 0 && HW > 0);
     const long long P = (long long)N * HW;
     const int blocks = (int)((P + 255) / 256 < FLOW_HEAD_MAX_BLOCKS ? (P + 255) / 256 : FLOW_HEAD_MAX_BLOCKS);
     UNFLOW_LAUNCH(flow_head_bwd_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, gy, partials, HW, P);
-    UNFLOW_LAUNCH(flow_head_bias_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, blocks, gbias);
+    if (gbias) UNFLOW_LAUNCH(flow_head_bias_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, blocks, gbias);
     return unflow_launch_status();
 }
 
@@ -702,5 +733,27 @@ extern "C" int unflow_img_pyramid(const float* img, float* half, float* quarter,
     const size_t n = (size_t)planes * (H >> 2) * (W >> 2);
     const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
     UNFLOW_LAUNCH(img_pyramid_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, half, quarter, planes, H, W);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_bias_grad_finalize_batch(const void* const* partials, void* const* gbias, const int* n, const int* C,
+                                               const int* mode, int njobs, void* stream) {
+    UNFLOW_REQUIRE(partials && gbias && n && C && mode && njobs > 0);
+    for (int j0 = 0; j0 < njobs; j0 += BIAS_JOBS) {
+        BiasBatch b;
+        const int nj = njobs - j0 < BIAS_JOBS ? njobs - j0 : BIAS_JOBS;
+        int blocks = 0;
+        for (int j = 0; j < nj; ++j) {
+            UNFLOW_REQUIRE(partials[j0 + j] && gbias[j0 + j] && n[j0 + j] > 0 && C[j0 + j] > 0 && mode[j0 + j] >= 0 && mode[j0 + j] <= 2 &&
+                           (mode[j0 + j] != 2 || C[j0 + j] == 2));
+            b.job[j].partials = (const float*)partials[j0 + j]; b.job[j].gbias = (float*)gbias[j0 + j];
+            b.job[j].n = n[j0 + j]; b.job[j].C = C[j0 + j]; b.job[j].mode = mode[j0 + j]; b.job[j].pad = 0;
+            b.first[j] = blocks;
+            blocks += C[j0 + j];
+        }
+        for (int j = nj; j <= BIAS_JOBS; ++j) b.first[j] = blocks;
+        for (int j = nj; j < BIAS_JOBS; ++j) { b.job[j].partials = nullptr; b.job[j].gbias = nullptr; b.job[j].n = 0; b.job[j].C = 0; b.job[j].mode = 0; b.job[j].pad = 0; }
+        UNFLOW_LAUNCH(bias_grad_finalize_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b, nj);
+    }
     return unflow_launch_status();
 }

@@ -204,7 +204,7 @@ extern "C" int unflow_bias_leaky_fwd_bf16(uint16_t* y, const float* bias, int N,
 extern "C" int unflow_bias_leaky_bwd2_bf16(const uint16_t* y, const uint16_t* gout, long long gout_stride,
                                            const uint16_t* gout2, long long gout2_stride, uint16_t* gin, float* gbias,
                                            float* partials, int N, int C, int H, int W, float slope, void* stream) {
-    UNFLOW_REQUIRE(y && gout && gin && gbias && partials && N > 0 && C > 0 && H > 0 && W > 0 && N <= 65535 && C <= 65535);
+    UNFLOW_REQUIRE(y && gout && gin && partials && N > 0 && C > 0 && H > 0 && W > 0 && N <= 65535 && C <= 65535);
     const int HW = H * W, nchunk = ceil_div(HW, EWH_TILE);
     UNFLOW_REQUIRE(gout_stride >= (long long)C * HW && (!gout2 || gout2_stride >= (long long)C * HW));
     if ((HW & 7) == 0)      // the 16-byte path needs every sample block on a 16-byte boundary
@@ -217,7 +217,7 @@ extern "C" int unflow_bias_leaky_bwd2_bf16(const uint16_t* y, const uint16_t* go
     else
         UNFLOW_LAUNCH(bias_leaky_bwd_bf16_kernel<false>, dim3(nchunk, C, N), dim3(256), 0, s, y, gout, gout_stride, gout2,
                            gout2_stride, gin, partials, C, HW, slope);
-    UNFLOW_LAUNCH(bias_grad_finalize_bf16_kernel, dim3(C), dim3(256), 0, s, partials, N * nchunk, gbias);
+    if (gbias) UNFLOW_LAUNCH(bias_grad_finalize_bf16_kernel, dim3(C), dim3(256), 0, s, partials, N * nchunk, gbias);
     return unflow_launch_status();
 }
 
@@ -247,7 +247,7 @@ extern "C" int unflow_bias_leaky_fwd_nhwc_to_bf16(const uint16_t* y, const float
 static int launch_bwd_nhwc_bf16(const uint16_t* y, long long yps, const uint16_t* gout, long long gout_pstride, const uint16_t* gout2,
                                 long long gout2_pstride, uint16_t* gin, float* gbias, float* partials,
                                 long long P, int C, float slope, void* stream) {
-    UNFLOW_REQUIRE(y && gout && gin && gbias && partials && P > 0 && C >= 4 && (C & 3) == 0 && C <= 1024);
+    UNFLOW_REQUIRE(y && gout && gin && partials && P > 0 && C >= 4 && (C & 3) == 0 && C <= 1024);
     UNFLOW_REQUIRE(yps >= C && (yps & 3) == 0);
     UNFLOW_REQUIRE(gout_pstride >= C && (gout_pstride & 3) == 0 && (((size_t)gout | (size_t)y | (size_t)gin) & 7) == 0);
     UNFLOW_REQUIRE(!gout2 || (gout2_pstride >= C && (gout2_pstride & 3) == 0 && ((size_t)gout2 & 7) == 0));
@@ -262,7 +262,7 @@ static int launch_bwd_nhwc_bf16(const uint16_t* y, long long yps, const uint16_t
     else
         UNFLOW_LAUNCH(bias_leaky_bwd_nhwc_bf16_kernel<false>, dim3((unsigned)blocks), dim3(256), shmem, s, y, yps, gout, gout_pstride,
                       gout2, gout2_pstride, gin, partials, P, C, rows, slope);
-    UNFLOW_LAUNCH(bias_grad_finalize_bf16_kernel, dim3(C), dim3(256), 0, s, partials, (int)blocks, gbias);
+    if (gbias) UNFLOW_LAUNCH(bias_grad_finalize_bf16_kernel, dim3(C), dim3(256), 0, s, partials, (int)blocks, gbias);
     return unflow_launch_status();
 }
 

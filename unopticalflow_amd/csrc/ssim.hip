@@ -267,17 +267,329 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__
     }
 }
 
+
+// =============================================================================================
+// Round 4: the loss kernels the train step runs (even W, 8-byte aligned planes; the kernels above stay as the generic
+// fallback and as the bare-map kernel).
+//
+// What bounded the one-column-per-lane kernels (profiles/r3: forward 45-47 us = 0.26 of the HBM roofline, backward 81-83 us =
+// 0.20 at [16,3,256,832]): ~100 / ~180 scalar VALU instructions per pixel-channel (26 / 45 us of issue time on the whole
+// chip), x+-1 neighbours through ds_bpermute (hipcc's __shfl_up / __shfl_down), six IEEE divides per pixel-channel in the
+// backward, and one round of fat waves (all RS+2 / RS+4 rows requested up front, 3 channels per wave: 3400 waves for 4096
+// slots) whose load and arithmetic phases line up across the chip.
+//
+//   * a lane owns TWO adjacent columns: 8-byte loads, and every per-pixel operation is a packed fp32 instruction
+//     (v_pk_add/mul/fma_f32 on the column pair) -- half the VALU instructions, each component rounded exactly as the scalar
+//     operation was, so the forward keeps ATen's tap order bit for bit;
+//   * x+-1 neighbours by DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1): no LDS traffic;
+//   * the 3x3 sums are two RUNNING accumulators per statistic instead of a 3-row ring of raw taps: when row r arrives it is
+//     the bottom row of window r-1 (completes it), the middle row of window r and the top row of window r+1 -- each window
+//     still adds its nine taps in row-major order (0 + x00 is exact), nothing is shifted;
+//   * a wave owns ONE channel of a 124-column x RS-row tile (a workgroup = the tile's three channels, sharing the weight rows
+//     through L1): three times the waves at a third of the registers, rows stream through a 3-slot register ring requested two
+//     rows ahead, RS = 16 output rows per wave (backward row overhead 20/16 instead of 12/8);
+//   * backward: 1/d1 and 1/d2 once per pixel-channel as v_rcp_f32 + one Newton step; ssim, 1/(d1 d2), ssim/d2 are products
+//     of those (gradients have no bit-exact bar: 1e-4 of the largest, measured against the reference fixture).
+// =============================================================================================
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// tuning knobs (tools/gpu_r4.sh ssim_variants builds the library with other values; the defaults are what ships)
+#ifndef SSIM2_FWD_WAVES
+#define SSIM2_FWD_WAVES 6        // waves per SIMD the register budget is cut for: 7 workgroups of 3 waves per CU resident at once
+#endif
+#ifndef SSIM2_BWD_WAVES
+#define SSIM2_BWD_WAVES 6
+#endif
+#ifndef SSIM2_ROWS
+#define SSIM2_ROWS 0             // output rows per wave: 0 = by map height (16 from 128 rows up, else 8)
+#endif
+
+__device__ __forceinline__ float from_lane_below(float v) {       // lane i <- lane i-1 (0 into lane 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float from_lane_above(float v) {       // lane i <- lane i+1 (0 into lane 63)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+// the column pair one to the left / right of this lane's pair
+__device__ __forceinline__ f2 pair_left(f2 c) { f2 r; r.x = from_lane_below(c.y); r.y = c.x; return r; }
+__device__ __forceinline__ f2 pair_right(f2 c) { f2 r; r.x = c.y; r.y = from_lane_above(c.x); return r; }
+
+__device__ __forceinline__ f2 div9(f2 x) {                         // both components as div9(float)
+    const f2 y = {0.111111111f, 0.111111111f};
+    const f2 m9 = {-9.0f, -9.0f};
+    const f2 q0 = x * y;
+    const f2 r = __builtin_elementwise_fma(m9, q0, x);
+    return __builtin_elementwise_fma(r, y, q0);
+}
+
+struct Stats2 { f2 mu_x, mu_y, n1, n2, d1, d2; };
+
+// the algebra of window_stats() on a column pair, same operations in the same order (without the final quotient)
+__device__ __forceinline__ Stats2 pair_stats(const f2 (&fin)[5]) {
+    Stats2 s;
+    s.mu_x = div9(fin[0]); s.mu_y = div9(fin[1]);
+    const f2 sig_x = div9(fin[2]) - s.mu_x * s.mu_x;
+    const f2 sig_y = div9(fin[3]) - s.mu_y * s.mu_y;
+    const f2 sig_xy = div9(fin[4]) - s.mu_x * s.mu_y;
+    const f2 two = {2.0f, 2.0f};
+    s.n1 = two * s.mu_x * s.mu_y + kC1;
+    s.n2 = two * sig_xy + kC2;
+    s.d1 = s.mu_x * s.mu_x + s.mu_y * s.mu_y + kC1;
+    s.d2 = sig_x + sig_y + kC2;
+    return s;
+}
+
+// Window bookkeeping of one statistic: `a` = window r-1 (top and middle rows in), `b` = window r (top row in).
+// Feeding row r's taps (left, centre, right) completes window r-1 and advances the other two.
+// EXACT: every window adds its nine taps in ATen's row-major order (bit-equal to the one-column kernel and to the reference's
+// avg_pool2d); otherwise the row's three taps are added first and the three row sums then (half the additions; the loss is a
+// sum over 10^5..10^6 pixels whose own order is not the reference's either -- the bar there is 1e-4 relative).
+template <bool EXACT>
+__device__ __forceinline__ f2 feed(f2& a, f2& b, f2 tl, f2 tc, f2 tr) {
+    if (EXACT) {
+        const f2 fin = ((a + tl) + tc) + tr;
+        a = ((b + tl) + tc) + tr;
+        b = (tl + tc) + tr;
+        return fin;
+    }
+    const f2 h = (tl + tc) + tr;
+    const f2 fin = a + h;
+    a = b + h;
+    b = h;
+    return fin;
+}
+
+template <bool EXACT>
+__device__ __forceinline__ void feed_row(f2 (&a)[5], f2 (&b)[5], f2 xs, f2 ys, f2 (&fin)[5]) {
+    const f2 xl = pair_left(xs), xr = pair_right(xs), yl = pair_left(ys), yr = pair_right(ys);
+    fin[0] = feed<EXACT>(a[0], b[0], xl, xs, xr);
+    fin[1] = feed<EXACT>(a[1], b[1], yl, ys, yr);
+    fin[2] = feed<EXACT>(a[2], b[2], xl * xl, xs * xs, xr * xr);
+    fin[3] = feed<EXACT>(a[3], b[3], yl * yl, ys * ys, yr * yr);
+    fin[4] = feed<EXACT>(a[4], b[4], xl * yl, xs * ys, xr * yr);
+}
+
+constexpr int S2_COLS = 124;            // output columns per wave: lanes 1..62 x 2 (lanes 0 and 63 hold the halo pairs)
+__host__ __device__ inline int strips2(int W) { return ceil_div(W, S2_COLS); }
+
+struct Row2 { f2 x, y, m; };
+
+// Row r of this lane's column pair.  Always a real load from a clamped position (no exec-masked load, no zero-filled
+// destination registers); a row or pair outside the image gets weight 0, which zeroes x * m and y * m -- the zero padding
+// of AvgPool2d(3, 1, padding=1).
+__device__ __forceinline__ Row2 load_row2(const float* __restrict__ ip, const float* __restrict__ wp, const float* __restrict__ mp,
+                                           int r, bool rin, int H, int W, int xc, bool pin) {
+    Row2 v;
+    const int rc = min(max(r, 0), H - 1);
+    const size_t off = (size_t)rc * W + xc;
+    v.x = *reinterpret_cast<const f2*>(ip + off);
+    v.y = *reinterpret_cast<const f2*>(wp + off);
+    v.m = *reinterpret_cast<const f2*>(mp + off);
+    const bool ok = rin && pin;
+    v.m.x = ok ? v.m.x : 0.f;
+    v.m.y = ok ? v.m.y : 0.f;
+    return v;
+}
+
+__device__ __forceinline__ f2 rcp_refined(f2 d) {                 // 1/d: v_rcp_f32 (1 ulp) + one Newton step
+    f2 r;
+    r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
+    const f2 one = {1.0f, 1.0f};
+    return __builtin_elementwise_fma(__builtin_elementwise_fma(-d, r, one), r, r);
+}
+
+// n / d: the refined reciprocal, one product and one residual correction (q = q0 + (n - d q0) r): the correctly rounded
+// quotient in all but a vanishing share of cases, faithfully rounded otherwise -- 2 v_rcp + 5 packed instructions for the
+// pair instead of 2 x 13 for the IEEE expansion.
+__device__ __forceinline__ f2 quotient(f2 n, f2 d) {
+    const f2 r = rcp_refined(d);
+    const f2 q0 = n * r;
+    const f2 rem = __builtin_elementwise_fma(-d, q0, n);
+    return __builtin_elementwise_fma(rem, r, q0);
+}
+
+// grid = (strips2(W) * ceil(H / RS), B); block = 192: wave c = channel c of the tile.
+template <int RS, bool EXACT>
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_FWD_WAVES))) void ssim2_fwd_kernel(const float* __restrict__ img, const float* __restrict__ warped,
+                                                        const float* __restrict__ wgt, float* __restrict__ partials,
+                                                        int H, int W, int img_groups) {
+    __shared__ float red[6];
+    const int lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
+    const int grp = blockIdx.y;
+    const int nsx = strips2(W);
+    const int sx = blockIdx.x % nsx, cy = blockIdx.x / nsx;
+    const int x0 = sx * S2_COLS - 2 + 2 * lane;
+    const int ys = cy * RS, ye = min(ys + RS, H);
+    const bool pin = (x0 >= 0 && x0 < W);                       // (W even: the pair is inside or outside as a whole)
+    const bool outl = pin && lane >= 1 && lane <= 62;
+    const int xc = min(max(x0, 0), W - 2);
+    const size_t plane = (size_t)H * W;
+    const float* ip = img + ((size_t)(grp % img_groups) * 3 + ch) * plane;
+    const float* wp = warped + ((size_t)grp * 3 + ch) * plane;
+    const float* mp = wgt + (size_t)grp * plane;
+    const f2 z = {0.f, 0.f};
+    f2 a[5], b[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { a[q] = z; b[q] = z; }
+    f2 acc0 = z, acc1 = z;
+    const f2 keep = {outl ? 1.0f : 0.0f, outl ? 1.0f : 0.0f};
+    constexpr int NR = RS + 2;                                   // input rows ys-1 .. ye
+    Row2 buf[3];
+    buf[0] = load_row2(ip, wp, mp, ys - 1, ys - 1 >= 0, H, W, xc, pin);
+    buf[1] = load_row2(ip, wp, mp, ys, true, H, W, xc, pin);
+#pragma unroll 1
+    for (int k0 = 0; k0 < NR; k0 += 3) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int r = ys - 1 + k0 + j;
+            const int rn = r + 2;                                // requested two rows ahead
+            buf[(j + 2) % 3] = load_row2(ip, wp, mp, rn, rn < H && rn <= ye, H, W, xc, pin);
+            const Row2 v = buf[j];
+            const f2 xs = v.x * v.m, ysv = v.y * v.m;
+            if (ch == 0 && r >= ys && r < ye) acc1 += v.m * keep;
+            f2 fin[5];
+            feed_row<EXACT>(a, b, xs, ysv, fin);
+            const int ro = r - 1;                                // the row whose windows are now complete
+            if (ro >= ys && ro < ye) {
+                const Stats2 st = pair_stats(fin);
+                const f2 num = st.n1 * st.n2, den = st.d1 * st.d2;
+                f2 ssim;
+                if (EXACT) { ssim.x = num.x / den.x; ssim.y = num.y / den.y; }   // IEEE quotients, as ssim.py:20
+                else ssim = quotient(num, den);
+                const f2 one = {1.0f, 1.0f}, half = {0.5f, 0.5f};
+                f2 t = (one - ssim) * half;                      // == / 2.0f exactly
+                t = __builtin_elementwise_min(__builtin_elementwise_max(t, z), one);
+                acc0 += t * keep;
+            }
+        }
+    }
+    const float s0 = wave_sum(acc0.x + acc0.y);
+    const float s1 = wave_sum(acc1.x + acc1.y);
+    if (lane == 0) { red[ch * 2] = s0; red[ch * 2 + 1] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* p = partials + ((size_t)grp * gridDim.x + blockIdx.x) * 2;
+        p[0] = (red[0] + red[2]) + red[4];
+        p[1] = red[1];
+    }
+}
+
+// grid = (strips2(W) * ceil(H / RS), B); block = 192: wave c = channel c.  Rows ys-2 .. ye+1 stream through; row r completes
+// the statistics of row r-1 (-> coefficient row r-1, summed over x-1..x+1) and with them the gradient of row r-2.
+template <int RS>
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_BWD_WAVES))) void ssim2_bwd_kernel(const float* __restrict__ img, const float* __restrict__ warped,
+                                                        const float* __restrict__ wgt, const float* __restrict__ sums,
+                                                        const float* __restrict__ gloss, float* __restrict__ gwarped,
+                                                        int H, int W, int img_b) {
+    const int lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
+    const int bidx = blockIdx.y;
+    const int nsx = strips2(W);
+    const int sx = blockIdx.x % nsx, cy = blockIdx.x / nsx;
+    const int x0 = sx * S2_COLS - 2 + 2 * lane;
+    const int ys = cy * RS, ye = min(ys + RS, H);
+    const bool pin = (x0 >= 0 && x0 < W);
+    const bool outl = pin && lane >= 1 && lane <= 62;
+    const int xc = min(max(x0, 0), W - 2);
+    const size_t plane = (size_t)H * W;
+    const float* ip = img + ((size_t)(bidx % img_b) * 3 + ch) * plane;
+    const float* wp = warped + ((size_t)bidx * 3 + ch) * plane;
+    const float* mp = wgt + (size_t)bidx * plane;
+    float* gp = gwarped + ((size_t)bidx * 3 + ch) * plane;
+    const float hw = (float)H * (float)W;
+    // d loss[b] / d clamp-sum, times d clamp / d SSIM = -1/2 inside the clamp range; 0 for a pair outside the image
+    const float kb = pin ? gloss[bidx] / (3.0f * hw) / (sums[bidx * 2 + 1] / hw + 1e-12f) * -0.5f : 0.f;
+    const f2 z = {0.f, 0.f};
+    f2 a[5], b[5], t0[3], t1[3];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { a[q] = z; b[q] = z; }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { t0[q] = z; t1[q] = z; }
+    constexpr int NR = RS + 4;                                   // input rows ys-2 .. ye+1
+    Row2 buf[3];
+    f2 kx[3], ky[3], km[3];                                      // weighted x, y and the weight of the last three rows
+    buf[0] = load_row2(ip, wp, mp, ys - 2, ys - 2 >= 0, H, W, xc, pin);
+    buf[1] = load_row2(ip, wp, mp, ys - 1, ys - 1 >= 0, H, W, xc, pin);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { kx[q] = z; ky[q] = z; km[q] = z; }
+#pragma unroll 1
+    for (int k0 = 0; k0 < NR; k0 += 3) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int r = ys - 2 + k0 + j;
+            const int rn = r + 2;
+            buf[(j + 2) % 3] = load_row2(ip, wp, mp, rn, rn >= 0 && rn < H && rn <= ye + 1, H, W, xc, pin);
+            const Row2 v = buf[j];
+            const f2 xs = v.x * v.m, ysv = v.y * v.m;
+            kx[j] = xs; ky[j] = ysv; km[j] = v.m;
+            f2 fin[5];
+            feed_row<false>(a, b, xs, ysv, fin);
+            const int rs = r - 1;                                // statistics row: rows outside the image have none
+            const float kr = (rs >= 0 && rs < H) ? kb : 0.f;
+            const Stats2 st = pair_stats(fin);
+            const f2 inv = rcp_refined(st.d1 * st.d2);         // one reciprocal per pixel; 1/d1 = d2 inv, 1/d2 = d1 inv
+            const f2 r1 = st.d2 * inv, r2 = st.d1 * inv;
+            const f2 ssim = st.n1 * st.n2 * inv;
+            const f2 two = {2.0f, 2.0f};
+            // clamp((1 - ssim) / 2, 0, 1) passes gradient on [0, 1], i.e. for ssim in [-1, 1]
+            f2 kbv;
+            kbv.x = (ssim.x <= 1.0f && ssim.x >= -1.0f) ? kr : 0.f;
+            kbv.y = (ssim.y <= 1.0f && ssim.y >= -1.0f) ? kr : 0.f;
+            const f2 ca = kbv * (two * st.mu_x * (st.n2 - st.n1) * inv - two * st.mu_y * ssim * (r1 - r2));
+            const f2 cb = kbv * (-(ssim * r2));
+            const f2 cc = kbv * (two * st.n1 * inv);
+            // 3x3 box sum of the coefficients: over x here, over y through the running pair (t1 = rows r-3, r-2; t0 = row r-2)
+            const f2 ha = (pair_left(ca) + ca) + pair_right(ca);
+            const f2 hb = (pair_left(cb) + cb) + pair_right(cb);
+            const f2 hc = (pair_left(cc) + cc) + pair_right(cc);
+            const f2 A = t1[0] + ha, Bq = t1[1] + hb, Cq = t1[2] + hc;
+            t1[0] = t0[0] + ha; t1[1] = t0[1] + hb; t1[2] = t0[2] + hc;
+            t0[0] = ha; t0[1] = hb; t0[2] = hc;
+            const int ro = r - 2;                                // gradient row: its x, y, weight sit two slots back
+            if (ro >= ys && ro < ye) {
+                const int o = (j + 1) % 3;
+                const f2 gy = div9(A + two * ky[o] * Bq + kx[o] * Cq) * km[o];
+                if (outl) *reinterpret_cast<f2*>(gp + (size_t)ro * W + x0) = gy;
+            }
+        }
+    }
+}
+
 }  // namespace
 
-int unflow_ssim_blocks(int H, int W) { return ceil_div(strips(W, 1) * chunks(H), 4); }
+// the loss kernels' fast path: column pairs need an even width and 8-byte aligned planes
+static inline bool ssim2_ok(const void* a, const void* b, const void* c, const void* d, int W) {
+    return W % 2 == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 7) == 0;
+}
+// the loss forward's 3x3 sums: ATen's nine-tap order + IEEE quotient (true), or row sums first + refined-reciprocal quotient
+#ifndef SSIM2_EXACT
+#define SSIM2_EXACT false
+#endif
+static inline int ssim2_rows(int H) { return SSIM2_ROWS ? SSIM2_ROWS : (H >= 128 ? 16 : 8); }      // output rows per wave (small maps: more, shorter waves)
+static inline int ssim2_blocks(int H, int W) { return strips2(W) * ceil_div(H, ssim2_rows(H)); }
+
+int unflow_ssim_blocks(int H, int W) {
+    const int a = ceil_div(strips(W, 1) * chunks(H), 4), b = ssim2_blocks(H, W);
+    return a > b ? a : b;                   // (sizes the partial-sum scratch: whichever kernel runs must fit)
+}
 
 extern "C" int unflow_ssim_loss_fwd(const float* img, const float* warped, const float* w, float* loss,
                                     float* sums, float* partials, int B, int H, int W, int img_batch, void* stream) {
     UNFLOW_REQUIRE(img && warped && w && loss && sums && partials && B > 0 && H > 0 && W > 0 && img_batch > 0 && B % img_batch == 0);
     hipStream_t s = (hipStream_t)stream;
-    const int nblk = unflow_ssim_blocks(H, W);
-    UNFLOW_LAUNCH((ssim_fwd_kernel<3, true, false>), dim3(nblk, B), dim3(256), 0, s, img, warped, w,
-                       (float*)nullptr, partials, H, W, img_batch);
+    int nblk;
+    if (ssim2_ok(img, warped, w, w, W)) {
+        nblk = ssim2_blocks(H, W);
+        const dim3 grid(nblk, B);
+        switch (ssim2_rows(H)) {
+            case 32: UNFLOW_LAUNCH((ssim2_fwd_kernel<32, SSIM2_EXACT>), grid, dim3(192), 0, s, img, warped, w, partials, H, W, img_batch); break;
+            case 16: UNFLOW_LAUNCH((ssim2_fwd_kernel<16, SSIM2_EXACT>), grid, dim3(192), 0, s, img, warped, w, partials, H, W, img_batch); break;
+            default: UNFLOW_LAUNCH((ssim2_fwd_kernel<8, SSIM2_EXACT>), grid, dim3(192), 0, s, img, warped, w, partials, H, W, img_batch); break;
+        }
+    } else {
+        nblk = ceil_div(strips(W, 1) * chunks(H), 4);
+        UNFLOW_LAUNCH((ssim_fwd_kernel<3, true, false>), dim3(nblk, B), dim3(256), 0, s, img, warped, w,
+                           (float*)nullptr, partials, H, W, img_batch);
+    }
     UNFLOW_LAUNCH(ssim_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, sums, H, W);
     return unflow_launch_status();
 }
@@ -286,6 +598,16 @@ extern "C" int unflow_ssim_loss_bwd(const float* img, const float* warped, const
                                     const float* gloss, float* gwarped, int B, int H, int W, int img_batch, void* stream) {
     UNFLOW_REQUIRE(img && warped && w && sums && gloss && gwarped && B > 0 && H > 0 && W > 0 && img_batch > 0 && B % img_batch == 0);
     hipStream_t s = (hipStream_t)stream;
+    if (ssim2_ok(img, warped, w, gwarped, W)) {
+        const int nblk = ssim2_blocks(H, W);
+        const dim3 grid(nblk, B);
+        switch (ssim2_rows(H)) {
+            case 32: UNFLOW_LAUNCH((ssim2_bwd_kernel<32>), grid, dim3(192), 0, s, img, warped, w, sums, gloss, gwarped, H, W, img_batch); break;
+            case 16: UNFLOW_LAUNCH((ssim2_bwd_kernel<16>), grid, dim3(192), 0, s, img, warped, w, sums, gloss, gwarped, H, W, img_batch); break;
+            default: UNFLOW_LAUNCH((ssim2_bwd_kernel<8>), grid, dim3(192), 0, s, img, warped, w, sums, gloss, gwarped, H, W, img_batch); break;
+        }
+        return unflow_launch_status();
+    }
     const int nblk = ceil_div(strips(W, 2) * chunks(H), 4);
     UNFLOW_LAUNCH(ssim_bwd_kernel, dim3(nblk, B), dim3(256), 0, s, img, warped, w, sums, gloss, gwarped, H, W, img_batch);
     return unflow_launch_status();
@@ -295,7 +617,7 @@ extern "C" int unflow_ssim_map(const float* x, const float* y, float* out, int B
                                void* stream) {
     UNFLOW_REQUIRE(x && y && out && B > 0 && C > 0 && H > 0 && W > 0);
     hipStream_t s = (hipStream_t)stream;
-    const int nblk = unflow_ssim_blocks(H, W);
+    const int nblk = ceil_div(strips(W, 1) * chunks(H), 4);
     UNFLOW_LAUNCH((ssim_fwd_kernel<1, false, true>), dim3(nblk, B * C), dim3(256), 0, s, x, y,
                        (const float*)nullptr, out, (float*)nullptr, H, W, B * C);
     return unflow_launch_status();

@@ -126,6 +126,77 @@ class _KernelTimer:
 kernel_timer = _KernelTimer()
 
 
+class _DeferredBiasGrads:
+    """The second stage of every bias-gradient reduction of a backward pass as ONE launch at the end of the pass.
+
+    The conv() epilogues (net_utils.py:7-11) and the predict_flow heads (pwc_tf.py:93-94) reduce their bias gradient in two
+    stages: per-workgroup partial sums inside the backward kernel, then a tiny launch that adds them in a fixed order -- 49
+    such launches per backward pass of the flow network, ~5 us each (218 us of a 24 ms step, profiles/r3).  With ``enabled`` the
+    backward nodes stop after the first stage (C ABI: gbias == NULL), hand back the still unwritten ``gbias`` tensor, and
+    register the job here; the autograd engine runs ``flush`` as a final callback of the pass (on the stream ``backward()``
+    was called on, before it returns), where one ``unflow_bias_grad_finalize_batch`` launch finishes all of them with the
+    same summation order, i.e. the same bits.  Anything that must READ a bias gradient before the pass ends (the eager
+    data-parallel step packs all-reduce pieces from hooks) calls ``flush()`` first -- FlowTrainer wires that up.
+    """
+
+    def __init__(self):
+        self.enabled = True
+        self.jobs = []                 # (partials tensor, gbias tensor, n, C, mode)
+        self.queued = False
+        import threading
+        self.lock = threading.Lock()
+
+    def add(self, partials, gbias, n, C, mode):
+        with self.lock:
+            self.jobs.append((partials, gbias, int(n), int(C), int(mode)))
+            if not self.queued:
+                self.queued = True
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+
+    def _end_of_backward(self):
+        with self.lock:
+            self.queued = False
+        self.flush()
+
+    def flush(self):
+        with self.lock:
+            jobs, self.jobs = self.jobs, []
+        if not jobs:
+            return
+        by_dev = {}
+        for j in jobs:
+            by_dev.setdefault(j[0].device, []).append(j)
+        for dev, js in by_dev.items():
+            n = len(js)
+            P = (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in js])
+            G = (ctypes.c_void_p * n)(*[j[1].data_ptr() for j in js])
+            N_ = (ctypes.c_int * n)(*[j[2] for j in js])
+            C_ = (ctypes.c_int * n)(*[j[3] for j in js])
+            M_ = (ctypes.c_int * n)(*[j[4] for j in js])
+            with _on(dev):
+                _call('unflow_bias_grad_finalize_batch', P, G, N_, C_, M_, n, _stream(),
+                      nbytes=4 * sum(j[2] * j[3] + j[3] for j in js), shape=(n,))
+
+
+deferred_bias_grads = _DeferredBiasGrads()
+
+
+def _finish_bias_grad(partials, gbias, n, C, mode):
+    """-> the gbias pointer to hand to a backward entry point: NULL (and the job registered) when the reduction is deferred."""
+    if deferred_bias_grads.enabled and _in_backward():
+        deferred_bias_grads.add(partials, gbias, n, C, mode)
+        return ctypes.c_void_p(0)
+    return _ptr(gbias)
+
+
+def _in_backward():
+    """True while the autograd engine is executing a backward pass on this thread (a final callback can be queued)."""
+    try:
+        return torch._C._current_graph_task_id() != -1
+    except AttributeError:                              # (an older torch: no way to tell, do not defer)
+        return False
+
+
 def _partials(B, H, W, dev):
     n = _lib.load().unflow_partials_per_sample(H, W)
     return torch.empty(B * n, dtype=torch.float32, device=dev)
@@ -659,10 +730,11 @@ def _bias_leaky_backward(ctx, ga, gb):
         if gb is not None:
             gb, sb = _pixel_strided(gb, y.shape)
         P = N * H * W
-        part = torch.empty(_lib.load().unflow_bias_leaky_partials_nhwc(P, C), dtype=torch.float32, device=y.device)
+        npart = _lib.load().unflow_bias_leaky_partials_nhwc(P, C)
+        part = torch.empty(npart, dtype=torch.float32, device=y.device)
         with _on(y.device):
             _call('unflow_bias_leaky_bwd2_nhwc_bf16' if half else 'unflow_bias_leaky_bwd2_nhwc', _ptr(y), _ptr(ga), sa, _ptr(gb), sb,
-                  _ptr(gin), _ptr(gbias), _ptr(part), P, C, ctypes.c_float(ctx.slope), _stream(),
+                  _ptr(gin), _finish_bias_grad(part, gbias, npart // C, C, 1 if half else 0), _ptr(part), P, C, ctypes.c_float(ctx.slope), _stream(),
                   nbytes=(3 if gb is None else 4) * y.element_size() * N * C * H * W, shape=(N, C, H, W))
         return gin, gbias, None
     ga, sa = _sample_strided(ga, y.shape)
@@ -673,7 +745,7 @@ def _bias_leaky_backward(ctx, ga, gb):
     part = torch.empty(npart, dtype=torch.float32, device=y.device)
     with _on(y.device):
         _call('unflow_bias_leaky_bwd2_bf16' if half else 'unflow_bias_leaky_bwd2', _ptr(y), _ptr(ga), sa, _ptr(gb), sb,
-              _ptr(gin), _ptr(gbias), _ptr(part), N, C, H, W, ctypes.c_float(ctx.slope), _stream(),
+              _ptr(gin), _finish_bias_grad(part, gbias, npart // C, C, 1 if half else 0), _ptr(part), N, C, H, W, ctypes.c_float(ctx.slope), _stream(),
               nbytes=(3 if gb is None else 4) * y.element_size() * N * C * H * W, shape=(N, C, H, W))
     return gin, gbias, None
 
@@ -818,12 +890,13 @@ class _BiasLeakyInto(torch.autograd.Function):
         gin = torch.empty((N, C, H, W), dtype=dt, device=act.device, memory_format=torch.channels_last)
         gbias = torch.empty(C, dtype=torch.float32, device=act.device)
         P = N * H * W
-        part = torch.empty(_lib.load().unflow_bias_leaky_partials_nhwc(P, C), dtype=torch.float32, device=act.device)
+        npart = _lib.load().unflow_bias_leaky_partials_nhwc(P, C)
+        part = torch.empty(npart, dtype=torch.float32, device=act.device)
         g2 = ptrs[1] if len(ptrs) > 1 else (None, ctypes.c_void_p(0), 0)
         with _on(act.device):
             _call('unflow_bias_leaky_bwd2_nhwc_from_bf16' if half else 'unflow_bias_leaky_bwd2_nhwc_from',
                   ctypes.c_void_p(act.data_ptr() + ctx.act_off * es), ctx.act_ps, ptrs[0][1], ptrs[0][2], g2[1], g2[2],
-                  _ptr(gin), _ptr(gbias), _ptr(part), P, C, ctypes.c_float(slope), _stream(),
+                  _ptr(gin), _finish_bias_grad(part, gbias, npart // C, C, 1 if half else 0), _ptr(part), P, C, ctypes.c_float(slope), _stream(),
                   nbytes=(2 + len(ptrs)) * es * N * C * H * W, shape=(N, C, H, W))
         ctx.act = None
         # the buffers' incoming gradients pass through to whoever filled their other channels
@@ -955,8 +1028,9 @@ class _FlowHead(torch.autograd.Function):
         gbias = torch.empty(2, dtype=torch.float32, device=g.device)
         lib = _lib.load()
         partials = torch.empty(lib.unflow_flow_head_partials(), dtype=torch.float32, device=g.device)
+        nblk = min((N * H * W + 255) // 256, lib.unflow_flow_head_partials() // 2)
         with _on(g.device):
-            _call('unflow_flow_head_bwd_bf16' if ctx.half else 'unflow_flow_head_bwd', _ptr(g), _ptr(gy), _ptr(gbias), _ptr(partials), N, H * W,
+            _call('unflow_flow_head_bwd_bf16' if ctx.half else 'unflow_flow_head_bwd', _ptr(g), _ptr(gy), _finish_bias_grad(partials, gbias, nblk, 2, 2), _ptr(partials), N, H * W,
                   _stream(), nbytes=N * H * W * 2 * ((2 if ctx.half else 4) + 4), shape=(N, 2, H, W))
         return gy, gbias, (g if ctx.has_res else None)
 

@@ -101,6 +101,7 @@ class FlatGradients:
         self._works = [None] * self.chunks
         self._packed = [False] * self.chunks
         self._sources = None                              # gradient tensors of a captured hipGraph (remember_sources)
+        self.before_pack = None                           # called before gradients are READ (ops.deferred_bias_grads.flush on the GPU)
         self.launched_early = 0                           # pieces sent from a hook during the last backward
         self.overlap = False
         self._hooks = []
@@ -126,6 +127,8 @@ class FlatGradients:
         ``p.grad``, never the graph's buffers (they hold the previous replay's gradients)."""
         if self._packed[k]:
             return
+        if self.before_pack is not None:
+            self.before_pack()
         a, b = self._piece_params[k]
         dst, src = [], []
         for i in range(a, b):

@@ -31,6 +31,11 @@ class FlowTrainer:
         if distributed:
             self.grads = FlatGradients(params, chunks=allreduce_chunks, overlap=not use_graph,
                                        single_rank_collectives=single_rank_collectives, pack=True)
+            if params[0].is_cuda:
+                # bias gradients are finished by one batched launch at the END of a backward pass (ops.deferred_bias_grads); a piece
+                # packed from a hook in the middle of the pass must see finished values
+                from . import ops
+                self.grads.before_pack = ops.deferred_bias_grads.flush
             if self.grads.overlap and hasattr(model, 'weight_shadow_groups'):
                 # bf16 option: one weight-cast node per all-reduce piece, so that a piece's gradients exist (and its hook fires)
                 # when backward has passed ITS layers, not at the very end of backward (net_utils.WeightShadows)
