@@ -108,6 +108,7 @@ def parse():
     ap.add_argument('--fused-upsample', type=int, default=1, help='0: F.interpolate + multiply for the flow up-sampling instead of unflow_upsample_scaled_* (A/B; PWC_tf.fused_upsample)')
     ap.add_argument('--fill-cat', type=int, default=1, help='0: channels_last decoder with torch.cat inputs instead of epilogue-filled cat buffers (A/B; PWC_tf.fill_cat_buffers)')
     ap.add_argument('--gc-freeze', type=int, default=1, help='0: leave Python\'s cyclic collector alone; 1: FlowTrainer(gc_freeze_after=2), what train.py asks for too (gc.freeze() after the second step, once per process)')
+    ap.add_argument('--contended-host', action='store_true', help='experiment (profiles/r4_multirank_step_mode.md): for the TIMED steps confine this process to one core and run a busy-loop child on the same core -- what a slow or shared host does to the step mode')
     ap.add_argument('--force-ddp', action='store_true', help='N = 1 only: run the step through the RCCL data-parallel path with a one-rank communicator')
     return ap.parse_args()
 
@@ -348,6 +349,13 @@ def main():
             gc_log['ms'] += d
             gc_log['max_ms'] = max(gc_log['max_ms'], d)
     gc.callbacks.append(gc_watch)
+    busy = None
+    if args.contended_host:
+        import subprocess
+        core = sorted(os.sched_getaffinity(0))[0]
+        os.sched_setaffinity(0, {core})
+        busy = subprocess.Popen([sys.executable, '-c', 'import os\nos.sched_setaffinity(0, {%d})\nwhile True: pass' % core])
+        time.sleep(0.5)
     barrier()
     t0 = time.perf_counter()
     marks[0].record()
@@ -358,6 +366,9 @@ def main():
         host[i + 1] = time.perf_counter()
     barrier()
     dt = time.perf_counter() - t0
+    if busy is not None:
+        busy.kill(); busy.wait()                          # (our own child, by handle)
+        os.sched_setaffinity(0, set(range(os.cpu_count() or 1)))
     gc.callbacks.remove(gc_watch)
     step_stats = per_step_stats(marks, host, t0 + dt)
     step_stats['host_gc'] = {'collections_gen0_1_2': gc_log['collections'], 'total_ms': round(gc_log['ms'], 2),
@@ -481,7 +492,7 @@ def main():
             'metric': 'frame-pairs/s (train step) at %dx%d bs=%d' % (fw, fh, args.batch),
             'value': round(pairs / dt, 2), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'bf16', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'contended_host': bool(args.contended_host), 'dtype': 'f32' if args.precision == 'fp32' else 'bf16', 'data': 'synthetic',
             'step_mode': (('hipGraph replay: graph(forward + backward + gradient pack), one all-reduce of the flat gradient, graph(Adam)'
                            if (world > 1 or args.force_ddp) else 'hipGraph replay') if args.graph else
                           ('eager, gradient pieces all-reduced from hooks during backward' if (world > 1 or args.force_ddp) else 'eager')),

@@ -272,6 +272,22 @@ int unflow_flow_head_bwd_bf16(const float* g, uint16_t* gy, float* gbias, float*
 int unflow_bias_grad_finalize_batch(const void* const* partials, void* const* gbias, const int* n, const int* C,
                                     const int* mode, int njobs, void* stream);
 
+/* ---- Adam (ABI 9): torch.optim.Adam(lr, betas, eps) of the reference's train step (train.py:39,151; no weight decay, no amsgrad) over
+ * ALL parameter tensors in one launch.  A block updates one chunk of unflow_adam_chunk() elements of one tensor:
+ *   m = m + (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;  p -= (lr / (1 - beta1^t)) m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ * with t = steps[0] + 1 (the arithmetic of torch's fused Adam).
+ *   slots      DEVICE array [ntensors]: parameter / exp_avg / exp_avg_sq addresses (walked by memory offset: all three and the
+ *              gradient must share one dense layout) and the element count
+ *   chunk_map  DEVICE int pairs [nchunks][2] = (tensor, chunk of that tensor)
+ *   grads      HOST array [ntensors] of the gradients' device addresses (they change with every eager backward pass; passed to the
+ *              kernel by value); NULL: that tensor is skipped and its counter does not advance
+ *   steps      DEVICE float [ntensors]: the step counters (all equal when every tensor has a gradient), advanced by the kernel
+ *   counter    DEVICE unsigned, zero before the first call; the kernel leaves it zero */
+typedef struct { float* p; float* m; float* v; long long numel; } unflow_adam_slot;
+int unflow_adam_chunk(void);
+int unflow_adam_multi(const unflow_adam_slot* slots, const int* chunk_map, int nchunks, const void* const* grads, int ntensors,
+                      float* steps, unsigned* counter, float lr, float beta1, float beta2, float eps, void* stream);
+
 /* ---- loss bookkeeping (ABI 8).  Model_flow.forward sums every per-sample loss over the scales (`loss = 0; loss += term(scale)`,
  * model_flow_paper.py:92-99,140-148,171-177,183-195) and adds the two directions (:226-233); train.py:147-150 weights the four batch
  * means.  One launch each way per stage, same association of the fp32 additions.

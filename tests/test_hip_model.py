@@ -330,7 +330,6 @@ def test_sintel_1024x448_matches_oracle():
     x = R.synthetic_triplets(4, 448, 1024, seed=4, structured=True)
     ref = R.Model_flow(R.default_cfg())
     ref.load_state_dict(R.seeded_state_dict(ref, 1234, 0.25))
-    torch.set_num_threads(max(1, len(__import__('os').sched_getaffinity(0))))
     pack = model(x.cuda())
     pr = ref(x)
     for k in pr:
@@ -647,3 +646,78 @@ def test_hipgraph_replay_matches_eager():
     # the capture's warm-up iterations are rolled back by the trainer itself: same trajectory as eager from step 0
     np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-4)
     np.testing.assert_allclose(out[True], out[False], rtol=5e-3)        # later steps follow Adam's sign-normalised updates
+
+
+def test_flow_adam_matches_torch_adam(tmp_path):
+    """optim.FlowAdam (one HIP launch over all 98 tensors, csrc/optim.hip) against torch.optim.Adam on the same gradients: five
+    steps, channels_last and row-major parameters, a 2-element and a 196-element bias (misaligned tails); then the checkpoint
+    round trip in both directions (train.py:23-31: the optimizer_state_dict of one loads into the other) and the step inside a
+    captured hipGraph."""
+    from unopticalflow_amd.optim import FlowAdam
+    torch.manual_seed(3)
+    shapes = [(16, 3, 3, 3), (16,), (128, 115, 3, 3), (2,), (196, 196, 3, 3), (196,), (2, 96, 3, 3), (5,)]
+
+    def make():
+        ps = []
+        for i, sh in enumerate(shapes):
+            t = torch.randn(sh, generator=torch.Generator().manual_seed(i)).cuda()
+            if len(sh) == 4 and i % 2 == 0:
+                t = t.contiguous(memory_format=torch.channels_last)
+            ps.append(torch.nn.Parameter(t))
+        return ps
+    pa, pb = make(), make()
+    oa, ob = FlowAdam([{'params': pa, 'lr': 1e-3}]), torch.optim.Adam([{'params': pb, 'lr': 1e-3}])
+    for it in range(5):
+        for a, b in zip(pa, pb):
+            g = torch.randn(a.shape, generator=torch.Generator().manual_seed(100 * it + a.numel())).cuda() * (1.0 + it)
+            a.grad = g.contiguous(memory_format=torch.channels_last) if a.dim() == 4 and a.stride() != a.contiguous().stride() else g.clone()
+            b.grad = a.grad.clone()
+        oa.step(); ob.step()
+    assert oa.native_steps == 5
+    for a, b in zip(pa, pb):
+        assert float(oa.state[a]['step']) == 5.0
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(oa.state[a]['exp_avg_sq'].cpu().numpy(), ob.state[b]['exp_avg_sq'].cpu().numpy(), rtol=1e-5, atol=1e-12)
+    # state dicts interchange
+    oc = torch.optim.Adam([{'params': make(), 'lr': 1e-3}])
+    oc.load_state_dict(oa.state_dict())
+    od = FlowAdam([{'params': make(), 'lr': 1e-3}])
+    od.load_state_dict(ob.state_dict())
+    pd = od.param_groups[0]['params']
+    with torch.no_grad():
+        for d, a in zip(pd, pa):
+            d.copy_(a)
+    for d, a in zip(pd, pa):
+        d.grad = torch.ones_like(d); a.grad = torch.ones_like(a)
+    od.step(); oa.step()
+    assert od.native_steps == 1 and float(od.state[pd[0]]['step']) == 6.0
+    for d, a in zip(pd, pa):
+        np.testing.assert_allclose(d.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=0, atol=2e-6)
+    # a parameter without a gradient: torch's own step takes over for that call, the counters stay consistent
+    pa[3].grad = None
+    oa.step()
+    assert oa.native_steps == 6 and float(oa.state[pa[0]]['step']) == 7.0 and float(oa.state[pa[3]]['step']) == 6.0
+    # inside a captured graph: three replays = three steps
+    pg = make()
+    og = FlowAdam([{'params': pg, 'lr': 1e-3}])
+    for p in pg:
+        p.grad = torch.ones_like(p)
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        og.step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        og.step()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert float(og.state[pg[0]]['step']) == 4.0
+    pr = make()
+    orf = torch.optim.Adam([{'params': pr, 'lr': 1e-3}])
+    for _ in range(4):
+        for p in pr:
+            p.grad = torch.ones_like(p)
+        orf.step()
+    for g_, r in zip(pg, pr):
+        np.testing.assert_allclose(g_.detach().cpu().numpy(), r.detach().cpu().numpy(), rtol=0, atol=2e-6)

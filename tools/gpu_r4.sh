@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-4 GPU recipes.  One or more recipes per call:   gpurun -- bash tools/gpu_r4.sh <recipe> [<recipe> ...]
 # Outputs under gpurun_out/r4/ (copy what is to be judged into profiles/r4_*).
+#   newtests   the tests this round added or touched (-x, 10-minute cap per test)
 #   suite      the whole -m gpu suite (no -x: every failure is listed) + smoke()
 #   headline   the driver's exact bench command, twice
 #   ranks      `python3 bench.py --gpus 2` with NO launcher in front, two ranks sharing the GPU over gloo (UNFLOW_BENCH_ONE_GPU=1)
@@ -30,8 +31,11 @@ PY
 }
 for r in "$@"; do
 case $r in
+  newtests)   # what this round added or touched, first failure stops, no test may take more than 10 minutes
+    timeout 1500 python3 -m pytest -x -q -m gpu -p no:cacheprovider --timeout 600 tests/test_hip_ops.py -k "ssim or losses or reductions or deferred or bias_leaky or flow_head" > $out/newtests_ops.log 2>&1; echo "ops rc=$?"; tail -25 $out/newtests_ops.log
+    timeout 1500 python3 -m pytest -x -q -m gpu -p no:cacheprovider --timeout 600 tests/test_abi.py tests/test_cli.py tests/test_hip_model.py -k "c_program or bench_starts or graph_capture_keeps or replayed or flow_adam or kitti_256 or batch8 or sintel or hipgraph or rccl or module_128" > $out/newtests_model.log 2>&1; echo "model rc=$?"; tail -40 $out/newtests_model.log ;;
   suite)
-    python3 -m pytest tests -m gpu -q -p no:cacheprovider > $out/suite.log 2>&1; echo "suite rc=$?"; tail -15 $out/suite.log
+    timeout 2400 python3 -m pytest tests -m gpu -q -p no:cacheprovider --timeout 900 > $out/suite.log 2>&1; echo "suite rc=$?"; tail -15 $out/suite.log
     python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
   headline)
     for i in a b; do python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_n1_$i.json 2> $out/bench_n1_$i.err; done
@@ -40,13 +44,10 @@ case $r in
     UNFLOW_BENCH_ONE_GPU=1 python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_2ranks_onegpu.json 2> $out/bench_2ranks_onegpu.err
     echo "ranks rc=$?"; line $out/bench_2ranks_onegpu.json; tail -3 $out/bench_2ranks_onegpu.err ;;
   stepmode)
-    for prec in fp32 bf16; do for g in 1 0; do
-      python3 bench.py --force-ddp --graph $g --precision $prec --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing > $out/stepmode_${prec}_graph${g}_idle.json 2> $out/stepmode.err
-      # contended: this process on core 0 only, next to a busy loop on the same core
-      taskset -c 0 python3 -c "while True: pass" & busy=$!
-      taskset -c 0 python3 bench.py --force-ddp --graph $g --precision $prec --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing > $out/stepmode_${prec}_graph${g}_contended.json 2>> $out/stepmode.err
-      kill $busy; wait $busy 2>/dev/null
-    done; done
+    for prec in fp32 bf16; do for g in 1 0; do for c in "" "--contended-host"; do
+      tag=idle; [ -n "$c" ] && tag=contended
+      timeout 400 python3 bench.py --force-ddp --graph $g --precision $prec --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing $c > $out/stepmode_${prec}_graph${g}_$tag.json 2>> $out/stepmode.err
+    done; done; done
     line $out/stepmode_*.json ;;
   finddb) timeout 900 python3 tools/probes/finddb_run_to_run.py > $out/finddb_run_to_run.json 2> $out/finddb.err; cat $out/finddb_run_to_run.json | python3 -m json.tool ;;
   losses) timeout 300 python3 tools/probes/loss_kernel_times.py 2>&1 | tee $out/loss_kernel_times.txt | tail -30 ;;

@@ -22,7 +22,7 @@ LIB_TUNING = os.path.join(PKG, 'libunflow_hip_tuning.so')
 HOST_LIB = os.path.join(PKG, 'libunflow_host.so')
 TORCH_LIB = os.path.join(PKG, 'libunflow_torch.so')
 SOURCES = ('corr.hip', 'warp.hip', 'warp_corr.hip', 'ssim.hip', 'photo.hip', 'elementwise.hip', 'elementwise_bf16.hip',
-           'prepare.hip', 'png_host.cpp')
+           'prepare.hip', 'optim.hip', 'png_host.cpp')
 HOST_SOURCES = ('png_host.cpp',)
 # -ffp-contract=off: mask / SSIM arithmetic must follow the reference op by op; the kernels call
 # fmaf() explicitly where a fused multiply-add is wanted.

@@ -17,7 +17,7 @@ _PROCESS_GC_FROZEN = False
 
 class FlowTrainer:
     def __init__(self, cfg, model, distributed=False, allreduce_chunks=4, fused_adam=None, use_graph=False,
-                 single_rank_collectives=False, gc_freeze_after=None):
+                 single_rank_collectives=False, gc_freeze_after=None, own_adam=None):
         self.cfg = cfg
         self.model = model
         self.loss_weights = generate_loss_weights_dict(cfg)
@@ -46,11 +46,18 @@ class FlowTrainer:
         kw = {}
         if fused_adam is None:
             fused_adam = params[0].is_cuda
-        if fused_adam:
-            kw['fused'] = True
-        if use_graph and params[0].is_cuda:
-            kw['capturable'] = True                    # step counters live on the device
-        self.optimizer = torch.optim.Adam([{'params': params, 'lr': cfg.lr}], **kw)
+        if own_adam is None:
+            own_adam = fused_adam and params[0].is_cuda
+        if own_adam:
+            # torch.optim.Adam whose step is one HIP launch over all tensors (optim.FlowAdam; same state layout and state_dict)
+            from .optim import FlowAdam
+            self.optimizer = FlowAdam([{'params': params, 'lr': cfg.lr}])
+        else:
+            if fused_adam:
+                kw['fused'] = True
+            if use_graph and params[0].is_cuda:
+                kw['capturable'] = True                # step counters live on the device
+            self.optimizer = torch.optim.Adam([{'params': params, 'lr': cfg.lr}], **kw)
         self.iteration = 0
         # hipGraph replay of the step (forward + loss + backward [+ Adam]): ~3000 kernel launches per
         # step become one graph launch, so the host never starves the GPU.  Built lazily from the first
