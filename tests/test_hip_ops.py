@@ -818,8 +818,9 @@ def test_deferred_bias_gradients_are_the_same_bits(ops):
     CL = torch.channels_last
     torch.manual_seed(5)
 
+    import contextlib
+
     def run(deferred):
-        ops.deferred_bias_grads.enabled = deferred
         biases, total = [], 0
         try:
             for rep in range(10):
@@ -853,13 +854,16 @@ def test_deferred_bias_gradients_are_the_same_bits(ops):
                         out = ops.flow_head(y, b, None)
                     total = total + (out * torch.randn(out.shape, generator=gen).cuda()).sum()
                     biases.append(b)
-            assert not ops.deferred_bias_grads.jobs
-            total.backward()
-            assert not ops.deferred_bias_grads.jobs and not ops.deferred_bias_grads.queued      # flushed by the engine's final callback
+            assert not ops.deferred_bias_grads.jobs and not ops.deferred_bias_grads.enabled     # opt-in: off outside the scope
+            with (ops.deferred_bias_grads if deferred else contextlib.nullcontext()):
+                total.backward()
+                assert not ops.deferred_bias_grads.jobs and not ops.deferred_bias_grads.queued  # flushed by the engine's final callback
             torch.cuda.synchronize()
+            if deferred:
+                assert len(ops.deferred_bias_grads.last_addresses) == 60 and ops.deferred_bias_grads.adopted(biases)
             return [b.grad.clone() for b in biases]
         finally:
-            ops.deferred_bias_grads.enabled = True
+            assert not ops.deferred_bias_grads.enabled
     a, b = run(True), run(False)
     assert len(a) == 60
     for i, (u, v) in enumerate(zip(a, b)):

@@ -12,6 +12,7 @@
 #   capi       build tools/capi_bench and run it under rocprofv3 --kernel-trace --stats (Python-free cost-volume capture)
 #   profile    rocprofv3 kernel trace of bench.py reduced to the timed steps (+ MFMA counters): fp32
 #   traffic    tools/pmc_traffic.py (HBM bytes per launch, separate --pmc passes)
+#   rerank     bench A/B of find-db variants in which the runner-up solver is ranked first where it is within 3 / 10 / 30 us (tools/miopen_rerank.py)
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/r4
 mkdir -p $out
@@ -75,6 +76,16 @@ case $r in
     for lib in unopticalflow_amd/libunflow_hip_tuning_*.so; do
       echo "== $lib"; UNFLOW_LIB_PATH=$GRAFT_REPO_ROOT/$lib timeout 200 python3 tools/probes/loss_kernel_times.py 2>&1 | grep -E "ssim" | tee $out/ssim_$(basename $lib .so).txt
     done ;;
+  rerank)   # MIOpen picks re-ranked: the runner-up solver first wherever it is within X us of the split-K asm kernel (fwd / bwd-data)
+    python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing > $out/rerank_base.json 2> $out/rerank.err
+    for x in 3 10 30; do
+      python3 tools/miopen_rerank.py --write /tmp/unflow_db_$x --margin-us $x --dirs F,B
+      MIOPEN_USER_DB_PATH=/tmp/unflow_db_$x python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing > $out/rerank_fb_$x.json 2>> $out/rerank.err
+    done
+    python3 tools/miopen_rerank.py --write /tmp/unflow_db_w --margin-us 3 --dirs W
+    MIOPEN_USER_DB_PATH=/tmp/unflow_db_w python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing > $out/rerank_w_3.json 2>> $out/rerank.err
+    python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing > $out/rerank_base2.json 2>> $out/rerank.err
+    line $out/rerank_*.json ;;
   *) echo "unknown recipe $r" ;;
 esac
 done

@@ -300,6 +300,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef SSIM2_BWD_WAVES
 #define SSIM2_BWD_WAVES 6
 #endif
+#ifndef SSIM2_PF
+#define SSIM2_PF 1               // rows requested ahead of the one being processed (1 or 2; 2 costs the backward 10 registers: spills at 6 waves)
+#endif
 #ifndef SSIM2_ROWS
 #define SSIM2_ROWS 0             // output rows per wave: 0 = by map height (16 from 128 rows up, else 8)
 #endif
@@ -337,6 +340,43 @@ __device__ __forceinline__ Stats2 pair_stats(const f2 (&fin)[5]) {
     s.d1 = s.mu_x * s.mu_x + s.mu_y * s.mu_y + kC1;
     s.d2 = sig_x + sig_y + kC2;
     return s;
+}
+
+// The fast path works on window SUMS, not means: with Sx = sum x, Sy = sum y, Sq = sum (x^2 + y^2), Sxy = sum xy over the 3x3 window,
+// P = Sx Sy, Q = Sx^2 + Sy^2, K1 = 81 C1, K2 = 81 C2,
+//     SSIM = (2 mu_x mu_y + C1)(2 sig_xy + C2) / ((mu_x^2 + mu_y^2 + C1)(sig_x + sig_y + C2))
+//          = (2P + K1)(18 Sxy - 2P + K2) / ((Q + K1)(9 Sq - Q + K2))             (both factors of 1/81 cancel)
+// -- 14 packed instructions for the four factors instead of 32 (five /9 and the mean / variance algebra), and four running
+// statistics instead of five (sigma_x and sigma_y only ever appear as their sum).  Same cancellation behaviour as E[xx] - mu^2.
+struct Factors2 { f2 sx, sy, a1, a2, b1, b2; };
+
+__device__ __forceinline__ Factors2 pair_factors(const f2 (&fin)[4]) {
+    Factors2 s;
+    s.sx = fin[0]; s.sy = fin[1];
+    const f2 k1 = {81.0f * kC1, 81.0f * kC1}, k2 = {81.0f * kC2, 81.0f * kC2};
+    const f2 two = {2.0f, 2.0f}, nine = {9.0f, 9.0f}, eighteen = {18.0f, 18.0f};
+    const f2 p = s.sx * s.sy;
+    const f2 q = __builtin_elementwise_fma(s.sx, s.sx, s.sy * s.sy);
+    s.a1 = __builtin_elementwise_fma(two, p, k1);
+    s.a2 = __builtin_elementwise_fma(eighteen, fin[3], __builtin_elementwise_fma(-two, p, k2));
+    s.b1 = q + k1;
+    s.b2 = __builtin_elementwise_fma(nine, fin[2], k2 - q);
+    return s;
+}
+
+// row r of the four fast statistics: x, y, x^2 + y^2, xy
+__device__ __forceinline__ void feed_row4(f2 (&a)[4], f2 (&b)[4], f2 xs, f2 ys, f2 (&fin)[4]) {
+    const f2 xl = pair_left(xs), xr = pair_right(xs), yl = pair_left(ys), yr = pair_right(ys);
+    const f2 taps[4][3] = {{xl, xs, xr}, {yl, ys, yr},
+                           {__builtin_elementwise_fma(xl, xl, yl * yl), __builtin_elementwise_fma(xs, xs, ys * ys), __builtin_elementwise_fma(xr, xr, yr * yr)},
+                           {xl * yl, xs * ys, xr * yr}};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f2 h = (taps[q][0] + taps[q][1]) + taps[q][2];
+        fin[q] = a[q] + h;
+        a[q] = b[q] + h;
+        b[q] = h;
+    }
 }
 
 // Window bookkeeping of one statistic: `a` = window r-1 (top and middle rows in), `b` = window r (top row in).
@@ -381,7 +421,7 @@ __device__ __forceinline__ Row2 load_row2(const float* __restrict__ ip, const fl
                                            int r, bool rin, int H, int W, int xc, bool pin) {
     Row2 v;
     const int rc = min(max(r, 0), H - 1);
-    const size_t off = (size_t)rc * W + xc;
+    const unsigned off = (unsigned)(rc * W + xc);               // (a plane is far below 2^31 elements: scalar base + 32-bit lane offset)
     v.x = *reinterpret_cast<const f2*>(ip + off);
     v.y = *reinterpret_cast<const f2*>(wp + off);
     v.m = *reinterpret_cast<const f2*>(mp + off);
@@ -398,23 +438,14 @@ __device__ __forceinline__ f2 rcp_refined(f2 d) {                 // 1/d: v_rcp_
     return __builtin_elementwise_fma(__builtin_elementwise_fma(-d, r, one), r, r);
 }
 
-// n / d: the refined reciprocal, one product and one residual correction (q = q0 + (n - d q0) r): the correctly rounded
-// quotient in all but a vanishing share of cases, faithfully rounded otherwise -- 2 v_rcp + 5 packed instructions for the
-// pair instead of 2 x 13 for the IEEE expansion.
-__device__ __forceinline__ f2 quotient(f2 n, f2 d) {
-    const f2 r = rcp_refined(d);
-    const f2 q0 = n * r;
-    const f2 rem = __builtin_elementwise_fma(-d, q0, n);
-    return __builtin_elementwise_fma(rem, r, q0);
-}
-
 // grid = (strips2(W) * ceil(H / RS), B); block = 192: wave c = channel c of the tile.
 template <int RS, bool EXACT>
 __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_FWD_WAVES))) void ssim2_fwd_kernel(const float* __restrict__ img, const float* __restrict__ warped,
                                                         const float* __restrict__ wgt, float* __restrict__ partials,
                                                         int H, int W, int img_groups) {
     __shared__ float red[6];
-    const int lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int ch = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform: the plane addresses stay scalar
     const int grp = blockIdx.y;
     const int nsx = strips2(W);
     const int sx = blockIdx.x % nsx, cy = blockIdx.x / nsx;
@@ -428,34 +459,40 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_FWD_W
     const float* wp = warped + ((size_t)grp * 3 + ch) * plane;
     const float* mp = wgt + (size_t)grp * plane;
     const f2 z = {0.f, 0.f};
-    f2 a[5], b[5];
+    constexpr int NS = EXACT ? 5 : 4;
+    f2 a[NS], b[NS];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) { a[q] = z; b[q] = z; }
+    for (int q = 0; q < NS; ++q) { a[q] = z; b[q] = z; }
     f2 acc0 = z, acc1 = z;
     const f2 keep = {outl ? 1.0f : 0.0f, outl ? 1.0f : 0.0f};
     constexpr int NR = RS + 2;                                   // input rows ys-1 .. ye
     Row2 buf[3];
     buf[0] = load_row2(ip, wp, mp, ys - 1, ys - 1 >= 0, H, W, xc, pin);
-    buf[1] = load_row2(ip, wp, mp, ys, true, H, W, xc, pin);
+    if (SSIM2_PF > 1) buf[1] = load_row2(ip, wp, mp, ys, true, H, W, xc, pin);
 #pragma unroll 1
     for (int k0 = 0; k0 < NR; k0 += 3) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int r = ys - 1 + k0 + j;
-            const int rn = r + 2;                                // requested two rows ahead
-            buf[(j + 2) % 3] = load_row2(ip, wp, mp, rn, rn < H && rn <= ye, H, W, xc, pin);
+            const int rn = r + SSIM2_PF;                         // requested SSIM2_PF rows ahead
+            buf[(j + SSIM2_PF) % 3] = load_row2(ip, wp, mp, rn, rn < H && rn <= ye, H, W, xc, pin);
             const Row2 v = buf[j];
             const f2 xs = v.x * v.m, ysv = v.y * v.m;
             if (ch == 0 && r >= ys && r < ye) acc1 += v.m * keep;
-            f2 fin[5];
-            feed_row<EXACT>(a, b, xs, ysv, fin);
+            f2 fin[NS];
+            if constexpr (EXACT) feed_row<true>(a, b, xs, ysv, fin);
+            else feed_row4(a, b, xs, ysv, fin);
             const int ro = r - 1;                                // the row whose windows are now complete
             if (ro >= ys && ro < ye) {
-                const Stats2 st = pair_stats(fin);
-                const f2 num = st.n1 * st.n2, den = st.d1 * st.d2;
                 f2 ssim;
-                if (EXACT) { ssim.x = num.x / den.x; ssim.y = num.y / den.y; }   // IEEE quotients, as ssim.py:20
-                else ssim = quotient(num, den);
+                if constexpr (EXACT) {
+                    const Stats2 st = pair_stats(fin);
+                    const f2 num = st.n1 * st.n2, den = st.d1 * st.d2;
+                    ssim.x = num.x / den.x; ssim.y = num.y / den.y;          // IEEE quotients, as ssim.py:20
+                } else {
+                    const Factors2 st = pair_factors(fin);
+                    ssim = (st.a1 * st.a2) * rcp_refined(st.b1 * st.b2);
+                }
                 const f2 one = {1.0f, 1.0f}, half = {0.5f, 0.5f};
                 f2 t = (one - ssim) * half;                      // == / 2.0f exactly
                 t = __builtin_elementwise_min(__builtin_elementwise_max(t, z), one);
@@ -481,7 +518,8 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_BWD_W
                                                         const float* __restrict__ wgt, const float* __restrict__ sums,
                                                         const float* __restrict__ gloss, float* __restrict__ gwarped,
                                                         int H, int W, int img_b) {
-    const int lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int ch = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int bidx = blockIdx.y;
     const int nsx = strips2(W);
     const int sx = blockIdx.x % nsx, cy = blockIdx.x / nsx;
@@ -499,16 +537,16 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_BWD_W
     // d loss[b] / d clamp-sum, times d clamp / d SSIM = -1/2 inside the clamp range; 0 for a pair outside the image
     const float kb = pin ? gloss[bidx] / (3.0f * hw) / (sums[bidx * 2 + 1] / hw + 1e-12f) * -0.5f : 0.f;
     const f2 z = {0.f, 0.f};
-    f2 a[5], b[5], t0[3], t1[3];
+    f2 a[4], b[4], t0[3], t1[3];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) { a[q] = z; b[q] = z; }
+    for (int q = 0; q < 4; ++q) { a[q] = z; b[q] = z; }
 #pragma unroll
     for (int q = 0; q < 3; ++q) { t0[q] = z; t1[q] = z; }
     constexpr int NR = RS + 4;                                   // input rows ys-2 .. ye+1
     Row2 buf[3];
     f2 kx[3], ky[3], km[3];                                      // weighted x, y and the weight of the last three rows
     buf[0] = load_row2(ip, wp, mp, ys - 2, ys - 2 >= 0, H, W, xc, pin);
-    buf[1] = load_row2(ip, wp, mp, ys - 1, ys - 1 >= 0, H, W, xc, pin);
+    if (SSIM2_PF > 1) buf[1] = load_row2(ip, wp, mp, ys - 1, ys - 1 >= 0, H, W, xc, pin);
 #pragma unroll
     for (int q = 0; q < 3; ++q) { kx[q] = z; ky[q] = z; km[q] = z; }
 #pragma unroll 1
@@ -516,27 +554,30 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_BWD_W
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int r = ys - 2 + k0 + j;
-            const int rn = r + 2;
-            buf[(j + 2) % 3] = load_row2(ip, wp, mp, rn, rn >= 0 && rn < H && rn <= ye + 1, H, W, xc, pin);
+            const int rn = r + SSIM2_PF;
+            buf[(j + SSIM2_PF) % 3] = load_row2(ip, wp, mp, rn, rn >= 0 && rn < H && rn <= ye + 1, H, W, xc, pin);
             const Row2 v = buf[j];
             const f2 xs = v.x * v.m, ysv = v.y * v.m;
             kx[j] = xs; ky[j] = ysv; km[j] = v.m;
-            f2 fin[5];
-            feed_row<false>(a, b, xs, ysv, fin);
+            f2 fin[4];
+            feed_row4(a, b, xs, ysv, fin);
             const int rs = r - 1;                                // statistics row: rows outside the image have none
             const float kr = (rs >= 0 && rs < H) ? kb : 0.f;
-            const Stats2 st = pair_stats(fin);
-            const f2 inv = rcp_refined(st.d1 * st.d2);         // one reciprocal per pixel; 1/d1 = d2 inv, 1/d2 = d1 inv
-            const f2 r1 = st.d2 * inv, r2 = st.d1 * inv;
-            const f2 ssim = st.n1 * st.n2 * inv;
-            const f2 two = {2.0f, 2.0f};
+            // d SSIM / d(Sy, Syy, Sxy) in sum space (see pair_factors): with inv = 1 / (B1 B2), r1 = 1 / B1, r2 = 1 / B2
+            //   d/dSy  = 2 Sx (A2 - A1) inv - 2 Sy ssim (r1 - r2),   d/dSyy = -9 ssim r2,   d/dSxy = 18 A1 inv
+            // and d loss / d y_q = sum over the windows that hold q of (cSy + 2 y_q cSyy + x_q cSxy): no division by 9 anywhere
+            const Factors2 st = pair_factors(fin);
+            const f2 inv = rcp_refined(st.b1 * st.b2);           // one reciprocal per pixel; 1/B1 = B2 inv, 1/B2 = B1 inv
+            const f2 r1 = st.b2 * inv, r2 = st.b1 * inv;
+            const f2 ssim = st.a1 * st.a2 * inv;
             // clamp((1 - ssim) / 2, 0, 1) passes gradient on [0, 1], i.e. for ssim in [-1, 1]
             f2 kbv;
             kbv.x = (ssim.x <= 1.0f && ssim.x >= -1.0f) ? kr : 0.f;
             kbv.y = (ssim.y <= 1.0f && ssim.y >= -1.0f) ? kr : 0.f;
-            const f2 ca = kbv * (two * st.mu_x * (st.n2 - st.n1) * inv - two * st.mu_y * ssim * (r1 - r2));
-            const f2 cb = kbv * (-(ssim * r2));
-            const f2 cc = kbv * (two * st.n1 * inv);
+            const f2 two = {2.0f, 2.0f}, m18 = {-18.0f, -18.0f}, p18 = {18.0f, 18.0f};
+            const f2 ca = (two * kbv) * (st.sx * (st.a2 - st.a1) * inv - st.sy * ssim * (r1 - r2));
+            const f2 cb = (m18 * kbv) * (ssim * r2);             // (the 2 of 2 y_q cSyy folded in: -9 * 2)
+            const f2 cc = (p18 * kbv) * (st.a1 * inv);
             // 3x3 box sum of the coefficients: over x here, over y through the running pair (t1 = rows r-3, r-2; t0 = row r-2)
             const f2 ha = (pair_left(ca) + ca) + pair_right(ca);
             const f2 hb = (pair_left(cb) + cb) + pair_right(cb);
@@ -547,8 +588,8 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_BWD_W
             const int ro = r - 2;                                // gradient row: its x, y, weight sit two slots back
             if (ro >= ys && ro < ye) {
                 const int o = (j + 1) % 3;
-                const f2 gy = div9(A + two * ky[o] * Bq + kx[o] * Cq) * km[o];
-                if (outl) *reinterpret_cast<f2*>(gp + (size_t)ro * W + x0) = gy;
+                const f2 gy = __builtin_elementwise_fma(kx[o], Cq, __builtin_elementwise_fma(ky[o], Bq, A)) * km[o];
+                if (outl) *reinterpret_cast<f2*>(gp + (unsigned)(ro * W + x0)) = gy;
             }
         }
     }

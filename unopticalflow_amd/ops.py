@@ -131,26 +131,47 @@ class _DeferredBiasGrads:
 
     The conv() epilogues (net_utils.py:7-11) and the predict_flow heads (pwc_tf.py:93-94) reduce their bias gradient in two
     stages: per-workgroup partial sums inside the backward kernel, then a tiny launch that adds them in a fixed order -- 49
-    such launches per backward pass of the flow network, ~5 us each (218 us of a 24 ms step, profiles/r3).  With ``enabled`` the
-    backward nodes stop after the first stage (C ABI: gbias == NULL), hand back the still unwritten ``gbias`` tensor, and
-    register the job here; the autograd engine runs ``flush`` as a final callback of the pass (on the stream ``backward()``
-    was called on, before it returns), where one ``unflow_bias_grad_finalize_batch`` launch finishes all of them with the
-    same summation order, i.e. the same bits.  Anything that must READ a bias gradient before the pass ends (the eager
-    data-parallel step packs all-reduce pieces from hooks) calls ``flush()`` first -- FlowTrainer wires that up.
+    such launches per backward pass of the flow network, ~5 us each (218 us of a 24 ms step, profiles/r3).  Inside
+    ``with ops.deferred_bias_grads:`` the backward nodes stop after the first stage (C ABI: gbias == NULL), hand autograd the
+    still unwritten ``gbias`` tensor and register the job; the autograd engine runs ``flush`` as a final callback of the pass
+    (on the stream ``backward()`` was called on, before it returns), where one ``unflow_bias_grad_finalize_batch`` launch
+    finishes all of them with the same summation order, i.e. the same bits.
+
+    OPT-IN, and only for a caller that knows two things about its backward pass (FlowTrainer does, a library user calling
+    ``loss.backward()`` gets the immediate second stage): (1) every bias gradient is ASSIGNED, not accumulated -- ``p.grad`` is
+    None when the pass starts, so AccumulateGrad adopts the tensor it is handed instead of reading it; only the tensor's STORAGE
+    is kept here (a second reference to the tensor itself would make AccumulateGrad clone it -- still unwritten); (2) anything
+    that READS a bias gradient before the pass ends calls ``flush()`` first (the eager data-parallel step packs all-reduce
+    pieces from hooks: ``FlatGradients.before_pack``).  ``adopted(params)`` checks (1) after a pass.
     """
 
     def __init__(self):
-        self.enabled = True
-        self.jobs = []                 # (partials tensor, gbias tensor, n, C, mode)
+        self.enabled = False
+        self.jobs = []                 # (partials tensor, gbias storage, gbias address, n, C, mode)
         self.queued = False
+        self.last_addresses = ()       # gbias addresses of the last flush (adopted())
         import threading
         self.lock = threading.Lock()
+        self._depth = 0
+
+    def __enter__(self):
+        self._depth += 1
+        self.enabled = True
+        return self
+
+    def __exit__(self, *exc):
+        self._depth -= 1
+        if self._depth == 0:
+            self.enabled = False
+            self.flush()               # (normally empty: the engine's final callback ran inside the pass)
+        return False
 
     def add(self, partials, gbias, n, C, mode):
         with self.lock:
-            self.jobs.append((partials, gbias, int(n), int(C), int(mode)))
+            self.jobs.append((partials, gbias.untyped_storage(), gbias.data_ptr(), gbias.device, int(n), int(C), int(mode)))
             if not self.queued:
                 self.queued = True
+                self.last_addresses = ()
                 torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
 
     def _end_of_backward(self):
@@ -163,19 +184,26 @@ class _DeferredBiasGrads:
             jobs, self.jobs = self.jobs, []
         if not jobs:
             return
+        self.last_addresses = tuple(self.last_addresses) + tuple(j[2] for j in jobs)
         by_dev = {}
         for j in jobs:
-            by_dev.setdefault(j[0].device, []).append(j)
+            by_dev.setdefault(j[3], []).append(j)
         for dev, js in by_dev.items():
             n = len(js)
             P = (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in js])
-            G = (ctypes.c_void_p * n)(*[j[1].data_ptr() for j in js])
-            N_ = (ctypes.c_int * n)(*[j[2] for j in js])
-            C_ = (ctypes.c_int * n)(*[j[3] for j in js])
-            M_ = (ctypes.c_int * n)(*[j[4] for j in js])
+            G = (ctypes.c_void_p * n)(*[j[2] for j in js])
+            N_ = (ctypes.c_int * n)(*[j[4] for j in js])
+            C_ = (ctypes.c_int * n)(*[j[5] for j in js])
+            M_ = (ctypes.c_int * n)(*[j[6] for j in js])
             with _on(dev):
                 _call('unflow_bias_grad_finalize_batch', P, G, N_, C_, M_, n, _stream(),
-                      nbytes=4 * sum(j[2] * j[3] + j[3] for j in js), shape=(n,))
+                      nbytes=4 * sum(j[4] * j[5] + j[5] for j in js), shape=(n,))
+
+    def adopted(self, params):
+        """True when every bias gradient finished by the last pass IS some parameter's ``.grad`` (autograd adopted the tensors it
+        was handed: nothing was cloned or accumulated before the deferred launch wrote them)."""
+        have = {p.grad.data_ptr() for p in params if p.grad is not None}
+        return all(a in have for a in self.last_addresses)
 
 
 deferred_bias_grads = _DeferredBiasGrads()

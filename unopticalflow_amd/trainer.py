@@ -17,7 +17,7 @@ _PROCESS_GC_FROZEN = False
 
 class FlowTrainer:
     def __init__(self, cfg, model, distributed=False, allreduce_chunks=4, fused_adam=None, use_graph=False,
-                 single_rank_collectives=False, gc_freeze_after=None, own_adam=None):
+                 single_rank_collectives=False, gc_freeze_after=None, own_adam=None, defer_bias_grads=None):
         self.cfg = cfg
         self.model = model
         self.loss_weights = generate_loss_weights_dict(cfg)
@@ -43,6 +43,8 @@ class FlowTrainer:
         else:
             self.grads = PlainGradients(params)
         self.distributed = distributed
+        self._defer_bias_grads = params[0].is_cuda if defer_bias_grads is None else bool(defer_bias_grads)
+        self._defer_checks = 2
         kw = {}
         if fused_adam is None:
             fused_adam = params[0].is_cuda
@@ -89,11 +91,29 @@ class FlowTrainer:
             loss = term if loss is None else loss + term
         return loss
 
+    def _backward(self, loss):
+        """``loss.backward()`` of a step whose gradients were dropped by ``self.grads.zero()``: on the GPU the bias-gradient
+        reductions of the pass finish in one launch at its end (ops.deferred_bias_grads; p.grad is None, so autograd adopts the
+        tensors).  The first passes check that it did."""
+        if not self._defer_bias_grads:
+            loss.backward()
+            return
+        from . import ops
+        with ops.deferred_bias_grads:
+            loss.backward()
+        if self._defer_checks > 0 and not torch.cuda.is_current_stream_capturing():
+            self._defer_checks -= 1
+            params = self.grads.params
+            # (pack mode re-points p.grad at the flat buffer when a piece is sent: the check only applies to what is still unpacked)
+            if not getattr(self.grads, 'pack', False) and not ops.deferred_bias_grads.adopted(params):
+                raise RuntimeError('deferred bias gradients were not adopted by autograd (a gradient was accumulated or cloned); '
+                                   'construct FlowTrainer(defer_bias_grads=False)')
+
     def _eager_fwd_bwd(self, inputs):
         self.grads.zero()
         loss_pack = self.model(inputs)
         loss = self.total_loss(loss_pack)
-        loss.backward()
+        self._backward(loss)
         return loss, loss_pack
 
     def _build_graph(self, inputs):
@@ -107,7 +127,9 @@ class FlowTrainer:
         is the eager one.  The warm-up exchanges nothing (its updates are discarded on every rank alike)."""
         self._static_in = inputs.clone()
         saved_model = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
-        saved_opt = {id(v): v.detach().clone() for st in self.optimizer.state.values() for v in st.values() if torch.is_tensor(v)}
+        # (by parameter and key, not by tensor identity: FlowAdam re-homes the step counters into its own vector at its first step)
+        saved_opt = {(p, k): torch.as_tensor(v).detach().clone() for p, st in self.optimizer.state.items() for k, v in st.items()
+                     if torch.is_tensor(v) or k == 'step'}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                  # warm-up off the capture
@@ -119,11 +141,11 @@ class FlowTrainer:
         with torch.no_grad():
             for k, v in self.model.state_dict().items():
                 v.copy_(saved_model[k])
-            for st in self.optimizer.state.values():   # in place: the graphs keep these tensors
-                for v in st.values():
+            for p, st in self.optimizer.state.items():   # in place: the graphs keep these tensors
+                for k, v in st.items():
                     if torch.is_tensor(v):
-                        if id(v) in saved_opt:
-                            v.copy_(saved_opt[id(v)])
+                        if (p, k) in saved_opt:
+                            v.copy_(saved_opt[(p, k)])
                         else:
                             v.zero_()
         self._graph = torch.cuda.CUDAGraph()
@@ -181,7 +203,7 @@ class FlowTrainer:
         self.grads.zero()
         loss_pack = self.model(inputs)
         loss = self.total_loss(loss_pack)
-        loss.backward()
+        self._backward(loss)
         if self.distributed:
             self.grads.all_reduce_mean()
         self.optimizer.step()
