@@ -35,6 +35,8 @@ case $r in
   newtests)   # what this round added or touched, first failure stops, no test may take more than 10 minutes
     timeout 1500 python3 -m pytest -x -q -m gpu -p no:cacheprovider --timeout 600 tests/test_hip_ops.py -k "ssim or losses or reductions or deferred or bias_leaky or flow_head" > $out/newtests_ops.log 2>&1; echo "ops rc=$?"; tail -25 $out/newtests_ops.log
     timeout 1500 python3 -m pytest -x -q -m gpu -p no:cacheprovider --timeout 600 tests/test_abi.py tests/test_cli.py tests/test_hip_model.py -k "c_program or bench_starts or graph_capture_keeps or replayed or flow_adam or kitti_256 or batch8 or sintel or hipgraph or rccl or module_128" > $out/newtests_model.log 2>&1; echo "model rc=$?"; tail -40 $out/newtests_model.log ;;
+  resttests)
+    timeout 900 python3 -m pytest -x -q -m gpu -p no:cacheprovider --timeout 600 tests/test_hip_model.py -k "graph_capture_keeps or flow_adam or hipgraph or rccl or two_ranks" > $out/resttests.log 2>&1; echo "resttests rc=$?"; tail -30 $out/resttests.log ;;
   suite)
     timeout 2400 python3 -m pytest tests -m gpu -q -p no:cacheprovider --timeout 900 > $out/suite.log 2>&1; echo "suite rc=$?"; tail -15 $out/suite.log
     python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;

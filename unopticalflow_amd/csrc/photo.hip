@@ -246,6 +246,127 @@ __global__ __launch_bounds__(256) void smooth2_bwd_tile_kernel(const float* __re
     }
 }
 
+// Round 4: both directions through ONE staged tile.  The per-pixel forward re-read every flow value six times and divided it by 20
+// each time (12 IEEE divisions and 18 loads per pixel: 38.8 us for 47.7 MB at scale 0, 0.15 of the HBM roofline); round 3's
+// backward computed its S values from global memory with the same redundancy (44.5 us, 0.21).  Here a workgroup stages its
+// 64 x 8 pixels plus a 2-pixel ring ONCE: flow / 20 (both channels) and the three image planes, 68 x 12 positions, 16 KB of LDS;
+// every second difference and every edge weight is then computed from LDS, with the operations of the per-pixel forms in the same
+// order (same values; only the grouping of the forward's partial sums changes).
+constexpr int SG_W = SM_TW + 4, SG_H = SM_TH + 4, SG_N = SG_W * SG_H;
+struct SmoothStage { float f0[SG_N], f1[SG_N], i0[SG_N], i1[SG_N], i2[SG_N]; };
+
+__device__ __forceinline__ void smooth_stage(SmoothStage& t, const float* __restrict__ f, const float* __restrict__ im, int HW,
+                                             int H, int W, int x0, int y0) {
+    for (int i = threadIdx.x; i < SG_N; i += 256) {
+        const int ry = i / SG_W, rx = i - ry * SG_W;
+        const int y = y0 - 2 + ry, x = x0 - 2 + rx;
+        float a = 0.f, b = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        if (x >= 0 && x < W && y >= 0 && y < H) {
+            const int q = y * W + x;
+            a = f[q] / 20.0f; b = f[HW + q] / 20.0f;
+            c0 = im[q]; c1 = im[HW + q]; c2 = im[2 * HW + q];
+        }
+        t.f0[i] = a; t.f1[i] = b; t.i0[i] = c0; t.i1[i] = c1; t.i2[i] = c2;
+    }
+}
+
+// edge_w() between two staged positions
+__device__ __forceinline__ float stage_edge_w(const SmoothStage& t, int j0, int j1) {
+    float s = 0.f;
+    s = s + fabsf(t.i0[j1] - t.i0[j0]);
+    s = s + fabsf(t.i1[j1] - t.i1[j0]);
+    s = s + fabsf(t.i2[j1] - t.i2[j0]);
+    return expf(-10.0f * (s / 3.0f));
+}
+
+// grid = (tiles_x, tiles_y, B); partials[(b * tiles + tile) * 2] = {sum over the tile of wx |dx2|, of wy |dy2|}
+__global__ __launch_bounds__(256) void smooth2_fwd_tile_kernel(const float* __restrict__ flow, const float* __restrict__ img,
+                                                               float* __restrict__ partials, int H, int W, int img_b) {
+    __shared__ SmoothStage t;
+    __shared__ float red[8];
+    const int b = blockIdx.z, x0 = blockIdx.x * SM_TW, y0 = blockIdx.y * SM_TH;
+    const int HW = H * W;
+    smooth_stage(t, flow + (size_t)b * 2 * HW, img + (size_t)(b % img_b) * 3 * HW, HW, H, W, x0, y0);
+    __syncthreads();
+    float acc[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < SM_TW * SM_TH / 256; ++k) {
+        const int idx = k * 256 + (int)threadIdx.x;
+        const int r = idx / SM_TW, c = idx - r * SM_TW;
+        const int y = y0 + r, x = x0 + c;
+        if (x >= W || y >= H) continue;
+        const int j = (r + 2) * SG_W + c + 2;
+        if (x + 2 < W) {                                 // dx2 at x, weight w_x[x+1]
+            const float wx = stage_edge_w(t, j + 1, j + 2);
+            acc[0] += wx * fabsf((t.f0[j + 2] - t.f0[j + 1]) - (t.f0[j + 1] - t.f0[j]));
+            acc[0] += wx * fabsf((t.f1[j + 2] - t.f1[j + 1]) - (t.f1[j + 1] - t.f1[j]));
+        }
+        if (y + 2 < H) {
+            const float wy = stage_edge_w(t, j + SG_W, j + 2 * SG_W);
+            acc[1] += wy * fabsf((t.f0[j + 2 * SG_W] - t.f0[j + SG_W]) - (t.f0[j + SG_W] - t.f0[j]));
+            acc[1] += wy * fabsf((t.f1[j + 2 * SG_W] - t.f1[j + SG_W]) - (t.f1[j + SG_W] - t.f1[j]));
+        }
+    }
+    block_sum_256<2>(acc, red);
+    if (threadIdx.x == 0) {
+        float* o = partials + ((size_t)b * gridDim.x * gridDim.y + (size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+        o[0] = acc[0]; o[1] = acc[1];
+    }
+}
+
+// the backward of smooth2_bwd_tile_kernel with its S values computed from the staged tile
+__global__ __launch_bounds__(256) void smooth2_bwd_stage_kernel(const float* __restrict__ flow, const float* __restrict__ img,
+                                                                const float* __restrict__ gloss, float* __restrict__ gflow,
+                                                                int H, int W, int img_b) {
+    constexpr int NX = SM_TH * (SM_TW + 2), NY = (SM_TH + 2) * SM_TW;
+    __shared__ SmoothStage t;
+    __shared__ float2 s_x[NX], s_y[NY];
+    const int b = blockIdx.z, x0 = blockIdx.x * SM_TW, y0 = blockIdx.y * SM_TH;
+    const int HW = H * W;
+    smooth_stage(t, flow + (size_t)b * 2 * HW, img + (size_t)(b % img_b) * 3 * HW, HW, H, W, x0, y0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < NX + NY; i += 256) {
+        float2 v = make_float2(0.f, 0.f);
+        if (i < NX) {
+            const int r = i / (SM_TW + 2), c = i - r * (SM_TW + 2);
+            const int y = y0 + r, x = x0 - 2 + c;                    // dx2 starting at x, weight w_x[x+1]
+            if (y < H && x >= 0 && x + 2 < W) {
+                const int j = (r + 2) * SG_W + c;
+                const float w = stage_edge_w(t, j + 1, j + 2);
+                v = make_float2(w * sgn((t.f0[j + 2] - t.f0[j + 1]) - (t.f0[j + 1] - t.f0[j])),
+                                w * sgn((t.f1[j + 2] - t.f1[j + 1]) - (t.f1[j + 1] - t.f1[j])));
+            }
+            s_x[i] = v;
+        } else {
+            const int k = i - NX;
+            const int r = k / SM_TW, c = k - r * SM_TW;
+            const int y = y0 - 2 + r, x = x0 + c;
+            if (x < W && y >= 0 && y + 2 < H) {
+                const int j = r * SG_W + c + 2;
+                const float w = stage_edge_w(t, j + SG_W, j + 2 * SG_W);
+                v = make_float2(w * sgn((t.f0[j + 2 * SG_W] - t.f0[j + SG_W]) - (t.f0[j + SG_W] - t.f0[j])),
+                                w * sgn((t.f1[j + 2 * SG_W] - t.f1[j + SG_W]) - (t.f1[j + SG_W] - t.f1[j])));
+            }
+            s_y[k] = v;
+        }
+    }
+    __syncthreads();
+    const float kx = gloss[b] / (2.0f * (2.0f * (float)H * (float)(W - 2))) / 20.0f;
+    const float ky = gloss[b] / (2.0f * (2.0f * (float)(H - 2) * (float)W)) / 20.0f;
+#pragma unroll
+    for (int k = 0; k < SM_TW * SM_TH / 256; ++k) {
+        const int idx = k * 256 + (int)threadIdx.x;
+        const int r = idx / SM_TW, c = idx - r * SM_TW;
+        const int y = y0 + r, x = x0 + c;
+        if (x >= W || y >= H) continue;
+        const float2 xa = s_x[r * (SM_TW + 2) + c], xb = s_x[r * (SM_TW + 2) + c + 1], xc = s_x[r * (SM_TW + 2) + c + 2];      // starts x-2, x-1, x
+        const float2 ya = s_y[r * SM_TW + c], yb = s_y[(r + 1) * SM_TW + c], yc = s_y[(r + 2) * SM_TW + c];                    // starts y-2, y-1, y
+        const size_t o = (size_t)b * 2 * HW + (size_t)y * W + x;
+        gflow[o] = kx * ((xa.x - 2.f * xb.x) + xc.x) + ky * ((ya.x - 2.f * yb.x) + yc.x);
+        gflow[o + HW] = kx * ((xa.y - 2.f * xb.y) + xc.y) + ky * ((ya.y - 2.f * yb.y) + yc.y);
+    }
+}
+
 // gather form of the backward: pixel q collects the three second differences it takes part in.
 __global__ void smooth2_bwd_kernel(const float* __restrict__ flow, const float* __restrict__ img,
                                    const float* __restrict__ gloss, float* __restrict__ gflow,
@@ -528,7 +649,9 @@ extern "C" int unflow_partials_per_sample(int H, int W) {
     if (H <= 0 || W <= 0) return UNFLOW_EINVAL;
     const int flat = ceil_div(H * W, TILE);
     const int ss = unflow_ssim_blocks(H, W);
-    return 2 * (flat > ss ? flat : ss);     // floats per sample (K = 2 everywhere)
+    const int sm = ceil_div(W, SM_TW) * ceil_div(H, SM_TH);              // smooth2_fwd_tile_kernel: one partial pair per 64 x 8 tile
+    const int m = flat > ss ? flat : ss;
+    return 2 * (m > sm ? m : sm);     // floats per sample (K = 2 everywhere)
 }
 
 extern "C" int unflow_occ_weight_fwd(const float* img, const float* from_l, const float* from_r,
@@ -574,6 +697,17 @@ extern "C" int unflow_smooth2_fwd(const float* flow, const float* img, float* lo
                                   int B, int H, int W, int img_batch, void* stream) {
     UNFLOW_REQUIRE(flow && img && loss && partials && B > 0 && H > 0 && W > 0 && img_batch > 0 && B % img_batch == 0);
     hipStream_t s = (hipStream_t)stream;
+#ifdef UNFLOW_TUNING
+    const bool per_pixel = getenv("UNFLOW_SMOOTH_OLD") != nullptr;      // A/B against the per-pixel form (tools/probes/loss_kernel_times.py)
+#else
+    const bool per_pixel = false;
+#endif
+    if (!per_pixel && B <= 65535) {
+        const dim3 grid(ceil_div(W, SM_TW), ceil_div(H, SM_TH), B);
+        UNFLOW_LAUNCH(smooth2_fwd_tile_kernel, grid, dim3(256), 0, s, flow, img, partials, H, W, img_batch);
+        UNFLOW_LAUNCH(smooth2_finalize_kernel, dim3(B), dim3(256), 0, s, partials, (int)(grid.x * grid.y), loss, H, W);
+        return unflow_launch_status();
+    }
     const int nblk = ceil_div(H * W, TILE);
     UNFLOW_LAUNCH(smooth2_partial_kernel, dim3(nblk, B), dim3(256), 0, s, flow, img, partials, H, W, img_batch);
     UNFLOW_LAUNCH(smooth2_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, H, W);
@@ -590,7 +724,14 @@ extern "C" int unflow_smooth2_bwd(const float* flow, const float* img, const flo
     const bool per_pixel = false;
 #endif
     if (!per_pixel && B <= 65535 && H >= 3 && W >= 3) {
-        UNFLOW_LAUNCH(smooth2_bwd_tile_kernel, dim3(ceil_div(W, SM_TW), ceil_div(H, SM_TH), B), dim3(256), 0, s, flow, img, gloss, gflow,
+#ifdef UNFLOW_TUNING
+        if (getenv("UNFLOW_SMOOTH_R3") != nullptr) {                     // round 3's tile kernel (S values from global memory)
+            UNFLOW_LAUNCH(smooth2_bwd_tile_kernel, dim3(ceil_div(W, SM_TW), ceil_div(H, SM_TH), B), dim3(256), 0, s, flow, img, gloss, gflow,
+                               H, W, img_batch);
+            return unflow_launch_status();
+        }
+#endif
+        UNFLOW_LAUNCH(smooth2_bwd_stage_kernel, dim3(ceil_div(W, SM_TW), ceil_div(H, SM_TH), B), dim3(256), 0, s, flow, img, gloss, gflow,
                            H, W, img_batch);
         return unflow_launch_status();
     }
