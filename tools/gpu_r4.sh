@@ -35,6 +35,10 @@ case $r in
   newtests)   # what this round added or touched, first failure stops, no test may take more than 10 minutes
     timeout 1500 python3 -m pytest -x -q -m gpu -p no:cacheprovider --timeout 600 tests/test_hip_ops.py -k "ssim or losses or reductions or deferred or bias_leaky or flow_head" > $out/newtests_ops.log 2>&1; echo "ops rc=$?"; tail -25 $out/newtests_ops.log
     timeout 1500 python3 -m pytest -x -q -m gpu -p no:cacheprovider --timeout 600 tests/test_abi.py tests/test_cli.py tests/test_hip_model.py -k "c_program or bench_starts or graph_capture_keeps or replayed or flow_adam or kitti_256 or batch8 or sintel or hipgraph or rccl or module_128" > $out/newtests_model.log 2>&1; echo "model rc=$?"; tail -40 $out/newtests_model.log ;;
+  smooth)
+    timeout 600 python3 -m pytest -x -q -m gpu -p no:cacheprovider --timeout 300 tests/test_hip_ops.py -k "smooth or losses or reductions or golden" > $out/smooth_tests.log 2>&1; echo "smooth tests rc=$?"; tail -8 $out/smooth_tests.log
+    timeout 900 python3 -m pytest -x -q -m gpu -p no:cacheprovider --timeout 800 tests/test_hip_model.py -k "flow_adam or find_db or module_128" > $out/smooth_model.log 2>&1; echo "model rc=$?"; tail -8 $out/smooth_model.log
+    timeout 300 python3 tools/probes/loss_kernel_times.py 2>&1 | tee $out/loss_kernel_times_b.txt | grep -E "smooth|ssim" ;;
   resttests)
     timeout 900 python3 -m pytest -x -q -m gpu -p no:cacheprovider --timeout 600 tests/test_hip_model.py -k "graph_capture_keeps or flow_adam or hipgraph or rccl or two_ranks" > $out/resttests.log 2>&1; echo "resttests rc=$?"; tail -30 $out/resttests.log ;;
   suite)
