@@ -107,6 +107,7 @@ def parse():
     ap.add_argument('--fused-loss-sums', type=int, default=1, help='0: eager adds / means for the loss bookkeeping instead of unflow_loss_combine_* and unflow_weighted_mean_sum_* (A/B)')
     ap.add_argument('--fused-upsample', type=int, default=1, help='0: F.interpolate + multiply for the flow up-sampling instead of unflow_upsample_scaled_* (A/B; PWC_tf.fused_upsample)')
     ap.add_argument('--fill-cat', type=int, default=1, help='0: channels_last decoder with torch.cat inputs instead of epilogue-filled cat buffers (A/B; PWC_tf.fill_cat_buffers)')
+    ap.add_argument('--fused-warp-bwd', type=int, default=1, help='0: zero-fill + scatter for the feature-map warps\' backward instead of the one-pass gather (A/B; ops.fused_warp_bwd)')
     ap.add_argument('--gc-freeze', type=int, default=1, help='0: leave Python\'s cyclic collector alone; 1: FlowTrainer(gc_freeze_after=2), what train.py asks for too (gc.freeze() after the second step, once per process)')
     ap.add_argument('--contended-host', action='store_true', help='experiment (profiles/r4_multirank_step_mode.md): for the TIMED steps confine this process to one core and run a busy-loop child on the same core -- what a slow or shared host does to the step mode')
     ap.add_argument('--force-ddp', action='store_true', help='N = 1 only: run the step through the RCCL data-parallel path with a one-rank communicator')
@@ -252,6 +253,7 @@ def main():
     import types
 
     _lib.load()                                   # no HIP library -> fail loudly, never fall back
+    ops.fused_warp_bwd = bool(args.fused_warp_bwd)
     # one rank per GPU over RCCL.  UNFLOW_BENCH_ONE_GPU=1 is a rehearsal mode for boxes with a single GPU: every rank
     # shares device 0 and the collectives go through gloo (RCCL refuses two ranks on one device) -- it exercises the
     # multi-rank plumbing, its numbers mean nothing.
@@ -325,7 +327,7 @@ def main():
             trainer.fused_total_loss = bool(args.fused_loss_sums)
     for _ in range(warm):
         trainer.step(inputs)
-    CW = ('unflow_corr_fwd', 'unflow_corr_bwd', 'unflow_warp_fwd', 'unflow_warp_bwd', 'unflow_warp_bwd_det', 'unflow_warp_corr_fwd', 'unflow_warp_corr_bwd')
+    CW = ('unflow_corr_fwd', 'unflow_corr_bwd', 'unflow_warp_fwd', 'unflow_warp_bwd', 'unflow_warp_bwd_det', 'unflow_warp_bwd_fused', 'unflow_warp_corr_fwd', 'unflow_warp_corr_bwd')
     # the second timed set: the occlusion-aware loss kernels (north_star names the SSIM window reduction and the occlusion-mask
     # ops next to corr / warp) -> roofline.losses
     LOSSES = ('unflow_ssim_loss_fwd', 'unflow_ssim_loss_bwd', 'unflow_occ_weight_fwd', 'unflow_absdiff_bwd', 'unflow_masked_mean_fwd',

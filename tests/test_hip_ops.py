@@ -270,6 +270,43 @@ def test_warp_feature_tiles_vs_oracle(ops, kind, C, h, w):
             runs.append(x3.grad.clone())
         if C >= 8 and w >= 8 and h * w >= 512:            # (the shapes the tile kernels serve; smaller maps keep the per-tap atomics)
             assert torch.equal(runs[0], runs[1])
+            # round 4: the whole backward as ONE gather pass (unflow_warp_bwd_fused: source gradient by gather + flow gradient by the
+            # tile's owner); forced here -- at B = 3 the launch is below the size the op picks it for -- same bars, both gradients
+            # bit-identical from run to run
+            runs = []
+            for _ in range(2):
+                x4, f4 = dev(xc.detach()).requires_grad_(), dev(fc.detach()).requires_grad_()
+                ops.warp_flow(x4, f4, align_corners=ac, fused_backward=True).backward(dev(g))
+                close(x4.grad, xc.grad, rtol=1e-4, atol=2e-5, what='fused gsrc %s' % kind)
+                close(f4.grad, fc.grad, rtol=1e-4, atol=2e-5 * scale, what='fused gflow %s' % kind)
+                runs.append((x4.grad.clone(), f4.grad.clone()))
+            assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+
+
+def test_warp_backward_fused_at_the_step_shapes(ops):
+    """The shapes the op picks the one-pass backward for by itself (levels 2 and 3 of the 832x256 step at the step's batch of 16
+    directed pairs): chosen without being asked, equal to the zero-fill + scatter form within the float-atomic noise of the latter,
+    and bit-identical from run to run."""
+    lib = __import__('unopticalflow_amd._lib', fromlist=['load']).load()
+    assert lib.unflow_warp_bwd_fused_supported(16, 32, 64, 208) == 2 and lib.unflow_warp_bwd_fused_supported(16, 64, 32, 104) == 2
+    assert lib.unflow_warp_bwd_fused_supported(16, 96, 16, 52) == 1 and lib.unflow_warp_bwd_fused_supported(16, 3, 256, 832) == 0
+    for C, h, w in ((32, 64, 208), (64, 32, 104)):
+        x0, g = rnd(500 + C, (16, C, h, w)), rnd(501 + C, (16, C, h, w))
+        f0 = _structured_flow(16, h, w, 'mixed', seed=C)
+        res = {}
+        for fused in (None, False, None):
+            x, f = dev(x0).requires_grad_(), dev(f0).requires_grad_()
+            ops.kernel_timer.enable(True)
+            ops.warp_flow(x, f, fused_backward=fused).backward(dev(g))
+            torch.cuda.synchronize()
+            ops.kernel_timer.disable()
+            names = {r['entry'] for r in ops.kernel_timer.rows()}
+            assert ('unflow_warp_bwd_fused' in names) == (fused is None), names
+            res.setdefault(fused, []).append((x.grad.clone(), f.grad.clone()))
+        (a, fa), (b, fb) = res[None]
+        assert torch.equal(a, b) and torch.equal(fa, fb)
+        close(a, res[False][0][0], rtol=1e-4, atol=2e-5)
+        close(fa, res[False][0][1], rtol=1e-4, atol=2e-5 * max(fa.abs().max().item(), 1e-6))
 
 
 @pytest.mark.parametrize('kind', ['smooth', 'mixed', 'edge', 'outside', 'noise'])

@@ -39,6 +39,18 @@ case $r in
     timeout 600 python3 -m pytest -x -q -m gpu -p no:cacheprovider --timeout 300 tests/test_hip_ops.py -k "smooth or losses or reductions or golden" > $out/smooth_tests.log 2>&1; echo "smooth tests rc=$?"; tail -8 $out/smooth_tests.log
     timeout 900 python3 -m pytest -x -q -m gpu -p no:cacheprovider --timeout 800 tests/test_hip_model.py -k "flow_adam or find_db or module_128" > $out/smooth_model.log 2>&1; echo "model rc=$?"; tail -8 $out/smooth_model.log
     timeout 300 python3 tools/probes/loss_kernel_times.py 2>&1 | tee $out/loss_kernel_times_b.txt | grep -E "smooth|ssim" ;;
+  warpfused)
+    timeout 900 python3 -m pytest -x -q -m gpu -p no:cacheprovider --timeout 600 tests/test_hip_ops.py -k "warp" > $out/warpfused_tests.log 2>&1; echo "warp tests rc=$?"; tail -12 $out/warpfused_tests.log
+    for v in 1 0; do python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --fused-warp-bwd $v > $out/warpfused_$v.json 2> $out/warpfused_$v.err; done
+    line $out/warpfused_1.json $out/warpfused_0.json
+    python3 - <<'PY'
+import json
+for v in (1, 0):
+    d = json.loads(open('gpurun_out/r4/warpfused_%d.json' % v).read().strip().splitlines()[-1])
+    for e in d['roofline']['aggregate']['per_level']:
+        if 'warp_bwd' in e['entry'] and e['shape'][1] > 3: print(v, e['entry'], e['shape'], e['avg_us'], e['frac'])
+PY
+    ;;
   resttests)
     timeout 900 python3 -m pytest -x -q -m gpu -p no:cacheprovider --timeout 600 tests/test_hip_model.py -k "graph_capture_keeps or flow_adam or hipgraph or rccl or two_ranks" > $out/resttests.log 2>&1; echo "resttests rc=$?"; tail -30 $out/resttests.log ;;
   suite)

@@ -967,11 +967,16 @@ __device__ __forceinline__ void gather_cell_global(float (&acc)[CC], const float
     }
 }
 
-template <int PPT, int CC>
+// WITH_FLOW (round 4): the workgroup also owes the FLOW gradient of the destination pixels at its tile's coordinates (the same
+// 2 pixels per thread): per channel one coalesced read of the upstream gradient and the four taps of the source map (L1 / L2: the
+// neighbours of a warp's lanes share cache lines), accumulated over the channel chunks in registers and written once, plain
+// stores -- so one launch does the whole backward, and the upstream gradient leaves HBM once.  (Several channel groups per tile
+// would each hold a partial flow gradient: the host only asks for WITH_FLOW when a tile's channels stay in one workgroup.)
+template <int PPT, int CC, bool WITH_FLOW>
 __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __restrict__ flow, const float* __restrict__ gout,
                                                               const TileBounds* __restrict__ table, float* __restrict__ gsrc,
                                                               int C, int H, int W, int ac, int TW, int TH, int tiles_x, int tiles_y,
-                                                              int cpg, int vec_ok) {
+                                                              int cpg, int vec_ok, const float* __restrict__ src, float* __restrict__ gflow) {
     constexpr int DWP = 80, DHMAX = 8 + GK - 1;             // LDS row stride (64 + GK - 1 + 3 alignment columns) / rows of the staged region
     constexpr int REGION = DHMAX * DWP;                     // floats per channel
     constexpr int kNone = -0x7fffffff - 1;
@@ -1021,11 +1026,61 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
         cx[q] = sx0 + lx; cy[q] = sy0 + ly;
         live[q] = ly < TH && cx[q] < W && cy[q] < H;
     }
+    // the flow gradient of this thread's pixels (destination role): taps once, then per channel chunk
+    float t_s[PPT], t_n[PPT], t_e[PPT], t_w[PPT];
+    int t_o[PPT][4];
+    bool t_v[PPT][4];
+    float gix[PPT], giy[PPT];
+    if (WITH_FLOW) {
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            gix[q] = 0.f; giy[q] = 0.f;
+            const int pix = live[q] ? cy[q] * W + cx[q] : 0;
+            const Taps tp = make_taps(live[q] ? fb[pix] : 0.f, live[q] ? fb[plane + pix] : 0.f, live[q] ? cx[q] : 0, live[q] ? cy[q] : 0, H, W, ac);
+            t_s[q] = tp.s; t_n[q] = tp.n; t_e[q] = tp.e; t_w[q] = tp.w;
+            t_o[q][0] = tp.o_nw; t_o[q][1] = tp.o_ne; t_o[q][2] = tp.o_sw; t_o[q][3] = tp.o_se;
+            t_v[q][0] = live[q] && tp.v_nw; t_v[q][1] = live[q] && tp.v_ne; t_v[q][2] = live[q] && tp.v_sw; t_v[q][3] = live[q] && tp.v_se;
+        }
+    }
+    const float* sp = WITH_FLOW ? src + (size_t)b * C * plane : nullptr;
+    auto flow_grad = [&](int c0, int nc) {                  // channels [c0, c0 + nc) of this workgroup's pixels
+        if (!WITH_FLOW) return;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            if (!live[q]) continue;
+            const int pix = cy[q] * W + cx[q];
+#pragma unroll 4
+            for (int c = 0; c < nc; ++c) {
+                const float* p = sp + (size_t)(c0 + c) * plane;
+                const float gv = gp[(size_t)(c0 + c) * plane + pix];
+                const float a = t_v[q][0] ? p[t_o[q][0]] : 0.f, bq = t_v[q][1] ? p[t_o[q][1]] : 0.f;
+                const float cq = t_v[q][2] ? p[t_o[q][2]] : 0.f, dq = t_v[q][3] ? p[t_o[q][3]] : 0.f;
+                gix[q] += gv * ((bq - a) * t_s[q] + (dq - cq) * t_n[q]);
+                giy[q] += gv * ((cq - a) * t_e[q] + (dq - bq) * t_w[q]);
+            }
+        }
+    };
+    auto flow_grad_store = [&]() {
+        if (!WITH_FLOW) return;
+        const float mx = ac ? (float)(W - 1) * 0.5f : (float)W * 0.5f;
+        const float my = ac ? (float)(H - 1) * 0.5f : (float)H * 0.5f;
+        const float ddx = (float)(W > 1 ? W - 1 : 1), ddy = (float)(H > 1 ? H - 1 : 1);
+        float* gf = gflow + (size_t)b * 2 * plane;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            if (!live[q]) continue;
+            const int pix = cy[q] * W + cx[q];
+            gf[pix] = (gix[q] * mx) / ddx * 2.0f;
+            gf[plane + pix] = (giy[q] * my) / ddy * 2.0f;
+        }
+    };
     if (dx0 > dx1) {                                        // nothing lands on this tile
 #pragma unroll
         for (int q = 0; q < PPT; ++q)
             if (live[q])
                 for (int c = c_begin; c < c_end; ++c) dp[(size_t)c * plane + cy[q] * W + cx[q]] = 0.f;
+        flow_grad(c_begin, c_end - c_begin);
+        flow_grad_store();
         return;
     }
     const int kx0 = -dx1 - 1, ky0 = -dy1 - 1;               // candidate p = s + (kx0 + kx, ky0 + ky)
@@ -1045,7 +1100,9 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
                 for (int c = 0; c < CC; ++c)
                     if (c < nc) dp[(size_t)(c0 + c) * plane + cy[q] * W + cx[q]] = acc[c];
             }
+            flow_grad(c0, nc);
         }
+        flow_grad_store();
         return;
     }
 
@@ -1190,16 +1247,18 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
                     if (c < nc) dp[(size_t)(c0 + c) * plane + cy[q] * W + cx[q]] = acc[c];
             }
         }
+        flow_grad(c0, nc);
         __syncthreads();
     }
+    flow_grad_store();
 }
 
 // Tile geometry for an H x W map with C channels: tiles as wide as the map allows up to 64 (52 for the 13 * 2^k wide
 // KITTI levels: no dead lanes), channel groups so that the launch has >= ~1024 workgroups.
 struct TilePlan { int TW, TH, tiles_x, tiles_y, groups, cpg; };
-inline TilePlan plan_tiles(int B, int C, int H, int W, int TH, int CC, int want_wgs) {
+inline TilePlan plan_tiles(int B, int C, int H, int W, int TH, int CC, int want_wgs, int maxw = 64) {
     TilePlan p;
-    p.tiles_x = ceil_div(W, 64);
+    p.tiles_x = ceil_div(W, maxw);
     p.TW = ceil_div(ceil_div(W, p.tiles_x), 4) * 4;
     p.tiles_x = ceil_div(W, p.TW);
     p.TH = TH;
@@ -1279,8 +1338,8 @@ static int warp_bwd_impl(const float* src, const float* flow, const float* gout,
         TileBounds* table = reinterpret_cast<TileBounds*>(gflow);       // gflow is scratch until its own kernel (below) writes it
         UNFLOW_LAUNCH((warp_tile_bounds_kernel<2>), dim3(ntiles), dim3(256), 0, s, flow, table, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y);
         const int vec_g = ((W & 3) == 0 && (((size_t)gout) & 15) == 0) ? 1 : 0;
-        UNFLOW_LAUNCH((warp_bwd_gather_kernel<2, 8>), dim3(ntiles, p.groups), dim3(256), 0, s, flow, gout, table, gsrc,
-                           C, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y, p.cpg, vec_g);
+        UNFLOW_LAUNCH((warp_bwd_gather_kernel<2, 8, false>), dim3(ntiles, p.groups), dim3(256), 0, s, flow, gout, table, gsrc,
+                           C, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y, p.cpg, vec_g, (const float*)nullptr, (float*)nullptr);
         gsrc = nullptr;                                                  // the kernels below only owe the flow gradient
     }
     if (gsrc) unflow_zero_async(gsrc, (size_t)B * C * H * W, s);
@@ -1326,6 +1385,48 @@ extern "C" int unflow_warp_bwd(const float* src, const float* flow, const float*
                                float* gsrc, float* gflow, int B, int C, int H, int W, int align_corners,
                                void* stream) {
     return warp_bwd_impl(src, flow, gout, mask, gsrc, gflow, B, C, H, W, align_corners, stream, 0);
+}
+
+// (ABI 9) The whole backward of a feature-map warp in one pass over the upstream gradient: source gradient as a gather (no
+// zero-fill, no float atomics, every element written once) AND the flow gradient, by the workgroup that owns the tile -- bitwise
+// reproducible.  `table` = unflow_warp_bwd_table_bytes() bytes of scratch (the per-tile displacement ranges a pre-pass leaves
+// there).  Shapes this form does not take (masked image warps, < 8 channels, small maps whose tiles would need several channel
+// groups) return UNFLOW_EINVAL from unflow_warp_bwd_fused_supported() == 0: use unflow_warp_bwd.
+// -> 0: the shape is not served; 1: served, but the launch would not fill the chip (fewer than 256 workgroups even with 32-wide
+// tiles: the scatter form with channel groups is the faster one); 2: served and recommended
+static int warp_fused_plan(int B, int C, int H, int W, TilePlan* out) {
+    if (C < 8 || W < 8 || H * W < 512 || B <= 0) return 0;
+    TilePlan p;
+    for (int maxw = 64; maxw >= 32; maxw >>= 1) {                        // narrower tiles on smaller maps
+        p = plan_tiles(B, C, H, W, 8, 8, 0, maxw);                       // one channel group: the flow gradient stays in one workgroup
+        if (p.groups != 1 || p.TW > 64) return 0;
+        if (p.tiles_x * p.tiles_y * B >= 256) {
+            if (out) *out = p;
+            return 2;
+        }
+    }
+    if (out) *out = p;
+    return 1;
+}
+extern "C" int unflow_warp_bwd_fused_supported(int B, int C, int H, int W) { return warp_fused_plan(B, C, H, W, nullptr); }
+extern "C" int unflow_warp_bwd_table_bytes(int B, int C, int H, int W) {
+    TilePlan p;
+    if (!warp_fused_plan(B, C, H, W, &p)) return 0;
+    return (int)((size_t)p.tiles_x * p.tiles_y * B * sizeof(TileBounds));
+}
+extern "C" int unflow_warp_bwd_fused(const float* src, const float* flow, const float* gout, float* gsrc, float* gflow, void* table,
+                                     int B, int C, int H, int W, int align_corners, void* stream) {
+    UNFLOW_REQUIRE(src && flow && gout && gsrc && gflow && table && B > 0 && C > 0 && H > 0 && W > 0);
+    TilePlan p;
+    UNFLOW_REQUIRE(warp_fused_plan(B, C, H, W, &p));
+    hipStream_t s = (hipStream_t)stream;
+    const int ac = align_corners ? 1 : 0;
+    const int ntiles = p.tiles_x * p.tiles_y * B;
+    UNFLOW_LAUNCH((warp_tile_bounds_kernel<2>), dim3(ntiles), dim3(256), 0, s, flow, (TileBounds*)table, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y);
+    const int vec_g = ((W & 3) == 0 && (((size_t)gout) & 15) == 0) ? 1 : 0;
+    UNFLOW_LAUNCH((warp_bwd_gather_kernel<2, 8, true>), dim3(ntiles, 1), dim3(256), 0, s, flow, gout, (const TileBounds*)table, gsrc,
+                       C, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y, p.cpg, vec_g, src, gflow);
+    return unflow_launch_status();
 }
 
 extern "C" int unflow_warp_bwd_det(const float* src, const float* flow, const float* gout, const uint8_t* mask,

@@ -268,9 +268,13 @@ def corr(input1, input2, d=4):
 # ------------------------------------------------------------------------------------------
 # warp
 # ------------------------------------------------------------------------------------------
+# the feature-map warps' backward as one gather pass (unflow_warp_bwd_fused) where the shape allows; False: zero-fill + scatter (A/B: bench.py --fused-warp-bwd)
+fused_warp_bwd = True
+
+
 class _Warp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, flow, use_mask, align_corners, deterministic=False):
+    def forward(ctx, x, flow, use_mask, align_corners, deterministic=False, fused=None):
         _dev(x, flow)
         x, flow = x.contiguous(), flow.contiguous()
         B, C, H, W = x.shape
@@ -284,6 +288,7 @@ class _Warp(torch.autograd.Function):
         ctx.set_materialize_grads(False)             # (no zero-filled "gradient" for the mask: a fill launch per warp otherwise)
         ctx.ac = int(align_corners)
         ctx.entry = 'unflow_warp_bwd_det' if deterministic else 'unflow_warp_bwd'
+        ctx.fused = fused                            # None: by shape (ops.fused_warp_bwd); True / False: forced
         if use_mask:
             ctx.mark_non_differentiable(mask)
             return out, mask
@@ -294,15 +299,23 @@ class _Warp(torch.autograd.Function):
         x, flow, mask = ctx.saved_tensors
         B, C, H, W = x.shape
         if g is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         g = g.contiguous()
         gsrc = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gflow = torch.empty_like(flow)
+        want = ctx.fused if ctx.fused is not None else fused_warp_bwd
+        if want and mask is None and gsrc is not None and _lib.load().unflow_warp_bwd_fused_supported(B, C, H, W) >= (1 if ctx.fused else 2):
+            # one pass: source gradient as a gather + flow gradient, no zero-fill, no atomics, bitwise reproducible
+            table = torch.empty(_lib.load().unflow_warp_bwd_table_bytes(B, C, H, W), dtype=torch.uint8, device=x.device)
+            with _on(x.device):
+                _call('unflow_warp_bwd_fused', _ptr(x), _ptr(flow), _ptr(g), _ptr(gsrc), _ptr(gflow), _ptr(table), B, C, H, W, ctx.ac, _stream(),
+                      nbytes=4 * B * H * W * (3 * C + 4), shape=(B, C, H, W))
+            return gsrc, (gflow if ctx.needs_input_grad[1] else None), None, None, None, None
         with _on(x.device):
             _call(ctx.entry, _ptr(x), _ptr(flow), _ptr(g), _ptr(mask), _ptr(gsrc), _ptr(gflow),
                   B, C, H, W, ctx.ac, _stream(),
                   nbytes=4 * B * H * W * ((3 * C + 4) if gsrc is not None else (2 * C + 4)), shape=(B, C, H, W))
-        return gsrc, (gflow if ctx.needs_input_grad[1] else None), None, None, None
+        return gsrc, (gflow if ctx.needs_input_grad[1] else None), None, None, None, None
 
 
 def _check_flow_shape(x, flow):
@@ -312,11 +325,13 @@ def _check_flow_shape(x, flow):
             torch.Size((B, 2, H, W)), flow.shape))
 
 
-def warp_flow(x, flow, use_mask=False, align_corners=False, deterministic=False):
-    """warp_flow (net_utils.py:16-54): backward-warp x [B,C,H,W] by flow [B,2,H,W].  ``deterministic``: the source gradient of a
-    feature-map warp as a gather (unflow_warp_bwd_det: no float atomics, bitwise reproducible; a few per cent to 2x slower)."""
+def warp_flow(x, flow, use_mask=False, align_corners=False, deterministic=False, fused_backward=None):
+    """warp_flow (net_utils.py:16-54): backward-warp x [B,C,H,W] by flow [B,2,H,W].  The backward of a feature-map warp whose tiles
+    fill the chip (levels 2 / 3 of the 832x256 step) is ONE gather pass (unflow_warp_bwd_fused: no zero-fill, no float atomics, bitwise
+    reproducible); other shapes zero-fill and scatter.  ``fused_backward``: True / False force / forbid the gather pass (None: by
+    shape); ``deterministic``: the older two-launch gather form (unflow_warp_bwd_det) for the shapes the fused pass does not take."""
     _check_flow_shape(x, flow)
-    out, _ = _Warp.apply(x, flow, bool(use_mask), bool(align_corners), bool(deterministic))
+    out, _ = _Warp.apply(x, flow, bool(use_mask), bool(align_corners), bool(deterministic), fused_backward)
     return out
 
 
