@@ -90,9 +90,9 @@ int unflow_warp_bwd_det(const float* src, const float* flow, const float* gout, 
  * source gradient as a gather (as unflow_warp_bwd_det: no zero-fill, no float atomics, every element written once) AND the flow gradient,
  * both by the workgroup that owns the tile -- bitwise reproducible, the upstream gradient is read from HBM once.  `table`:
  * unflow_warp_bwd_table_bytes(B, C, H, W) bytes of scratch.  unflow_warp_bwd_fused_supported(): 0 = shape not served (fewer than 8
- * channels or 512 pixels: UNFLOW_EINVAL, use unflow_warp_bwd; the masked image warps have no source gradient), 1 = served, but the launch
- * has fewer than 256 workgroups even with 32-wide tiles (levels 4 / 5 of the 832x256 step: the scatter form with channel groups is
- * faster there), 2 = served and recommended (levels 2 and 3). */
+ * channels or 512 pixels: UNFLOW_EINVAL, use unflow_warp_bwd; the masked image warps have no source gradient), 1 = served, but fewer
+ * than 256 workgroups of full-width tiles (levels 3-5 of the 832x256 step: the scatter form with channel groups measures faster
+ * there), 2 = served and recommended (level 2; 448x1024 levels 2 and 3). */
 int unflow_warp_bwd_fused_supported(int B, int C, int H, int W);
 int unflow_warp_bwd_table_bytes(int B, int C, int H, int W);
 int unflow_warp_bwd_fused(const float* src, const float* flow, const float* gout, float* gsrc, float* gflow, void* table,

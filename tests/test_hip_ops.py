@@ -284,15 +284,17 @@ def test_warp_feature_tiles_vs_oracle(ops, kind, C, h, w):
 
 
 def test_warp_backward_fused_at_the_step_shapes(ops):
-    """The shapes the op picks the one-pass backward for by itself (levels 2 and 3 of the 832x256 step at the step's batch of 16
-    directed pairs): chosen without being asked, equal to the zero-fill + scatter form within the float-atomic noise of the latter,
+    """The shapes the op picks the one-pass backward for by itself (level 2 of the 832x256 step at the step's batch of 16 directed
+    pairs, level 2 of 1024x448 at 8): chosen without being asked, equal to the zero-fill + scatter form within the float-atomic noise of the latter,
     and bit-identical from run to run."""
     lib = __import__('unopticalflow_amd._lib', fromlist=['load']).load()
-    assert lib.unflow_warp_bwd_fused_supported(16, 32, 64, 208) == 2 and lib.unflow_warp_bwd_fused_supported(16, 64, 32, 104) == 2
+    assert lib.unflow_warp_bwd_fused_supported(16, 32, 64, 208) == 2 and lib.unflow_warp_bwd_fused_supported(16, 64, 32, 104) == 1
     assert lib.unflow_warp_bwd_fused_supported(16, 96, 16, 52) == 1 and lib.unflow_warp_bwd_fused_supported(16, 3, 256, 832) == 0
-    for C, h, w in ((32, 64, 208), (64, 32, 104)):
-        x0, g = rnd(500 + C, (16, C, h, w)), rnd(501 + C, (16, C, h, w))
-        f0 = _structured_flow(16, h, w, 'mixed', seed=C)
+    assert lib.unflow_warp_bwd_fused_supported(8, 32, 112, 256) == 2                  # (448x1024, bs 4: level 2)
+    for C, h, w in ((32, 64, 208), (32, 112, 256)):
+        Bq = 16 if h == 64 else 8
+        x0, g = rnd(500 + C, (Bq, C, h, w)), rnd(501 + C, (Bq, C, h, w))
+        f0 = _structured_flow(Bq, h, w, 'mixed', seed=C)
         res = {}
         for fused in (None, False, None):
             x, f = dev(x0).requires_grad_(), dev(f0).requires_grad_()

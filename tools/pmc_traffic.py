@@ -17,8 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import sources_sha16   # noqa: E402
 
-ENTRIES = [('unflow_corr_bwd', 'L2'), ('unflow_corr_fwd', 'L2'), ('unflow_warp_bwd', 'L2'), ('unflow_warp_fwd', 'L2'),
-           ('unflow_corr_bwd', 'L3'), ('unflow_warp_bwd', 'L3')]
+ENTRIES = [('unflow_corr_bwd', 'L2'), ('unflow_corr_fwd', 'L2'), ('unflow_warp_bwd_fused', 'L2'), ('unflow_warp_bwd', 'L2'), ('unflow_warp_fwd', 'L2'),
+           ('unflow_corr_bwd', 'L3'), ('unflow_warp_bwd', 'L3'), ('unflow_ssim_loss_fwd', 'S0'), ('unflow_ssim_loss_bwd', 'S0')]
 REPS = 3
 SKIP = ('randn', 'distribution', 'elementwise', 'fill', 'Fill', 'copy', 'sin', 'cos', 'mul', 'add', 'stack', 'repeat', 'cat', 'arange')
 
@@ -52,7 +52,10 @@ def main():
            'entries': {}}
     entries = [tuple(a.split(':')) for a in sys.argv[1:]] or ENTRIES
     for entry, lvl in entries:
-        C, h, w = LEVELS[lvl]
+        if lvl.startswith('S'):
+            C, h, w = 3, 256 >> int(lvl[1:]), 832 >> int(lvl[1:])
+        else:
+            C, h, w = LEVELS[lvl]
         fetch, write = one_pass(entry, lvl, 'FETCH_SIZE'), one_pass(entry, lvl, 'WRITE_SIZE')
         f_kb = sum(sum(v) for v in fetch.values()) / REPS
         w_kb = sum(sum(v) for v in write.values()) / REPS

@@ -1392,8 +1392,8 @@ extern "C" int unflow_warp_bwd(const float* src, const float* flow, const float*
 // reproducible.  `table` = unflow_warp_bwd_table_bytes() bytes of scratch (the per-tile displacement ranges a pre-pass leaves
 // there).  Shapes this form does not take (masked image warps, < 8 channels, small maps whose tiles would need several channel
 // groups) return UNFLOW_EINVAL from unflow_warp_bwd_fused_supported() == 0: use unflow_warp_bwd.
-// -> 0: the shape is not served; 1: served, but the launch would not fill the chip (fewer than 256 workgroups even with 32-wide
-// tiles: the scatter form with channel groups is the faster one); 2: served and recommended
+// -> 0: the shape is not served; 1: served, but the scatter form with channel groups is the faster one (fewer than 256 workgroups of
+// full-width tiles); 2: served and recommended
 static int warp_fused_plan(int B, int C, int H, int W, TilePlan* out) {
     if (C < 8 || W < 8 || H * W < 512 || B <= 0) return 0;
     TilePlan p;
@@ -1402,7 +1402,10 @@ static int warp_fused_plan(int B, int C, int H, int W, TilePlan* out) {
         if (p.groups != 1 || p.TW > 64) return 0;
         if (p.tiles_x * p.tiles_y * B >= 256) {
             if (out) *out = p;
-            return 2;
+            // measured in the step (profiles/r4_warp_bwd_fused.md): level 2 (512 tiles of 52 x 8, 4 chunks of 8 channels) 50.0 us against
+            // 50.6 for zero-fill + scatter; level 3 (256 tiles of 28 x 8, 8 chunks) 48.6 against 37.6 -- the per-tile set-up and the
+            // exposed latency of a chunk do not amortise on 224-pixel tiles, so only full-width tiles are recommended
+            return maxw == 64 ? 2 : 1;
         }
     }
     if (out) *out = p;
