@@ -96,6 +96,11 @@ int unflow_warp_bwd_det(const float* src, const float* flow, const float* gout, 
 int unflow_warp_bwd_fused_supported(int B, int C, int H, int W);
 int unflow_warp_bwd_table_bytes(int B, int C, int H, int W);
 int unflow_warp_bwd_fused(const float* src, const float* flow, const float* gout, float* gsrc, float* gflow, void* table,
+                          int table_ready, int B, int C, int H, int W, int align_corners, void* stream);
+/* The table is a by-product of the forward's tap set-up: unflow_warp_fwd_table == unflow_warp_fwd(mask = NULL) that also fills `table`
+ * (only where unflow_warp_bwd_fused_supported() == 2), and unflow_warp_bwd_fused(table_ready = 1) for the SAME flow then skips its
+ * pre-pass over the flow; table_ready = 0: the backward computes the table itself. */
+int unflow_warp_fwd_table(const float* src, const float* flow, float* out, void* table,
                           int B, int C, int H, int W, int align_corners, void* stream);
 
 /* ---- fused warp + cost volume: one decoder level of PWC_tf.forward, pwc_tf.py:121-122 (134-135, 146-147, 159-160) ----

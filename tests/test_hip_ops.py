@@ -968,7 +968,7 @@ def test_kernel_exact_timing_slots(ops):
     ops.corr(f1, f2, 4)
     e1.record()
     x = f2.clone().requires_grad_()
-    ops.warp_flow(x, fl).sum().backward()
+    ops.warp_flow(x, fl, fused_backward=False).sum().backward()          # (the two-launch form: zero-fill + scatter kernel)
     torch.cuda.synchronize()
     ops.kernel_timer.disable()
     rows = {r['entry']: r for r in ops.kernel_timer.rows()}

@@ -12,7 +12,7 @@ from microbench import LEVELS, _smooth_flow   # noqa: E402
 entry, lvl = sys.argv[1], sys.argv[2]
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 B = 16
-C, h, w = LEVELS[lvl]
+C, h, w = LEVELS['L2'] if lvl.startswith('S') else LEVELS[lvl]
 lib = _lib.load()
 P = ops._ptr
 f1 = torch.randn(B, C, h, w, device='cuda'); f2 = torch.randn(B, C, h, w, device='cuda')
@@ -48,7 +48,7 @@ for _ in range(reps):
         lib.unflow_warp_bwd_det(P(f1), P(fl), P(f2), None, P(o1), P(gfl), B, C, h, w, 0, ops._stream())
     elif entry == 'unflow_warp_bwd_fused':
         tab = torch.empty(lib.unflow_warp_bwd_table_bytes(B, C, h, w), dtype=torch.uint8, device='cuda')
-        lib.unflow_warp_bwd_fused(P(f1), P(fl), P(f2), P(o1), P(gfl), P(tab), B, C, h, w, 0, ops._stream())
+        lib.unflow_warp_bwd_fused(P(f1), P(fl), P(f2), P(o1), P(gfl), P(tab), 0, B, C, h, w, 0, ops._stream())
     elif entry == 'unflow_warp_corr_fwd':
         lib.unflow_warp_corr_fwd(P(f1), P(f2), P(fl), P(cv), B, C, h, w, 4, 0, ops._stream())
     else:

@@ -65,8 +65,8 @@ def main():
                                'kernels': {k: {'fetch_kb': round(sum(v) / REPS, 1), 'write_kb': round(sum(write.get(k, [0])) / REPS, 1)}
                                            for k, v in fetch.items()}}
         print(key, res['entries'][key]['hbm_bytes_per_launch'], flush=True)
-    os.makedirs(os.path.join(ROOT, 'gpurun_out', 'r4'), exist_ok=True)
-    json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'r4', 'r4_pmc_traffic.json'), 'w'), indent=1)
+        os.makedirs(os.path.join(ROOT, 'gpurun_out', 'r4'), exist_ok=True)       # (after every entry: a late failure keeps what was measured)
+        json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'r4', 'r4_pmc_traffic.json'), 'w'), indent=1)
 
 
 if __name__ == '__main__':

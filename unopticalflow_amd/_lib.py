@@ -29,7 +29,8 @@ SIGNATURES = {
     'unflow_warp_bwd_det': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'unflow_warp_bwd_fused_supported': [_I, _I, _I, _I],
     'unflow_warp_bwd_table_bytes': [_I, _I, _I, _I],
-    'unflow_warp_bwd_fused': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'unflow_warp_bwd_fused': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    'unflow_warp_fwd_table': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'unflow_warp_corr_supported': [_I, _I, _I, _I],
     'unflow_warp_corr_fwd': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'unflow_warp_corr_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -142,6 +142,7 @@ __global__ void warp_bwd_kernel(const float* __restrict__ src, const float* __re
 // atomics for that tile only (noise flows, motion boundaries): always correct, decided per workgroup.
 // ---------------------------------------------------------------------------------------------
 constexpr int kBig = 0x3fffffff;
+struct TileBounds { int dxmin, dxmax, dymin, dymax; };     // range of a tile's tap displacements (nw tap - pixel); empty: dxmin > dxmax
 
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
@@ -318,10 +319,14 @@ __device__ __forceinline__ void tap_offsets(const Window<WIN>& w, const TileCtx<
     }
 }
 
+// `table` (may be NULL): the forward leaves, per tile, the range of its pixels' tap displacements -- what the one-pass backward
+// (warp_bwd_gather_kernel) needs to know before it can gather, and what would otherwise cost it a pre-pass over the flow
+// (warp_tile_bounds_kernel): the taps are computed here anyway.
 template <int PPT, int WIN, int CC>
 __global__ __launch_bounds__(256) void warp_fwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow,
                                                             float* __restrict__ out, int C, int H, int W, int ac,
-                                                            int TW, int TH, int tiles_x, int tiles_y, int cpg, int vec_ok) {
+                                                            int TW, int TH, int tiles_x, int tiles_y, int cpg, int vec_ok,
+                                                            TileBounds* __restrict__ table) {
     __shared__ __attribute__((aligned(16))) float s_src[CC * WIN];
     __shared__ int s_box[16];
     int t = blockIdx.x;
@@ -332,6 +337,32 @@ __global__ __launch_bounds__(256) void warp_fwd_tile_kernel(const float* __restr
     const int plane = H * W;
     TileCtx<PPT> k;
     tile_setup<PPT>(k, flow + (size_t)b * 2 * plane, H, W, ac, bx * TW, by * TH, TW, TH, s_box);
+    if (table != nullptr && blockIdx.y == 0) {              // (workgroup-uniform)
+        int x0 = kBig, x1 = -kBig, y0 = kBig, y1 = -kBig;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const Taps& tp = k.t[q];
+            if (k.live[q] && (tp.v_nw || tp.v_ne || tp.v_sw || tp.v_se)) {
+                const int py = k.pix[q] / W, px = k.pix[q] - py * W;
+                x0 = min(x0, tp.x0 - px); x1 = max(x1, tp.x0 - px);
+                y0 = min(y0, tp.y0 - py); y1 = max(y1, tp.y0 - py);
+            }
+        }
+        x0 = wave_min_i(x0); y0 = wave_min_i(y0); x1 = wave_max_i(x1); y1 = wave_max_i(y1);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        __syncthreads();                                    // (tile_setup's readers of s_box are done)
+        if (lane == 0) { s_box[wave * 4 + 0] = x0; s_box[wave * 4 + 1] = y0; s_box[wave * 4 + 2] = x1; s_box[wave * 4 + 3] = y1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            TileBounds tb;
+            tb.dxmin = min(min(s_box[0], s_box[4]), min(s_box[8], s_box[12]));
+            tb.dymin = min(min(s_box[1], s_box[5]), min(s_box[9], s_box[13]));
+            tb.dxmax = max(max(s_box[2], s_box[6]), max(s_box[10], s_box[14]));
+            tb.dymax = max(max(s_box[3], s_box[7]), max(s_box[11], s_box[15]));
+            table[blockIdx.x] = tb;
+        }
+        __syncthreads();                                    // (s_box is not reused below, but keep the waves together for the staging)
+    }
     const float* sp = src + (size_t)b * C * plane;
     float* op = out + (size_t)b * C * plane;
     Window<WIN> w;
@@ -892,7 +923,6 @@ __global__ __launch_bounds__(256) void warp_bwd_cell_kernel(const float* __restr
 // spread, noise) take a generic per-cell loop over the candidates with global reads: slow, exact, rare.
 // The flow gradient stays with the destination-tile kernel (gsrc == nullptr: no accumulation, no flush).
 // ---------------------------------------------------------------------------------------------
-struct TileBounds { int dxmin, dxmax, dymin, dymax; };     // empty: dxmin > dxmax
 
 template <int PPT>
 __global__ __launch_bounds__(256) void warp_tile_bounds_kernel(const float* __restrict__ flow, TileBounds* __restrict__ table,
@@ -1288,22 +1318,29 @@ static inline int wenv(const char*, int dflt) { return dflt; }
 // Feature maps (no mask, >= 8 channels, >= 512 pixels: pyramid levels 2-4) go through the LDS-tile kernels.
 static bool use_tiles(const uint8_t* mask, int C, int H, int W) { return mask == nullptr && C >= 8 && W >= 8 && H * W >= wenv("UNFLOW_WARP_MINPIX", 512); }
 
-extern "C" int unflow_warp_fwd(const float* src, const float* flow, float* out, uint8_t* mask,
-                               int B, int C, int H, int W, int align_corners, void* stream) {
+static int warp_fused_plan(int B, int C, int H, int W, TilePlan* out);
+
+static int warp_fwd_impl(const float* src, const float* flow, float* out, uint8_t* mask, TileBounds* table,
+                         int B, int C, int H, int W, int align_corners, void* stream) {
     UNFLOW_REQUIRE(src && flow && out && B > 0 && C > 0 && H > 0 && W > 0);
     hipStream_t s = (hipStream_t)stream;
     const int ac = align_corners ? 1 : 0;
     if (use_tiles(mask, C, H, W) && wenv("UNFLOW_WARP_TILES", 1)) {
         const int th = wenv("UNFLOW_WARP_TH", 8);              // measured: 64x8 tiles, ~1024 workgroups (levels 2-4: 17 / 9 / 7.5 us)
         const TilePlan p = plan_tiles(B, C, H, W, th, 8, wenv("UNFLOW_WARP_WGS", 1024));
+        if (table) {                                             // the table is only good for a backward with the very same tiles
+            TilePlan pb;
+            UNFLOW_REQUIRE(warp_fused_plan(B, C, H, W, &pb) == 2 && pb.TW == p.TW && pb.TH == p.TH && pb.tiles_x == p.tiles_x && pb.tiles_y == p.tiles_y);
+        }
         dim3 grid(p.tiles_x * p.tiles_y * B, p.groups);
         const int vec_ok = ((W & 3) == 0 && (((size_t)src) & 15) == 0) ? 1 : 0;
 #define LAUNCH_T(PPT, WIN) UNFLOW_LAUNCH((warp_fwd_tile_kernel<PPT, WIN, 8>), grid, dim3(256), 0, s, src, flow, out, \
-                                              C, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y, p.cpg, vec_ok)
+                                              C, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y, p.cpg, vec_ok, table)
         if (p.TH == 16) LAUNCH_T(4, 1600); else LAUNCH_T(2, 1024);
 #undef LAUNCH_T
         return unflow_launch_status();
     }
+    UNFLOW_REQUIRE(table == nullptr);                            // (only the tile kernels know tiles)
     dim3 grid(ceil_div(W, 64), H, B);
     if (C <= 4) {
         if (mask) UNFLOW_LAUNCH((warp_fwd_kernel<1, true>), grid, dim3(64, 1), 0, s, src, flow, out, mask, C, H, W, ac);
@@ -1316,6 +1353,18 @@ extern "C" int unflow_warp_fwd(const float* src, const float* flow, float* out, 
         else      UNFLOW_LAUNCH((warp_fwd_kernel<4, false>), grid, dim3(64, 4), 0, s, src, flow, out, mask, C, H, W, ac);
     }
     return unflow_launch_status();
+}
+
+extern "C" int unflow_warp_fwd(const float* src, const float* flow, float* out, uint8_t* mask,
+                               int B, int C, int H, int W, int align_corners, void* stream) {
+    return warp_fwd_impl(src, flow, out, mask, nullptr, B, C, H, W, align_corners, stream);
+}
+
+// (ABI 9) the forward of a feature-map warp that also leaves the displacement table unflow_warp_bwd_fused(table_ready = 1) reads
+extern "C" int unflow_warp_fwd_table(const float* src, const float* flow, float* out, void* table,
+                                     int B, int C, int H, int W, int align_corners, void* stream) {
+    UNFLOW_REQUIRE(table);
+    return warp_fwd_impl(src, flow, out, nullptr, (TileBounds*)table, B, C, H, W, align_corners, stream);
 }
 
 static int warp_bwd_impl(const float* src, const float* flow, const float* gout, const uint8_t* mask,
@@ -1414,18 +1463,19 @@ static int warp_fused_plan(int B, int C, int H, int W, TilePlan* out) {
 extern "C" int unflow_warp_bwd_fused_supported(int B, int C, int H, int W) { return warp_fused_plan(B, C, H, W, nullptr); }
 extern "C" int unflow_warp_bwd_table_bytes(int B, int C, int H, int W) {
     TilePlan p;
-    if (!warp_fused_plan(B, C, H, W, &p)) return 0;
+    if (warp_fused_plan(B, C, H, W, &p) == 0) return 0;
     return (int)((size_t)p.tiles_x * p.tiles_y * B * sizeof(TileBounds));
 }
 extern "C" int unflow_warp_bwd_fused(const float* src, const float* flow, const float* gout, float* gsrc, float* gflow, void* table,
-                                     int B, int C, int H, int W, int align_corners, void* stream) {
+                                     int table_ready, int B, int C, int H, int W, int align_corners, void* stream) {
     UNFLOW_REQUIRE(src && flow && gout && gsrc && gflow && table && B > 0 && C > 0 && H > 0 && W > 0);
     TilePlan p;
-    UNFLOW_REQUIRE(warp_fused_plan(B, C, H, W, &p));
+    UNFLOW_REQUIRE(warp_fused_plan(B, C, H, W, &p) > 0);
     hipStream_t s = (hipStream_t)stream;
     const int ac = align_corners ? 1 : 0;
     const int ntiles = p.tiles_x * p.tiles_y * B;
-    UNFLOW_LAUNCH((warp_tile_bounds_kernel<2>), dim3(ntiles), dim3(256), 0, s, flow, (TileBounds*)table, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y);
+    if (!table_ready)                                            // (1: unflow_warp_fwd_table filled it for this very flow)
+        UNFLOW_LAUNCH((warp_tile_bounds_kernel<2>), dim3(ntiles), dim3(256), 0, s, flow, (TileBounds*)table, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y);
     const int vec_g = ((W & 3) == 0 && (((size_t)gout) & 15) == 0) ? 1 : 0;
     UNFLOW_LAUNCH((warp_bwd_gather_kernel<2, 8, true>), dim3(ntiles, 1), dim3(256), 0, s, flow, gout, (const TileBounds*)table, gsrc,
                        C, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y, p.cpg, vec_g, src, gflow);

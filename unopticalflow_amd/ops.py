@@ -280,10 +280,21 @@ class _Warp(torch.autograd.Function):
         B, C, H, W = x.shape
         out = torch.empty_like(x)
         mask = torch.empty((B, 1, H, W), dtype=torch.uint8, device=x.device) if use_mask else None
+        # the one-pass backward needs the per-tile displacement table: the forward's tap set-up leaves it behind for free
+        lib = _lib.load()
+        want = fused if fused is not None else fused_warp_bwd
+        table = None
+        if want and not use_mask and x.requires_grad and torch.is_grad_enabled() and lib.unflow_warp_bwd_fused_supported(B, C, H, W) == 2:
+            table = torch.empty(lib.unflow_warp_bwd_table_bytes(B, C, H, W), dtype=torch.uint8, device=x.device)
         with _on(x.device):
-            _call('unflow_warp_fwd', _ptr(x), _ptr(flow), _ptr(out), _ptr(mask), B, C, H, W,
-                  int(align_corners), _stream(), nbytes=B * H * W * (8 * C + 8 + (1 if use_mask else 0)),
-                  shape=(B, C, H, W))
+            if table is not None:
+                _call('unflow_warp_fwd_table', _ptr(x), _ptr(flow), _ptr(out), _ptr(table), B, C, H, W, int(align_corners), _stream(),
+                      nbytes=B * H * W * (8 * C + 8), shape=(B, C, H, W))
+            else:
+                _call('unflow_warp_fwd', _ptr(x), _ptr(flow), _ptr(out), _ptr(mask), B, C, H, W,
+                      int(align_corners), _stream(), nbytes=B * H * W * (8 * C + 8 + (1 if use_mask else 0)),
+                      shape=(B, C, H, W))
+        ctx.table = table
         ctx.save_for_backward(x, flow, mask)
         ctx.set_materialize_grads(False)             # (no zero-filled "gradient" for the mask: a fill launch per warp otherwise)
         ctx.ac = int(align_corners)
@@ -306,9 +317,11 @@ class _Warp(torch.autograd.Function):
         want = ctx.fused if ctx.fused is not None else fused_warp_bwd
         if want and mask is None and gsrc is not None and _lib.load().unflow_warp_bwd_fused_supported(B, C, H, W) >= (1 if ctx.fused else 2):
             # one pass: source gradient as a gather + flow gradient, no zero-fill, no atomics, bitwise reproducible
-            table = torch.empty(_lib.load().unflow_warp_bwd_table_bytes(B, C, H, W), dtype=torch.uint8, device=x.device)
+            table, ready = ctx.table, 1
+            if table is None:
+                table, ready = torch.empty(_lib.load().unflow_warp_bwd_table_bytes(B, C, H, W), dtype=torch.uint8, device=x.device), 0
             with _on(x.device):
-                _call('unflow_warp_bwd_fused', _ptr(x), _ptr(flow), _ptr(g), _ptr(gsrc), _ptr(gflow), _ptr(table), B, C, H, W, ctx.ac, _stream(),
+                _call('unflow_warp_bwd_fused', _ptr(x), _ptr(flow), _ptr(g), _ptr(gsrc), _ptr(gflow), _ptr(table), ready, B, C, H, W, ctx.ac, _stream(),
                       nbytes=4 * B * H * W * (3 * C + 4), shape=(B, C, H, W))
             return gsrc, (gflow if ctx.needs_input_grad[1] else None), None, None, None, None
         with _on(x.device):
