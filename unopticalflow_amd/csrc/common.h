@@ -31,6 +31,15 @@ UnflowTimingArm& unflow_timing_arm();             // this thread's armed pair (s
 
 __host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Bijective remap of the linear workgroup id so that consecutive work items share an XCD (workgroups are dealt round-robin over
+// the 8 XCDs, each with its own L2): neighbouring tiles then find each other's halo lines in L2 instead of fetching them from
+// HBM once per XCD.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int lin, int total) {
+    const int q = total >> 3, r = total & 7;          // XCD x gets q (+1 if x < r) workgroups
+    const int xcd = lin & 7, k = lin >> 3;
+    return xcd * q + (xcd < r ? xcd : r) + k;
+}
+
 // Zero-fill as a kernel launch (not hipMemsetAsync): every piece of work of an entry point is then an ordinary
 // kernel node when the caller captures the stream into a hipGraph.  n floats, p 4-byte aligned.
 __global__ static void unflow_zero_kernel(float* __restrict__ p, size_t n) {

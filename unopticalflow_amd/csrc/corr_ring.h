@@ -7,14 +7,6 @@
 
 namespace {
 
-// Bijective remap of the linear workgroup id so that consecutive tiles share an XCD (workgroups
-// are dealt round-robin over the 8 XCDs): speed only, never correctness.
-__device__ __forceinline__ int xcd_remap(int lin, int total) {
-    const int q = total >> 3, r = total & 7;          // XCD x gets q (+1 if x < r) workgroups
-    const int xcd = lin & 7, k = lin >> 3;
-    return xcd * q + (xcd < r ? xcd : r) + k;
-}
-
 typedef __attribute__((address_space(3))) const float lds_cfloat;
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const v2f lds_cfloat2;

@@ -446,9 +446,13 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_FWD_W
     __shared__ float red[6];
     const int lane = threadIdx.x & 63;
     const int ch = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform: the plane addresses stay scalar
-    const int grp = blockIdx.y;
-    const int nsx = strips2(W);
-    const int sx = blockIdx.x % nsx, cy = blockIdx.x / nsx;
+    // work item = (sample, strip, row chunk), the chunks of a strip consecutive and consecutive items on one XCD: a chunk's four
+    // halo rows are its vertical neighbours' rows, and only an L2 that both use keeps them from being fetched from HBM twice
+    const int nsx = strips2(W), per = (int)gridDim.x;           // per sample: nsx * chunks
+    const int item = xcd_remap((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
+    const int grp = item / per, tile = item - grp * per;
+    const int nch = per / nsx;
+    const int sx = tile / nch, cy = tile - sx * nch;
     const int x0 = sx * S2_COLS - 2 + 2 * lane;
     const int ys = cy * RS, ye = min(ys + RS, H);
     const bool pin = (x0 >= 0 && x0 < W);                       // (W even: the pair is inside or outside as a whole)
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_FWD_W
     if (lane == 0) { red[ch * 2] = s0; red[ch * 2 + 1] = s1; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float* p = partials + ((size_t)grp * gridDim.x + blockIdx.x) * 2;
+        float* p = partials + ((size_t)grp * per + tile) * 2;
         p[0] = (red[0] + red[2]) + red[4];
         p[1] = red[1];
     }
@@ -520,9 +524,11 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_BWD_W
                                                         int H, int W, int img_b) {
     const int lane = threadIdx.x & 63;
     const int ch = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int bidx = blockIdx.y;
-    const int nsx = strips2(W);
-    const int sx = blockIdx.x % nsx, cy = blockIdx.x / nsx;
+    const int nsx = strips2(W), per = (int)gridDim.x;           // (work-item order: see the forward kernel)
+    const int item = xcd_remap((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
+    const int bidx = item / per, tile = item - bidx * per;
+    const int nch = per / nsx;
+    const int sx = tile / nch, cy = tile - sx * nch;
     const int x0 = sx * S2_COLS - 2 + 2 * lane;
     const int ys = cy * RS, ye = min(ys + RS, H);
     const bool pin = (x0 >= 0 && x0 < W);

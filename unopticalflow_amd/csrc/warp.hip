@@ -1013,7 +1013,8 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
     __shared__ __attribute__((aligned(16))) float s_g[CC * REGION];      // tap records first (6 x REGION words), then gout chunks
     __shared__ int s_red[16];
     static_assert(CC >= 6, "the tap records alias the gout staging area");
-    int t = blockIdx.x;
+    // (XCD-local tile order when the launch is one-dimensional: neighbouring tiles share halo lines of gout, flow and src)
+    int t = gridDim.y == 1 ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const int bx = t % tiles_x; t /= tiles_x;
     const int by = t % tiles_y;
     const int b = t / tiles_y;
