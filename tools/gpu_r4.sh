@@ -12,6 +12,7 @@
 #   capi       build tools/capi_bench and run it under rocprofv3 --kernel-trace --stats (Python-free cost-volume capture)
 #   profile    rocprofv3 kernel trace of bench.py reduced to the timed steps (+ MFMA counters): fp32
 #   traffic    tools/pmc_traffic.py (HBM bytes per launch, separate --pmc passes)
+#   configs    bf16 / 1024x448 bs 4 / one-rank RCCL / eager bench lines
 #   rerank     bench A/B of find-db variants in which the runner-up solver is ranked first where it is within 3 / 10 / 30 us (tools/miopen_rerank.py)
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/r4
@@ -94,6 +95,12 @@ PY
     for lib in unopticalflow_amd/libunflow_hip_tuning_*.so; do
       echo "== $lib"; UNFLOW_LIB_PATH=$GRAFT_REPO_ROOT/$lib timeout 200 python3 tools/probes/loss_kernel_times.py 2>&1 | grep -E "ssim" | tee $out/ssim_$(basename $lib .so).txt
     done ;;
+  configs)  # the other BASELINE configurations on one GPU: bf16 conv stacks, 1024x448 bs 4, the one-rank RCCL path (all replayed)
+    python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --precision bf16 > $out/bench_precisionbf16.json 2> $out/configs.err
+    python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --hw 448 1024 --batch 4 > $out/bench_hw4481024batch4.json 2>> $out/configs.err
+    python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-ddp > $out/bench_forceddp.json 2>> $out/configs.err
+    python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --graph 0 > $out/bench_n1_graph0.json 2>> $out/configs.err
+    line $out/bench_precisionbf16.json $out/bench_hw4481024batch4.json $out/bench_forceddp.json $out/bench_n1_graph0.json ;;
   rerank)   # MIOpen picks re-ranked: the runner-up solver first wherever it is within X us of the split-K asm kernel (fwd / bwd-data)
     python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing > $out/rerank_base.json 2> $out/rerank.err
     for x in 3 10 30; do
