@@ -4,7 +4,7 @@ The reference takes its GPU list on ONE command (``python train.py --gpu 0,1,2,3
 single-process DataParallel).  Here the data-parallel job is one process per GPU over RCCL; ``spawn_ranks`` is what lets
 ``python bench.py --gpus N`` and ``python -m unopticalflow_amd.train --gpu 0,..,N-1 --multi_gpu`` keep that one-command form
 without ``torch.distributed.run`` in front: the parent starts N FRESH children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
-their environment), relays rank 0's stdout as its own and returns the worst exit code.
+their environment), relays rank 0's stdout as its own and returns the exit code of the rank that failed first (0: all succeeded).
 
 The parent never touches the GPU: this module imports nothing but the standard library, and a caller must invoke it
 before it initialises HIP (a process that has initialised the GPU must not exec or fork workers that use it).
