@@ -1074,20 +1074,36 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
         }
     }
     const float* sp = WITH_FLOW ? src + (size_t)b * C * plane : nullptr;
-    auto flow_grad = [&](int c0, int nc) {                  // channels [c0, c0 + nc) of this workgroup's pixels
+    // `g_lds`: the chunk's staged upstream gradients (channel stride `g_cs` floats) when this thread's own pixels lie inside the
+    // staged region (`own_idx`), else NULL: read them from global memory.  All tap loads of a pixel's chunk go out before the first
+    // is used (the offsets are clamped, always valid: no exec-masked loads; validity is applied to the values).
+    int own_idx[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) own_idx[q] = 0;
+    auto flow_grad = [&](int c0, int nc, const float* g_lds, int g_cs) {      // channels [c0, c0 + nc) of this workgroup's pixels
         if (!WITH_FLOW) return;
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             if (!live[q]) continue;
             const int pix = cy[q] * W + cx[q];
-#pragma unroll 4
-            for (int c = 0; c < nc; ++c) {
-                const float* p = sp + (size_t)(c0 + c) * plane;
-                const float gv = gp[(size_t)(c0 + c) * plane + pix];
-                const float a = t_v[q][0] ? p[t_o[q][0]] : 0.f, bq = t_v[q][1] ? p[t_o[q][1]] : 0.f;
-                const float cq = t_v[q][2] ? p[t_o[q][2]] : 0.f, dq = t_v[q][3] ? p[t_o[q][3]] : 0.f;
-                gix[q] += gv * ((bq - a) * t_s[q] + (dq - cq) * t_n[q]);
-                giy[q] += gv * ((cq - a) * t_e[q] + (dq - bq) * t_w[q]);
+            float gv[CC], tv[CC][4];
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                if (c < nc) {
+                    const float* p = sp + (size_t)(c0 + c) * plane;
+                    gv[c] = g_lds ? g_lds[c * g_cs + own_idx[q]] : gp[(size_t)(c0 + c) * plane + pix];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) tv[c][k] = p[t_o[q][k]];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                if (c < nc) {
+                    const float a = t_v[q][0] ? tv[c][0] : 0.f, bq = t_v[q][1] ? tv[c][1] : 0.f;
+                    const float cq = t_v[q][2] ? tv[c][2] : 0.f, dq = t_v[q][3] ? tv[c][3] : 0.f;
+                    gix[q] += gv[c] * ((bq - a) * t_s[q] + (dq - cq) * t_n[q]);
+                    giy[q] += gv[c] * ((cq - a) * t_e[q] + (dq - bq) * t_w[q]);
+                }
             }
         }
     };
@@ -1110,7 +1126,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
         for (int q = 0; q < PPT; ++q)
             if (live[q])
                 for (int c = c_begin; c < c_end; ++c) dp[(size_t)c * plane + cy[q] * W + cx[q]] = 0.f;
-        flow_grad(c_begin, c_end - c_begin);
+        for (int c0 = c_begin; c0 < c_end; c0 += CC) flow_grad(c0, min(CC, c_end - c0), nullptr, 0);
         flow_grad_store();
         return;
     }
@@ -1131,7 +1147,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
                 for (int c = 0; c < CC; ++c)
                     if (c < nc) dp[(size_t)(c0 + c) * plane + cy[q] * W + cx[q]] = acc[c];
             }
-            flow_grad(c0, nc);
+            flow_grad(c0, nc, nullptr, 0);
         }
         flow_grad_store();
         return;
@@ -1141,6 +1157,45 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
     const int ox = sx0 + kx0, oy = sy0 + ky0;
     const int oxa = vec_ok ? (ox & ~3) : ox;                // staged rows start 16-byte aligned
     const int DW = (sx1 - sx0 + 1) + kw - 1 + (ox - oxa), DH = (sy1 - sy0 + 1) + kh - 1;      // <= 78, <= DHMAX
+    // staging: thread t moves the 16-byte piece (region row t / (DWP/4), column t % (DWP/4)) of EVERY channel of a chunk --
+    // one constant division per tile, no per-slot index arithmetic
+    const int s_ry = (int)threadIdx.x / (DWP / 4), s_r4 = (int)threadIdx.x - s_ry * (DWP / 4);
+    int s_goff = kNone;
+    {
+        const int px = oxa + s_r4 * 4, py = oy + s_ry;
+        if (s_ry < DH && s_r4 * 4 < DW && py >= 0 && py < H && px >= 0 && px < W) s_goff = py * W + px;      // (vec: all or nothing)
+    }
+    const int s_loff = s_ry * DWP + s_r4 * 4;
+    static_assert(DHMAX * (DWP / 4) <= 512, "one or two staging pieces per thread and channel");
+    // (rows beyond 256 / (DWP/4) = 12: a second piece per thread)
+    const int s_ry2 = s_ry + 256 / (DWP / 4);
+    int s_goff2 = kNone;
+    {
+        const int t2 = (int)threadIdx.x + 256;
+        const int ry2 = t2 / (DWP / 4), r42 = t2 - ry2 * (DWP / 4);
+        const int px = oxa + r42 * 4, py = oy + ry2;
+        if (ry2 < DH && r42 * 4 < DW && py >= 0 && py < H && px >= 0 && px < W) s_goff2 = py * W + px;
+    }
+    const int s_loff2 = ((int)threadIdx.x + 256) / (DWP / 4) * DWP + (((int)threadIdx.x + 256) % (DWP / 4)) * 4;
+    (void)s_ry2;
+    // software pipeline over the channel chunks: the NEXT chunk's pieces are requested into registers before the current
+    // chunk's gather and written to LDS after it (one HBM round trip per chunk would otherwise sit on the critical path of a
+    // workgroup that has only one or two neighbours on its CU)
+    float4 vpre[CC];
+    auto fetch = [&](int c0n) {
+        const int ncn = min(CC, c_end - c0n);
+        const float* gn = gp + (size_t)c0n * plane;
+#pragma unroll
+        for (int c = 0; c < CC; ++c)
+            vpre[c] = (s_goff != kNone && c < ncn) ? *reinterpret_cast<const float4*>(gn + (size_t)c * plane + s_goff) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    if (vec_ok) fetch(c_begin);                              // (the first chunk's pieces fly under the record / list phases below)
+    // this thread's own pixels inside the staged region? (workgroup-uniform: the candidate window then contains displacement 0)
+    const bool own_in = WITH_FLOW && kx0 <= 0 && kx0 + kw > 0 && ky0 <= 0 && ky0 + kh > 0;
+    if (own_in) {
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) own_idx[q] = live[q] ? (cy[q] - oy) * DWP + (cx[q] - oxa) : 0;
+    }
     // tap records of D's pixels: ints x0, y0 and the four weights, region-indexed [y][x] with row stride DWP
     int* r_x0 = reinterpret_cast<int*>(s_g);
     int* r_y0 = r_x0 + REGION;
@@ -1194,40 +1249,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
     __syncthreads();                                        // (also: everyone is done with the records)
     nmax = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
     for (int i = threadIdx.x; i < CC * REGION; i += 256) s_g[i] = 0.f;        // (entries outside the image are never staged)
-    // staging: thread t moves the 16-byte piece (region row t / (DWP/4), column t % (DWP/4)) of EVERY channel of a chunk --
-    // one constant division per tile, no per-slot index arithmetic
-    const int s_ry = (int)threadIdx.x / (DWP / 4), s_r4 = (int)threadIdx.x - s_ry * (DWP / 4);
-    int s_goff = kNone;
-    {
-        const int px = oxa + s_r4 * 4, py = oy + s_ry;
-        if (s_ry < DH && s_r4 * 4 < DW && py >= 0 && py < H && px >= 0 && px < W) s_goff = py * W + px;      // (vec: all or nothing)
-    }
-    const int s_loff = s_ry * DWP + s_r4 * 4;
-    static_assert(DHMAX * (DWP / 4) <= 512, "one or two staging pieces per thread and channel");
-    // (rows beyond 256 / (DWP/4) = 12: a second piece per thread)
-    const int s_ry2 = s_ry + 256 / (DWP / 4);
-    int s_goff2 = kNone;
-    {
-        const int t2 = (int)threadIdx.x + 256;
-        const int ry2 = t2 / (DWP / 4), r42 = t2 - ry2 * (DWP / 4);
-        const int px = oxa + r42 * 4, py = oy + ry2;
-        if (ry2 < DH && r42 * 4 < DW && py >= 0 && py < H && px >= 0 && px < W) s_goff2 = py * W + px;
-    }
-    const int s_loff2 = ((int)threadIdx.x + 256) / (DWP / 4) * DWP + (((int)threadIdx.x + 256) % (DWP / 4)) * 4;
-    (void)s_ry2;
     __syncthreads();
-    // software pipeline over the channel chunks: the NEXT chunk's pieces are requested into registers before the current
-    // chunk's gather and written to LDS after it (one HBM round trip per chunk would otherwise sit on the critical path of a
-    // workgroup that has only one or two neighbours on its CU)
-    float4 vpre[CC];
-    auto fetch = [&](int c0n) {
-        const int ncn = min(CC, c_end - c0n);
-        const float* gn = gp + (size_t)c0n * plane;
-#pragma unroll
-        for (int c = 0; c < CC; ++c)
-            vpre[c] = (s_goff != kNone && c < ncn) ? *reinterpret_cast<const float4*>(gn + (size_t)c * plane + s_goff) : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    if (vec_ok) fetch(c_begin);
 #pragma unroll 1
     for (int c0 = c_begin; c0 < c_end; c0 += CC) {
         const int nc = min(CC, c_end - c0);
@@ -1278,7 +1300,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
                     if (c < nc) dp[(size_t)(c0 + c) * plane + cy[q] * W + cx[q]] = acc[c];
             }
         }
-        flow_grad(c0, nc);
+        flow_grad(c0, nc, own_in ? s_g : nullptr, REGION);
         __syncthreads();
     }
     flow_grad_store();
