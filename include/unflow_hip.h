@@ -297,12 +297,12 @@ int unflow_bias_grad_finalize_batch(const void* const* partials, void* const* gb
  *   chunk_map  DEVICE int pairs [nchunks][2] = (tensor, chunk of that tensor)
  *   grads      HOST array [ntensors] of the gradients' device addresses (they change with every eager backward pass; passed to the
  *              kernel by value); NULL: that tensor is skipped and its counter does not advance
- *   steps      DEVICE float [ntensors]: the step counters (all equal when every tensor has a gradient), advanced by the kernel
- *   counter    DEVICE unsigned, zero before the first call; the kernel leaves it zero */
+ *   steps      DEVICE float [ntensors]: the step counters (all equal when every tensor has a gradient), advanced by a one-block
+ *              launch behind the update */
 typedef struct { float* p; float* m; float* v; long long numel; } unflow_adam_slot;
 int unflow_adam_chunk(void);
 int unflow_adam_multi(const unflow_adam_slot* slots, const int* chunk_map, int nchunks, const void* const* grads, int ntensors,
-                      float* steps, unsigned* counter, float lr, float beta1, float beta2, float eps, void* stream);
+                      float* steps, float lr, float beta1, float beta2, float eps, void* stream);
 
 /* ---- loss bookkeeping (ABI 8).  Model_flow.forward sums every per-sample loss over the scales (`loss = 0; loss += term(scale)`,
  * model_flow_paper.py:92-99,140-148,171-177,183-195) and adds the two directions (:226-233); train.py:147-150 weights the four batch

@@ -64,7 +64,7 @@ SIGNATURES = {
     'unflow_flow_head_bwd_bf16': [_P, _P, _P, _P, _I, _I, _P],
     'unflow_bias_grad_finalize_batch': [_P, _P, _P, _P, _P, _I, _P],
     'unflow_adam_chunk': [],
-    'unflow_adam_multi': [_P, _P, _I, _P, _I, _P, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P],
+    'unflow_adam_multi': [_P, _P, _I, _P, _I, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P],
     'unflow_loss_combine_fwd': [_P, _I, _I, _P, _P],
     'unflow_loss_combine_bwd': [_P, _I, _P, _P],
     'unflow_weighted_mean_sum_fwd': [_P, _P, _I, _I, _P, _P],

@@ -5,8 +5,8 @@
 // 5.1 M parameters, less than one per CU, 137 us for 144 MB (profiles/r3_aten_sources_fp32.txt).  Here a block owns a chunk of
 // 4,096 elements of one tensor (16-byte accesses: four streams in, three out), ~1,300 blocks; the gradients' addresses travel as
 // kernel arguments (they change with every eager backward pass), parameter / moment addresses and the chunk map sit in a device
-// table written once.  The step counters live on the device (hipGraph replay): every block reads step[0], the last block to finish
-// writes step + 1 to every tensor's counter.
+// table written once.  The step counters live on the device (hipGraph replay): every block reads step[0]; a one-block launch behind the
+// update writes step + 1 to every tensor's counter.
 #include "common.h"
 
 namespace {
@@ -17,8 +17,8 @@ constexpr int ADAM_CHUNK = 4096;
 struct AdamGrads { const float* g[ADAM_MAX_TENSORS]; };
 
 __global__ __launch_bounds__(256) void adam_multi_kernel(const unflow_adam_slot* __restrict__ slots, const int* __restrict__ chunk_map,
-                                                         AdamGrads grads, float* __restrict__ steps, unsigned* __restrict__ counter,
-                                                         int ntensors, float lr, float beta1, float beta2, float eps) {
+                                                         AdamGrads grads, const float* __restrict__ steps,
+                                                         float lr, float beta1, float beta2, float eps) {
     const int t = chunk_map[2 * blockIdx.x], ck = chunk_map[2 * blockIdx.x + 1];
     const float step = steps[0] + 1.0f;
     const float bc1 = 1.0f - powf(beta1, step);
@@ -53,16 +53,16 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const unflow_adam_slot*
             for (long long i = threadIdx.x; i < n; i += 256) upd(p[i], g[i], m[i], v[i]);
         }
     }
-    // the last block to get here advances the counters (every block has read steps[0] by then)
-    __shared__ bool last;
-    __threadfence();
-    if (threadIdx.x == 0) last = (atomicAdd(counter, 1u) == gridDim.x - 1);
+}
+
+// steps[i] <- steps[0] + 1 for every tensor that had a gradient: its own one-block launch BEHIND the update (a "last block to finish
+// advances the counters" inside the update kernel needs a device-scope fence per block, and on this chip that fence writes the XCD's
+// dirty L2 lines back -- the 61 MB the kernel has just written: measured 253 us for the update instead of ~40)
+__global__ __launch_bounds__(128) void adam_advance_kernel(AdamGrads grads, float* __restrict__ steps, int ntensors) {
+    const float step = steps[0] + 1.0f;
     __syncthreads();
-    if (last) {
-        for (int i = threadIdx.x; i < ntensors; i += 256)
-            if (grads.g[i] != nullptr) steps[i] = step;
-        if (threadIdx.x == 0) *counter = 0u;
-    }
+    for (int i = threadIdx.x; i < ntensors; i += 128)
+        if (grads.g[i] != nullptr) steps[i] = step;
 }
 
 }  // namespace
@@ -70,11 +70,12 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const unflow_adam_slot*
 extern "C" int unflow_adam_chunk(void) { return ADAM_CHUNK; }
 
 extern "C" int unflow_adam_multi(const unflow_adam_slot* slots, const int* chunk_map, int nchunks, const void* const* grads, int ntensors,
-                                 float* steps, unsigned* counter, float lr, float beta1, float beta2, float eps, void* stream) {
-    UNFLOW_REQUIRE(slots && chunk_map && grads && steps && counter && nchunks > 0 && ntensors > 0 && ntensors <= ADAM_MAX_TENSORS);
+                                 float* steps, float lr, float beta1, float beta2, float eps, void* stream) {
+    UNFLOW_REQUIRE(slots && chunk_map && grads && steps && nchunks > 0 && ntensors > 0 && ntensors <= ADAM_MAX_TENSORS);
     AdamGrads a;
     for (int i = 0; i < ADAM_MAX_TENSORS; ++i) a.g[i] = i < ntensors ? (const float*)grads[i] : nullptr;
-    UNFLOW_LAUNCH(adam_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, slots, chunk_map, a, steps, counter, ntensors,
+    UNFLOW_LAUNCH(adam_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, slots, chunk_map, a, (const float*)steps,
                   lr, beta1, beta2, eps);
+    UNFLOW_LAUNCH(adam_advance_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, a, steps, ntensors);
     return unflow_launch_status();
 }

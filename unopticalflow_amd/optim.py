@@ -40,7 +40,6 @@ class FlowAdam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, capturable=True)
         self._tables = None                # (device slots, device chunk map, nchunks, key) of the current state tensors
         self._steps = None                 # one float per parameter; state[p]['step'] are its 0-dim views
-        self._counter = None
         self.native_steps = 0              # steps taken by the HIP kernel (tests / diagnostics)
 
     # ---- state
@@ -51,7 +50,6 @@ class FlowAdam(torch.optim.Adam):
         dev = params[0].device
         if self._steps is None or self._steps.numel() != len(params) or self._steps.device != dev:
             self._steps = torch.zeros(len(params), dtype=torch.float32, device=dev)
-            self._counter = torch.zeros(1, dtype=torch.int32, device=dev)
         for i, p in enumerate(params):
             st = self.state[p]
             if len(st) == 0:
@@ -119,7 +117,7 @@ class FlowAdam(torch.optim.Adam):
         lib = _lib.load()
         with torch.cuda.device(params[0].device):
             rc = lib.unflow_adam_multi(ctypes.c_void_p(slots.data_ptr()), ctypes.c_void_p(cmap.data_ptr()), nchunks, grads, len(params),
-                                       ctypes.c_void_p(self._steps.data_ptr()), ctypes.c_void_p(self._counter.data_ptr()),
+                                       ctypes.c_void_p(self._steps.data_ptr()),
                                        ctypes.c_float(g['lr']), ctypes.c_float(g['betas'][0]), ctypes.c_float(g['betas'][1]),
                                        ctypes.c_float(g['eps']), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(rc, 'unflow_adam_multi')
