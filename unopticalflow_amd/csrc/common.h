@@ -60,6 +60,29 @@ static inline void unflow_zero_async(float* p, size_t n, hipStream_t s) {
     UNFLOW_LAUNCH(unflow_zero_kernel, dim3(blocks), dim3(256), 0, s, p, n);
 }
 
+// Two buffers in ONE launch (the warp backward's scatter form zeroes gsrc and, with channel groups, gflow: a launch less).
+__global__ static void unflow_zero2_kernel(float* __restrict__ p, size_t n, float* __restrict__ q, size_t m) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (((((size_t)p) | ((size_t)q)) & 15) == 0) {
+        float4* p4 = reinterpret_cast<float4*>(p);
+        float4* q4 = reinterpret_cast<float4*>(q);
+        const size_t n4 = n >> 2, m4 = m >> 2;
+        for (size_t k = i; k < n4; k += stride) p4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (size_t k = i; k < m4; k += stride) q4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (size_t k = (n4 << 2) + i; k < n; k += stride) p[k] = 0.f;
+        for (size_t k = (m4 << 2) + i; k < m; k += stride) q[k] = 0.f;
+    } else {
+        for (size_t k = i; k < n; k += stride) p[k] = 0.f;
+        for (size_t k = i; k < m; k += stride) q[k] = 0.f;
+    }
+}
+static inline void unflow_zero2_async(float* p, size_t n, float* q, size_t m, hipStream_t s) {
+    const size_t want = ((n > m ? n : m) / 4 + 255) / 256;
+    const int blocks = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+    UNFLOW_LAUNCH(unflow_zero2_kernel, dim3(blocks), dim3(256), 0, s, p, n, q, m);
+}
+
 // 64-lane butterfly sum (DPP/ds_swizzle shuffles, no LDS).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -1414,13 +1414,15 @@ static int warp_bwd_impl(const float* src, const float* flow, const float* gout,
                            C, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y, p.cpg, vec_g, (const float*)nullptr, (float*)nullptr);
         gsrc = nullptr;                                                  // the kernels below only owe the flow gradient
     }
-    if (gsrc) unflow_zero_async(gsrc, (size_t)B * C * H * W, s);
     if (tiles) {
         const int th = 8;                                       // 64x8 tiles, 2 px per lane: 152 VGPRs, 3 workgroups per CU
         const TilePlan p = plan_tiles(B, C, H, W, th, 4, wenv("UNFLOW_WARP_WGS", 512));   // level 2: 512 tiles, all channels in one workgroup
         dim3 tgrid(p.tiles_x * p.tiles_y * B, p.groups);
         const int vec_ok = ((W & 3) == 0 && (((size_t)src) & 15) == 0) ? 1 : 0;
-        if (p.groups > 1) unflow_zero_async(gflow, (size_t)B * 2 * H * W, s);     // channel groups add their partials
+        // the scatter targets are zeroed by ONE launch: gsrc, and gflow when channel groups add their partials to it
+        if (gsrc && p.groups > 1) unflow_zero2_async(gsrc, (size_t)B * C * H * W, gflow, (size_t)B * 2 * H * W, s);
+        else if (gsrc) unflow_zero_async(gsrc, (size_t)B * C * H * W, s);
+        else if (p.groups > 1) unflow_zero_async(gflow, (size_t)B * 2 * H * W, s);
 #define LAUNCH_T(KERNEL, PPT, WIN, SPLIT) UNFLOW_LAUNCH((KERNEL<PPT, WIN, 4, SPLIT>), tgrid, dim3(256), 0, s, src, flow, \
                                                      gout, gsrc, gflow, C, H, W, ac, p.TW, p.TH, p.tiles_x, p.tiles_y, p.cpg, vec_ok, wenv("UNFLOW_WARP_DEBUG", 0))
 #define LAUNCH_S(KERNEL, PPT, WIN) do { if (p.groups > 1) LAUNCH_T(KERNEL, PPT, WIN, true); else LAUNCH_T(KERNEL, PPT, WIN, false); } while (0)
@@ -1434,6 +1436,7 @@ static int warp_bwd_impl(const float* src, const float* flow, const float* gout,
 #undef LAUNCH_T
         return unflow_launch_status();
     }
+    if (gsrc) unflow_zero_async(gsrc, (size_t)B * C * H * W, s);
     dim3 grid(ceil_div(W, 64), H, B);
 #define LAUNCH(NY, M, G) UNFLOW_LAUNCH((warp_bwd_kernel<NY, M, G>), grid, dim3(64, NY), 0, s, src, flow, gout, mask, gsrc, gflow, C, H, W, ac)
     // few pixels, many channels (pyramid levels 4-6): 16 channel phases per workgroup instead of 4 -- the launch
