@@ -53,3 +53,36 @@ def test_bench_parent_does_not_import_torch_before_launching():
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py')).read()
     assert src.index('self_launch_if_needed()\n\nimport torch') > 0
     assert src.index('def self_launch_if_needed') < src.index('\nimport torch')
+
+
+def test_train_cli_starts_one_rank_per_listed_gpu(tmp_path, monkeypatch):
+    """`python -m unopticalflow_amd.train --gpu 0,1,2 --multi_gpu` with no launcher in front (the reference's command form,
+    train.py:198-214): the parent hands its own command line to spawn_ranks with one rank per listed GPU and exits with its code --
+    before it creates directories, touches a GPU or reads a dataset; behind a launcher nothing is started again."""
+    import pytest
+    from unopticalflow_amd import launch, train as train_cli
+    cfg = tmp_path / 'k.yaml'
+    cfg.write_text("dataset: 'kitti_depth'\nimg_hw: [64, 128]\nnum_scales: 3\nnum_iterations: 4\n")
+    seen = {}
+
+    def fake_spawn(cmd, world):
+        seen['cmd'], seen['world'] = cmd, world
+        return 7
+    monkeypatch.setattr(launch, 'spawn_ranks', fake_spawn)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        monkeypatch.delenv(k, raising=False)
+    argv = ['-c', str(cfg), '--gpu', '0,1,2', '--multi_gpu', '--synthetic', '--model_dir', str(tmp_path / 'm')]
+    with pytest.raises(SystemExit) as e:
+        train_cli.main(argv)
+    assert e.value.code == 7 and seen['world'] == 3
+    assert seen['cmd'][1:3] == ['-m', 'unopticalflow_amd.train'] and seen['cmd'][3:] == argv
+    assert not (tmp_path / 'm').exists()
+    # the reference's own consistency check between --gpu and --multi_gpu (train.py:208-210) still comes first
+    with pytest.raises(ValueError):
+        train_cli.main(['-c', str(cfg), '--gpu', '0,1', '--synthetic'])
+    # behind a launcher (RANK / WORLD_SIZE set) the world size must match the list: no second launch, a clear error otherwise
+    monkeypatch.setenv('RANK', '0'); monkeypatch.setenv('WORLD_SIZE', '2'); monkeypatch.setenv('LOCAL_RANK', '0')
+    seen.clear()
+    with pytest.raises(ValueError, match='launcher started 2'):
+        train_cli.main(argv)
+    assert not seen
