@@ -329,7 +329,11 @@ __global__ __launch_bounds__(256) void warp_fwd_tile_kernel(const float* __restr
                                                             TileBounds* __restrict__ table) {
     __shared__ __attribute__((aligned(16))) float s_src[CC * WIN];
     __shared__ int s_box[16];
-    int t = blockIdx.x;
+    // XCD-local tile order (workgroups are dealt round-robin over the XCDs in x-major order: with grid.y channel groups the
+    // linear id is x + gridDim.x * y, and a tile's groups land on the same XCD when gridDim.x is a multiple of 8 -- 512 at level 2):
+    // vertically / horizontally adjacent tiles share window rows, which then come from ONE L2
+    const int tile_id = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    int t = tile_id;
     const int bx = t % tiles_x; t /= tiles_x;
     const int by = t % tiles_y;
     const int b = t / tiles_y;
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(256) void warp_fwd_tile_kernel(const float* __restr
             tb.dymin = min(min(s_box[1], s_box[5]), min(s_box[9], s_box[13]));
             tb.dxmax = max(max(s_box[2], s_box[6]), max(s_box[10], s_box[14]));
             tb.dymax = max(max(s_box[3], s_box[7]), max(s_box[11], s_box[15]));
-            table[blockIdx.x] = tb;
+            table[tile_id] = tb;
         }
         __syncthreads();                                    // (s_box is not reused below, but keep the waves together for the staging)
     }
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(const float* __restr
     __shared__ __attribute__((aligned(16))) float s_src[CC * WINP];
     __shared__ __attribute__((aligned(16))) float s_acc[CC * WINP];
     __shared__ int s_box[16];
-    int t = blockIdx.x;
+    int t = xcd_remap((int)blockIdx.x, (int)gridDim.x);          // (XCD-local tile order, as the forward)
     const int bx = t % tiles_x; t /= tiles_x;
     const int by = t % tiles_y;
     const int b = t / tiles_y;
