@@ -284,7 +284,13 @@ __global__ __launch_bounds__(256) void smooth2_fwd_tile_kernel(const float* __re
                                                                float* __restrict__ partials, int H, int W, int img_b) {
     __shared__ SmoothStage t;
     __shared__ float red[8];
-    const int b = blockIdx.z, x0 = blockIdx.x * SM_TW, y0 = blockIdx.y * SM_TH;
+    // XCD-local tile order: the staged region is 68 x 12 positions for 64 x 8 pixels -- the ring is the neighbours' pixels, and only a
+    // shared L2 keeps it from being fetched from HBM once per tile
+    const int tiles = (int)(gridDim.x * gridDim.y);
+    int wi = xcd_remap((int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)), tiles * (int)gridDim.z);
+    const int b = wi / tiles; wi -= b * tiles;
+    const int tyi = wi / (int)gridDim.x, txi = wi - tyi * (int)gridDim.x;
+    const int x0 = txi * SM_TW, y0 = tyi * SM_TH;
     const int HW = H * W;
     smooth_stage(t, flow + (size_t)b * 2 * HW, img + (size_t)(b % img_b) * 3 * HW, HW, H, W, x0, y0);
     __syncthreads();
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(256) void smooth2_fwd_tile_kernel(const float* __re
     }
     block_sum_256<2>(acc, red);
     if (threadIdx.x == 0) {
-        float* o = partials + ((size_t)b * gridDim.x * gridDim.y + (size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+        float* o = partials + ((size_t)b * tiles + (size_t)tyi * gridDim.x + txi) * 2;
         o[0] = acc[0]; o[1] = acc[1];
     }
 }
@@ -321,7 +327,11 @@ __global__ __launch_bounds__(256) void smooth2_bwd_stage_kernel(const float* __r
     constexpr int NX = SM_TH * (SM_TW + 2), NY = (SM_TH + 2) * SM_TW;
     __shared__ SmoothStage t;
     __shared__ float2 s_x[NX], s_y[NY];
-    const int b = blockIdx.z, x0 = blockIdx.x * SM_TW, y0 = blockIdx.y * SM_TH;
+    const int tiles = (int)(gridDim.x * gridDim.y);             // (XCD-local tile order, as the forward)
+    int wi = xcd_remap((int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)), tiles * (int)gridDim.z);
+    const int b = wi / tiles; wi -= b * tiles;
+    const int tyi = wi / (int)gridDim.x, txi = wi - tyi * (int)gridDim.x;
+    const int x0 = txi * SM_TW, y0 = tyi * SM_TH;
     const int HW = H * W;
     smooth_stage(t, flow + (size_t)b * 2 * HW, img + (size_t)(b % img_b) * 3 * HW, HW, H, W, x0, y0);
     __syncthreads();
