@@ -680,7 +680,7 @@ __global__ __launch_bounds__(256) void warp_bwd_cell_kernel(const float* __restr
     __shared__ unsigned char s_flag[WINP];          // window cells that receive something through s_dup
     __shared__ int s_mark[MK];
     __shared__ int s_box[16];
-    int t = blockIdx.x;
+    int t = xcd_remap((int)blockIdx.x, (int)gridDim.x);          // (XCD-local tile order, as the tile kernels)
     const int bx = t % tiles_x; t /= tiles_x;
     const int by = t % tiles_y;
     const int b = t / tiles_y;
