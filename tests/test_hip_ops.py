@@ -304,6 +304,8 @@ def test_warp_backward_fused_at_the_step_shapes(ops):
             ops.kernel_timer.disable()
             names = {r['entry'] for r in ops.kernel_timer.rows()}
             assert ('unflow_warp_bwd_fused' in names) == (fused is None), names
+            # the forward leaves the displacement table behind exactly when the one-pass backward will want it (so that pass is ONE launch)
+            assert ('unflow_warp_fwd_table' in names) == (fused is None) and ('unflow_warp_fwd' in names) == (fused is not None), names
             res.setdefault(fused, []).append((x.grad.clone(), f.grad.clone()))
         (a, fa), (b, fb) = res[None]
         assert torch.equal(a, b) and torch.equal(fa, fb)

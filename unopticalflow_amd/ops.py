@@ -284,7 +284,8 @@ class _Warp(torch.autograd.Function):
         lib = _lib.load()
         want = fused if fused is not None else fused_warp_bwd
         table = None
-        if want and not use_mask and x.requires_grad and torch.is_grad_enabled() and lib.unflow_warp_bwd_fused_supported(B, C, H, W) == 2:
+        # (ctx.needs_input_grad, not torch.is_grad_enabled(): grad mode is OFF inside an autograd.Function's forward)
+        if want and not use_mask and ctx.needs_input_grad[0] and lib.unflow_warp_bwd_fused_supported(B, C, H, W) == 2:
             table = torch.empty(lib.unflow_warp_bwd_table_bytes(B, C, H, W), dtype=torch.uint8, device=x.device)
         with _on(x.device):
             if table is not None:
