@@ -196,6 +196,11 @@ class FlatGradients:
         current stream waits for it -- the host does not."""
         if not self._active():
             return
+        if self.flat.is_cuda and dist.get_backend(self.group) == 'gloo':
+            # gloo blocks the host for its staged copy anyway, but its own wait on a stream with a hipGraph replay in flight stalls
+            # for seconds at a time (two ranks sharing one GPU: 6 ms after a synchronise, up to 18 s without,
+            # profiles/r4_multirank_step_mode.md); gloo with device tensors is the one-GPU rehearsal, never the product path
+            torch.cuda.current_stream().synchronize()
         dist.all_reduce(self.flat, op=self._averaging_op(), group=self.group)
         if self._averaging_op() != dist.ReduceOp.AVG and dist.get_world_size(self.group) > 1:
             self.flat.mul_(1.0 / dist.get_world_size(self.group))
