@@ -352,26 +352,30 @@ def main():
             gc_log['ms'] += d
             gc_log['max_ms'] = max(gc_log['max_ms'], d)
     gc.callbacks.append(gc_watch)
-    busy = None
-    if args.contended_host:
-        import subprocess
-        core = sorted(os.sched_getaffinity(0))[0]
-        os.sched_setaffinity(0, {core})
-        busy = subprocess.Popen([sys.executable, '-c', 'import os\nos.sched_setaffinity(0, {%d})\nwhile True: pass' % core])
-        time.sleep(0.5)
-    barrier()
-    t0 = time.perf_counter()
-    marks[0].record()
-    host[0] = t0
-    for i in range(args.steps):
-        loss, _ = trainer.step(inputs)
-        marks[i + 1].record()
-        host[i + 1] = time.perf_counter()
-    barrier()
-    dt = time.perf_counter() - t0
-    if busy is not None:
-        busy.kill(); busy.wait()                          # (our own child, by handle)
-        os.sched_setaffinity(0, set(range(os.cpu_count() or 1)))
+    busy, affinity = None, None
+    try:
+        if args.contended_host:
+            import subprocess
+            affinity = os.sched_getaffinity(0)                # the mask this process was STARTED with (cpuset / taskset): restored below
+            core = sorted(affinity)[0]
+            os.sched_setaffinity(0, {core})
+            busy = subprocess.Popen([sys.executable, '-c', 'import os\nos.sched_setaffinity(0, {%d})\nwhile True: pass' % core])
+            time.sleep(0.5)
+        barrier()
+        t0 = time.perf_counter()
+        marks[0].record()
+        host[0] = t0
+        for i in range(args.steps):
+            loss, _ = trainer.step(inputs)
+            marks[i + 1].record()
+            host[i + 1] = time.perf_counter()
+        barrier()
+        dt = time.perf_counter() - t0
+    finally:                                                  # also when a step raises: no busy loop left behind, the rest of the run on the old mask
+        if busy is not None:
+            busy.kill(); busy.wait()                          # (our own child, by handle)
+        if affinity is not None:
+            os.sched_setaffinity(0, affinity)
     gc.callbacks.remove(gc_watch)
     step_stats = per_step_stats(marks, host, t0 + dt)
     step_stats['host_gc'] = {'collections_gen0_1_2': gc_log['collections'], 'total_ms': round(gc_log['ms'], 2),
@@ -490,6 +494,8 @@ def main():
         base = None
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_baseline(args.cpu_sample)
+        elif world > 1:
+            base = 'see the N=1 line (the CPU oracle is timed on rank 0 at N=1 only)'
         pairs = 2 * args.batch * world * args.steps
         out = {
             'metric': 'frame-pairs/s (train step) at %dx%d bs=%d' % (fw, fh, args.batch),

@@ -36,7 +36,7 @@ extern "C" {
 /* ABI version of this header (bumped on any signature change).  The library returns the value it was BUILT with; a C user
  * compares `unflow_abi_version() == UNFLOW_ABI_VERSION` (tools/capi_bench.cpp), the Python binding reads this very line
  * (unopticalflow_amd/_lib.py). */
-#define UNFLOW_ABI_VERSION 9
+#define UNFLOW_ABI_VERSION 10
 int unflow_abi_version(void);
 
 /* ---- kernel-exact timing (bench.py's roofline legs; nothing in the reference corresponds) ----

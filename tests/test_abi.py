@@ -145,7 +145,7 @@ def test_one_abi_version_number():
     """include/unflow_hip.h's UNFLOW_ABI_VERSION is what the library returns (csrc/photo.hip returns the macro), what the Python
     binding expects (_lib.ABI_VERSION is read from the header) and what the C program compares with."""
     from unopticalflow_amd import _lib
-    assert _lib.ABI_VERSION == _lib.header_abi_version() >= 8
+    assert _lib.ABI_VERSION == _lib.header_abi_version() == _lib.BINDING_ABI >= 10          # library == header == ctypes table (ADVICE r4)
     assert 'return UNFLOW_ABI_VERSION;' in open(os.path.join(ROOT, 'unopticalflow_amd', 'csrc', 'photo.hip')).read()
     assert 'unflow_abi_version() != UNFLOW_ABI_VERSION' in open(os.path.join(ROOT, 'tools', 'capi_bench.cpp')).read()
     lib = ctypes.CDLL(_lib.LIB_PATH)
@@ -164,12 +164,13 @@ def test_c_program_runs_and_matches_the_oracle(tmp_path):
     from oracle import ref_cpu as R
     exe = _build_capi_bench(tmp_path)
     B, C, H, W, d = 2, 12, 24, 68, 4
-    r = subprocess.run([exe] + [str(v) for v in (B, C, H, W, d, 2)], capture_output=True, text=True, timeout=300)
+    mask_file = str(tmp_path / 'mask.bin')
+    r = subprocess.run([exe] + [str(v) for v in (B, C, H, W, d, 2)] + [mask_file], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
     got = {m.group(1): [float(x) for x in m.group(2).split()] for m in re.finditer(r'^(\w+) = (.*)$', r.stdout, re.M)}
     D = 2 * d + 1
     nf, nc = B * C * H * W, B * D * D * H * W
-    i = np.arange(max(nf, nc) + 8, dtype=np.uint64)
+    i = np.arange(max(nf, nc) + 16, dtype=np.uint64)
     v = ((i * np.uint64(2654435761)) % np.uint64(2001)).astype(np.float32) / np.float32(1000.0) - np.float32(1.0)
     f1 = torch.from_numpy(v[:nf].reshape(B, C, H, W).copy()).requires_grad_()
     f2 = torch.from_numpy(v[7:7 + nf].reshape(B, C, H, W).copy()).requires_grad_()
@@ -181,6 +182,15 @@ def test_c_program_runs_and_matches_the_oracle(tmp_path):
     for name, t in (('sum_abs_cv', cv.detach()), ('sum_abs_gf1', f1.grad), ('sum_abs_gf2', f2.grad)):
         np.testing.assert_allclose(got[name][0], t.double().abs().sum().item(), rtol=1e-5, err_msg=name)
     assert 'GB/s algorithmic' in r.stdout
+    # the integer half of the parity bar through the same Python-free boundary: the binary validity mask of the masked image warp
+    # (net_utils.py:47-52), byte for byte against the oracle, and the warped image
+    img = torch.from_numpy(((v[11:11 + B * 3 * H * W] + np.float32(1.0)) / np.float32(2.0)).reshape(B, 3, H, W).copy())
+    fl = torch.from_numpy((np.float32(6.0) * v[5:5 + B * 2 * H * W]).reshape(B, 2, H, W).copy())
+    m_ref = R.warp_mask(img.shape, fl, False).numpy().astype(np.uint8).reshape(-1)
+    m_got = np.fromfile(mask_file, dtype=np.uint8)
+    assert got['mask_not_binary'][0] == 0 and 0 < got['mask_ones'][0] < m_ref.size      # (a flow of +-6 px leaves both kinds of pixels)
+    assert np.array_equal(m_got, m_ref) and got['mask_ones'][0] == int(m_ref.sum())
+    np.testing.assert_allclose(got['sum_abs_warped'][0], R.warp_flow(img, fl, True, False).double().abs().sum().item(), rtol=1e-5)
 
 
 def test_miopen_tuning_paths(monkeypatch):

@@ -99,3 +99,52 @@ def test_bench_starts_its_own_ranks(tmp_path):
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 2 and line['steps'] == 3 and line['value'] > 0 and line['config']['parallelism'] == 'dp2'
     assert line['step_mode'].startswith('hipGraph replay') and line['rank_spread']['max_over_ranks']['step_ms_median'] > 0
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_rehearsal_and_a_killed_rank(tmp_path):
+    """nobody can measure eight GPUs here, so the eight-rank form of the driver's command is rehearsed on the one-GPU box
+    (eight self-launched ranks sharing device 0 over gloo): port / rendezvous, eight private find-db copies, the OMP_NUM_THREADS
+    split, rank_spread, one JSON line with n_gpus 8 -- and a rank that is killed ends the whole job non-zero within the grace period
+    (the reference's one-command form, train.py:208-214)."""
+    import json
+    import signal
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UNFLOW_BENCH_ONE_GPU='1', UNFLOW_MIOPEN_FIND='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'OMP_NUM_THREADS'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '3', '--hw', '64', '128', '--batch', '2',
+           '--no-cpu-baseline']
+    r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 8 and line['config']['parallelism'] == 'dp8' and line['config']['global_batch'] == 16 and line['value'] > 0
+    assert line['scaling'] == 'weak' and isinstance(line['cpu_baseline'], str) and 'N=1' in line['cpu_baseline']
+    assert line['rank_spread']['max_over_ranks']['step_ms_median'] >= line['rank_spread']['min_over_ranks']['step_ms_median'] > 0
+    # one rank killed in the middle of a (long) run: the launcher ends every other rank and reports failure
+    p = subprocess.Popen(cmd[:4] + ['--steps', '2000', '--warmup', '3'] + cmd[8:], env=env, cwd=str(tmp_path), stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True)
+    victim = None
+    t0 = time.monotonic()
+    while time.monotonic() - t0 < 600 and victim is None:              # a rank process of OUR launcher: a child of p with RANK=3
+        time.sleep(1.0)
+        for d in os.listdir('/proc'):
+            if not d.isdigit():
+                continue
+            try:
+                stat = open('/proc/%s/stat' % d).read().rsplit(')', 1)[1].split()
+                if int(stat[1]) != p.pid:
+                    continue
+                if b'RANK=3' in open('/proc/%s/environ' % d, 'rb').read().split(b'\0'):
+                    victim = int(d)
+            except (OSError, IndexError, ValueError):
+                continue
+    assert victim is not None, 'rank 3 never appeared'
+    time.sleep(20.0)                                                   # (let the ranks get past the rendezvous and into the steps)
+    os.kill(victim, signal.SIGKILL)                                    # an exact PID, found by parent + environment
+    t1 = time.monotonic()
+    rc = p.wait(timeout=120)
+    assert rc != 0 and time.monotonic() - t1 < 60, rc

@@ -107,9 +107,25 @@ def test_kitti_flow_task_end_to_end(tmp_path):
     model = get_model('flow')(cfg).cuda().eval()
     model.load_state_dict(R.seeded_state_dict(model, 1234, 0.25))
     gt, noc = E.load_gt_flow_kitti(root, 'kitti_2015', 2)
-    res = T.test_kitti_2015(cfg, model, gt, noc, E.load_gt_mask(root, 2), num=2)
+    masks = E.load_gt_mask(root, 2)
+    res = T.test_kitti_2015(cfg, model, gt, noc, masks, num=2)
     vals = [float(t) for t in res.strip().split('\n')[1].split(',')]
     assert len(vals) == 8 and all(np.isfinite(vals))
+    # the same task on the CPU oracle (test.py:43-76 restated: per pair inference_flow at img_hw, then eval_flow_avg on the same PNGs,
+    # the same seeded weights): the eight numbers of the result line agree
+    cpu = R.get_model('flow')(cfg).eval()
+    cpu.load_state_dict(R.seeded_state_dict(cpu, 1234, 0.25))
+    ds = E.KITTI_2015(root, cfg.img_hw, 2)
+    preds = []
+    for idx in range(len(ds)):
+        img = ds[idx][None]
+        hh = img.shape[2] // 2
+        with torch.no_grad():
+            preds.append(cpu.inference_flow(img[:, :, :hh], img[:, :, hh:])[0].numpy().transpose(1, 2, 0))
+    ref = [float(t) for t in E.eval_flow_avg(gt, noc, preds, cfg, moving_masks=masks).strip().split('\n')[1].split(',')]
+    assert res.strip().split('\n')[0] == E.eval_flow_avg(gt, noc, preds, cfg, moving_masks=masks).strip().split('\n')[0]
+    np.testing.assert_allclose(vals, ref, rtol=1e-3, atol=1e-3)
+    assert max(vals[:3]) > 0.5                               # (a random-weight network is far from the ground truth: the numbers are not trivially 0)
 
 
 def test_metrics_match_the_reference_fixture(golden):

@@ -86,3 +86,56 @@ def test_train_cli_starts_one_rank_per_listed_gpu(tmp_path, monkeypatch):
     with pytest.raises(ValueError, match='launcher started 2'):
         train_cli.main(argv)
     assert not seen
+
+
+def _pid_alive(pid):
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    try:                                                   # (a zombie still answers kill 0: look at its state)
+        return open('/proc/%d/stat' % pid).read().rsplit(')', 1)[1].split()[0] != 'Z'
+    except OSError:
+        return False
+
+
+def _start_launcher(tmp_path, sleep_s=120):
+    import subprocess
+    w = tmp_path / 'w.py'
+    w.write_text(textwrap.dedent('''
+        import os, sys, time
+        open(os.path.join(%r, 'pid%%s' %% os.environ['RANK']), 'w').write(str(os.getpid()))
+        time.sleep(%d)
+    ''' % (str(tmp_path), sleep_s)))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    parent = subprocess.Popen([sys.executable, '-c',
+                               'import sys; sys.path.insert(0, %r)\n'
+                               'from unopticalflow_amd.launch import spawn_ranks\n'
+                               'sys.exit(spawn_ranks([sys.executable, %r], 2, grace_s=3.0))' % (root, str(w))])
+    t0 = time.monotonic()
+    while time.monotonic() - t0 < 30 and not all((tmp_path / ('pid%d' % r)).exists() and (tmp_path / ('pid%d' % r)).read_text() for r in (0, 1)):
+        time.sleep(0.05)
+    pids = [int((tmp_path / ('pid%d' % r)).read_text()) for r in (0, 1)]
+    assert all(_pid_alive(p) for p in pids)
+    return parent, pids
+
+
+def test_sigterm_to_the_launcher_stops_every_rank(tmp_path):
+    """ADVICE r4: `timeout ... python bench.py --gpus N` / a scheduler stop sends SIGTERM to the PARENT only: it is forwarded to the
+    exact child PIDs, the launcher waits for them and exits 128 + 15 -- no rank is left holding a GPU or the rendezvous port."""
+    import signal
+    parent, pids = _start_launcher(tmp_path)
+    parent.send_signal(signal.SIGTERM)
+    assert parent.wait(timeout=20) == 128 + signal.SIGTERM
+    assert not any(_pid_alive(p) for p in pids)
+
+
+def test_a_killed_launcher_takes_its_ranks_with_it(tmp_path):
+    """SIGKILL cannot be forwarded: the ranks carry PR_SET_PDEATHSIG and die with the launcher."""
+    parent, pids = _start_launcher(tmp_path)
+    parent.kill()
+    parent.wait(timeout=20)
+    t0 = time.monotonic()
+    while time.monotonic() - t0 < 10 and any(_pid_alive(p) for p in pids):
+        time.sleep(0.1)
+    assert not any(_pid_alive(p) for p in pids)

@@ -5,10 +5,12 @@
 //
 //   hipcc -O2 --offload-arch=gfx950 tools/capi_bench.cpp -Iinclude -Lunopticalflow_amd -lunflow_hip \
 //         -Wl,-rpath,$PWD/unopticalflow_amd -o tools/capi_bench
-//   tools/capi_bench [B C H W d iters]        (default 16 32 64 208 4 50 = level 2 of the 832x256, B=8 step)
+//   tools/capi_bench [B C H W d iters [mask.bin]]        (default 16 32 64 208 4 50 = level 2 of the 832x256, B=8 step)
 //
 // Input (restated by the test in numpy): v(i) = float((i * 2654435761) mod 2001) / 1000 - 1 over 64-bit i;
 // f1[i] = v(i), f2[i] = v(i + 7), g[i] = v(i + 3) (the upstream gradient of the backward).
+// Then the masked image warp (net_utils.py:47-52, the integer half of the parity bar) of img[i] = (v(i + 11) + 1) / 2, [B,3,H,W],
+// by flow[i] = 6 v(i + 5), [B,2,H,W]: the uint8 mask goes to `mask.bin` byte for byte (the test compares it with the oracle's).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -67,5 +69,30 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(out.data(), gf2, nf * 4, hipMemcpyDeviceToHost));
     sa = 0; for (size_t i = 0; i < nf; ++i) sa += out[i] < 0 ? -out[i] : out[i];
     printf("sum_abs_gf2 = %.9g\n", sa);
+
+    // masked image warp through unflow_warp_fwd: values and the binary mask
+    const size_t ni = (size_t)B * 3 * H * W, nfl = (size_t)B * 2 * H * W, nm = (size_t)B * H * W;
+    std::vector<float> himg(ni), hfl(nfl);
+    for (size_t i = 0; i < ni; ++i) himg[i] = (v(i + 11) + 1.f) / 2.f;
+    for (size_t i = 0; i < nfl; ++i) hfl[i] = 6.f * v(i + 5);
+    float *img, *fl, *wimg; uint8_t* mask;
+    CK(hipMalloc(&img, ni * 4)); CK(hipMalloc(&fl, nfl * 4)); CK(hipMalloc(&wimg, ni * 4)); CK(hipMalloc(&mask, nm));
+    CK(hipMemcpy(img, himg.data(), ni * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(fl, hfl.data(), nfl * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(mask, 0xff, nm));
+    { int rc = unflow_warp_fwd(img, fl, wimg, mask, B, 3, H, W, 0, s); if (rc) { fprintf(stderr, "warp launch failed: %d\n", rc); return 1; } }
+    CK(hipStreamSynchronize(s));
+    std::vector<uint8_t> hm(nm);
+    CK(hipMemcpy(hm.data(), mask, nm, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(himg.data(), wimg, ni * 4, hipMemcpyDeviceToHost));
+    size_t ones = 0, other = 0;
+    for (size_t i = 0; i < nm; ++i) { ones += hm[i] == 1; other += hm[i] > 1; }
+    sa = 0; for (size_t i = 0; i < ni; ++i) sa += himg[i] < 0 ? -himg[i] : himg[i];
+    printf("mask_ones = %zu\nmask_not_binary = %zu\nsum_abs_warped = %.9g\n", ones, other, sa);
+    if (argc >= 8) {
+        FILE* f = fopen(argv[7], "wb");
+        if (!f || fwrite(hm.data(), 1, nm, f) != nm) { fprintf(stderr, "cannot write %s\n", argv[7]); return 1; }
+        fclose(f);
+    }
     return 0;
 }

@@ -106,7 +106,21 @@ class UnflowLibraryError(RuntimeError):
     pass
 
 
-ABI_VERSION = header_abi_version()
+# The ABI this file's SIGNATURES table was written for.  Bump it together with UNFLOW_ABI_VERSION of include/unflow_hip.h whenever an
+# entry point changes: load() wants library == header == this number, so a header bump + rebuild with a stale ctypes table is caught
+# (reading the number from the header alone only detects a stale .so).
+BINDING_ABI = 10
+
+
+def _abi_version():
+    """The header's number when the header travels with the package (the in-tree layout), else the binding's own."""
+    try:
+        return header_abi_version()
+    except OSError:                                        # a copied / installed package without include/: checked against the library in load()
+        return BINDING_ABI
+
+
+ABI_VERSION = _abi_version()
 _lib = None
 
 
@@ -130,9 +144,9 @@ def load():
             raise UnflowLibraryError('%s does not export %s (stale build?)' % (LIB_PATH, name))
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
-    if lib.unflow_abi_version() != ABI_VERSION:
-        raise UnflowLibraryError('ABI version mismatch: library %d, binding %d'
-                                 % (lib.unflow_abi_version(), ABI_VERSION))
+    if not (lib.unflow_abi_version() == ABI_VERSION == BINDING_ABI):
+        raise UnflowLibraryError('ABI version mismatch: library %d, include/unflow_hip.h %d, ctypes binding (_lib.BINDING_ABI) %d'
+                                 % (lib.unflow_abi_version(), ABI_VERSION, BINDING_ABI))
     _lib = lib
     return lib
 

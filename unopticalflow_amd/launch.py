@@ -46,54 +46,99 @@ def rank_env(rank, world, port, base=None):
     return env
 
 
+def _die_with_parent():
+    """preexec hook of a rank (runs in the child between fork and exec): SIGKILL when the launcher dies -- a launcher killed with
+    SIGKILL (OOM killer, ``timeout -s KILL``) cannot forward anything, and orphaned ranks would keep the GPUs and the port."""
+    try:
+        import ctypes
+        ctypes.CDLL('libc.so.6', use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)          # PR_SET_PDEATHSIG
+    except Exception:                                              # not Linux / no libc: the forwarding below still covers SIGTERM / SIGHUP
+        pass
+
+
 def spawn_ranks(argv, world, poll_s=0.2, grace_s=10.0, out=None, err=None):
     """Run ``argv`` (a full command, e.g. ``[sys.executable, 'bench.py', '--gpus', '8']``) as ``world`` ranks.
 
     Rank 0's stdout is forwarded line by line to ``out`` (default: this process's stdout) -- a rank-0 program that prints its
     result last keeps it last; the other ranks' stdout goes to ``err`` (stderr), every rank's stderr is inherited.  When a rank
     fails, the others (which would wait for it in a collective until the watchdog fires) are terminated by PID.  Returns 0 when
-    every rank succeeded, else the exit code of the rank that failed first (128 + signal for a killed rank)."""
+    every rank succeeded, else the exit code of the rank that failed first (128 + signal for a killed rank).
+
+    A SIGTERM / SIGHUP / Ctrl-C to the launcher (scheduler stop, ``timeout ... python bench.py --gpus N``, closed terminal) is
+    forwarded to the exact child PIDs; ranks still alive ``grace_s`` later are killed; the launcher then returns 128 + signal
+    (Ctrl-C: re-raises KeyboardInterrupt) -- no rank outlives it, and a launcher that is SIGKILLed takes its ranks with it
+    (PR_SET_PDEATHSIG)."""
     if world < 1:
         raise ValueError('world must be >= 1')
     out = sys.stdout if out is None else out
     err = sys.stderr if err is None else err
     port = free_port()
-    procs = []
-    for r in range(world):
-        procs.append(subprocess.Popen(list(argv), env=rank_env(r, world, port), stdout=subprocess.PIPE,
-                                      stderr=None, text=True, bufsize=1))
+    stop = {'sig': None}
 
-    def pump(p, sink):
-        for line in p.stdout:
-            sink.write(line)
-            sink.flush()
-    threads = [threading.Thread(target=pump, args=(p, out if r == 0 else err), daemon=True) for r, p in enumerate(procs)]
-    for t in threads:
-        t.start()
-    failed, first_bad = None, 0
+    def on_signal(signum, frame):
+        stop['sig'] = signum
+    old = {}
+    if threading.current_thread() is threading.main_thread():      # (signal.signal is main-thread only; elsewhere the defaults stay)
+        for sg in (signal.SIGTERM, signal.SIGHUP):
+            old[sg] = signal.signal(sg, on_signal)
+    procs = []
     try:
+        for r in range(world):
+            procs.append(subprocess.Popen(list(argv), env=rank_env(r, world, port), stdout=subprocess.PIPE,
+                                          stderr=None, text=True, bufsize=1, preexec_fn=_die_with_parent))
+
+        def pump(p, sink):
+            for line in p.stdout:
+                sink.write(line)
+                sink.flush()
+        threads = [threading.Thread(target=pump, args=(p, out if r == 0 else err), daemon=True) for r, p in enumerate(procs)]
+        for t in threads:
+            t.start()
+
+        def signal_all(sg):
+            for p in procs:                                       # exact PIDs of our own children, never a pattern
+                if p.poll() is None:
+                    p.send_signal(sg)
+        failed, first_bad, forwarded, interrupted = None, 0, None, False
         while True:
-            codes = [p.poll() for p in procs]
-            bad = [c for c in codes if c not in (None, 0)]
-            if bad and failed is None:
-                failed, first_bad = time.monotonic(), (128 - bad[0] if bad[0] < 0 else bad[0])
-                for p in procs:                                   # exact PIDs of our own children, never a pattern
-                    if p.poll() is None:
-                        p.send_signal(signal.SIGTERM)
-            if all(c is not None for c in codes):
-                break
-            if failed is not None and time.monotonic() - failed > grace_s:
-                for p in procs:
-                    if p.poll() is None:
-                        p.kill()
-            time.sleep(poll_s)
-    except KeyboardInterrupt:
-        for p in procs:
+            try:
+                codes = [p.poll() for p in procs]
+                if stop['sig'] is not None and forwarded is None:
+                    forwarded = stop['sig']
+                    signal_all(forwarded)
+                    failed = failed if failed is not None else time.monotonic()
+                bad = [c for c in codes if c not in (None, 0)]
+                if bad and failed is None:
+                    failed, first_bad = time.monotonic(), (128 - bad[0] if bad[0] < 0 else bad[0])
+                    signal_all(signal.SIGTERM)
+                if all(c is not None for c in codes):
+                    break
+                if failed is not None and time.monotonic() - failed > grace_s:
+                    for p in procs:
+                        if p.poll() is None:
+                            p.kill()
+                time.sleep(poll_s)
+            except KeyboardInterrupt:                              # (the terminal sent SIGINT to the ranks too; make sure, then wait like above)
+                if interrupted:
+                    for p in procs:
+                        if p.poll() is None:
+                            p.kill()
+                interrupted = True
+                signal_all(signal.SIGTERM)
+                failed = failed if failed is not None else time.monotonic()
+        for t in threads:
+            t.join(timeout=5.0)
+    finally:
+        for p in procs:                                           # (an exception on the way: nothing of ours is left behind)
             if p.poll() is None:
-                p.send_signal(signal.SIGTERM)
-        raise
-    for t in threads:
-        t.join(timeout=5.0)
+                p.kill()
+        for sg, h in old.items():
+            signal.signal(sg, h)
+    if interrupted:
+        raise KeyboardInterrupt
+    if forwarded is not None:
+        err.write('launch: stopped by signal %d\n' % forwarded)
+        return 128 + int(forwarded)
     worst = 0
     for r, p in enumerate(procs):
         c = p.returncode

@@ -199,10 +199,13 @@ class _DeferredBiasGrads:
                 _call('unflow_bias_grad_finalize_batch', P, G, N_, C_, M_, n, _stream(),
                       nbytes=4 * sum(j[4] * j[5] + j[5] for j in js), shape=(n,))
 
-    def adopted(self, params):
+    def adopted(self, params, extra=()):
         """True when every bias gradient finished by the last pass IS some parameter's ``.grad`` (autograd adopted the tensors it
-        was handed: nothing was cloned or accumulated before the deferred launch wrote them)."""
+        was handed: nothing was cloned or accumulated before the deferred launch wrote them).  ``extra``: addresses of gradients
+        that were already copied elsewhere and re-pointed (the data-parallel trainer packs all-reduce pieces during the pass:
+        ``FlatGradients.seen_sources``)."""
         have = {p.grad.data_ptr() for p in params if p.grad is not None}
+        have.update(extra)
         return all(a in have for a in self.last_addresses)
 
 

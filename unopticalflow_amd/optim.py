@@ -83,6 +83,27 @@ class FlowAdam(torch.optim.Adam):
         self._tables = (raw, cm, len(cmap), key)
         return self._tables
 
+    def prepare(self):
+        """Create everything a native step needs -- moments, the step vector, the device tables -- for ALL parameters now, whether
+        or not they have a gradient yet.  A trainer calls it before it captures ``step()`` into a hipGraph: allocations, zero-fills
+        and host-to-device copies made DURING a capture would become graph nodes (every replay would reset the moments and the
+        step counters) or fail the capture outright."""
+        params = self._params()
+        if not params or not all(p.is_cuda and p.dtype == torch.float32 for p in params) or len(params) > 128:
+            return False
+        self._init_state(params)
+        self._build_tables(params)
+        return True
+
+    def _capture_ready(self, params):
+        if self._steps is None or self._steps.numel() != len(params) or self._tables is None:
+            return False
+        for i, p in enumerate(params):
+            st = self.state.get(p)
+            if not st or not torch.is_tensor(st.get('step')) or st['step'].data_ptr() != self._steps[i].data_ptr():
+                return False
+        return self._tables[3] == tuple((p.data_ptr(), self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr()) for p in params)
+
     def _native_ok(self, params):
         if not params or len(params) > 128:
             return False
@@ -102,10 +123,19 @@ class FlowAdam(torch.optim.Adam):
     @torch.no_grad()
     def step(self, closure=None):
         params = self._params()
+        capturing = bool(params) and params[0].is_cuda and torch.cuda.is_current_stream_capturing()
         if closure is not None or not self._native_ok(params):
+            if capturing and self._steps is not None:
+                # torch's Adam under capture next to native steps outside it would walk two sets of step counters
+                raise RuntimeError('FlowAdam.step() inside a hipGraph capture would fall back to torch.optim.Adam (a parameter without a '
+                                   'gradient, or a layout the kernel does not take) after native steps: give the warm-up steps the '
+                                   'gradient view of the capture')
             if self._steps is not None:
                 self._tables = None
             return super().step(closure)
+        if capturing and not self._capture_ready(params):
+            raise RuntimeError('FlowAdam.step() inside a hipGraph capture would have to allocate its state (moments, step vector, device '
+                               'tables): call FlowAdam.prepare() -- or take one step with the same gradients -- before the capture')
         self._init_state(params)
         for p in params:                   # the moments walk the parameter's memory: same dense layout (trainer.relayout_optimizer_state)
             st = self.state[p]

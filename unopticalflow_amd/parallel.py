@@ -101,6 +101,8 @@ class FlatGradients:
         self._works = [None] * self.chunks
         self._packed = [False] * self.chunks
         self._sources = None                              # gradient tensors of a captured hipGraph (remember_sources)
+        self.track_sources = False                        # first passes of a trainer: remember where the packed gradients came from
+        self.seen_sources = set()                         # ... (addresses; ops.deferred_bias_grads.adopted(extra=...))
         self.before_pack = None                           # called before gradients are READ (ops.deferred_bias_grads.flush on the GPU)
         self.launched_early = 0                           # pieces sent from a hook during the last backward
         self.overlap = False
@@ -137,6 +139,8 @@ class FlatGradients:
                 self.views[i].zero_()                     # a parameter the loss did not reach
             elif g.data_ptr() != self.views[i].data_ptr():
                 dst.append(self.views[i]); src.append(g)
+                if self.track_sources:
+                    self.seen_sources.add(g.data_ptr())
         if dst:
             torch._foreach_copy_(dst, src)
         for i in range(a, b):
@@ -224,6 +228,7 @@ class FlatGradients:
         self._works = [None] * self.chunks
         self._packed = [False] * self.chunks
         self.launched_early = 0
+        self.seen_sources.clear()
 
     def vector(self):
         """The gradients as one vector in LOGICAL element order, parameter by parameter (a copy).  ``flat`` itself is

@@ -99,13 +99,17 @@ class FlowTrainer:
             loss.backward()
             return
         from . import ops
+        checking = self._defer_checks > 0 and not torch.cuda.is_current_stream_capturing()
+        if hasattr(self.grads, 'track_sources'):
+            self.grads.track_sources = checking        # pack mode: pieces sent from hooks re-point p.grad; remember what they copied from
         with ops.deferred_bias_grads:
             loss.backward()
-        if self._defer_checks > 0 and not torch.cuda.is_current_stream_capturing():
+        if checking:
             self._defer_checks -= 1
-            params = self.grads.params
-            # (pack mode re-points p.grad at the flat buffer when a piece is sent: the check only applies to what is still unpacked)
-            if not getattr(self.grads, 'pack', False) and not ops.deferred_bias_grads.adopted(params):
+            # every finished bias gradient must be a tensor autograd adopted: still some p.grad, or (data-parallel pack mode, eager
+            # with hooks or not) the source a piece was packed from during this pass -- otherwise a clone of the unwritten tensor
+            # would be averaged over the ranks
+            if not ops.deferred_bias_grads.adopted(self.grads.params, extra=getattr(self.grads, 'seen_sources', ())):
                 raise RuntimeError('deferred bias gradients were not adopted by autograd (a gradient was accumulated or cloned); '
                                    'construct FlowTrainer(defer_bias_grads=False)')
 
@@ -135,6 +139,11 @@ class FlowTrainer:
         with torch.cuda.stream(side):                  # warm-up off the capture
             for it in range(3):
                 self._eager_fwd_bwd(self._static_in)
+                if self.distributed:
+                    # the capture's Adam graph reads the flat buffer's views (never None, zero where backward reached nothing); the
+                    # warm-up must see the same gradients, or a parameter without one sends FlowAdam to torch's Adam here and to its
+                    # own -- still stateless -- kernel inside the capture
+                    self.grads.pack_all()
                 self.optimizer.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -148,6 +157,8 @@ class FlowTrainer:
                             v.copy_(saved_opt[(p, k)])
                         else:
                             v.zero_()
+        if hasattr(self.optimizer, 'prepare'):
+            self.optimizer.prepare()                   # state / step vector / device tables of ALL parameters exist before any capture
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             loss, pack = self._eager_fwd_bwd(self._static_in)
