@@ -108,6 +108,8 @@ def parse():
     ap.add_argument('--fused-upsample', type=int, default=1, help='0: F.interpolate + multiply for the flow up-sampling instead of unflow_upsample_scaled_* (A/B; PWC_tf.fused_upsample)')
     ap.add_argument('--fill-cat', type=int, default=1, help='0: channels_last decoder with torch.cat inputs instead of epilogue-filled cat buffers (A/B; PWC_tf.fill_cat_buffers)')
     ap.add_argument('--fused-warp-bwd', type=int, default=1, help='0: zero-fill + scatter for the feature-map warps\' backward instead of the one-pass gather (A/B; ops.fused_warp_bwd)')
+    ap.add_argument('--deferred-loss-sums', type=int, default=1, help='0: one second-stage launch per loss reduction instead of one per forward pass (A/B; Model_flow.deferred_loss_sums)')
+    ap.add_argument('--corr-bwd', default='auto', choices=['auto', 'fp32', 'mfma'], help='cost-volume backward arithmetic (ops.set_corr_backward): mfma = the matrix-core form at d = 4 too (A/B)')
     ap.add_argument('--gc-freeze', type=int, default=1, help='0: leave Python\'s cyclic collector alone; 1: FlowTrainer(gc_freeze_after=2), what train.py asks for too (gc.freeze() after the second step, once per process)')
     ap.add_argument('--contended-host', action='store_true', help='experiment (profiles/r4_multirank_step_mode.md): for the TIMED steps confine this process to one core and run a busy-loop child on the same core -- what a slow or shared host does to the step mode')
     ap.add_argument('--force-ddp', action='store_true', help='N = 1 only: run the step through the RCCL data-parallel path with a one-rank communicator')
@@ -254,6 +256,7 @@ def main():
 
     _lib.load()                                   # no HIP library -> fail loudly, never fall back
     ops.fused_warp_bwd = bool(args.fused_warp_bwd)
+    ops.set_corr_backward(args.corr_bwd)
     # one rank per GPU over RCCL.  UNFLOW_BENCH_ONE_GPU=1 is a rehearsal mode for boxes with a single GPU: every rank
     # shares device 0 and the collectives go through gloo (RCCL refuses two ranks on one device) -- it exercises the
     # multi-rank plumbing, its numbers mean nothing.
@@ -286,6 +289,7 @@ def main():
     model.pwc_model.fused_upsample = bool(args.fused_upsample)
     model.pwc_model.fused_head = bool(args.fused_head)
     model.fused_loss_sums = bool(args.fused_loss_sums)
+    model.deferred_loss_sums = bool(args.deferred_loss_sums)
     model.dup_centre = bool(args.dup_centre)
     trainer = FlowTrainer(cfg, model, distributed=(world > 1 or args.force_ddp), use_graph=bool(args.graph),
                           single_rank_collectives=args.force_ddp, gc_freeze_after=2 if args.gc_freeze else None)
@@ -321,6 +325,7 @@ def main():
             model.pwc_model.fused_upsample = bool(args.fused_upsample)
             model.pwc_model.fused_head = bool(args.fused_head)
             model.fused_loss_sums = bool(args.fused_loss_sums)
+            model.deferred_loss_sums = bool(args.deferred_loss_sums)
             model.dup_centre = bool(args.dup_centre)
             trainer = FlowTrainer(cfg, model, distributed=(world > 1 or args.force_ddp), use_graph=False,
                                   single_rank_collectives=args.force_ddp, gc_freeze_after=2 if args.gc_freeze else None)
@@ -468,7 +473,14 @@ def main():
             tot_us, tot_b = sum(r['total_us'] for r in timed_rows) / K, sum(r['total_bytes'] for r in timed_rows) / K
             traffic, traffic_note = measured_traffic(top['entry'], top['shape'])
             gbs = top['algorithmic_GBps'] or 0.0
-            roof = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
+            # `bound` names the roofline the fraction is taken against (HBM for every hand-written kernel); `limited_by` what the
+            # counters say holds the kernel below it today
+            limited = None
+            if top['entry'] == 'unflow_corr_bwd':
+                limited = ('valu: packed fp32 FMA issue (15.0 M VALU instructions in 51 M wave-cycles at level 2, LDS array busy 26 %, VALU issuing 41 % of all SIMD cycles, no bank '
+                           'conflicts: profiles/r5_corr_bwd_mfma/pmc_sq_counters.txt; the matrix-core form of the same sums, csrc/corr_mfma.h, is the '
+                           'default only at d = 8: profiles/r5_corr_bwd_mfma.md)')
+            roof = {'bound': 'hbm', 'limited_by': limited, 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
                     'traffic': traffic, 'traffic_source': traffic_note,
                     'kernel': '%s %s: the cost-volume / warp entry point with the largest time per step' % (top['entry'], top['shape']),
                     'measured_in': ('%d eager steps right behind the timed region (the timed region replays a hipGraph, which cannot carry per-launch events; --graph 0 times them inside it)' % int(roofline_steps)

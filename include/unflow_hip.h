@@ -64,6 +64,12 @@ int unflow_corr_fwd(const float* f1, const float* f2, float* cv,
 /* autograd of the above: gcv [B,(2d+1)^2,H,W] -> gf1, gf2 [B,C,H,W] (both written in full). */
 int unflow_corr_bwd(const float* f1, const float* f2, const float* gcv, float* gf1, float* gf2,
                     int B, int C, int H, int W, int d, void* stream);
+/* Which arithmetic unflow_corr_bwd uses where both exist (round 5; process-wide): 0 (default) = the matrix-core form -- banded
+ * bf16 hi/lo split products, fp32 accumulation, ~4e-6 of the largest gradient away from the fp32 sums, deterministic -- where it
+ * measured faster (d = 8 on maps of >= 8192 pixels with C % 16 == 0, W % 4 == 0); 1 = fp32 FMA kernels everywhere (the results of
+ * ABI <= 9, bit for bit); 2 = the matrix-core form wherever the shape is served (d = 4 too).  Returns the previous mode, or
+ * UNFLOW_EINVAL.  The reference has one arithmetic (ATen's fp32 sums, pwc_tf.py:97-106); both forms hold its 1e-4 bar. */
+int unflow_corr_set_backward(int mode);
 
 /* ---- flow warp: warp_flow, core/networks/structures/net_utils.py:16-54 ----
  * out[b,c,y,x] = bilinear sample of src[b,c] at (x+u, y+v) through the reference's
@@ -131,6 +137,17 @@ int unflow_occ_weight_fwd(const float* img, const float* from_l, const float* fr
  * runs both warp directions of a pair as ONE launch of 2B samples over the B centre images (img_batch = B). */
 int unflow_absdiff_bwd(const float* img, const float* from, const float* gdiff, float* gfrom,
                        int B, int H, int W, int img_batch, void* stream);
+
+/* ---- the per-sample reductions below are two stages: partial sums per workgroup, then one workgroup per sample adds them in a
+ * fixed order.  Round 5: a forward entry called with loss == NULL (masked mean, SSIM loss, smoothness, consistency) stops after the
+ * first stage, and unflow_loss_finalize_batch finishes any number of them with ONE launch and the same bits (12 second-stage
+ * launches per train step -> 1).  Job q: partials[q] as the entry filled them, nblk[q] = unflow_loss_partial_blocks(op, H, W, B,
+ * aligned) (op 0 masked mean, 1 SSIM loss -- aligned: every tensor 8-byte aligned --, 2 smoothness, 3 consistency), B[q] samples,
+ * kind[q] 0: loss = (s0/n0) / (s1/n1 + 1e-12), sums[q][b] = {s0, s1};  1: loss = (s0/n0 + s1/n1) / 2, sums[q] ignored (may be NULL).
+ * n0 / n1: masked mean HW / HW, SSIM 3HW / HW, consistency 2HW / HW, smoothness 2 H (W-2) / 2 (H-2) W (as floats). */
+int unflow_loss_partial_blocks(int op, int H, int W, int B, int aligned);
+int unflow_loss_finalize_batch(const void* const* partials, void* const* loss, void* const* sums, const int* nblk,
+                               const int* B, const int* kind, const float* n0, const float* n1, int njobs, void* stream);
 
 /* ---- masked mean: Model_flow.compute_loss_with_mask (one scale), model_flow_paper.py:93-97 ----
  * loss[b] = mean_p(diff*w) / (mean_p(w) + 1e-12).  partials: K=2.  sums[b] = {sum diff*w, sum w}

@@ -27,9 +27,7 @@ import json
 for f in ('bench_gc0','bench_gc1'):
     d=json.loads(open('$out/%s.json'%f).read().strip().splitlines()[-1]); print(f, d['value'], d['ms_per_step'], d['step_ms'], d['host_gc'])" ;;
   tolerances) python3 tools/tolerance_probe.py 2>&1 | tee $out/tolerance_probe.txt | tail -40 ;;
-  corr_bwd)
-    UNFLOW_RS_VARIANTS=${UNFLOW_RS_VARIANTS:-7,9} UNFLOW_MICROBENCH_TUNING=1 timeout 200 python3 tools/microbench.py corr_bwd_rs 2>&1 | tee $out/corr_bwd_rs.txt | grep corr_bwd
-    UNFLOW_MICROBENCH_TUNING=1 timeout 200 python3 tools/microbench.py corr8_bwd_rs 2>&1 | tee $out/corr8_bwd_rs.txt | grep corr_bwd ;;
+  corr_bwd) echo 'round 5: the row-streamed variants this recipe swept were removed from csrc/corr.hip (profiles/r3_experiments.md has their numbers); see tools/gpu_r5.sh mfma_sweep' ;;
   instep)
     python3 tools/bench_with_lib.py --steps 20 --warmup 5 --no-cpu-baseline > $out/instep_rs.json 2> $out/instep.err
     UNFLOW_CORR_BWD=4 python3 tools/bench_with_lib.py --steps 20 --warmup 5 --no-cpu-baseline > $out/instep_gs.json 2>> $out/instep.err

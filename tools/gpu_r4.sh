@@ -13,7 +13,6 @@
 #   profile    rocprofv3 kernel trace of bench.py reduced to the timed steps (+ MFMA counters): fp32
 #   traffic    tools/pmc_traffic.py (HBM bytes per launch, separate --pmc passes)
 #   configs    bf16 / 1024x448 bs 4 / one-rank RCCL / eager bench lines
-#   walker     build + run tools/proto/corr_bwd_walker.hip (prototype of the level-2 cost-volume backward): bit comparison, timings, ablations
 #   rerank     bench A/B of find-db variants in which the runner-up solver is ranked first where it is within 3 / 10 / 30 us (tools/miopen_rerank.py)
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/r4
@@ -53,9 +52,6 @@ for v in (1, 0):
         if 'warp_bwd' in e['entry'] and e['shape'][1] > 3: print(v, e['entry'], e['shape'], e['avg_us'], e['frac'])
 PY
     ;;
-  walker)
-    /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude tools/proto/corr_bwd_walker.hip -o $out/corr_bwd_walker || exit 1
-    timeout 60 $out/corr_bwd_walker 2>&1 | tee $out/proto_walker.txt; timeout 60 $out/corr_bwd_walker 16 64 32 104 2>&1 | tee $out/proto_walker_l3.txt ;;
   resttests)
     timeout 900 python3 -m pytest -x -q -m gpu -p no:cacheprovider --timeout 600 tests/test_hip_model.py -k "graph_capture_keeps or flow_adam or hipgraph or rccl or two_ranks" > $out/resttests.log 2>&1; echo "resttests rc=$?"; tail -30 $out/resttests.log ;;
   suite)

@@ -130,10 +130,10 @@ def warp_c(B=16):
 
 
 def corr_bwd_sweep(B=16):
-    """d=4 backward variants (tuning library): tile kernel, group-split ring kernel at 64x4 / 64x8 tiles."""
+    """d=4 backward variants (tuning library): the default pick against the group-split ring kernel (4) and the tile kernel (6)."""
     lib = _lib.load()
     P = ops._ptr
-    envs = [{}] + [{'UNFLOW_CORR_BWD': v, 'UNFLOW_CORR_GROUPS': g_} for v in (4, 3, 1, 6) for g_ in (1, 4)]
+    envs = [{}] + [{'UNFLOW_CORR_BWD': v, 'UNFLOW_CORR_GROUPS': g_} for v in (4, 6) for g_ in (1, 4)]
     for name, (C, h, w) in list(LEVELS.items())[:3]:
         f1 = torch.randn(B, C, h, w, device='cuda')
         f2 = torch.randn(B, C, h, w, device='cuda')
@@ -150,31 +150,6 @@ def corr_bwd_sweep(B=16):
             err = max((gf1 - ref['a']).abs().max().item(), (gf2 - ref['b']).abs().max().item())
             print('corr_bwd %s [%d,%d,%d,%d] %-34s %7.1f us (%6.0f GB/s)  max|diff vs default| %.2e' % (
                 name, B, C, h, w, tag, tb, bb / tb / 1e3, err), flush=True)
-        _sweep(envs, run)
-
-
-def corr_bwd_rs(B=16):
-    """Round 3: the row-streamed backward (UNFLOW_CORR_BWD=7: 16 channels per work item, 8: 8) against the group-split ring
-    kernel (default), levels 2-4, with the largest difference between their results."""
-    lib = _lib.load()
-    P = ops._ptr
-    envs = [{}, {'UNFLOW_CORR_GROUPS': 64}] + [{'UNFLOW_CORR_BWD': v} for v in (os.environ.get('UNFLOW_RS_VARIANTS', '7,8,9,10,11').split(','))]      # (CORR_GROUPS=64: 64-wide tiles only, no mixed launch)
-    for name, (C, h, w) in list(LEVELS.items())[:3]:
-        f1 = torch.randn(B, C, h, w, device='cuda')
-        f2 = torch.randn(B, C, h, w, device='cuda')
-        g = torch.randn(B, 81, h, w, device='cuda')
-        gf1, gf2 = torch.empty_like(f1), torch.empty_like(f2)
-        bb = 4 * B * h * w * (4 * C + 81)
-        ref = {}
-
-        def run(tag):
-            gf1.fill_(float('nan')); gf2.fill_(float('nan'))
-            tb = timeit(lambda: lib.unflow_corr_bwd(P(f1), P(f2), P(g), P(gf1), P(gf2), B, C, h, w, 4, ops._stream()))
-            if not ref:
-                ref['a'], ref['b'] = gf1.clone(), gf2.clone()
-            err = max((gf1 - ref['a']).abs().max().item(), (gf2 - ref['b']).abs().max().item())
-            print('corr_bwd %s [%d,%d,%d,%d] %-40s %7.1f us (%6.0f GB/s)  max|diff vs default| %.2e (max|ref| %.2f)' % (
-                name, B, C, h, w, tag, tb, bb / tb / 1e3, err, ref['a'].abs().max().item()), flush=True)
         _sweep(envs, run)
 
 
@@ -204,28 +179,38 @@ def warp_gather(B=16):
             _sweep([{}, {"UNFLOW_WARP_GATHER": 1}], run)
 
 
-def corr8_bwd_rs(B=16):
-    """d = 8 backward: row-streamed kernel (UNFLOW_CORR_BWD=7: 8 channels per item, 8: 4) against the group-split ring kernel."""
+def corr_bwd_mf(B=16):
+    """Round 5: the cost-volume backward on the matrix cores (csrc/corr_mfma.h) against the fp32 kernels at levels 2-4 of 832x256 and
+    level 2 of 1024x448, d = 4 and 8; with the tuning library also the rows-per-wave sweep (UNFLOW_CORR_MF_ROWS)."""
     lib = _lib.load()
     P = ops._ptr
-    envs = [{}, {'UNFLOW_CORR_BWD': 7}, {'UNFLOW_CORR_BWD': 8}]
-    for name, (C, h, w) in list(LEVELS.items())[:3]:
-        f1 = torch.randn(B, C, h, w, device='cuda')
-        f2 = torch.randn(B, C, h, w, device='cuda')
-        g = torch.randn(B, 289, h, w, device='cuda')
-        gf1, gf2 = torch.empty_like(f1), torch.empty_like(f2)
-        bb = 4 * B * h * w * (4 * C + 289)
-        ref = {}
+    tuning = os.environ.get('UNFLOW_MICROBENCH_TUNING') == '1'
+    shapes = [('L2', 16, 32, 64, 208), ('L3', 16, 64, 32, 104), ('L4', 16, 96, 16, 52), ('S2', 8, 32, 112, 256), ('S3', 8, 64, 56, 128)]
+    for d in (4, 8):
+        D2 = (2 * d + 1) ** 2
+        for name, Bq, C, h, w in shapes:
+            f1 = torch.randn(Bq, C, h, w, device='cuda')
+            f2 = torch.randn(Bq, C, h, w, device='cuda')
+            g = torch.randn(Bq, D2, h, w, device='cuda') * 0.05
+            gf1, gf2 = torch.empty_like(f1), torch.empty_like(f2)
+            bb = 4 * Bq * h * w * (4 * C + D2)
+            ref = {}
 
-        def run(tag):
-            gf1.fill_(float('nan')); gf2.fill_(float('nan'))
-            tb = timeit(lambda: lib.unflow_corr_bwd(P(f1), P(f2), P(g), P(gf1), P(gf2), B, C, h, w, 8, ops._stream()))
-            if not ref:
-                ref['a'], ref['b'] = gf1.clone(), gf2.clone()
-            err = max((gf1 - ref['a']).abs().max().item(), (gf2 - ref['b']).abs().max().item())
-            print('corr_bwd d=8 %s [%d,%d,%d,%d] %-40s %7.1f us (%6.0f GB/s)  max|diff vs default| %.2e (max|ref| %.2f)' % (
-                name, B, C, h, w, tag, tb, bb / tb / 1e3, err, ref['a'].abs().max().item()), flush=True)
-        _sweep(envs, run)
+            def run(tag, mode):
+                lib.unflow_corr_set_backward(mode)
+                gf1.fill_(float('nan')); gf2.fill_(float('nan'))
+                tb = timeit(lambda: lib.unflow_corr_bwd(P(f1), P(f2), P(g), P(gf1), P(gf2), Bq, C, h, w, d, ops._stream()), n=30)
+                if not ref:
+                    ref['a'], ref['b'] = gf1.clone(), gf2.clone()
+                err = max((gf1 - ref['a']).abs().max().item(), (gf2 - ref['b']).abs().max().item())
+                print('corr_bwd d=%d %s [%d,%d,%d,%d] %-22s %7.1f us (%6.0f GB/s = %.3f of 8 TB/s)  max|diff vs fp32| %.2e (max|ref| %.2f)' % (
+                    d, name, Bq, C, h, w, tag, tb, bb / tb / 1e3, bb / tb / 1e3 / 8000.0, err, ref['a'].abs().max().item()), flush=True)
+            run('fp32 kernels', 1)
+            if tuning:
+                _sweep([{'UNFLOW_CORR_MF_ROWS': r} for r in (8, 16, 32, 64)], lambda tag: run('mfma ' + tag, 2))
+            else:
+                run('mfma (shipped pick)', 2)
+            lib.unflow_corr_set_backward(0)
 
 
 def ablate(B=16):
@@ -246,7 +231,7 @@ def ablate(B=16):
     print('zero-fill of gsrc alone: %.1f us' % tz, flush=True)
     f1 = torch.randn(B, C, h, w, device='cuda'); f2 = torch.randn(B, C, h, w, device='cuda')
     gc = torch.randn(B, 81, h, w, device='cuda'); gf1, gf2 = torch.empty_like(f1), torch.empty_like(f2)
-    for fb in (3, 4):
+    for fb in (4,):
         for dbg in (0, 8):
             os.environ.update({'UNFLOW_CORR_BWD': str(fb), 'UNFLOW_CORR_DEBUG': str(dbg)})
             tb = timeit(lambda: lib.unflow_corr_bwd(P(f1), P(f2), P(gc), P(gf1), P(gf2), B, C, h, w, 4, ops._stream()))

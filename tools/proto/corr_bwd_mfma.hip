@@ -8,10 +8,7 @@
 #include <cmath>
 #include <vector>
 
-#ifndef UNFLOW_CORR_MFMA_INCLUDED
-#include "../../unopticalflow_amd/csrc/corr_mfma.h"
 UnflowTimingArm& unflow_timing_arm() { static thread_local UnflowTimingArm arm{nullptr, nullptr, false}; return arm; }
-#endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 

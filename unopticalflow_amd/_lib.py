@@ -24,6 +24,7 @@ SIGNATURES = {
     'unflow_partials_per_sample': [_I, _I],
     'unflow_corr_fwd': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     'unflow_corr_bwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'unflow_corr_set_backward': [_I],
     'unflow_warp_fwd': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'unflow_warp_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'unflow_warp_bwd_det': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -64,6 +65,8 @@ SIGNATURES = {
     'unflow_flow_head_bwd_bf16': [_P, _P, _P, _P, _I, _I, _P],
     'unflow_bias_grad_finalize_batch': [_P, _P, _P, _P, _P, _I, _P],
     'unflow_adam_chunk': [],
+    'unflow_loss_partial_blocks': [_I, _I, _I, _I, _I],
+    'unflow_loss_finalize_batch': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     'unflow_adam_multi': [_P, _P, _I, _P, _I, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P],
     'unflow_loss_combine_fwd': [_P, _I, _I, _P, _P],
     'unflow_loss_combine_bwd': [_P, _I, _P, _P],

@@ -43,6 +43,7 @@ class Model_flow(nn.Module):
         self.weight_shadow_groups = int(getattr(cfg, 'weight_shadow_groups', 1))     # cast nodes of the bf16 option (net_utils.WeightShadows)
         self.dup_centre = True           # the pyramid hand-off writes the centre features twice (False: torch.cat((c, c)); A/B)
         self.fused_loss_sums = True      # the sums over scales and directions of forward() as one launch each way (False: eager adds; tests compare)
+        self.deferred_loss_sums = True   # the second stage of the per-sample loss reductions as one launch in front of loss_combine (False: one per reduction; same bits)
         self.fpyramid = FeaturePyramid(channels_last=self.channels_last)
         self.pwc_model = PWC_tf(align_corners=self.align_corners, fused_warp_corr=bool(getattr(cfg, 'fused_warp_corr', False)),
                                 channels_last=self.channels_last)
@@ -224,15 +225,21 @@ class Model_flow(nn.Module):
         # compute_loss_flow_smooth x2 :232-233, compute_loss_flow_consis :235.  Sums over scales first, then fwd + bwd,
         # exactly the reference's association.
         pixel, ssim, smooth, consis = [], [], [], []
-        for s in range(n):
-            diff, wgt = ops.occ_weight_stacked(img_pyramid[s], warped[s])       # (diff_bwd | diff_fwd), (weight_bwd | weight_fwd)
-            pixel.append(ops.masked_mean(diff, wgt))
-            ssim.append(ops.ssim_loss(img_pyramid[s], warped[s], wgt))
-            smooth.append(ops.smooth2_loss(flows_lr[s], img_pyramid[s]))
-            consis.append(ops.consis_loss(optical_flows_fwd[s], optical_flows_bwd[s], wgt[B:]))
-        if self.fused_loss_sums and n <= 4:
-            # `loss = 0; loss += term(scale)` per loss, then fwd + bwd (:226-233), as one launch each way (ops.loss_combine)
-            packed = ops.loss_combine(pixel, ssim, smooth, consis)
+        fused_sums = self.fused_loss_sums and n <= 4
+        # round 5: the second stage of the 4 x n per-sample reductions below is ONE launch in front of loss_combine (its only reader)
+        # instead of one per reduction -- ops.deferred_loss_sums, same bits
+        with (ops.deferred_loss_sums if (fused_sums and self.deferred_loss_sums and images.is_cuda) else contextlib.nullcontext()):
+            for s in range(n):
+                diff, wgt = ops.occ_weight_stacked(img_pyramid[s], warped[s])       # (diff_bwd | diff_fwd), (weight_bwd | weight_fwd)
+                pixel.append(ops.masked_mean(diff, wgt))
+                ssim.append(ops.ssim_loss(img_pyramid[s], warped[s], wgt))
+                smooth.append(ops.smooth2_loss(flows_lr[s], img_pyramid[s]))
+                consis.append(ops.consis_loss(optical_flows_fwd[s], optical_flows_bwd[s], wgt[B:]))
+            if fused_sums:
+                # `loss = 0; loss += term(scale)` per loss, then fwd + bwd (:226-233), as one launch each way (ops.loss_combine)
+                packed = ops.loss_combine(pixel, ssim, smooth, consis)
+        if fused_sums:
+            pass
         else:
             packed = [sum(t[1:], t[0]) for t in (pixel, ssim, smooth, consis)]
             packed = [t[B:] + t[:B] for t in packed[:3]] + packed[3:]           # fwd + bwd (:226-227)

@@ -19,6 +19,8 @@
 // (except in the tile kernel when the displacement rows are split over workgroups, R > 4).
 #include "common.h"
 #include "corr_ring.h"
+#include "corr_mfma.h"
+#include <atomic>
 #include <stdlib.h>
 #include <utility>
 
@@ -1020,7 +1022,7 @@ int launch_bwd_gs(const float* f1, const float* f2, const float* g, float* gf1, 
 // 64-wide tiles leave the fourth tile column three quarters empty, 19 % of all lanes idle).
 template <int R, int CH, int TYB_ = 8>
 struct BwdRsCfg {
-    static constexpr int DD = 2 * R + 1, TYB = TYB_, THREADS = (TYB_ == 16 ? 512 : 256), TWL = THREADS / TYB, TW = 2 * TWL;     // (TYB 16: 64 x 16 tiles, 8 waves)
+    static constexpr int DD = 2 * R + 1, TYB = TYB_, THREADS = 256, TWL = THREADS / TYB, TW = 2 * TWL;
     static_assert(TWL == 32 || TWL == 8, "lane mappings below");
     static constexpr int LW = TW + 2 * R, LH = TYB + 2 * R;
     static constexpr int SC = LH * LW / 4;                                      // float4 slots per channel
@@ -1039,8 +1041,7 @@ struct RowWeights {        // one displacement row of GsWeights
 };
 
 // One row-step of the row-streamed backward: ST = channel of the group.
-// ABL (tuning builds only): 1 no LDS reads, 2 no FMAs, 4 no weight loads -- wrong results, only the times matter
-template <int ST, int STEPS, int PF, int R, int NCOL, int CH_BYTES, int HALF, int ABL = 0>
+template <int ST, int STEPS, int PF, int R, int NCOL, int CH_BYTES, int HALF>
 struct RsStep {
     template <int Q, int... Ks>
     static __device__ __forceinline__ void load_cols(v2f (&row)[PF + 1][NCOL], unsigned a_lo, unsigned a_hi,
@@ -1050,7 +1051,7 @@ struct RsStep {
     }
     template <int Q>
     static __device__ __forceinline__ void load(v2f (&row)[PF + 1][NCOL], unsigned a_lo, unsigned a_hi) {
-        if constexpr (Q < STEPS && !(ABL & 1)) load_cols<Q>(row, a_lo, a_hi, std::make_integer_sequence<int, NCOL>{});
+        if constexpr (Q < STEPS) load_cols<Q>(row, a_lo, a_hi, std::make_integer_sequence<int, NCOL>{});
     }
     static __device__ __forceinline__ void run(const RowWeights<R>& w, v2f (&acc)[STEPS][2], v2f (&row)[PF + 1][NCOL],
                                                unsigned a_lo, unsigned a_hi) {
@@ -1058,12 +1059,8 @@ struct RsStep {
         if constexpr (ST < STEPS) {
             load<ST + PF>(row, a_lo, a_hi);
             constexpr int newer = (STEPS - 1 - ST < PF ? STEPS - 1 - ST : PF) * NCOL;
-            if constexpr (!(ABL & 1)) lds_wait<newer>();
+            lds_wait<newer>();
             constexpr int rb = ST % (PF + 1);
-            if constexpr (ABL & 2) {
-                acc[ST][0] += row[rb][0] + row[rb][1] + row[rb][2];     // (keeps the reads alive)
-                acc[ST][1] += row[rb][3] + row[rb][R];
-            } else {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 acc[ST][0] = __builtin_elementwise_fma(w.p0[k], row[rb][k], acc[ST][0]);
@@ -1071,31 +1068,25 @@ struct RsStep {
             }
             acc[ST][0].x = fmaf(w.s0, row[rb][R].x, acc[ST][0].x);
             acc[ST][1].y = fmaf(w.s1, row[rb][0].y, acc[ST][1].y);
-            }
             __builtin_amdgcn_sched_barrier(0);
-            RsStep<ST + 1, STEPS, PF, R, NCOL, CH_BYTES, HALF, ABL>::run(w, acc, row, a_lo, a_hi);
+            RsStep<ST + 1, STEPS, PF, R, NCOL, CH_BYTES, HALF>::run(w, acc, row, a_lo, a_hi);
         }
     }
 };
 
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
-// WS wave sets share one tile: set s keeps channels [s * CH / WS, (s + 1) * CH / WS) of the item (a wave issues ~1 instruction per
-// 5 cycles, so the VALU wants 4 waves per SIMD; LDS allows two 72 KB tiles per CU, i.e. 2 x 4 waves -- with WS = 2 the same two
-// tiles carry 16 waves, each with half the accumulators)
-// RSETS = 2 (tuning): two wave sets share one tile and split the DISPLACEMENT ROWS (set 0: rows 0-4, set 1: rows 5-8 at R = 4), each
-// streaming only its own rows of weights; set 1 hands its partial sums to set 0 through the tile's LDS once, at the end.
-template <int R, int CH, int TYB, int AHEAD, int ABL = 0, int WS = 1, int RSETS = 1>
+// (Variants measured and removed in round 5 -- wave sets sharing a tile's channels or its displacement rows, 64 x 16 tiles, register
+// staging, the two-half phase-shifted persistent form: none beat this one; profiles/r3_experiments.md has their numbers.)
+template <int R, int CH, int TYB, int AHEAD>
 __device__ __forceinline__ void corr_bwd_rs_body(float* __restrict__ tile, int t, int x_origin,
                                                  const float* __restrict__ f1, const float* __restrict__ f2,
                                                  const float* __restrict__ g, float* __restrict__ gf1,
                                                  float* __restrict__ gf2, int Ctot, int H, int W,
                                                  int tiles_x, int tiles_y, int ngrp, float inv_c) {
     using K = BwdRsCfg<R, CH, TYB>;
-    constexpr int DD = K::DD, LW = K::LW, NCOL = R + 1, NT = K::THREADS * WS * RSETS, CHL = CH / WS, RPS = (DD + RSETS - 1) / RSETS;
-    static_assert(WS == 1 || RSETS == 1, "either channel sets or row sets");
+    constexpr int DD = K::DD, LW = K::LW, NCOL = R + 1, NT = K::THREADS;
     constexpr int ITER = (CH * K::SC + NT - 1) / NT;
-    static_assert(CH % WS == 0, "channels per wave set");
 
     const int cg = t % ngrp; t /= ngrp;              // the channel groups of a (tile, gradient) share its gradient planes
     const int mode = t & 1; t >>= 1;                 // ... and so do the two gradients of a tile
@@ -1106,10 +1097,7 @@ __device__ __forceinline__ void corr_bwd_rs_body(float* __restrict__ tile, int t
     const int b = t / tiles_y;
     const int c_begin = cg * CH;
     const int C = min(CH, Ctot - c_begin);
-    const int l = threadIdx.x % K::THREADS, wave = threadIdx.x >> 6;
-    const int set_ = __builtin_amdgcn_readfirstlane((int)threadIdx.x / K::THREADS);    // wave set (wave-uniform)
-    const int ws = RSETS > 1 ? 0 : set_, rs = RSETS > 1 ? set_ : 0;
-    const int i_begin = rs * RPS, i_end = min(DD, i_begin + RPS);
+    const int l = threadIdx.x, wave = threadIdx.x >> 6;
     // lane -> (tx, ty).  A ds_read_b64 is serviced in two groups of 32 lanes; the 32 lanes of a group must fall into 64
     // different banks.  64-wide tiles: a group is one row of 32 lanes (64 consecutive floats).  16-wide tiles (row stride
     // LW = 24 floats): a group takes 4 rows of 8 lanes; rows 2 apart start 48 = -16 (mod 64) banks apart, so lanes 0-31 take
@@ -1126,8 +1114,6 @@ __device__ __forceinline__ void corr_bwd_rs_body(float* __restrict__ tile, int t
     {
         const float* baseF = F + ((size_t)b * Ctot + c_begin) * plane;
         const auto frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(baseF), 0, (int)((size_t)C * plane * 4), 0x00020000);
-        typedef unsigned v4u __attribute__((ext_vector_type(4)));
-        v4u stg[(ABL & 8) ? ITER : 1];
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int s = it * NT + (int)threadIdx.x;
@@ -1137,17 +1123,7 @@ __device__ __forceinline__ void corr_bwd_rs_body(float* __restrict__ tile, int t
             const int gy = y0 - R + ly, gx = x0 - R + (r - ly * (LW / 4)) * 4;
             const bool in = (c < CH) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);      // (no short circuit: no branches)
             const unsigned off = in ? ((unsigned)c * plane + (unsigned)(gy * W + gx)) * 4u : kOut;
-            if constexpr (ABL & 8) stg[it] = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(frs, (int)off, 0, 0));
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(frs, (lds_ptr)(tile + (it * NT + wave * 64) * 4), 16, (int)off, 0, 0, 0);
-        }
-        if constexpr (ABL & 8) {                     // through registers instead of LDS-DMA: all loads out first, then the LDS writes
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const unsigned a = (unsigned)(size_t)(lds_cfloat*)(tile + (it * NT + (int)threadIdx.x) * 4);
-                asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(stg[it]) : "memory");
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(frs, (lds_ptr)(tile + (it * NT + wave * 64) * 4), 16, (int)off, 0, 0, 0);
         }
     }
 
@@ -1176,82 +1152,57 @@ __device__ __forceinline__ void corr_bwd_rs_body(float* __restrict__ tile, int t
     RowWeights<R> w;
     v2u raw[AHEAD][DD];
 #pragma unroll
-    for (int k = 0; k < AHEAD; ++k) request_row(raw[k], min(i_begin + k, DD - 1));
+    for (int k = 0; k < AHEAD; ++k) request_row(raw[k], min(k, DD - 1));
 
-    // this wave's pieces of the tile have landed (the weights may still fly; the row-set variant is register-capped and may spill,
-    // and scratch traffic shares the counter: it waits for everything)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RSETS > 1 ? 0 : (AHEAD * DD > 63 ? 63 : AHEAD * DD)) : "memory");
+    // this wave's pieces of the tile have landed (the weights may still fly)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * DD > 63 ? 63 : AHEAD * DD) : "memory");
     __builtin_amdgcn_s_barrier();                    // ... and everyone else's.  The waves do not meet again.
 
-    v2f acc[CHL][2];
+    v2f acc[CH][2];
 #pragma unroll
-    for (int c = 0; c < CHL; ++c) { acc[c][0] = v2f{0.f, 0.f}; acc[c][1] = v2f{0.f, 0.f}; }
-    const unsigned rows_addr = (unsigned)(size_t)(lds_cfloat*)(tile + ws * CHL * K::SC * 4 + ty * LW + tx * 2);
+    for (int c = 0; c < CH; ++c) { acc[c][0] = v2f{0.f, 0.f}; acc[c][1] = v2f{0.f, 0.f}; }
+    const unsigned rows_addr = (unsigned)(size_t)(lds_cfloat*)(tile + ty * LW + tx * 2);
     constexpr int PF = (2 * NCOL <= 15) ? 2 : 1;
-    constexpr int HALF = (CHL + 1) / 2;
+    constexpr int HALF = (CH + 1) / 2;
     static_assert((HALF - 1) * K::SC * 16 + (LW + 2 * R) * 4 < 65536, "ds_read offset field");
-    using Step0 = RsStep<0, CHL, PF, R, NCOL, K::SC * 16, HALF, ABL>;
+    using Step0 = RsStep<0, CH, PF, R, NCOL, K::SC * 16, HALF>;
 #pragma unroll 1
-    for (int i0 = i_begin; i0 < i_end; i0 += AHEAD) {
+    for (int i0 = 0; i0 < DD; i0 += AHEAD) {
 #pragma unroll
         for (int k = 0; k < AHEAD; ++k) {
             const int i = i0 + k;
-            if ((RSETS > 1 || DD % AHEAD != 0) && i >= i_end) break;   // (wave-uniform)
+            if (DD % AHEAD != 0 && i >= DD) break;   // (wave-uniform)
             take_row(w, raw[k]);                     // (the only vmcnt wait of the row: it was requested AHEAD rows ago)
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(ABL & 4)) request_row(raw[k], min(i + AHEAD, DD - 1));
+            request_row(raw[k], min(i + AHEAD, DD - 1));
             __builtin_amdgcn_sched_barrier(0);
             const unsigned a_lo = rows_addr + (unsigned)(i * LW * 4);
             const unsigned a_hi = a_lo + (unsigned)(HALF * K::SC * 16);
             v2f row[PF + 1][NCOL];
-            if constexpr (ABL & 1) {
-#pragma unroll
-                for (int q = 0; q <= PF; ++q)
-#pragma unroll
-                    for (int c = 0; c < NCOL; ++c) row[q][c] = v2f{(float)(i + q), (float)c};
-            }
             Step0::template load<0>(row, a_lo, a_hi);
             if constexpr (PF > 1) Step0::template load<1>(row, a_lo, a_hi);
             Step0::run(w, acc, row, a_lo, a_hi);
         }
     }
-    if constexpr (RSETS > 1) {
-        // set 1's partial sums -> set 0, through the tile's LDS (every wave is done reading it behind the first barrier)
-        float2* slab = reinterpret_cast<float2*>(tile);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (rs == 1) {
-#pragma unroll
-            for (int c = 0; c < CHL; ++c) slab[c * K::THREADS + l] = make_float2(acc[c][0].x + acc[c][0].y, acc[c][1].x + acc[c][1].y);
-        }
-        __syncthreads();
-        if (rs != 0) return;
-#pragma unroll
-        for (int c = 0; c < CHL; ++c) {
-            const float2 o = slab[c * K::THREADS + l];
-            acc[c][0] = v2f{acc[c][0].x + acc[c][0].y + o.x, 0.f};
-            acc[c][1] = v2f{acc[c][1].x + acc[c][1].y + o.y, 0.f};
-        }
-    }
     if (py < H && px < W) {
-        float* op = out + (((size_t)b * Ctot + c_begin + ws * CHL) * H + py) * W + px;
+        float* op = out + (((size_t)b * Ctot + c_begin) * H + py) * W + px;
 #pragma unroll
-        for (int c = 0; c < CHL; ++c)
-            if (ws * CHL + c < C)
+        for (int c = 0; c < CH; ++c)
+            if (c < C)
                 *reinterpret_cast<float2*>(op + (size_t)c * plane) = make_float2(acc[c][0].x + acc[c][0].y, acc[c][1].x + acc[c][1].y);
     }
 }
 
-template <int R, int CH, int TYB, int AHEAD, int ABL = 0, int WS = 1, int RSETS = 1>
-__global__ __launch_bounds__((BwdRsCfg<R, CH, TYB>::THREADS * WS * RSETS), (RSETS > 1 ? 4 : 1)) void corr_bwd_rs_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+template <int R, int CH, int TYB, int AHEAD>
+__global__ __launch_bounds__((BwdRsCfg<R, CH, TYB>::THREADS)) void corr_bwd_rs_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                          const float* __restrict__ g, float* __restrict__ gf1,
                                                          float* __restrict__ gf2, int Ctot, int H, int W,
                                                          int tiles_x, int tiles_y, int ngrp, float inv_c) {
     using K = BwdRsCfg<R, CH, TYB>;
-    constexpr int NT = K::THREADS * WS * RSETS, ITER = (CH * K::SC + NT - 1) / NT;
+    constexpr int NT = K::THREADS, ITER = (CH * K::SC + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) float tile[ITER * NT * 4];
-    corr_bwd_rs_body<R, CH, TYB, AHEAD, ABL, WS, RSETS>(tile, xcd_remap(blockIdx.x, gridDim.x), 0, f1, f2, g, gf1, gf2, Ctot, H, W,
-                                                        tiles_x, tiles_y, ngrp, inv_c);
+    corr_bwd_rs_body<R, CH, TYB, AHEAD>(tile, xcd_remap(blockIdx.x, gridDim.x), 0, f1, f2, g, gf1, gf2, Ctot, H, W,
+                                        tiles_x, tiles_y, ngrp, inv_c);
 }
 
 // Mixed tile shapes in one launch: 64x8 tiles over the whole 64-pixel columns of the map and 16x32 tiles over the remaining
@@ -1289,176 +1240,13 @@ int launch_bwd_rs_mixed(const float* f1, const float* f2, const float* g, float*
     return unflow_launch_status();
 }
 
-template <int R, int CH, int TYB, int AHEAD, int ABL = 0, int WS = 1, int RSETS = 1>
+template <int R, int CH, int TYB, int AHEAD>
 int launch_bwd_rs(const float* f1, const float* f2, const float* g, float* gf1, float* gf2,
                   int B, int C, int H, int W, hipStream_t s) {
     using K = BwdRsCfg<R, CH, TYB>;
     const int tx = ceil_div(W, K::TW), ty = ceil_div(H, K::TYB), ngrp = ceil_div(C, CH);
-    UNFLOW_LAUNCH((corr_bwd_rs_kernel<R, CH, TYB, AHEAD, ABL, WS, RSETS>), dim3(tx * ty * B * 2 * ngrp), dim3(K::THREADS * WS * RSETS), 0, s,
+    UNFLOW_LAUNCH((corr_bwd_rs_kernel<R, CH, TYB, AHEAD>), dim3(tx * ty * B * 2 * ngrp), dim3(K::THREADS), 0, s,
                        f1, f2, g, gf1, gf2, C, H, W, tx, ty, ngrp, 1.0f / C);
-    return unflow_launch_status();
-}
-
-// ---------------------------------------------------------------------------------------------
-// Row-streamed backward, two phase-shifted halves per workgroup (round 3).  The kernel above spends its life in two phases
-// that use different parts of the chip -- staging (HBM -> LDS) and arithmetic (VALU + LDS reads; 55 TFLOP/s is what packed
-// fp32 FMAs deliver here, ~40 us for level 2) -- and because a launch starts every workgroup at once and all work items take
-// the same time, the two workgroups of a CU stay in lock-step: everybody stages, then everybody computes (ablations: staging +
-// stores alone 27 us, arithmetic alone 40 us, the kernel 63-67 us).  Here a persistent 512-thread workgroup per CU is two
-// independent halves (4 waves and one 72 KB tile buffer each) that alternate between two slot types,
-//     A: the nine displacement rows of an item          B: store it, stage the next item, wait for it
-// separated by workgroup barriers, with half 1 started one slot late: while one half computes the other one stages, by
-// construction.  The barriers are exactly the two a half needs anyway (tile landed -> first read; last read -> next DMA).
-// A half walks a contiguous run of items, so the items that share gradient planes (channel groups, both gradients of a
-// tile) follow each other on one CU / XCD.
-// ---------------------------------------------------------------------------------------------
-template <int R, int CH, int AHEAD>
-__global__ __launch_bounds__(512) void corr_bwd_rs2_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
-                                                          const float* __restrict__ g, float* __restrict__ gf1,
-                                                          float* __restrict__ gf2, int Ctot, int H, int W,
-                                                          int tiles_x, int tiles_y, int ngrp, int total, int nK, float inv_c) {
-    using K = BwdRsCfg<R, CH, 8>;
-    constexpr int DD = K::DD, LW = K::LW, NCOL = R + 1;
-    __shared__ __attribute__((aligned(16))) float tiles[2 * K::TILE];
-    const int h = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));     // which half (wave-uniform)
-    const int lt = threadIdx.x & 255, wave = lt >> 6;
-    float* tile = tiles + h * K::TILE;
-    const int tx = lt & 31, ty = lt >> 5;
-    const unsigned plane = (unsigned)(H * W);
-    constexpr unsigned kOut = 0x40000000u;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const unsigned rows_addr = (unsigned)(size_t)(lds_cfloat*)(tile + ty * LW + tx * 2);
-    constexpr int PF = (2 * NCOL <= 15) ? 2 : 1;
-    static_assert((K::HALF - 1) * K::SC * 16 + (LW + 2 * R) * 4 < 65536, "ds_read offset field");
-    using Step0 = RsStep<0, CH, PF, R, NCOL, K::SC * 16, K::HALF>;
-
-    // the item this half is working on
-    int mode = 0, b = 0, c_begin = 0, C = 0, x0 = 0, y0 = 0;
-    bool valid = false;
-    auto decode = [&](int k) {
-        int t = (wg * nK + k) * 2 + h;
-        valid = t < total;
-        t = valid ? t : 0;
-        const int cg = t % ngrp; t /= ngrp;
-        mode = t & 1; t >>= 1;
-        const int bx = t % tiles_x; t /= tiles_x;
-        const int by = t % tiles_y;
-        b = t / tiles_y;
-        c_begin = cg * CH;
-        C = min(CH, Ctot - c_begin);
-        x0 = bx * K::TW; y0 = by * K::TYB;
-    };
-    RowWeights<R> w;
-    v2u raw[AHEAD][DD];
-    v2f acc[CH][2];
-
-    auto request_row = [&](v2u (&rw)[DD], int i) {
-        const float* gb = g + (size_t)b * DD * DD * plane;
-        const auto grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gb), 0, (int)((size_t)DD * DD * plane * 4), 0x00020000);
-        const unsigned lane_off = (unsigned)((y0 + ty) * W + x0 + tx * 2) * 4u;
-#pragma unroll
-        for (int j = 0; j < DD; ++j) {
-            const int pl = mode ? (2 * R - i) * DD + (2 * R - j) : i * DD + j;
-            const unsigned uni = (unsigned)pl * plane * 4u + (unsigned)(mode * ((i - R) * W + (j - R)) * 4);
-            rw[j] = __builtin_bit_cast(v2u, __builtin_amdgcn_raw_buffer_load_b64(grs, (int)(lane_off + uni), 0, 0));
-        }
-    };
-    auto take_row = [&](const v2u (&rw)[DD]) {
-#pragma unroll
-        for (int j = 0; j < DD; ++j) w.set(j, __uint_as_float(rw[j].x) * inv_c, __uint_as_float(rw[j].y) * inv_c);
-    };
-    // slot B, second part: the item's F halo tile -> this half's buffer, and its first AHEAD rows of weights
-    auto stage = [&]() {
-        const float* F = mode ? f1 : f2;
-        const float* baseF = F + ((size_t)b * Ctot + c_begin) * plane;
-        const auto frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(baseF), 0, (int)((size_t)C * plane * 4), 0x00020000);
-#pragma unroll
-        for (int it = 0; it < K::ITER; ++it) {
-            const int s_ = it * 256 + lt;
-            const int c = s_ / K::SC;
-            const int r = s_ - c * K::SC;
-            const int ly = r / (LW / 4);
-            const int gy = y0 - R + ly, gx = x0 - R + (r - ly * (LW / 4)) * 4;
-            const bool in = (c < CH) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
-            const unsigned off = in ? ((unsigned)c * plane + (unsigned)(gy * W + gx)) * 4u : kOut;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(frs, (lds_ptr)(tile + (it * 256 + wave * 64) * 4), 16, (int)off, 0, 0, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < AHEAD; ++k) request_row(raw[k], min(k, DD - 1));
-    };
-    auto landed = [&]() {        // this wave's pieces of the tile are in LDS (the AHEAD rows of weights behind them may still fly)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * DD > 63 ? 63 : AHEAD * DD) : "memory");
-    };
-    // slot A
-    auto compute = [&]() {
-#pragma unroll
-        for (int c = 0; c < CH; ++c) { acc[c][0] = v2f{0.f, 0.f}; acc[c][1] = v2f{0.f, 0.f}; }
-#pragma unroll 1
-        for (int i0 = 0; i0 < DD; i0 += AHEAD) {
-#pragma unroll
-            for (int k = 0; k < AHEAD; ++k) {
-                const int i = i0 + k;
-                if (DD % AHEAD != 0 && i >= DD) break;
-                take_row(raw[k]);
-                __builtin_amdgcn_sched_barrier(0);
-                request_row(raw[k], min(i + AHEAD, DD - 1));
-                __builtin_amdgcn_sched_barrier(0);
-                const unsigned a_lo = rows_addr + (unsigned)(i * LW * 4);
-                const unsigned a_hi = a_lo + (unsigned)(K::HALF * K::SC * 16);
-                v2f row[PF + 1][NCOL];
-                Step0::template load<0>(row, a_lo, a_hi);
-                if constexpr (PF > 1) Step0::template load<1>(row, a_lo, a_hi);
-                Step0::run(w, acc, row, a_lo, a_hi);
-            }
-        }
-    };
-    // slot B, first part
-    auto store = [&]() {
-        const int px = x0 + tx * 2, py = y0 + ty;
-        if (py < H && px < W) {
-            float* out = mode ? gf2 : gf1;
-            float* op = out + (((size_t)b * Ctot + c_begin) * H + py) * W + px;
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-                if (c < C)
-                    *reinterpret_cast<float2*>(op + (size_t)c * plane) = make_float2(acc[c][0].x + acc[c][0].y, acc[c][1].x + acc[c][1].y);
-        }
-    };
-
-    // Both halves execute exactly 2 nK barriers:
-    //   half 0:  B0 | A0 | B1 | A1 | ... | A(nK-1) | (store)          half 1:  (issue) | (wait) | A0 | B1 | ... | A(nK-1), store
-    decode(0);
-    if (valid) stage();
-    if (h == 0) landed();
-    __builtin_amdgcn_s_barrier();
-    if (h == 1) { landed(); __builtin_amdgcn_s_barrier(); }
-#pragma unroll 1
-    for (int k = 0; k < nK; ++k) {
-        if (valid) compute();
-        if (k + 1 < nK) {
-            __builtin_amdgcn_s_barrier();            // every wave of this half is done reading the tile
-            if (valid) store();
-            decode(k + 1);
-            if (valid) stage();
-            landed();
-            __builtin_amdgcn_s_barrier();            // the next tile has landed for all four waves
-        } else {
-            if (h == 0) __builtin_amdgcn_s_barrier();    // pairs with half 1's barrier in front of its last A
-            if (valid) store();
-        }
-    }
-}
-
-template <int R, int CH, int AHEAD>
-int launch_bwd_rs2(const float* f1, const float* f2, const float* g, float* gf1, float* gf2,
-                   int B, int C, int H, int W, hipStream_t s) {
-    using K = BwdRsCfg<R, CH, 8>;
-    const int tx = ceil_div(W, K::TW), ty = ceil_div(H, K::TYB), ngrp = ceil_div(C, CH);
-    const int total = tx * ty * B * 2 * ngrp, pairs = ceil_div(total, 2);
-    const int G = pairs < 256 ? pairs : 256;                  // one persistent workgroup per CU
-    const int nK = ceil_div(pairs, G);
-    UNFLOW_LAUNCH((corr_bwd_rs2_kernel<R, CH, AHEAD>), dim3(G), dim3(512), 0, s,
-                       f1, f2, g, gf1, gf2, C, H, W, tx, ty, ngrp, total, nK, 1.0f / C);
     return unflow_launch_status();
 }
 
@@ -1691,6 +1479,27 @@ static inline int forced_groups() { return 0; }
 
 static inline bool mid_size(int variant) { return variant == 9 || variant == 12 || variant == 13; }   // levels 3, 4
 
+// The backward on the matrix cores (corr_mfma.h): 0 = where it measured faster (d = 8), 1 = never (fp32 kernels, bit-identical to
+// rounds 1-4), 2 = wherever the shape is served (d = 4 too).  Process-wide, read once per call.
+static std::atomic<int> g_bwd_mfma_mode{0};
+static bool mfma_served(const float* f1, const float* f2, const float* g, const float* gf1, const float* gf2, int B, int C, int H, int W, int R) {
+    return (W & 3) == 0 && (C & 15) == 0 && (long)B * H * W >= 8192 && W >= 16 && H >= 4 * R      // (level 4 at d = 8, 16 rows: 50 us against 47 for the fp32 kernel)
+           && ((((size_t)f1 | (size_t)f2 | (size_t)g | (size_t)gf1 | (size_t)gf2) & 15) == 0) && mf_offsets_fit(C, H, W, R);
+}
+// rows per wave (tools/microbench.py corr_bwd_mf, rows sweep on the tuning library): the halo steps of a chunk cost loads but no row
+// pairs, and the fastest launch is the one with about one wave per SIMD at d = 8 (412 registers: one wave per SIMD fits) and one and
+// a half at d = 4 -- level 2 / 3 of 832x256 at d = 8: 32 / 16 rows (150 / 85 us; 194 / 130 with the next size), d = 4: 16 / 8 rows
+static int mfma_rows(int B, int C, int H, int W, int NCG, int R) {
+#ifdef UNFLOW_TUNING
+    if (getenv("UNFLOW_CORR_MF_ROWS")) return atoi(getenv("UNFLOW_CORR_MF_ROWS"));
+#endif
+    const long cols = (long)B * 2 * ceil_div(W, 16) * ceil_div(C, 16 * NCG);
+    const long want = R > 4 ? 768 : 1536;
+    int rows = 32;
+    while (rows > 8 && cols * ceil_div(H, rows) < want) rows >>= 1;
+    return rows;
+}
+
 static int pick_variant(int B, int C, int H, int W) {
     const int f = forced_variant();
     if (f) return f;
@@ -1775,6 +1584,10 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
         case 2: return launch_bwd<2, 2, 5, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
         case 4: {
                 variant = pick_variant(B, C, H, W);
+                // matrix-core form (corr_mfma.h): at d = 4 level 2 it measures level with the fp32 row-streamed kernel back to back
+                // (59 vs 57 us), so it is taken only on request (unflow_corr_set_backward(2))
+                if (g_bwd_mfma_mode.load(std::memory_order_relaxed) == 2 && mfma_served(f1, f2, gcv, gf1, gf2, B, C, H, W, 4))
+                    return launch_bwd_mf<4, 2, 1, true>(f1, f2, gcv, gf1, gf2, B, C, H, W, mfma_rows(B, C, H, W, 2, 4), s);
                 const bool ring_ok = (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0)     // LDS-DMA moves aligned 16-byte pieces
                                      && gs_offsets_fit(C, H, W, 4);
                 const int fb = forced_bwd();
@@ -1783,35 +1596,6 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 // 4 groups: 20 us; more groups than that only repeat the upstream-gradient gather)
                 const int items = ceil_div(W, 64) * ceil_div(H, 8) * B * 2;
                 int groups = forced_groups() ? forced_groups() : (items >= 256 ? 1 : 256 / items);
-#ifdef UNFLOW_TUNING
-                // row-streamed variants for tools/microbench.py corr_bwd_rs (UNFLOW_CORR_BWD): 7 / 9 prefetch depth 3 / 1, 8 / 11 eight channels
-                // per item, 10 16 x 32 tiles, 12-14 the two-half phase-shifted form, 15-17 wave sets sharing a tile, 21-29 phase ablations
-                if (ring_ok && fb == 7) return launch_bwd_rs<4, 16, 8, 3>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                if (ring_ok && fb == 8) return launch_bwd_rs<4, 8, 8, 3>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                if (ring_ok && fb == 9) return launch_bwd_rs<4, 16, 8, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                if (ring_ok && fb == 10) return launch_bwd_rs<4, 16, 32, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                if (ring_ok && fb == 11) return launch_bwd_rs<4, 8, 8, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                if (ring_ok && fb == 12) return launch_bwd_rs2<4, 16, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                if (ring_ok && fb == 15) return launch_bwd_rs<4, 16, 8, 1, 0, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                if (ring_ok && fb == 16) return launch_bwd_rs<4, 16, 8, 2, 0, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                if (ring_ok && fb == 17) return launch_bwd_rs<4, 32, 8, 1, 0, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                if (ring_ok && fb == 13) return launch_bwd_rs2<4, 16, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                if (ring_ok && fb == 33 && W % 64 > 0 && W % 64 <= 48 && W >= 64 && H >= 32) return launch_bwd_rs_mixed<4, 16, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                if (ring_ok && fb == 18) return launch_bwd_rs<4, 16, 16, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);      // 64 x 16 tiles, one 8-wave workgroup per CU
-                if (ring_ok && fb == 19) return launch_bwd_rs<4, 16, 8, 1, 0, 1, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // two wave sets split the displacement rows
-                if (ring_ok && fb == 20) return launch_bwd_rs<4, 16, 8, 2, 0, 1, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                if (ring_ok && fb == 14) return launch_bwd_rs2<4, 16, 3>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-                if (ring_ok && fb == 21) return launch_bwd_rs<4, 16, 8, 1, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // no LDS reads
-                if (ring_ok && fb == 22) return launch_bwd_rs<4, 16, 8, 1, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // no FMAs
-                if (ring_ok && fb == 24) return launch_bwd_rs<4, 16, 8, 1, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // no weight loads
-                if (ring_ok && fb == 23) return launch_bwd_rs<4, 16, 8, 1, 3>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // neither reads nor FMAs
-                if (ring_ok && fb == 27) return launch_bwd_rs<4, 16, 8, 1, 7>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // staging + stores only
-                if (ring_ok && fb == 28) return launch_bwd_rs<4, 16, 8, 1, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // register staging
-                if (ring_ok && fb == 29) return launch_bwd_rs<4, 16, 8, 1, 15>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);  // register staging + stores only
-#endif
-                if (ring_ok && fb == 1) return launch_bwd_gs<4, 2, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, groups, s);
-                if (ring_ok && fb == 3) return launch_bwd_gs<4, 2, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, groups, s);
-                if (ring_ok && fb == 5) return launch_bwd_gs<4, 4, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, groups, s);
                 // group-split ring kernel, 64x8 tiles, 4 channels per stage: levels 2-4 (83 / 35 / 20 us; the tile kernel
                 // with all 81 gradients per lane takes 107 us at level 2)
                 // (measured and dropped: a persistent form -- 256 workgroups walking 4 items each, the next tile's gradient
@@ -1840,9 +1624,6 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 }
                 if (ring_ok && fb == 4)
                     return launch_bwd_gs<4, 4, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, groups, s);
-#ifdef UNFLOW_TUNING
-                if (ring_ok && fb == 32) return launch_bwd_rs<4, 16, 32, 2>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);   // (tuning: 16 x 32 tiles)
-#endif
                 if (fb == 6 || variant == 1 || variant == 7) return launch_bwd<4, 2, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (variant == 2 || variant == 3 || (mid_size(variant) && (long)B * H * W >= 32768))
                     return launch_bwd<4, 1, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
@@ -1854,13 +1635,13 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 break;
         }
         case 8: variant = pick_variant(B, C, H, W);
+                // round 5: banded bf16x3 products on the matrix cores: level 2 149 us against 271 for the fp32 row-streamed kernel
+                // (tools/proto/corr_bwd_mfma.hip); ~4e-6 of the largest gradient away from the fp32 sums
+                if (g_bwd_mfma_mode.load(std::memory_order_relaxed) != 1 && mfma_served(f1, f2, gcv, gf1, gf2, B, C, H, W, 8))
+                    return launch_bwd_mf<8, 2, 2, true>(f1, f2, gcv, gf1, gf2, B, C, H, W, mfma_rows(B, C, H, W, 2, 8), s);
                 if (variant == 4 || (long)B * H * W < 8192) break;      // small maps: one lane per element (117 / 57 us at levels 5 / 6, tile kernel 283 / 378)
                 if ((variant == 7 || mid_size(variant)) && (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0) && gs_offsets_fit(C, H, W, 8)) {
                     // round 3: row-streamed, 8 channels per item: 290 / 117 / 49 us at levels 2 / 3 / 4 (group-split ring kernel 343 / 129 / 85)
-#ifdef UNFLOW_TUNING
-                    if (forced_bwd() == 4) return launch_bwd_gs<8, 1, 4>(f1, f2, gcv, gf1, gf2, B, C, H, W, 1, s);
-                    if (forced_bwd() == 8) return launch_bwd_rs<8, 4, 8, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
-#endif
                     return launch_bwd_rs<8, 8, 8, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 }
                 return launch_bwd<8, 1, 6, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
@@ -1870,4 +1651,9 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
     const int blocks = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
     UNFLOW_LAUNCH(corr_bwd_generic, dim3(blocks), dim3(256), 0, s, f1, f2, gcv, gf1, gf2, B, C, H, W, d, 1.0f / C);
     return unflow_launch_status();
+}
+
+extern "C" int unflow_corr_set_backward(int mode) {
+    if (mode < 0 || mode > 2) return UNFLOW_EINVAL;
+    return g_bwd_mfma_mode.exchange(mode, std::memory_order_relaxed);
 }

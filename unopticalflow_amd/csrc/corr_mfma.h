@@ -24,6 +24,7 @@
 // (r, x' + j - R), as the fp32 kernels do; outside the image F is an exact 0, so those weights need no validity test.
 // Results are deterministic (no atomics) but not bit-identical to the fp32 kernels.
 #pragma once
+#define UNFLOW_CORR_MFMA_INCLUDED 1
 #include "corr_ring.h"
 
 namespace {

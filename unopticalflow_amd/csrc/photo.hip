@@ -664,6 +664,66 @@ extern "C" int unflow_partials_per_sample(int H, int W) {
     return 2 * (m > sm ? m : sm);     // floats per sample (K = 2 everywhere)
 }
 
+// ---- the second stage of several per-sample reductions in ONE launch (round 5): a forward entry called with loss == NULL stops after
+// its partial sums; this finishes up to LOSS_JOBS of them -- a block = one (job, sample), summed exactly like the entry's own second
+// stage (same sum_partials, same divisions): same bits.  kind 0: loss = (s0 / n0) / (s1 / n1 + 1e-12), sums = {s0, s1} (masked mean,
+// SSIM loss, consistency); kind 1: loss = (s0 / n0 + s1 / n1) / 2 (second-order smoothness).
+constexpr int LOSS_JOBS = 16;
+struct LossJob { const float* partials; float* loss; float* sums; int nblk, B, kind; float n0, n1; };
+struct LossBatch { LossJob job[LOSS_JOBS]; };
+__global__ __launch_bounds__(256) void loss_finalize_batch_kernel(LossBatch batch, int njobs) {
+    __shared__ float red[4];
+    int b = blockIdx.x, k = 0;
+    while (k < njobs - 1 && b >= batch.job[k].B) { b -= batch.job[k].B; ++k; }      // (block-uniform)
+    const LossJob j = batch.job[k];
+    const float* p = j.partials + (size_t)b * j.nblk * 2;
+    const float s0 = sum_partials(p, j.nblk, 2, 0, red);
+    const float s1 = sum_partials(p, j.nblk, 2, 1, red);
+    if (threadIdx.x == 0) {
+        if (j.kind == 0) {
+            j.loss[b] = (s0 / j.n0) / (s1 / j.n1 + 1e-12f);
+            if (j.sums) { j.sums[b * 2] = s0; j.sums[b * 2 + 1] = s1; }
+        } else {
+            j.loss[b] = (s0 / j.n0 + s1 / j.n1) / 2.0f;
+        }
+    }
+}
+
+int unflow_ssim_loss_blocks(int H, int W, int fast);      // ssim.hip
+
+extern "C" int unflow_loss_partial_blocks(int op, int H, int W, int B, int aligned) {
+    if (H <= 0 || W <= 0 || B <= 0) return UNFLOW_EINVAL;
+    switch (op) {
+        case 0: case 3: return ceil_div(H * W, TILE);                                   // masked mean, consistency
+        case 1: return unflow_ssim_loss_blocks(H, W, aligned);                          // SSIM loss
+        case 2:
+#ifdef UNFLOW_TUNING
+            if (getenv("UNFLOW_SMOOTH_OLD") != nullptr) return ceil_div(H * W, TILE);
+#endif
+            return B <= 65535 ? ceil_div(W, SM_TW) * ceil_div(H, SM_TH) : ceil_div(H * W, TILE);    // smoothness
+        default: return UNFLOW_EINVAL;
+    }
+}
+
+extern "C" int unflow_loss_finalize_batch(const void* const* partials, void* const* loss, void* const* sums, const int* nblk,
+                                          const int* B, const int* kind, const float* n0, const float* n1, int njobs, void* stream) {
+    UNFLOW_REQUIRE(partials && loss && sums && nblk && B && kind && n0 && n1 && njobs > 0);
+    hipStream_t s = (hipStream_t)stream;
+    for (int first = 0; first < njobs; first += LOSS_JOBS) {
+        LossBatch batch;
+        const int n = njobs - first < LOSS_JOBS ? njobs - first : LOSS_JOBS;
+        int blocks = 0;
+        for (int k = 0; k < n; ++k) {
+            const int q = first + k;
+            UNFLOW_REQUIRE(partials[q] && loss[q] && nblk[q] > 0 && B[q] > 0 && (kind[q] == 0 || kind[q] == 1));
+            batch.job[k] = LossJob{(const float*)partials[q], (float*)loss[q], (float*)sums[q], nblk[q], B[q], kind[q], n0[q], n1[q]};
+            blocks += B[q];
+        }
+        UNFLOW_LAUNCH(loss_finalize_batch_kernel, dim3(blocks), dim3(256), 0, s, batch, n);
+    }
+    return unflow_launch_status();
+}
+
 extern "C" int unflow_occ_weight_fwd(const float* img, const float* from_l, const float* from_r,
                                      float* diff_l, float* diff_r, float* w_bwd, float* w_fwd,
                                      uint8_t* valid_bwd, uint8_t* valid_fwd, int B, int H, int W, void* stream) {
@@ -685,12 +745,13 @@ extern "C" int unflow_absdiff_bwd(const float* img, const float* from, const flo
 
 extern "C" int unflow_masked_mean_fwd(const float* diff, const float* w, float* loss, float* sums,
                                       float* partials, int B, int H, int W, void* stream) {
-    UNFLOW_REQUIRE(diff && w && loss && sums && partials && B > 0 && H > 0 && W > 0);
+    UNFLOW_REQUIRE(diff && w && (loss == nullptr || sums) && partials && B > 0 && H > 0 && W > 0);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = ceil_div(H * W, TILE);
     UNFLOW_LAUNCH(masked_mean_partial_kernel, dim3(nblk, B), dim3(256), 0, s, diff, w, partials, H * W);
-    UNFLOW_LAUNCH(ratio_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, sums,
-                       (float)H * (float)W, (float)H * (float)W);
+    if (loss)                                            // (NULL: the caller finishes the sums later, unflow_loss_finalize_batch)
+        UNFLOW_LAUNCH(ratio_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, sums,
+                           (float)H * (float)W, (float)H * (float)W);
     return unflow_launch_status();
 }
 
@@ -705,7 +766,7 @@ extern "C" int unflow_masked_mean_bwd(const float* w, const float* sums, const f
 
 extern "C" int unflow_smooth2_fwd(const float* flow, const float* img, float* loss, float* partials,
                                   int B, int H, int W, int img_batch, void* stream) {
-    UNFLOW_REQUIRE(flow && img && loss && partials && B > 0 && H > 0 && W > 0 && img_batch > 0 && B % img_batch == 0);
+    UNFLOW_REQUIRE(flow && img && partials && B > 0 && H > 0 && W > 0 && img_batch > 0 && B % img_batch == 0);
     hipStream_t s = (hipStream_t)stream;
 #ifdef UNFLOW_TUNING
     const bool per_pixel = getenv("UNFLOW_SMOOTH_OLD") != nullptr;      // A/B against the per-pixel form (tools/probes/loss_kernel_times.py)
@@ -715,12 +776,12 @@ extern "C" int unflow_smooth2_fwd(const float* flow, const float* img, float* lo
     if (!per_pixel && B <= 65535) {
         const dim3 grid(ceil_div(W, SM_TW), ceil_div(H, SM_TH), B);
         UNFLOW_LAUNCH(smooth2_fwd_tile_kernel, grid, dim3(256), 0, s, flow, img, partials, H, W, img_batch);
-        UNFLOW_LAUNCH(smooth2_finalize_kernel, dim3(B), dim3(256), 0, s, partials, (int)(grid.x * grid.y), loss, H, W);
+        if (loss) UNFLOW_LAUNCH(smooth2_finalize_kernel, dim3(B), dim3(256), 0, s, partials, (int)(grid.x * grid.y), loss, H, W);
         return unflow_launch_status();
     }
     const int nblk = ceil_div(H * W, TILE);
     UNFLOW_LAUNCH(smooth2_partial_kernel, dim3(nblk, B), dim3(256), 0, s, flow, img, partials, H, W, img_batch);
-    UNFLOW_LAUNCH(smooth2_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, H, W);
+    if (loss) UNFLOW_LAUNCH(smooth2_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, H, W);
     return unflow_launch_status();
 }
 
@@ -752,13 +813,14 @@ extern "C" int unflow_smooth2_bwd(const float* flow, const float* img, const flo
 
 extern "C" int unflow_consis_fwd(const float* fwd_flow, const float* bwd_flow, const float* w_fwd, float* loss,
                                  float* sums, float* partials, int B, int H, int W, void* stream) {
-    UNFLOW_REQUIRE(fwd_flow && bwd_flow && w_fwd && loss && sums && partials && B > 0 && H > 0 && W > 0);
+    UNFLOW_REQUIRE(fwd_flow && bwd_flow && w_fwd && (loss == nullptr || sums) && partials && B > 0 && H > 0 && W > 0);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = ceil_div(H * W, TILE);
     UNFLOW_LAUNCH(consis_partial_kernel, dim3(nblk, B), dim3(256), 0, s, fwd_flow, bwd_flow, w_fwd, partials,
                        H * W);
-    UNFLOW_LAUNCH(ratio_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, sums,
-                       2.0f * (float)H * (float)W, (float)H * (float)W);
+    if (loss)
+        UNFLOW_LAUNCH(ratio_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, sums,
+                           2.0f * (float)H * (float)W, (float)H * (float)W);
     return unflow_launch_status();
 }
 

@@ -623,7 +623,7 @@ int unflow_ssim_blocks(int H, int W) {
 
 extern "C" int unflow_ssim_loss_fwd(const float* img, const float* warped, const float* w, float* loss,
                                     float* sums, float* partials, int B, int H, int W, int img_batch, void* stream) {
-    UNFLOW_REQUIRE(img && warped && w && loss && sums && partials && B > 0 && H > 0 && W > 0 && img_batch > 0 && B % img_batch == 0);
+    UNFLOW_REQUIRE(img && warped && w && (loss == nullptr || sums) && partials && B > 0 && H > 0 && W > 0 && img_batch > 0 && B % img_batch == 0);
     hipStream_t s = (hipStream_t)stream;
     int nblk;
     if (ssim2_ok(img, warped, w, w, W)) {
@@ -639,8 +639,14 @@ extern "C" int unflow_ssim_loss_fwd(const float* img, const float* warped, const
         UNFLOW_LAUNCH((ssim_fwd_kernel<3, true, false>), dim3(nblk, B), dim3(256), 0, s, img, warped, w,
                            (float*)nullptr, partials, H, W, img_batch);
     }
-    UNFLOW_LAUNCH(ssim_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, sums, H, W);
+    if (loss)                                            // (NULL: the caller finishes the sums later, unflow_loss_finalize_batch)
+        UNFLOW_LAUNCH(ssim_finalize_kernel, dim3(B), dim3(256), 0, s, partials, nblk, loss, sums, H, W);
     return unflow_launch_status();
+}
+
+// partial sums per sample that unflow_ssim_loss_fwd writes (fast: even width and 8-byte aligned tensors -> the column-pair kernel)
+int unflow_ssim_loss_blocks(int H, int W, int fast) {
+    return (fast && W % 2 == 0) ? ssim2_blocks(H, W) : ceil_div(strips(W, 1) * chunks(H), 4);
 }
 
 extern "C" int unflow_ssim_loss_bwd(const float* img, const float* warped, const float* w, const float* sums,

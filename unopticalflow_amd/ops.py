@@ -212,6 +212,72 @@ class _DeferredBiasGrads:
 deferred_bias_grads = _DeferredBiasGrads()
 
 
+class _DeferredLossSums:
+    """The second stage of the loss reductions of a forward pass as ONE launch.
+
+    Masked mean, SSIM loss, smoothness and consistency (model_flow_paper.py:90-99, 137-195) each end in a per-sample reduction of two
+    stages -- partial sums per workgroup, then one workgroup per sample adds them in a fixed order: 12 such second stages per train
+    step (4 losses x 3 scales), ~4-10 us each for a few KB.  Inside ``with ops.deferred_loss_sums:`` the forward ops stop after the
+    first stage (C ABI: loss == NULL) and register the job; ``flush()`` finishes all of them with one
+    ``unflow_loss_finalize_batch`` launch -- same summation order, same divisions, same bits.  ``loss_combine`` and
+    ``weighted_mean_sum`` (the only readers of the per-scale losses in Model_flow.forward) flush first, leaving the block flushes too.
+    OPT-IN: a caller that reads a loss tensor inside the block by other means must call ``flush()`` itself."""
+
+    def __init__(self):
+        self.enabled = False
+        self.jobs = []                 # (partials, loss, sums or None, nblk, B, kind, n0, n1, device): tensors kept alive until the flush
+        self._depth = 0
+        self.launches = 0
+
+    def __enter__(self):
+        self._depth += 1
+        self.enabled = True
+        return self
+
+    def __exit__(self, *exc):
+        self._depth -= 1
+        if self._depth == 0:
+            self.enabled = False
+            self.flush()
+        return False
+
+    def add(self, partials, loss, sums, op, H, W, kind, n0, n1, aligned=True):
+        B = loss.shape[0]
+        nblk = _lib.load().unflow_loss_partial_blocks(op, H, W, B, 1 if aligned else 0)
+        if nblk <= 0:
+            raise RuntimeError('unflow_loss_partial_blocks(%d, %d, %d) failed' % (op, H, W))
+        self.jobs.append((partials, loss, sums, nblk, B, kind, float(n0), float(n1), loss.device))
+
+    def flush(self):
+        jobs, self.jobs = self.jobs, []
+        by_dev = {}
+        for j in jobs:
+            by_dev.setdefault(j[8], []).append(j)
+        for dev, js in by_dev.items():
+            n = len(js)
+            P = (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in js])
+            L = (ctypes.c_void_p * n)(*[j[1].data_ptr() for j in js])
+            S = (ctypes.c_void_p * n)(*[None if j[2] is None else j[2].data_ptr() for j in js])
+            N_ = (ctypes.c_int * n)(*[j[3] for j in js])
+            B_ = (ctypes.c_int * n)(*[j[4] for j in js])
+            K_ = (ctypes.c_int * n)(*[j[5] for j in js])
+            A_ = (ctypes.c_float * n)(*[j[6] for j in js])
+            C_ = (ctypes.c_float * n)(*[j[7] for j in js])
+            with _on(dev):
+                _call('unflow_loss_finalize_batch', P, L, S, N_, B_, K_, A_, C_, n, _stream(),
+                      nbytes=4 * sum(j[3] * j[4] * 2 + 3 * j[4] for j in js), shape=(n,))
+            self.launches += 1
+
+
+deferred_loss_sums = _DeferredLossSums()
+
+
+def _f32(x):
+    """x rounded to fp32 (the second-stage kernels take their divisors as C floats computed in fp32)."""
+    import struct
+    return struct.unpack('f', struct.pack('f', x))[0]
+
+
 def _finish_bias_grad(partials, gbias, n, C, mode):
     """-> the gbias pointer to hand to a backward entry point: NULL (and the job registered) when the reduction is deferred."""
     if deferred_bias_grads.enabled and _in_backward():
@@ -260,6 +326,20 @@ class _Corr(torch.autograd.Function):
             _call('unflow_corr_bwd', _ptr(f1), _ptr(f2), _ptr(g), _ptr(gf1), _ptr(gf2), B, C, H, W, ctx.d,
                   _stream(), nbytes=4 * B * H * W * (4 * C + (2 * ctx.d + 1) ** 2), shape=(B, C, H, W))
         return gf1, gf2, None
+
+
+CORR_BACKWARD_MODES = {'auto': 0, 'fp32': 1, 'mfma': 2}
+
+
+def set_corr_backward(mode):
+    """Which arithmetic the cost-volume backward uses where two exist (unflow_corr_set_backward; process-wide): 'auto' = the
+    matrix-core form (banded bf16 hi/lo split products, fp32 accumulation; ~4e-6 of the largest gradient away from the fp32 sums,
+    deterministic) where it measured faster (d = 8); 'fp32' = the fp32 FMA kernels everywhere; 'mfma' = the matrix-core form
+    wherever the shape is served.  Returns the previous mode's name."""
+    prev = _lib.load().unflow_corr_set_backward(CORR_BACKWARD_MODES[mode])
+    if prev < 0:
+        raise ValueError(mode)
+    return {v: k for k, v in CORR_BACKWARD_MODES.items()}[prev]
 
 
 def corr(input1, input2, d=4):
@@ -507,9 +587,14 @@ class _MaskedMean(torch.autograd.Function):
         B, _, H, W = diff.shape
         loss = torch.empty(B, dtype=torch.float32, device=dev)
         sums = torch.empty((B, 2), dtype=torch.float32, device=dev)
+        part = _partials(B, H, W, dev)
+        later = deferred_loss_sums.enabled
         with _on(dev):
-            _call('unflow_masked_mean_fwd', _ptr(diff), _ptr(w), _ptr(loss), _ptr(sums),
-                  _ptr(_partials(B, H, W, dev)), B, H, W, _stream(), nbytes=4 * B * H * W * 2, shape=(B, 1, H, W))       # reads diff, w
+            _call('unflow_masked_mean_fwd', _ptr(diff), _ptr(w), None if later else _ptr(loss), _ptr(sums),
+                  _ptr(part), B, H, W, _stream(), nbytes=4 * B * H * W * 2, shape=(B, 1, H, W))       # reads diff, w
+        if later:
+            hw = _f32(float(H) * float(W))
+            deferred_loss_sums.add(part, loss, sums, 0, H, W, 0, hw, hw)
         ctx.save_for_backward(w, sums)
         return loss
 
@@ -538,9 +623,15 @@ class _SsimLoss(torch.autograd.Function):
         assert C == 3 and B % img.shape[0] == 0 and w.shape[0] == B
         loss = torch.empty(B, dtype=torch.float32, device=dev)
         sums = torch.empty((B, 2), dtype=torch.float32, device=dev)
+        part = _partials(B, H, W, dev)
+        later = deferred_loss_sums.enabled
         with _on(dev):
-            _call('unflow_ssim_loss_fwd', _ptr(img), _ptr(warped), _ptr(w), _ptr(loss), _ptr(sums),
-                  _ptr(_partials(B, H, W, dev)), B, H, W, img.shape[0], _stream(), nbytes=4 * B * H * W * 7, shape=(B, 3, H, W))
+            _call('unflow_ssim_loss_fwd', _ptr(img), _ptr(warped), _ptr(w), None if later else _ptr(loss), _ptr(sums),
+                  _ptr(part), B, H, W, img.shape[0], _stream(), nbytes=4 * B * H * W * 7, shape=(B, 3, H, W))
+        if later:
+            hw = _f32(float(H) * float(W))
+            aligned = ((img.data_ptr() | warped.data_ptr() | w.data_ptr()) & 7) == 0
+            deferred_loss_sums.add(part, loss, sums, 1, H, W, 0, _f32(3.0 * hw), hw, aligned)
         ctx.save_for_backward(img, warped, w, sums)
         return loss
 
@@ -606,9 +697,15 @@ class _Smooth2(torch.autograd.Function):
         B, _, H, W = flow.shape                        # img may hold fewer samples: sample b pairs with image b % len(img)
         assert B % img.shape[0] == 0
         loss = torch.empty(B, dtype=torch.float32, device=dev)
+        part = _partials(B, H, W, dev)
+        later = deferred_loss_sums.enabled
         with _on(dev):
-            _call('unflow_smooth2_fwd', _ptr(flow), _ptr(img), _ptr(loss), _ptr(_partials(B, H, W, dev)),
+            _call('unflow_smooth2_fwd', _ptr(flow), _ptr(img), None if later else _ptr(loss), _ptr(part),
                   B, H, W, img.shape[0], _stream(), nbytes=4 * H * W * (2 * B + 3 * img.shape[0]), shape=(B, 2, H, W))   # reads flow and the images once
+        if later:
+            nx = _f32(_f32(2.0 * float(H)) * float(W - 2))
+            ny = _f32(_f32(2.0 * float(H - 2)) * float(W))
+            deferred_loss_sums.add(part, loss, None, 2, H, W, 1, nx, ny)
         ctx.save_for_backward(flow, img)
         return loss
 
@@ -636,9 +733,14 @@ class _Consis(torch.autograd.Function):
         B, _, H, W = ff.shape
         loss = torch.empty(B, dtype=torch.float32, device=dev)
         sums = torch.empty((B, 2), dtype=torch.float32, device=dev)
+        part = _partials(B, H, W, dev)
+        later = deferred_loss_sums.enabled
         with _on(dev):
-            _call('unflow_consis_fwd', _ptr(ff), _ptr(fb), _ptr(w), _ptr(loss), _ptr(sums),
-                  _ptr(_partials(B, H, W, dev)), B, H, W, _stream(), nbytes=4 * B * H * W * 5, shape=(B, 2, H, W))       # reads both flows and the weight
+            _call('unflow_consis_fwd', _ptr(ff), _ptr(fb), _ptr(w), None if later else _ptr(loss), _ptr(sums),
+                  _ptr(part), B, H, W, _stream(), nbytes=4 * B * H * W * 5, shape=(B, 2, H, W))       # reads both flows and the weight
+        if later:
+            hw = _f32(float(H) * float(W))
+            deferred_loss_sums.add(part, loss, sums, 3, H, W, 0, _f32(2.0 * hw), hw)
         ctx.save_for_backward(ff, fb, w, sums)
         return loss
 
@@ -666,6 +768,7 @@ def _ptr_array(tensors):
 class _LossCombine(torch.autograd.Function):
     @staticmethod
     def forward(ctx, n, B, *terms):
+        deferred_loss_sums.flush()                     # the per-scale losses are read here
         dev = _dev(*terms)
         terms = [t.contiguous() for t in terms]
         outs = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(4)]
@@ -706,6 +809,7 @@ def loss_combine(pixel, ssim, smooth, consis):
 class _WeightedMeanSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weights, *terms):
+        deferred_loss_sums.flush()                     # (a caller that skipped loss_combine reads the losses here)
         dev = _dev(*terms)
         terms = [t.contiguous() for t in terms]
         K, B = len(terms), terms[0].shape[0]
