@@ -88,10 +88,35 @@ def test_dma_ring_kernels_do_not_spill():
     assert len(names) == len(scratch) and names
     checked = 0
     for n, s in zip(names, scratch):
-        if 'ring_kernel' in n or 'ring_mixed_kernel' in n or 'gs_kernel' in n or 'rs_kernel' in n or 'rs2_kernel' in n or 'rs_mixed_kernel' in n:      # (row-streamed backward: counted vmcnt behind its LDS-DMA too)
+        if 'ring_kernel' in n or 'ring_mixed_kernel' in n or 'gs_kernel' in n or 'rs_kernel' in n or 'rs_mixed_kernel' in n or 'mf_kernel' in n:      # (row-streamed backward: counted vmcnt behind its LDS-DMA too; matrix-core backward: two request sets in flight)
             assert s == 0, (n, s)
             checked += 1
     assert checked >= 3      # ring<9 rows>, ring<3 rows>, group-split backward
+
+
+def test_round5_host_entry_points_without_gpu():
+    """The host-only entry points of ABI 10: the backward-arithmetic switch returns the previous mode and rejects unknown ones; the
+    partial-sum counts that ``unflow_loss_finalize_batch`` jobs are described with follow the kernels' tilings (masked mean /
+    consistency: 2048 pixels per workgroup; smoothness: 64 x 8 tiles; SSIM loss: 124-column strips x 8- or 16-row chunks when every
+    tensor is 8-byte aligned and the width even) and never exceed the scratch ``unflow_partials_per_sample`` sizes."""
+    from unopticalflow_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    assert lib.unflow_corr_set_backward(2) == 0 and lib.unflow_corr_set_backward(1) == 2 and lib.unflow_corr_set_backward(0) == 1
+    assert lib.unflow_corr_set_backward(3) == -22 and lib.unflow_corr_set_backward(-1) == -22 and lib.unflow_corr_set_backward(0) == 0
+    cdiv = lambda a, b: (a + b - 1) // b
+    for H, W in ((256, 832), (128, 416), (64, 208), (33, 57), (448, 1024), (1, 1)):
+        per_sample = lib.unflow_partials_per_sample(H, W) // 2
+        assert lib.unflow_loss_partial_blocks(0, H, W, 16, 1) == lib.unflow_loss_partial_blocks(3, H, W, 16, 1) == cdiv(H * W, 2048)
+        assert lib.unflow_loss_partial_blocks(2, H, W, 16, 1) == cdiv(W, 64) * cdiv(H, 8)
+        fast = lib.unflow_loss_partial_blocks(1, H, W, 16, 1)
+        if W % 2 == 0:
+            assert fast == cdiv(W, 124) * cdiv(H, 16 if H >= 128 else 8)
+        else:
+            assert fast == lib.unflow_loss_partial_blocks(1, H, W, 16, 0)
+        for op in range(4):
+            for aligned in (0, 1):
+                assert 0 < lib.unflow_loss_partial_blocks(op, H, W, 16, aligned) <= per_sample
+    assert lib.unflow_loss_partial_blocks(4, 8, 8, 1, 1) == -22 and lib.unflow_loss_partial_blocks(0, 0, 8, 1, 1) == -22
 
 
 def test_torch_library_is_built_in_tree():
