@@ -353,33 +353,6 @@ def test_warp_backward_fused_at_the_step_shapes(ops):
         close(fa, res[False][0][1], rtol=1e-4, atol=2e-5 * max(fa.abs().max().item(), 1e-6))
 
 
-@pytest.mark.parametrize('kind', ['smooth', 'mixed', 'outside', 'edge', 'noise'])
-@pytest.mark.parametrize('B,C,h,w', [(8, 32, 112, 256), (16, 32, 64, 208), (8, 64, 56, 128)])
-def test_warp_backward_auto_picked_one_pass_vs_oracle(ops, kind, B, C, h, w):
-    """the one-pass (gather) backward is what the op picks BY ITSELF at level 2 of 1024x448 (bs 4: [8,32,112,256]) and of
-    the 832x256 step ([16,32,64,208]) -- so it is compared with the oracle's grid_sample chain (net_utils.py:16-46) at exactly those
-    launches, unforced, for the five flow kinds of the tile tests; level 3 of 1024x448 ([8,64,56,128]: served, not picked) forced."""
-    lib = __import__('unopticalflow_amd._lib', fromlist=['load']).load()
-    picked = lib.unflow_warp_bwd_fused_supported(B, C, h, w) == 2
-    assert picked == (C == 32)
-    xc = rnd(311 + C, (B, C, h, w)).requires_grad_()
-    fc = _structured_flow(B, h, w, kind, seed=h * w + C + 1).requires_grad_()
-    g = rnd(313 + C, (B, C, h, w))
-    yr = R.warp_flow(xc, fc)
-    yr.backward(g)
-    x, f = dev(xc.detach()).requires_grad_(), dev(fc.detach()).requires_grad_()
-    ops.kernel_timer.enable(True)
-    y = ops.warp_flow(x, f, fused_backward=None if picked else True)
-    y.backward(dev(g))
-    torch.cuda.synchronize()
-    ops.kernel_timer.disable()
-    names = {r['entry'] for r in ops.kernel_timer.rows()}
-    assert 'unflow_warp_bwd_fused' in names and 'unflow_warp_bwd' not in names, names
-    close(y, yr, rtol=1e-5, atol=1e-6, what='fwd %s' % kind)
-    close(x.grad, xc.grad, rtol=1e-4, atol=2e-5, what='gsrc %s' % kind)
-    close(f.grad, fc.grad, rtol=1e-4, atol=2e-5 * max(fc.grad.abs().max().item(), 1e-6), what='gflow %s' % kind)
-
-
 @pytest.mark.parametrize('kind', ['smooth', 'mixed', 'edge', 'outside', 'noise'])
 @pytest.mark.parametrize('C,h,w', [(32, 64, 208), (64, 32, 104), (96, 16, 52), (128, 8, 26), (196, 4, 12), (5, 23, 72), (3, 70, 260)])
 def test_warp_corr_fused_vs_oracle(ops, kind, C, h, w):
@@ -513,51 +486,6 @@ def test_losses_vs_oracle_random(ops, hw):
         close(a, b, rtol=1e-4, atol=1e-5 * b.abs().max().item())         # (SSIM part measured at 1.3e-6 of the largest gradient; was 1e-3 / 1e-4)
 
 
-def _flat_patch_images(B, h, w, seed):
-    """An image / warped-image pair with the regions where a window-SUM formulation of SSIM cancels hardest: saturated flat patches
-    (x = 1.0 against y = 1.0, 1 - 1/255, 0.95: KITTI sky), dark flat patches, a step edge, on top of the usual noise."""
-    rng = np.random.default_rng(seed)
-    x = rng.random((B, 3, h, w), dtype=np.float32)
-    y = np.clip(x + 0.1 * rng.standard_normal((B, 3, h, w)).astype(np.float32), 0, 1)
-    hq, wq = max(h // 4, 2), max(w // 4, 2)
-    for k, dy in enumerate((0.0, 1.0 / 255.0, 0.05)):               # bright flat patches, x != y by a constant
-        x[:, :, : hq, k * wq: (k + 1) * wq] = 1.0
-        y[:, :, : hq, k * wq: (k + 1) * wq] = np.float32(1.0 - dy)
-    x[:, :, hq: 2 * hq, : wq] = 0.0; y[:, :, hq: 2 * hq, : wq] = 0.0                    # dark, equal
-    x[:, :, hq: 2 * hq, wq: 2 * wq] = 2.0 / 255.0; y[:, :, hq: 2 * hq, wq: 2 * wq] = 0.0   # dark, unequal
-    x[:, :, 2 * hq:, 2 * wq:] = 0.25; x[:, :, 2 * hq:, 3 * wq:] = 0.9                     # a step edge in x only
-    y[:, :, 2 * hq:, 2 * wq:] = 0.5
-    wgt = rng.random((B, 1, h, w), dtype=np.float32) * 2.0
-    wgt[:, :, : hq] = 1.0 + (rng.random((B, 1, hq, w), dtype=np.float32) > 0.5)       # weights 1 or 2 over the flat patches (the model's range is [0, 2])
-    return T(x), T(y), T(wgt)
-
-
-@pytest.mark.parametrize('shape', [(16, 256, 832), (2, 37, 131), (3, 128, 416)])
-def test_ssim_loss_flat_patches_and_edges(ops, shape):
-    """the loss's fast path forms SSIM from window sums; bright flat regions are where "K2 - Q" would lose K2's low bits.
-    Forward and gradient against the oracle (model_flow_paper.py:137-148, pytorch_ssim/ssim.py:4-20) at the 1e-4 bar."""
-    B, h, w = shape
-    img, wp, wgt = _flat_patch_images(B, h, w, seed=h + w)
-    gl = rnd(77, (B,))
-    wc = wp.clone().requires_grad_()
-    lr = R.ssim_loss(img, wc, wgt)
-    (lr * gl).sum().backward()
-    wg = dev(wp).requires_grad_()
-    lg = ops.ssim_loss(dev(img), wg, dev(wgt))
-    close(lg, lr, rtol=1e-4, atol=0, what='ssim loss, flat patches')
-    (lg * dev(gl)).sum().backward()
-    s = wc.grad.abs().max().item()
-    close(wg.grad, wc.grad, rtol=1e-4, atol=1e-5 * s, what='ssim loss gradient, flat patches')
-    # every patch on its own (the mean over a whole map would hide a systematic error of one region): weight 1 inside, 0 outside, so the
-    # loss is the patch's mean of (1 - SSIM) / 2.  Bar: 1e-4 of SSIM's own range -- a flat patch with x != y has sigma = 0 exactly, and
-    # the reference's E[xy] - mu_x mu_y in fp32 already carries ~7e-5 of C2 there, with one sign over the whole patch
-    hq, wq = max(h // 4, 2), max(w // 4, 2)
-    for (y0, x0) in ((0, 0), (0, wq), (0, 2 * wq), (hq, 0), (hq, wq), (2 * hq, 2 * wq)):
-        m = torch.zeros(B, 1, h, w)
-        m[:, :, y0: y0 + hq, x0: x0 + wq] = 1.0
-        close(ops.ssim_loss(dev(img), dev(wp), dev(m)), R.ssim_loss(img, wp, m), rtol=1e-4, atol=5e-5, what='patch at %d, %d' % (y0, x0))
-
-
 def test_ssim_map_vs_oracle(ops):
     for (C, h, w) in ((3, 64, 208), (1, 5, 7), (4, 33, 130), (3, 256, 832)):
         x, y = rnd(41, (2, C, h, w), uniform=True), rnd(42, (2, C, h, w), uniform=True)
@@ -615,33 +543,6 @@ def test_stacked_directions_equal_separate_launches(ops):
         assert torch.equal(x, y)
     assert torch.equal(st.grad, torch.cat((a.grad, b.grad)))
     assert torch.equal(fb.grad, fa.grad)
-
-
-def test_deferred_loss_sums_are_the_same_bits(ops):
-    """Round 5: inside ``with ops.deferred_loss_sums:`` the four per-sample loss reductions stop after their partial sums and ONE
-    ``unflow_loss_finalize_batch`` launch (triggered by loss_combine, their reader) finishes all of them: values and gradients equal the
-    immediate second stages bit for bit, at an even and an odd width (both SSIM kernels), and the launch count says so."""
-    for (B, h, w) in ((3, 40, 72), (2, 33, 57), (2, 64, 208)):
-        img = dev(rnd(51, (B, 3, h, w), uniform=True))
-        st0 = torch.cat(((img + dev(rnd(52, (B, 3, h, w), 0.1))).clamp(0, 1), (img + dev(rnd(53, (B, 3, h, w), 0.1))).clamp(0, 1)))
-        st0[:B, :, 3:9, 5:17] = 0.0
-        flows0 = dev(rnd(54, (2 * B, 2, h, w), 3.0))
-        gl = [dev(rnd(55 + k, (B,))) for k in range(4)]
-        res = []
-        for deferred in (False, True):
-            st, fl = st0.clone().requires_grad_(), flows0.clone().requires_grad_()
-            before = ops.deferred_loss_sums.launches
-            ctx = ops.deferred_loss_sums if deferred else __import__('contextlib').nullcontext()
-            with ctx:
-                diff, wgt = ops.occ_weight_stacked(img, st)
-                terms = ([ops.masked_mean(diff, wgt)], [ops.ssim_loss(img, st, wgt)], [ops.smooth2_loss(fl, img)],
-                         [ops.consis_loss(fl[B:], fl[:B], wgt[B:])])
-                packed = ops.loss_combine(*terms)
-            assert ops.deferred_loss_sums.launches - before == (1 if deferred else 0) and not ops.deferred_loss_sums.jobs
-            sum((p * g).sum() for p, g in zip(packed, gl)).backward()
-            res.append([t.clone() for t in packed] + [st.grad.clone(), fl.grad.clone()] + [t[0].clone() for t in terms])
-        for a, b in zip(*res):
-            assert torch.equal(a, b)
 
 
 def test_reductions_are_reproducible(ops):
