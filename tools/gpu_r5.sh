@@ -13,6 +13,9 @@
 #   mfma_pmc     SQ counter passes over that harness (three --pmc passes, no trace domains)
 #   mfma_sweep   microbench corr_bwd_mf on the tuning library: rows-per-wave sweep at levels 2-4, d = 4 and 8
 #   instep_ab    bench.py --corr-bwd {auto, mfma, fp32} and --deferred-loss-sums {1, 0}: in-step A/B of this round's switches
+#   loss_pending the loss-kernel changes written after the lease closed (-DUNFLOW_LOSS_R5B, libunflow_hip_tuning_lossr5b.so built on the
+#                build host): the loss tests against that library, kernel-exact loss times and the bench line, each next to the shipped one
+#   final        everything that gets recorded for one source state: suite, headline, configs, ranks8, profile_fp32, profile_bf16, traffic, corr8, capi
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/r5
 mkdir -p $out
@@ -100,6 +103,15 @@ PY
     for m in auto mfma fp32; do python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --corr-bwd $m > $out/ab_corr_bwd_$m.json 2>> $out/ab.err; done
     for v in 1 0; do python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --deferred-loss-sums $v > $out/ab_deferred_loss_sums_$v.json 2>> $out/ab.err; done
     line $out/ab_*.json ;;
+  loss_pending)
+    V=$GRAFT_REPO_ROOT/unopticalflow_amd/libunflow_hip_tuning_lossr5b.so
+    UNFLOW_LIB_PATH=$V timeout 900 python3 -m pytest tests/test_hip_ops.py tests/test_zz_round5_gpu.py -x -q -m gpu -p no:cacheprovider -k "loss or smooth or occ or reductions or stacked or deferred or golden" > $out/loss_pending_tests.log 2>&1; echo "variant tests rc=$?"; tail -4 $out/loss_pending_tests.log
+    echo "== shipped"; timeout 200 python3 tools/probes/loss_kernel_times.py 2>&1 | tee $out/loss_times_shipped.txt | grep -E "smooth|absdiff|masked" | head -20
+    echo "== variant"; UNFLOW_LIB_PATH=$V timeout 200 python3 tools/probes/loss_kernel_times.py 2>&1 | tee $out/loss_times_lossr5b.txt | grep -E "smooth|absdiff|masked" | head -20
+    python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $out/ab_loss_shipped.json 2>> $out/ab.err
+    UNFLOW_LIB_PATH=$V python3 tools/bench_with_lib.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $out/ab_loss_lossr5b.json 2>> $out/ab.err
+    line $out/ab_loss_shipped.json $out/ab_loss_lossr5b.json ;;
+  final) bash tools/gpu_r5.sh suite headline configs ranks8 profile_fp32 profile_bf16 traffic corr8 capi ;;
   *) echo "unknown recipe $r" ;;
 esac
 done
