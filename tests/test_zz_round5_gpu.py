@@ -7,6 +7,7 @@ import torch
 
 from oracle import ref_cpu as R
 from test_hip_ops import T, close, dev, ops, rnd, _structured_flow      # noqa: F401  (``ops`` is the module-scoped fixture)
+from test_hip_ops import test_corr_backward_on_the_matrix_cores as _matrix_core_backward_case
 
 # strict=False: a pass is reported as XPASS, a failure as xfailed -- either way the first run on a GPU tells what holds without stopping a
 # ``-x`` run of the validated suite; the marker goes once they have run (a failure here says the TEST's bar or set-up needs a second look
@@ -111,3 +112,10 @@ def test_deferred_loss_sums_are_the_same_bits(ops):
             res.append([t.clone() for t in packed] + [st.grad.clone(), fl.grad.clone()] + [t[0].clone() for t in terms])
         for a, b in zip(*res):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('d,B,C,h,w', [(8, 16, 96, 32, 52), (8, 6, 16, 37, 44)])
+def test_corr_backward_on_the_matrix_cores_ragged_d8(ops, d, B, C, h, w):
+    """The d = 8 shapes of test_hip_ops.py::test_corr_backward_on_the_matrix_cores that had not run when the lease closed: a last
+    segment of 4 / 12 pixels, three channel super-groups, a row count that is not a multiple of the chunk, 16 channels."""
+    _matrix_core_backward_case(ops, d, B, C, h, w)
