@@ -134,3 +134,35 @@ def test_weight_shadow_groups_split_the_cast_nodes():
     with WeightShadows((net,), groups=99):
         assert len({conv_weight(m).grad_fn for m in net.modules() if isinstance(m, nn.Conv2d)}) == 4
     assert not any('_w_half' in m.__dict__ for m in net.modules())
+
+
+def test_deferred_loss_sums_job_table(monkeypatch):
+    """ops.deferred_loss_sums (round 5): the jobs a forward pass registers are finished by ONE ``unflow_loss_finalize_batch`` call whose
+    arrays describe them as the entries' own second stages would: partial sums per sample from ``unflow_loss_partial_blocks`` (the
+    kernels' tilings), the divisors in fp32 exactly as photo.hip / ssim.hip compute them, kind 1 only for the smoothness term, the
+    partial-sum tensors kept alive until the flush.  No kernel runs: the C call is intercepted."""
+    import ctypes
+    calls = []
+    monkeypatch.setattr(ops, '_call', lambda name, *a, **k: calls.append((name, a)))
+    monkeypatch.setattr(ops, '_stream', lambda: ctypes.c_void_p(0))
+    d = ops._DeferredLossSums()
+    B, H, W = 4, 64, 208
+    mk = lambda *shape: torch.zeros(*shape)
+    with d:
+        assert d.enabled
+        d.add(mk(B * 64), mk(B), mk(B, 2), 0, H, W, 0, ops._f32(float(H) * W), ops._f32(float(H) * W))                   # masked mean
+        d.add(mk(B * 64), mk(B), mk(B, 2), 1, H, W, 0, ops._f32(3.0 * H * W), ops._f32(float(H) * W), True)             # SSIM loss
+        d.add(mk(B * 64), mk(B), None, 2, H, W, 1, ops._f32(2.0 * H * (W - 2)), ops._f32(2.0 * (H - 2) * W))            # smoothness
+        d.add(mk(2 * 64), mk(2), mk(2, 2), 3, H, W, 0, ops._f32(2.0 * H * W), ops._f32(float(H) * W))                    # consistency, B / 2 samples
+        assert len(d.jobs) == 4 and not calls
+        d.flush()
+        assert not d.jobs and len(calls) == 1 and d.launches == 1
+    assert not d.enabled and len(calls) == 1                                  # (leaving the block: nothing left to finish)
+    name, (P, L, S, N_, B_, K_, A_, C_, n, stream) = calls[0]
+    assert name == 'unflow_loss_finalize_batch' and n == 4
+    assert list(N_) == [7, 16, 32, 7]                                         # ceil(64 * 208 / 2048), 2 strips x 8 chunks of 8 rows, 4 x 8 tiles of 64 x 8
+    assert list(B_) == [B, B, B, 2] and list(K_) == [0, 0, 1, 0]
+    assert list(A_) == [13312.0, 39936.0, 26368.0, 26624.0] and list(C_) == [13312.0, 13312.0, 25792.0, 13312.0]
+    assert S[2] is None and all(S[k] for k in (0, 1, 3)) and all(P[k] and L[k] for k in range(4))
+    with pytest.raises(RuntimeError):
+        d.add(mk(8), mk(1), None, 9, H, W, 0, 1.0, 1.0)                       # an operator the library does not know
