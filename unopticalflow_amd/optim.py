@@ -125,8 +125,9 @@ class FlowAdam(torch.optim.Adam):
         params = self._params()
         capturing = bool(params) and params[0].is_cuda and torch.cuda.is_current_stream_capturing()
         if closure is not None or not self._native_ok(params):
-            if capturing and self._steps is not None:
-                # torch's Adam under capture next to native steps outside it would walk two sets of step counters
+            if capturing and self.native_steps > 0:
+                # torch's Adam under capture next to native steps outside it would walk two sets of step counters (a model with a
+                # parameter the loss never reaches takes torch's Adam in the warm-up AND in the capture: consistent, allowed)
                 raise RuntimeError('FlowAdam.step() inside a hipGraph capture would fall back to torch.optim.Adam (a parameter without a '
                                    'gradient, or a layout the kernel does not take) after native steps: give the warm-up steps the '
                                    'gradient view of the capture')
