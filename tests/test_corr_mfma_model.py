@@ -51,7 +51,11 @@ def model_backward(f1, f2, g, d, rows, mode, split, skip=True):
                                 Bm[k] = F[b, :, r, x]
                     for i in range(DD - 1, -1, -1):
                         y = r + d - i
-                        if skip and not (ya <= y < ybp):
+                        if skip == 'round':                               # (per round of four displacement rows: tuning variant)
+                            lo_i, hi_i = 4 * (i // 4), min(4 * (i // 4) + 3, DD - 1)
+                            if not (r + d - lo_i >= ya and r + d - hi_i < ybp):
+                                continue
+                        elif skip and not (ya <= y < ybp):
                             continue                                     # the slot keeps a stale value of a row outside the chunk
                         A = np.zeros((16, 32))
                         for xl in range(16):
@@ -93,6 +97,7 @@ def test_walker_model_equals_the_oracle(d, C, H, W, rows):
         np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
         # the stale-slot argument: skipping row pairs outside the chunk changes nothing
         np.testing.assert_array_equal(got, model_backward(f1, f2, g, d, rows, mode, split=False, skip=False))
+        np.testing.assert_array_equal(got, model_backward(f1, f2, g, d, rows, mode, split=False, skip='round'))
 
 
 def test_bf16_hi_lo_split_products_stay_inside_the_kernel_bar():

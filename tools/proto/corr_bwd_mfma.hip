@@ -47,16 +47,16 @@ static int run_shape(int B, int C, int H, int W, int iters) {
     CK(hipMemcpy(g, hg.data(), nc * 4, hipMemcpyHostToDevice));
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const char* names[6] = {"shipped fp32 entry (unflow_corr_bwd)", "mfma 16 rows, 2 sets, skip", "mfma 16 rows, 2 sets, no skip",
-                            "mfma 32 rows, 2 sets, skip", "mfma 8 rows, 2 sets, skip", "mfma 16 rows, 1 set, skip"};
+    const char* names[6] = {"shipped entry (unflow_corr_bwd)", "mfma 16 rows, 1 set, skip per pair", "mfma 16 rows, 1 set, skip per round",
+                            "mfma 32 rows, 2 sets, skip per pair", "mfma 32 rows, 2 sets, skip per round", "mfma 16 rows, 2 sets, skip per round"};
     auto run = [&](int v) -> int {
         switch (v) {
             case 0: return unflow_corr_bwd(f1, f2, g, out[0][0], out[0][1], B, C, H, W, d, s);
-            case 1: return launch_bwd_mf<R, 2, 2, true>(f1, f2, g, out[1][0], out[1][1], B, C, H, W, 16, s);
-            case 2: return launch_bwd_mf<R, 2, 2, false>(f1, f2, g, out[2][0], out[2][1], B, C, H, W, 16, s);
-            case 3: return launch_bwd_mf<R, 2, 2, true>(f1, f2, g, out[3][0], out[3][1], B, C, H, W, 32, s);
-            case 4: return launch_bwd_mf<R, 2, 2, true>(f1, f2, g, out[4][0], out[4][1], B, C, H, W, 8, s);
-            default: return launch_bwd_mf<R, 2, 1, true>(f1, f2, g, out[5][0], out[5][1], B, C, H, W, 16, s);
+            case 1: return launch_bwd_mf<R, 2, 1, 1>(f1, f2, g, out[1][0], out[1][1], B, C, H, W, 16, s);
+            case 2: return launch_bwd_mf<R, 2, 1, 2>(f1, f2, g, out[2][0], out[2][1], B, C, H, W, 16, s);
+            case 3: return launch_bwd_mf<R, 2, 2, 1>(f1, f2, g, out[3][0], out[3][1], B, C, H, W, 32, s);
+            case 4: return launch_bwd_mf<R, 2, 2, 2>(f1, f2, g, out[4][0], out[4][1], B, C, H, W, 32, s);
+            default: return launch_bwd_mf<R, 2, 2, 2>(f1, f2, g, out[5][0], out[5][1], B, C, H, W, 16, s);
         }
     };
     printf("== d = %d  [%d,%d,%d,%d]  (algorithmic bytes %.1f MB)\n", d, B, C, H, W, 4.0 * B * H * W * (4.0 * C + DD) / 1e6);

@@ -1587,7 +1587,7 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 // matrix-core form (corr_mfma.h): at d = 4 level 2 it measures level with the fp32 row-streamed kernel back to back
                 // (59 vs 57 us), so it is taken only on request (unflow_corr_set_backward(2))
                 if (g_bwd_mfma_mode.load(std::memory_order_relaxed) == 2 && mfma_served(f1, f2, gcv, gf1, gf2, B, C, H, W, 4))
-                    return launch_bwd_mf<4, 2, 1, true>(f1, f2, gcv, gf1, gf2, B, C, H, W, mfma_rows(B, C, H, W, 2, 4), s);
+                    return launch_bwd_mf<4, 2, 1, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, mfma_rows(B, C, H, W, 2, 4), s);
                 const bool ring_ok = (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0)     // LDS-DMA moves aligned 16-byte pieces
                                      && gs_offsets_fit(C, H, W, 4);
                 const int fb = forced_bwd();
@@ -1638,7 +1638,7 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 // round 5: banded bf16x3 products on the matrix cores: level 2 149 us against 271 for the fp32 row-streamed kernel
                 // (tools/proto/corr_bwd_mfma.hip); ~4e-6 of the largest gradient away from the fp32 sums
                 if (g_bwd_mfma_mode.load(std::memory_order_relaxed) != 1 && mfma_served(f1, f2, gcv, gf1, gf2, B, C, H, W, 8))
-                    return launch_bwd_mf<8, 2, 2, true>(f1, f2, gcv, gf1, gf2, B, C, H, W, mfma_rows(B, C, H, W, 2, 8), s);
+                    return launch_bwd_mf<8, 2, 2, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, mfma_rows(B, C, H, W, 2, 8), s);
                 if (variant == 4 || (long)B * H * W < 8192) break;      // small maps: one lane per element (117 / 57 us at levels 5 / 6, tile kernel 283 / 378)
                 if ((variant == 7 || mid_size(variant)) && (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0) && gs_offsets_fit(C, H, W, 8)) {
                     // round 3: row-streamed, 8 channels per item: 290 / 117 / 49 us at levels 2 / 3 / 4 (group-split ring kernel 343 / 129 / 85)

@@ -55,7 +55,7 @@ __device__ __forceinline__ void mf_split2(float a, float b, unsigned& hi, unsign
     lo = __builtin_bit_cast(unsigned, l);
 }
 
-template <int R, int NCG, int MODE, int DEPTH, bool SKIP>
+template <int R, int NCG, int MODE, int DEPTH, int SKIP>
 __device__ __forceinline__ void corr_bwd_mf_body(lds_byte* __restrict__ tab, const float* __restrict__ F, const float* __restrict__ g,
                                                  float* __restrict__ out, int b, int c_begin, int S, int ya, int ybp,
                                                  int Ctot, int H, int W, float inv_c) {
@@ -206,7 +206,9 @@ __device__ __forceinline__ void corr_bwd_mf_body(lds_byte* __restrict__ tab, con
 #pragma unroll
             for (int t = 3; t >= 0; --t) {
                 const int i = 4 * rho + t;
-                if (i < DD && (!SKIP || (unsigned)(r + R - i - ya) < span)) {
+                // (SKIP 1: per row pair, every pair its own basic block; 2: per round of four -- the pairs of a round stay in one block,
+                // so hipcc can interleave their MFMA chains, at the price of zero-weight pairs at the two ends of a chunk)
+                if (i < DD && (SKIP == 0 || (SKIP == 2 ? round_on : (unsigned)(r + R - i - ya) < span))) {
                     const v4u_t ah = *(__attribute__((address_space(3))) const v4u_t*)(rbase + t * TAB);
                     const v4u_t al = *(__attribute__((address_space(3))) const v4u_t*)(rbase + 4 * TAB + t * TAB);
 #pragma unroll
@@ -238,7 +240,7 @@ __device__ __forceinline__ void corr_bwd_mf_body(lds_byte* __restrict__ tab, con
 
 // grid: one workgroup of four waves = four neighbouring segments of (sample, row chunk, gradient, channel group); the items
 // that read the same gradient planes (channel groups, both gradients) are neighbours in the XCD-local order
-template <int R, int NCG, int DEPTH, bool SKIP>
+template <int R, int NCG, int DEPTH, int SKIP>
 __global__ __launch_bounds__(256, 1) void corr_bwd_mf_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                              const float* __restrict__ g, float* __restrict__ gf1,
                                                              float* __restrict__ gf2, int Ctot, int H, int W,
@@ -265,7 +267,7 @@ static inline bool mf_offsets_fit(int C, int H, int W, int R) {
     return (dd * dd + 2 * R + 1) * plane < 0x20000000u && (size_t)C * plane < 0x20000000u;
 }
 
-template <int R, int NCG, int DEPTH = 2, bool SKIP = true>
+template <int R, int NCG, int DEPTH = 2, int SKIP = 1>
 int launch_bwd_mf(const float* f1, const float* f2, const float* g, float* gf1, float* gf2,
                   int B, int C, int H, int W, int rows, hipStream_t s) {
     const int nseg = ceil_div(W, 16), nsb = ceil_div(nseg, 4), nchunk = ceil_div(H, rows), ngrp = ceil_div(C, NCG * 16);
