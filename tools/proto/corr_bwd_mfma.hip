@@ -3,6 +3,7 @@
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude tools/proto/corr_bwd_mfma.hip -o tools/proto/corr_bwd_mfma
 //   tools/proto/corr_bwd_mfma [B C H W [iters]]
 #include "../../unopticalflow_amd/csrc/corr.hip"
+#include "corr_mfma2.h"
 #include <cstdio>
 #include <cstring>
 #include <cmath>
@@ -32,6 +33,8 @@ static Err compare(const std::vector<float>& ref, const std::vector<float>& got)
     return e;
 }
 
+constexpr int NV = 9;
+
 template <int R>
 static int run_shape(int B, int C, int H, int W, int iters) {
     const int d = R, DD = (2 * d + 1) * (2 * d + 1);
@@ -39,16 +42,17 @@ static int run_shape(int B, int C, int H, int W, int iters) {
     std::vector<float> h1(nf), h2(nf), hg(nc);
     for (size_t i = 0; i < nf; ++i) { h1[i] = vv(i, 1.f); h2[i] = vv(i + 77777777ull, 1.f); }
     for (size_t i = 0; i < nc; ++i) hg[i] = vv(i + 555555555ull, 0.05f);
-    float *f1, *f2, *g, *out[6][2];
+    float *f1, *f2, *g, *out[NV][2];
     CK(hipMalloc(&f1, nf * 4)); CK(hipMalloc(&f2, nf * 4)); CK(hipMalloc(&g, nc * 4));
-    for (int v = 0; v < 6; ++v) for (int k = 0; k < 2; ++k) { CK(hipMalloc(&out[v][k], nf * 4)); CK(hipMemset(out[v][k], 0xff, nf * 4)); }
+    for (int v = 0; v < NV; ++v) for (int k = 0; k < 2; ++k) { CK(hipMalloc(&out[v][k], nf * 4)); CK(hipMemset(out[v][k], 0xff, nf * 4)); }
     CK(hipMemcpy(f1, h1.data(), nf * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(f2, h2.data(), nf * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(g, hg.data(), nc * 4, hipMemcpyHostToDevice));
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const char* names[6] = {"shipped entry (unflow_corr_bwd)", "mfma 16 rows, 1 set, skip per pair", "mfma 16 rows, 1 set, skip per round",
-                            "mfma 32 rows, 2 sets, skip per pair", "mfma 32 rows, 2 sets, skip per round", "mfma 16 rows, 2 sets, skip per round"};
+    const char* names[NV] = {"shipped entry (unflow_corr_bwd)", "mfma 16 rows, 1 set, skip per pair", "mfma 16 rows, 1 set, skip per round",
+                             "mfma 32 rows, 2 sets, skip per pair", "mfma 32 rows, 2 sets, skip per round", "mfma 16 rows, 2 sets, skip per round",
+                             "mfma2 (pixel pairs) 16 rows, per pair", "mfma2 (pixel pairs) 16 rows, per round", "mfma2 (pixel pairs) 32 rows, per pair"};
     auto run = [&](int v) -> int {
         switch (v) {
             case 0: return unflow_corr_bwd(f1, f2, g, out[0][0], out[0][1], B, C, H, W, d, s);
@@ -56,12 +60,15 @@ static int run_shape(int B, int C, int H, int W, int iters) {
             case 2: return launch_bwd_mf<R, 2, 1, 2>(f1, f2, g, out[2][0], out[2][1], B, C, H, W, 16, s);
             case 3: return launch_bwd_mf<R, 2, 2, 1>(f1, f2, g, out[3][0], out[3][1], B, C, H, W, 32, s);
             case 4: return launch_bwd_mf<R, 2, 2, 2>(f1, f2, g, out[4][0], out[4][1], B, C, H, W, 32, s);
-            default: return launch_bwd_mf<R, 2, 2, 2>(f1, f2, g, out[5][0], out[5][1], B, C, H, W, 16, s);
+            case 5: return launch_bwd_mf<R, 2, 2, 2>(f1, f2, g, out[5][0], out[5][1], B, C, H, W, 16, s);
+            case 6: return launch_bwd_mf2<R, 2, 1>(f1, f2, g, out[6][0], out[6][1], B, C, H, W, 16, s);
+            case 7: return launch_bwd_mf2<R, 2, 2>(f1, f2, g, out[7][0], out[7][1], B, C, H, W, 16, s);
+            default: return launch_bwd_mf2<R, 2, 1>(f1, f2, g, out[8][0], out[8][1], B, C, H, W, 32, s);
         }
     };
     printf("== d = %d  [%d,%d,%d,%d]  (algorithmic bytes %.1f MB)\n", d, B, C, H, W, 4.0 * B * H * W * (4.0 * C + DD) / 1e6);
     for (int round = 0; round < 2; ++round)
-        for (int v = 0; v < 6; ++v) {
+        for (int v = 0; v < NV; ++v) {
             for (int i = 0; i < 3; ++i) { int rc = run(v); if (rc) { fprintf(stderr, "%s: launch failed %d\n", names[v], rc); return 1; } }
             CK(hipStreamSynchronize(s));
             CK(hipEventRecord(e0, s));
@@ -72,7 +79,7 @@ static int run_shape(int B, int C, int H, int W, int iters) {
             printf("round %d  %-44s %8.2f us/launch\n", round, names[v], ms * 1e3 / iters);
         }
     std::vector<float> ref(nf), got(nf);
-    for (int v = 1; v < 6; ++v)
+    for (int v = 1; v < NV; ++v)
         for (int k = 0; k < 2; ++k) {
             CK(hipMemcpy(ref.data(), out[0][k], nf * 4, hipMemcpyDeviceToHost));
             CK(hipMemcpy(got.data(), out[v][k], nf * 4, hipMemcpyDeviceToHost));
@@ -115,7 +122,7 @@ static int run_shape(int B, int C, int H, int W, int iters) {
         }
         printf("gf1 against a float64 sum (4000 samples, max |value| %.3g): fp32 kernel worst %.3g, mfma kernel worst %.3g (%.3g of max)\n", vmax, e_ref, e_got, e_got / vmax);
     }
-    for (int v = 0; v < 6; ++v) for (int k = 0; k < 2; ++k) CK(hipFree(out[v][k]));
+    for (int v = 0; v < NV; ++v) for (int k = 0; k < 2; ++k) CK(hipFree(out[v][k]));
     CK(hipFree(f1)); CK(hipFree(f2)); CK(hipFree(g));
     return 0;
 }
