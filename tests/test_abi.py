@@ -94,6 +94,55 @@ def test_dma_ring_kernels_do_not_spill():
     assert checked >= 3      # ring<9 rows>, ring<3 rows>, group-split backward
 
 
+# Device code that differs from commit 8bbc033, whose `-m gpu` suite the driver ran green on an MI355X (GPUTEST_r04: 249 passed).
+# Every other kernel the library ships is, instruction for instruction, one that suite exercised.  What is listed here has its own
+# GPU evidence from round 5: see DESIGN.md section 7.
+ROUND5_DEVICE_CODE = {
+    'corr.hip': {'new': {'corr_bwd_mf_kernel<4, 2, 1, 1>', 'corr_bwd_mf_kernel<8, 2, 2, 1>'},        # csrc/corr_mfma.h
+                 'renamed': {'corr_bwd_rs_kernel<4, 16, 8, 2>': 'corr_bwd_rs_kernel<4, 16, 8, 2, 0, 1, 1>',
+                             'corr_bwd_rs_kernel<4, 8, 8, 2>': 'corr_bwd_rs_kernel<4, 8, 8, 2, 0, 1, 1>',
+                             'corr_bwd_rs_kernel<8, 8, 8, 1>': 'corr_bwd_rs_kernel<8, 8, 8, 1, 0, 1, 1>'},
+                 'removed': {'corr_bwd_gs_kernel<4, 2, 4>', 'corr_bwd_gs_kernel<4, 2, 8>', 'corr_bwd_gs_kernel<4, 4, 4>'}},
+    'photo.hip': {'new': {'loss_finalize_batch_kernel'}},
+    'ssim.hip': {'changed': {'ssim2_fwd_kernel<8, false>', 'ssim2_fwd_kernel<16, false>', 'ssim2_fwd_kernel<32, false>',
+                             'ssim2_bwd_kernel<8>', 'ssim2_bwd_kernel<16>', 'ssim2_bwd_kernel<32>'}},     # pair_factors: fma forms
+}
+
+
+def test_fp32_cost_volume_kernels_are_the_validated_ones():
+    """The round-5 pruning of csrc/corr.hip (and everything else that was not meant to change device code) changed no machine
+    code: per kernel, hipcc's gfx950 instruction stream hashes to what the round-4 sources give (tests/golden/isa_validated_r4.json,
+    written by `tools/isa_hashes.py --tree`); the kernels that do differ are exactly ROUND5_DEVICE_CODE."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    try:
+        import isa_hashes
+    finally:
+        sys.path.pop(0)
+    golden = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'isa_validated_r4.json')))
+    if isa_hashes.hipcc_version() != golden['hipcc']:
+        pytest.skip('hashes were taken with %s, this is %s' % (golden['hipcc'], isa_hashes.hipcc_version()))
+    now = isa_hashes.tree_hashes(ROOT)
+    assert set(now) == set(golden['files'])
+    for f, kernels in now.items():
+        allow = ROUND5_DEVICE_CODE.get(f, {})
+        old = golden['files'][f]
+        renamed = allow.get('renamed', {})
+        for k, v in kernels.items():
+            if k in allow.get('new', ()):
+                assert k not in old, (f, k)
+                continue
+            was = old.get(renamed.get(k, k))
+            assert was is not None, 'kernel %s of %s did not exist in round 4 and is not listed' % (k, f)
+            if k in allow.get('changed', ()):
+                assert was['sha16'] != v['sha16'], 'listed as changed but identical: ' + k
+            else:
+                assert was == v, 'device code of %s (%s) differs from the GPU-validated build' % (k, f)
+        gone = set(old) - set(kernels) - set(renamed.values())
+        assert gone == allow.get('removed', set()), (f, gone)
+
+
 def test_round5_host_entry_points_without_gpu():
     """The host-only entry points of ABI 10: the backward-arithmetic switch returns the previous mode and rejects unknown ones; the
     partial-sum counts that ``unflow_loss_finalize_batch`` jobs are described with follow the kernels' tilings (masked mean /

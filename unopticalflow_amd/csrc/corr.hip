@@ -1097,7 +1097,11 @@ __device__ __forceinline__ void corr_bwd_rs_body(float* __restrict__ tile, int t
     const int b = t / tiles_y;
     const int c_begin = cg * CH;
     const int C = min(CH, Ctot - c_begin);
-    const int l = threadIdx.x, wave = threadIdx.x >> 6;
+    // (`l` and `ws` are written as round 4 wrote them -- ws is 0: one wave set -- because with exactly these expressions hipcc emits round 4's
+    // instruction stream for all four instantiations, byte for byte: the kernels that passed GPUTEST_r04 are the kernels that ship
+    // (tests/test_abi.py::test_fp32_cost_volume_kernels_are_the_validated_ones, tools/isa_hashes.py))
+    const int l = threadIdx.x % K::THREADS, wave = threadIdx.x >> 6;
+    const int ws = __builtin_amdgcn_readfirstlane((int)threadIdx.x / K::THREADS);
     // lane -> (tx, ty).  A ds_read_b64 is serviced in two groups of 32 lanes; the 32 lanes of a group must fall into 64
     // different banks.  64-wide tiles: a group is one row of 32 lanes (64 consecutive floats).  16-wide tiles (row stride
     // LW = 24 floats): a group takes 4 rows of 8 lanes; rows 2 apart start 48 = -16 (mod 64) banks apart, so lanes 0-31 take
@@ -1161,7 +1165,7 @@ __device__ __forceinline__ void corr_bwd_rs_body(float* __restrict__ tile, int t
     v2f acc[CH][2];
 #pragma unroll
     for (int c = 0; c < CH; ++c) { acc[c][0] = v2f{0.f, 0.f}; acc[c][1] = v2f{0.f, 0.f}; }
-    const unsigned rows_addr = (unsigned)(size_t)(lds_cfloat*)(tile + ty * LW + tx * 2);
+    const unsigned rows_addr = (unsigned)(size_t)(lds_cfloat*)(tile + ws * CH * K::SC * 4 + ty * LW + tx * 2);
     constexpr int PF = (2 * NCOL <= 15) ? 2 : 1;
     constexpr int HALF = (CH + 1) / 2;
     static_assert((HALF - 1) * K::SC * 16 + (LW + 2 * R) * 4 < 65536, "ds_read offset field");
@@ -1185,10 +1189,10 @@ __device__ __forceinline__ void corr_bwd_rs_body(float* __restrict__ tile, int t
         }
     }
     if (py < H && px < W) {
-        float* op = out + (((size_t)b * Ctot + c_begin) * H + py) * W + px;
+        float* op = out + (((size_t)b * Ctot + c_begin + ws * CH) * H + py) * W + px;
 #pragma unroll
         for (int c = 0; c < CH; ++c)
-            if (c < C)
+            if (ws * CH + c < C)
                 *reinterpret_cast<float2*>(op + (size_t)c * plane) = make_float2(acc[c][0].x + acc[c][0].y, acc[c][1].x + acc[c][1].y);
     }
 }
