@@ -1,5 +1,7 @@
 """CPU tests of the host-side logic around the HIP operators (no kernel runs here): the bf16 option's weight shadows, the argument
 checks the operators make before they touch a device, the torch forms the model falls back to off the GPU."""
+import os
+
 import pytest
 import torch
 import torch.nn as nn
@@ -166,3 +168,31 @@ def test_deferred_loss_sums_job_table(monkeypatch):
     assert S[2] is None and all(S[k] for k in (0, 1, 3)) and all(P[k] and L[k] for k in range(4))
     with pytest.raises(RuntimeError):
         d.add(mk(8), mk(1), None, 9, H, W, 0, 1.0, 1.0)                       # an operator the library does not know
+
+
+def test_conv_split_emulation_helpers():
+    """tests/conv_split_emulation.py (what profiles/r5_conv_split_emulation.md was measured with): the parts are bf16 numbers that add up
+    to the value, the product sets are hi.hi + hi.lo + lo.hi / the six products of three parts, and a split convolution is a convolution
+    to 2^-16 (two parts) / fp32 rounding (three parts), gradients included."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('conv_split_emulation', os.path.join(os.path.dirname(__file__), 'conv_split_emulation.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4096, generator=g)
+    hi, lo = m.split_parts(x, 2)
+    assert torch.equal(hi, hi.to(torch.bfloat16).float()) and torch.equal(lo, lo.to(torch.bfloat16).float())
+    assert float((x - hi - lo).abs().max() / x.abs().max()) < 2.0 ** -16
+    assert m.product_pairs(2) == [(0, 0), (0, 1), (1, 0)] and len(m.product_pairs(3)) == 6
+    conv = torch.nn.Conv2d(5, 7, 3, padding=1)
+    inp = torch.randn(2, 5, 9, 11, generator=g, requires_grad=True)
+    ref = conv(inp)
+    gr = torch.autograd.grad(ref.square().sum(), [inp, conv.weight, conv.bias])
+    for parts, tol in ((2, 3e-5), (3, 2e-6)):
+        with m.patched_convolutions(parts):
+            out = conv(inp)
+            gs = torch.autograd.grad(out.square().sum(), [inp, conv.weight, conv.bias])
+        assert float((out - ref).abs().max() / ref.abs().max()) < tol
+        for a, b in zip(gs, gr):
+            assert float((a - b).abs().max() / b.abs().max()) < 4 * tol
+    assert torch.equal(conv(inp), ref)                                # the patch is gone after the block
