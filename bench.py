@@ -108,6 +108,7 @@ def parse():
     ap.add_argument('--fused-upsample', type=int, default=1, help='0: F.interpolate + multiply for the flow up-sampling instead of unflow_upsample_scaled_* (A/B; PWC_tf.fused_upsample)')
     ap.add_argument('--fill-cat', type=int, default=1, help='0: channels_last decoder with torch.cat inputs instead of epilogue-filled cat buffers (A/B; PWC_tf.fill_cat_buffers)')
     ap.add_argument('--fused-warp-bwd', type=int, default=1, help='0: zero-fill + scatter for the feature-map warps\' backward instead of the one-pass gather (A/B; ops.fused_warp_bwd)')
+    ap.add_argument('--multiscale-losses', type=int, default=0, help='1: every loss of the scale loop as one launch over the three scales (A/B; Model_flow.multiscale_losses, off until GPU-validated)')
     ap.add_argument('--deferred-loss-sums', type=int, default=1, help='0: one second-stage launch per loss reduction instead of one per forward pass (A/B; Model_flow.deferred_loss_sums)')
     ap.add_argument('--corr-bwd', default='auto', choices=['auto', 'fp32', 'mfma'], help='cost-volume backward arithmetic (ops.set_corr_backward): mfma = the matrix-core form at d = 4 too (A/B)')
     ap.add_argument('--gc-freeze', type=int, default=1, help='0: leave Python\'s cyclic collector alone; 1: FlowTrainer(gc_freeze_after=2), what train.py asks for too (gc.freeze() after the second step, once per process)')
@@ -290,6 +291,7 @@ def main():
     model.pwc_model.fused_head = bool(args.fused_head)
     model.fused_loss_sums = bool(args.fused_loss_sums)
     model.deferred_loss_sums = bool(args.deferred_loss_sums)
+    model.multiscale_losses = bool(args.multiscale_losses)
     model.dup_centre = bool(args.dup_centre)
     trainer = FlowTrainer(cfg, model, distributed=(world > 1 or args.force_ddp), use_graph=bool(args.graph),
                           single_rank_collectives=args.force_ddp, gc_freeze_after=2 if args.gc_freeze else None)
@@ -326,6 +328,7 @@ def main():
             model.pwc_model.fused_head = bool(args.fused_head)
             model.fused_loss_sums = bool(args.fused_loss_sums)
             model.deferred_loss_sums = bool(args.deferred_loss_sums)
+            model.multiscale_losses = bool(args.multiscale_losses)
             model.dup_centre = bool(args.dup_centre)
             trainer = FlowTrainer(cfg, model, distributed=(world > 1 or args.force_ddp), use_graph=False,
                                   single_rank_collectives=args.force_ddp, gc_freeze_after=2 if args.gc_freeze else None)
@@ -338,6 +341,7 @@ def main():
     # ops next to corr / warp) -> roofline.losses
     LOSSES = ('unflow_ssim_loss_fwd', 'unflow_ssim_loss_bwd', 'unflow_occ_weight_fwd', 'unflow_absdiff_bwd', 'unflow_masked_mean_fwd',
               'unflow_masked_mean_bwd', 'unflow_smooth2_fwd', 'unflow_smooth2_bwd', 'unflow_consis_fwd', 'unflow_consis_bwd')
+    LOSSES += tuple(e + '_ms' for e in LOSSES)           # (--multiscale-losses 1: the same ten entries, one launch over the scales each)
     TIMED = CW + LOSSES
     if not args.no_kernel_timing:
         ops.kernel_timer.enable(TIMED, reserve=96 * args.steps)     # every such launch of the timed steps: kernel-exact event pairs
@@ -522,7 +526,8 @@ def main():
                                                                             (1 if args.precision == 'fp32' else 2) if (fh, fw) == (H, W) else 3),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                        'conv_memory_format': 'channels_last' if cfg.channels_last else 'NCHW',
-                       'triplets_per_s': round(pairs / 2 / dt, 2)},
+                       'triplets_per_s': round(pairs / 2 / dt, 2),
+                       'loss_launch_form': 'one per loss over the scales' if args.multiscale_losses else 'one per loss and scale'},
             'step_ms': step_stats['step_ms'], 'host_enqueue_ms': step_stats['host_enqueue_ms'], 'drain_ms': step_stats['drain_ms'],
             'pairs_per_s_at_median_step': round(2 * args.batch * world / (step_stats['step_ms']['median'] * 1e-3), 2),
             'all_step_ms': step_stats['all_step_ms'], 'host_gc': step_stats['host_gc'], 'rank_spread': rank_spread,

@@ -36,7 +36,7 @@ extern "C" {
 /* ABI version of this header (bumped on any signature change).  The library returns the value it was BUILT with; a C user
  * compares `unflow_abi_version() == UNFLOW_ABI_VERSION` (tools/capi_bench.cpp), the Python binding reads this very line
  * (unopticalflow_amd/_lib.py). */
-#define UNFLOW_ABI_VERSION 10
+#define UNFLOW_ABI_VERSION 11
 int unflow_abi_version(void);
 
 /* ---- kernel-exact timing (bench.py's roofline legs; nothing in the reference corresponds) ----
@@ -191,6 +191,40 @@ int unflow_consis_fwd(const float* fwd_flow, const float* bwd_flow, const float*
 int unflow_consis_bwd(const float* fwd_flow, const float* bwd_flow, const float* w_fwd,
                       const float* sums, const float* gloss, float* gflow,
                       int B, int H, int W, void* stream);
+
+/* ---- the loss entries above, ONE launch over the n <= 4 scales of Model_flow.forward's loop (model_flow_paper.py:224-235) each
+ * (ABI 11).  Every array argument is a HOST array with one entry per scale (device pointers / sizes of that scale); B and img_batch
+ * are common to the scales.  The launch runs, per scale, exactly the workgroups of the single-scale entry with exactly its kernel
+ * body -- same values bit for bit; what it saves is 2 of 3 launches per loss and direction (scales 1 and 2 hold 1/4 and 1/16 of the
+ * pixels and sit on a 4-10 us floor each as launches of their own).  The FORWARD entries stop after the first stage of the
+ * per-sample reductions, like the single-scale entries called with loss == NULL: finish with unflow_loss_finalize_batch
+ * (nblk[q] = unflow_loss_partial_blocks(op, H, W, B, 1) at that scale).  -22 for what the single-scale entries serve through another
+ * kernel -- B > 65535; H or W < 3 (smoothness backward); an odd width or a tensor that is not 8-byte aligned (SSIM pair): call
+ * those per scale.
+ * occ_weight: the stacked layout of the train step -- warped[k] = (from_l | from_r) [2B,3,H,W] against img[k] [B,3,H,W] ->
+ * diff[k] = (diff_l | diff_r), wgt[k] = (w_bwd | w_fwd) [2B,1,H,W]; no validity masks. */
+int unflow_occ_weight_fwd_ms(int n, const float* const* img, const float* const* warped, float* const* diff, float* const* wgt,
+                             const int* H, const int* W, int B, void* stream);
+int unflow_absdiff_bwd_ms(int n, const float* const* img, const float* const* from, const float* const* gdiff, float* const* gfrom,
+                          const int* H, const int* W, int B, int img_batch, void* stream);
+int unflow_masked_mean_fwd_ms(int n, const float* const* diff, const float* const* w, float* const* partials,
+                              const int* H, const int* W, int B, void* stream);
+int unflow_masked_mean_bwd_ms(int n, const float* const* w, const float* const* sums, const float* const* gloss, float* const* gdiff,
+                              const int* H, const int* W, int B, void* stream);
+int unflow_ssim_loss_fwd_ms(int n, const float* const* img, const float* const* warped, const float* const* w, float* const* partials,
+                            const int* H, const int* W, int B, int img_batch, void* stream);
+int unflow_ssim_loss_bwd_ms(int n, const float* const* img, const float* const* warped, const float* const* w, const float* const* sums,
+                            const float* const* gloss, float* const* gwarped, const int* H, const int* W, int B, int img_batch,
+                            void* stream);
+int unflow_smooth2_fwd_ms(int n, const float* const* flow, const float* const* img, float* const* partials,
+                          const int* H, const int* W, int B, int img_batch, void* stream);
+int unflow_smooth2_bwd_ms(int n, const float* const* flow, const float* const* img, const float* const* gloss, float* const* gflow,
+                          const int* H, const int* W, int B, int img_batch, void* stream);
+int unflow_consis_fwd_ms(int n, const float* const* fwd_flow, const float* const* bwd_flow, const float* const* w_fwd,
+                         float* const* partials, const int* H, const int* W, int B, void* stream);
+int unflow_consis_bwd_ms(int n, const float* const* fwd_flow, const float* const* bwd_flow, const float* const* w_fwd,
+                         const float* const* sums, const float* const* gloss, float* const* gflow, const int* H, const int* W,
+                         int B, void* stream);
 
 /* ---- conv() epilogue: Conv2d bias + LeakyReLU(0.1), core/networks/structures/net_utils.py:7-11 ----
  * y [N,C,H,W] is a bias-free convolution output, updated in place: y = leaky_relu(y + bias[c]). */

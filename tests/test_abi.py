@@ -103,8 +103,12 @@ ROUND5_DEVICE_CODE = {
                              'corr_bwd_rs_kernel<4, 8, 8, 2>': 'corr_bwd_rs_kernel<4, 8, 8, 2, 0, 1, 1>',
                              'corr_bwd_rs_kernel<8, 8, 8, 1>': 'corr_bwd_rs_kernel<8, 8, 8, 1, 0, 1, 1>'},
                  'removed': {'corr_bwd_gs_kernel<4, 2, 4>', 'corr_bwd_gs_kernel<4, 2, 8>', 'corr_bwd_gs_kernel<4, 4, 4>'}},
-    'photo.hip': {'new': {'loss_finalize_batch_kernel'}},
-    'ssim.hip': {'changed': {'ssim2_fwd_kernel<8, false>', 'ssim2_fwd_kernel<16, false>', 'ssim2_fwd_kernel<32, false>',
+    'photo.hip': {'new': {'loss_finalize_batch_kernel',                                               # the batched second stage (GPU: smoke + bench)
+                          # csrc/multiscale.h, never run: the single-scale kernels' bodies (csrc/bodies/*.inc) behind a table of scales; off by default
+                          'occ_weight_fwd_ms_kernel', 'absdiff_bwd_ms_kernel', 'masked_mean_partial_ms_kernel', 'masked_mean_bwd_ms_kernel',
+                          'smooth2_fwd_tile_ms_kernel', 'smooth2_bwd_stage_ms_kernel', 'consis_partial_ms_kernel', 'consis_bwd_ms_kernel'}},
+    'ssim.hip': {'new': {'ssim2_fwd_ms_kernel<false>', 'ssim2_bwd_ms_kernel'},
+                 'changed': {'ssim2_fwd_kernel<8, false>', 'ssim2_fwd_kernel<16, false>', 'ssim2_fwd_kernel<32, false>',
                              'ssim2_bwd_kernel<8>', 'ssim2_bwd_kernel<16>', 'ssim2_bwd_kernel<32>'}},     # pair_factors: fma forms
 }
 
@@ -166,6 +170,87 @@ def test_round5_host_entry_points_without_gpu():
             for aligned in (0, 1):
                 assert 0 < lib.unflow_loss_partial_blocks(op, H, W, 16, aligned) <= per_sample
     assert lib.unflow_loss_partial_blocks(4, 8, 8, 1, 1) == -22 and lib.unflow_loss_partial_blocks(0, 0, 8, 1, 1) == -22
+
+
+def test_multiscale_entries_reject_what_they_do_not_serve():
+    """ABI 11 (`_ms`: one launch over the scales of a loss, csrc/multiscale.h): every argument check comes before the launch, so it can be
+    exercised here -- no scales, more than four, a NULL table, a NULL entry, B < 1, and the shapes the single-scale entries serve through
+    another kernel (odd width / unaligned tensor in the SSIM pair, a map under 3 x 3 in the smoothness backward, B > 65535)."""
+    from unopticalflow_amd import _lib
+    lib = _lib.load()
+    ptrs = lambda *v: (ctypes.c_void_p * len(v))(*v)
+    ints = lambda *v: (ctypes.c_int * len(v))(*v)
+    ok = 4096                                                          # (a fake 8-byte aligned device address: never dereferenced before the checks)
+    for n in (0, 5, -1):
+        assert lib.unflow_masked_mean_fwd_ms(n, ptrs(ok), ptrs(ok), ptrs(ok), ints(8), ints(8), 2, None) == -22
+        assert lib.unflow_ssim_loss_fwd_ms(n, ptrs(ok), ptrs(ok), ptrs(ok), ptrs(ok), ints(8), ints(8), 2, 1, None) == -22
+    assert lib.unflow_occ_weight_fwd_ms(1, None, ptrs(ok), ptrs(ok), ptrs(ok), ints(8), ints(8), 2, None) == -22
+    assert lib.unflow_occ_weight_fwd_ms(1, ptrs(ok), ptrs(0), ptrs(ok), ptrs(ok), ints(8), ints(8), 2, None) == -22
+    assert lib.unflow_occ_weight_fwd_ms(1, ptrs(ok), ptrs(ok), ptrs(ok), ptrs(ok), ints(8), ints(8), 0, None) == -22
+    assert lib.unflow_absdiff_bwd_ms(1, ptrs(ok), ptrs(ok), ptrs(ok), ptrs(ok), ints(8), ints(8), 3, 2, None) == -22       # B % img_batch
+    assert lib.unflow_masked_mean_bwd_ms(2, ptrs(ok, ok), ptrs(ok, 0), ptrs(ok, ok), ptrs(ok, ok), ints(8, 4), ints(8, 4), 2, None) == -22
+    assert lib.unflow_ssim_loss_fwd_ms(1, ptrs(ok), ptrs(ok), ptrs(ok), ptrs(ok), ints(8), ints(9), 2, 1, None) == -22      # odd width
+    assert lib.unflow_ssim_loss_fwd_ms(1, ptrs(ok), ptrs(ok + 4), ptrs(ok), ptrs(ok), ints(8), ints(8), 2, 1, None) == -22  # 4-byte aligned
+    assert lib.unflow_ssim_loss_bwd_ms(1, ptrs(ok), ptrs(ok), ptrs(ok), ptrs(ok), ptrs(ok), ptrs(ok + 4), ints(8), ints(8), 2, 1, None) == -22
+    assert lib.unflow_smooth2_bwd_ms(1, ptrs(ok), ptrs(ok), ptrs(ok), ptrs(ok), ints(2), ints(8), 2, 1, None) == -22       # H < 3
+    assert lib.unflow_smooth2_fwd_ms(1, ptrs(ok), ptrs(ok), ptrs(ok), ints(8), ints(8), 65536, 65536, None) == -22
+    assert lib.unflow_consis_fwd_ms(1, ptrs(ok), ptrs(ok), ptrs(ok), ptrs(ok), ints(8), ints(0), 2, None) == -22
+    assert lib.unflow_consis_bwd_ms(1, ptrs(ok), ptrs(ok), ptrs(ok), ptrs(ok), ptrs(ok), ptrs(ok), ints(8), ints(8), 0, None) == -22
+
+
+def test_multiscale_workgroup_table_covers_every_scale_once():
+    """csrc/multiscale.h restated: ms_grid_add pads a scale's workgroup range to a multiple of 8 and ms_locate maps a linear workgroup id
+    to (scale, virtual blockIdx).  For the grids of the train step's ten loss kernels: every (scale, x, y, z) of the per-scale grids is
+    produced exactly once, padding workgroups are recognised, a scale starts on an XCD boundary (id mod 8 is what xcd_remap relies on),
+    and xcd_remap over the virtual ids stays a bijection of the scale's tiles."""
+    def table(grids):
+        first = [0]
+        for gx, gy, gz in grids:
+            first.append(first[-1] + ((gx * gy * gz + 7) & ~7))
+        return first
+
+    def locate(first, grids, bid):
+        s = 0
+        while s < len(grids) - 1 and bid >= first[s + 1]:
+            s += 1
+        li = bid - first[s]
+        gx, gy, gz = grids[s]
+        if li >= gx * gy * gz:
+            return None
+        q = li // gx
+        return s, li - q * gx, q - (q // gy) * gy, q // gy
+
+    def xcd_remap(lin, total):
+        q, r = total >> 3, total & 7
+        xcd, k = lin & 7, lin >> 3
+        return xcd * q + min(xcd, r) + k
+
+    cdiv = lambda a, b: (a + b - 1) // b
+    B = 16
+    sizes = [(256, 832), (128, 416), (64, 208)]
+    flat = lambda n: min(max(cdiv(n, 256), 1), 8192)
+    families = {
+        'flat (occlusion weights)': [(flat(B // 2 * h * w), 1, 1) for h, w in sizes],
+        'partial sums (masked mean, consistency)': [(cdiv(h * w, 2048), B, 1) for h, w in sizes],
+        'smoothness tiles': [(cdiv(w, 64), cdiv(h, 8), B) for h, w in sizes],
+        'SSIM strips x chunks': [(cdiv(w, 124) * cdiv(h, 16 if h >= 128 else 8), B, 1) for h, w in sizes],
+        'ragged': [(3, 5, 2), (1, 1, 1), (7, 1, 3), (2, 2, 2)],
+    }
+    for name, grids in families.items():
+        first = table(grids)
+        assert all(f % 8 == 0 for f in first), name
+        seen = {}
+        for bid in range(first[-1]):
+            v = locate(first, grids, bid)
+            if v is not None:
+                assert v not in seen, (name, v)
+                seen[v] = bid
+                assert (bid - first[v[0]]) % 8 == bid % 8                          # the XCD of the virtual id is the real one
+        want = {(s, x, y, z) for s, (gx, gy, gz) in enumerate(grids) for x in range(gx) for y in range(gy) for z in range(gz)}
+        assert set(seen) == want, name
+        for s, (gx, gy, gz) in enumerate(grids):
+            total = gx * gy * gz
+            assert sorted(xcd_remap(x + gx * (y + gy * z), total) for x in range(gx) for y in range(gy) for z in range(gz)) == list(range(total))
 
 
 def test_torch_library_is_built_in_tree():

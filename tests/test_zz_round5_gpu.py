@@ -119,3 +119,71 @@ def test_corr_backward_on_the_matrix_cores_ragged_d8(ops, d, B, C, h, w):
     """The d = 8 shapes of test_hip_ops.py::test_corr_backward_on_the_matrix_cores that had not run when the lease closed: a last
     segment of 4 / 12 pixels, three channel super-groups, a row count that is not a multiple of the chunk, 16 channels."""
     _matrix_core_backward_case(ops, d, B, C, h, w)
+
+
+@pytest.mark.parametrize('B,h,w', [(2, 64, 208), (3, 60, 104), (8, 256, 832)])
+def test_multiscale_losses_are_the_same_bits(ops, B, h, w):
+    """Round 5 (csrc/multiscale.h, C ABI 11): every loss of the scale loop as ONE launch over the three scales -- the `_ms` kernels
+    include the single-scale kernels' bodies and run their grids, so losses, saved sums and every gradient equal the per-scale ops
+    bit for bit, inside and outside ``deferred_loss_sums``; 5 forward + 1 second-stage + 5 backward loss launches instead of 31.
+    Shapes: tiles that divide, a ragged one (60 x 104 -> 15 x 26 at scale 2: partial tiles, SSIM 8-row chunks), and the train step's."""
+    n = 3
+    hs, ws = [h >> s for s in range(n)], [w >> s for s in range(n)]
+    imgs = [dev(rnd(71 + s, (B, 3, hs[s], ws[s]), uniform=True)) for s in range(n)]
+    warped0 = [torch.cat(((imgs[s] + dev(rnd(74 + s, (B, 3, hs[s], ws[s]), 0.1))).clamp(0, 1),
+                          (imgs[s] + dev(rnd(77 + s, (B, 3, hs[s], ws[s]), 0.1))).clamp(0, 1))) for s in range(n)]
+    for s in range(n):
+        warped0[s][:B, :, 1:5, 2:9] = 0.0                               # an all-zero (invalid) region in one direction
+    flows0 = [dev(rnd(80 + s, (2 * B, 2, hs[s], ws[s]), 3.0 / (1 << s))) for s in range(n)]
+    gl = [dev(rnd(90 + k, (B,))) for k in range(4)]
+    assert ops.multiscale_supported(imgs, warped0)
+    res = {}
+    for form in ('per scale', 'one launch', 'one launch, sums at once'):
+        wp = [t.clone().requires_grad_() for t in warped0]
+        fl = [t.clone().requires_grad_() for t in flows0]
+        halves = [f.split(B) for f in fl]
+        fb, ff = [x[0] for x in halves], [x[1] for x in halves]
+        ops.kernel_timer.enable(True)
+        ctx = __import__('contextlib').nullcontext() if form.endswith('at once') else ops.deferred_loss_sums
+        with ctx:
+            if form == 'per scale':
+                pixel, ssim, smooth, consis = [], [], [], []
+                for s in range(n):
+                    diff, wgt = ops.occ_weight_stacked(imgs[s], wp[s])
+                    pixel.append(ops.masked_mean(diff, wgt)); ssim.append(ops.ssim_loss(imgs[s], wp[s], wgt))
+                    smooth.append(ops.smooth2_loss(fl[s], imgs[s])); consis.append(ops.consis_loss(ff[s], fb[s], wgt[B:]))
+            else:
+                pixel, ssim, smooth, consis = ops.multiscale_losses(imgs, wp, fl, ff, fb)
+            packed = ops.loss_combine(pixel, ssim, smooth, consis)
+        sum((p * g).sum() for p, g in zip(packed, gl)).backward()
+        torch.cuda.synchronize()
+        ops.kernel_timer.disable()
+        rows = ops.kernel_timer.rows()
+        launches = sum(r['launches'] for r in rows if r['entry'] not in ('unflow_loss_combine_fwd', 'unflow_loss_combine_bwd'))
+        res[form] = ([t.clone() for t in packed] + [t.grad.clone() for t in wp] + [t.grad.clone() for t in fl] +
+                     [t.clone() for t in pixel + ssim + smooth + consis], launches, {r['entry'] for r in rows})
+    assert res['per scale'][1] == 10 * n + 1 and res['one launch'][1] == 11, (res['per scale'][1], res['one launch'][1])
+    assert all(e.endswith('_ms') or e in ('unflow_loss_finalize_batch', 'unflow_loss_combine_fwd', 'unflow_loss_combine_bwd') for e in res['one launch'][2])
+    for form in ('one launch', 'one launch, sums at once'):
+        for k, (a, b) in enumerate(zip(res['per scale'][0], res[form][0])):
+            assert torch.equal(a, b), (form, k, float((a - b).abs().max()))
+
+
+def test_multiscale_losses_in_the_model(ops):
+    """Model_flow.multiscale_losses: the same loss pack and the same loss-side gradients (the flows' and the warped images' come out of the
+    loss kernels; compared here through the total gradient norm, which also crosses MIOpen's run-to-run level) as the per-scale loop."""
+    from unopticalflow_amd import get_model, generate_loss_weights_dict
+    cfg = R.default_cfg()
+    inputs = R.synthetic_triplets(2, 128, 192, seed=5, structured=True).cuda()
+    packs, norms = [], []
+    for ms in (False, True):
+        model = get_model('flow')(cfg).cuda()
+        model.load_state_dict(R.seeded_state_dict(model, 1234, 0.25))
+        model.multiscale_losses = ms
+        pack = model(inputs)
+        R.total_loss(pack, generate_loss_weights_dict(cfg)).backward()
+        packs.append({k: v.detach().clone() for k, v in pack.items()})
+        norms.append(float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None))))
+    for k in packs[0]:
+        assert torch.equal(packs[0][k], packs[1][k]), k
+    assert abs(norms[0] - norms[1]) <= 1e-3 * norms[0], norms

@@ -49,7 +49,7 @@ profile() {   # $1 = fp32 | bf16
 for r in "$@"; do
 case $r in
   suite)
-    timeout 2400 python3 -m pytest tests -m gpu -q -p no:cacheprovider --timeout 900 --durations=15 > $out/suite.log 2>&1; echo "suite rc=$?"; tail -25 $out/suite.log
+    timeout 2400 python3 -m pytest tests -m gpu -q -p no:cacheprovider --timeout 900 --durations=30 > $out/suite.log 2>&1; echo "suite rc=$?"; tail -25 $out/suite.log
     python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
   headline)
     for i in a b; do python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_n1_$i.json 2> $out/bench_n1_$i.err; done

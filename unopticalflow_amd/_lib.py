@@ -67,6 +67,16 @@ SIGNATURES = {
     'unflow_adam_chunk': [],
     'unflow_loss_partial_blocks': [_I, _I, _I, _I, _I],
     'unflow_loss_finalize_batch': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    'unflow_occ_weight_fwd_ms': [_I, _P, _P, _P, _P, _P, _P, _I, _P],
+    'unflow_absdiff_bwd_ms': [_I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    'unflow_masked_mean_fwd_ms': [_I, _P, _P, _P, _P, _P, _I, _P],
+    'unflow_masked_mean_bwd_ms': [_I, _P, _P, _P, _P, _P, _P, _I, _P],
+    'unflow_ssim_loss_fwd_ms': [_I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    'unflow_ssim_loss_bwd_ms': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    'unflow_smooth2_fwd_ms': [_I, _P, _P, _P, _P, _P, _I, _I, _P],
+    'unflow_smooth2_bwd_ms': [_I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    'unflow_consis_fwd_ms': [_I, _P, _P, _P, _P, _P, _P, _I, _P],
+    'unflow_consis_bwd_ms': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     'unflow_adam_multi': [_P, _P, _I, _P, _I, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P],
     'unflow_loss_combine_fwd': [_P, _I, _I, _P, _P],
     'unflow_loss_combine_bwd': [_P, _I, _P, _P],
@@ -112,7 +122,7 @@ class UnflowLibraryError(RuntimeError):
 # The ABI this file's SIGNATURES table was written for.  Bump it together with UNFLOW_ABI_VERSION of include/unflow_hip.h whenever an
 # entry point changes: load() wants library == header == this number, so a header bump + rebuild with a stale ctypes table is caught
 # (reading the number from the header alone only detects a stale .so).
-BINDING_ABI = 10
+BINDING_ABI = 11
 
 
 def _abi_version():

@@ -32,6 +32,8 @@ FLAGS = ('-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-ffp-contract=o
 
 def _headers():
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    bodies = os.path.join(CSRC, 'bodies')                          # kernel bodies that a single-scale and a multi-scale kernel both include
+    deps += [os.path.join(bodies, f) for f in sorted(os.listdir(bodies)) if f.endswith('.inc')] if os.path.isdir(bodies) else []
     deps.append(os.path.join(os.path.dirname(PKG), 'include', 'unflow_hip.h'))
     deps.append(os.path.abspath(__file__))
     return deps

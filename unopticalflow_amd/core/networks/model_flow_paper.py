@@ -44,6 +44,10 @@ class Model_flow(nn.Module):
         self.dup_centre = True           # the pyramid hand-off writes the centre features twice (False: torch.cat((c, c)); A/B)
         self.fused_loss_sums = True      # the sums over scales and directions of forward() as one launch each way (False: eager adds; tests compare)
         self.deferred_loss_sums = True   # the second stage of the per-sample loss reductions as one launch in front of loss_combine (False: one per reduction; same bits)
+        # every loss of the scale loop as ONE launch over the scales per direction of the pass (ops.multiscale_losses, csrc/multiscale.h): same kernel
+        # bodies, same bits, 30 loss launches -> 10.  Off until its GPU tests have run (written after the round-5 GPU lease closed); bench.py
+        # --multiscale-losses 1 / tests/test_zz_round5_gpu.py switch it on
+        self.multiscale_losses = bool(getattr(cfg, 'multiscale_losses', False))
         self.fpyramid = FeaturePyramid(channels_last=self.channels_last)
         self.pwc_model = PWC_tf(align_corners=self.align_corners, fused_warp_corr=bool(getattr(cfg, 'fused_warp_corr', False)),
                                 channels_last=self.channels_last)
@@ -229,7 +233,11 @@ class Model_flow(nn.Module):
         # round 5: the second stage of the 4 x n per-sample reductions below is ONE launch in front of loss_combine (its only reader)
         # instead of one per reduction -- ops.deferred_loss_sums, same bits
         with (ops.deferred_loss_sums if (fused_sums and self.deferred_loss_sums and images.is_cuda) else contextlib.nullcontext()):
-            for s in range(n):
+            one_launch_per_loss = self.multiscale_losses and ops.multiscale_supported(img_pyramid[:n], warped[:n])
+            if one_launch_per_loss:
+                pixel, ssim, smooth, consis = ops.multiscale_losses(img_pyramid[:n], warped[:n], flows_lr[:n], optical_flows_fwd[:n],
+                                                                    optical_flows_bwd[:n])
+            for s in (() if one_launch_per_loss else range(n)):
                 diff, wgt = ops.occ_weight_stacked(img_pyramid[s], warped[s])       # (diff_bwd | diff_fwd), (weight_bwd | weight_fwd)
                 pixel.append(ops.masked_mean(diff, wgt))
                 ssim.append(ops.ssim_loss(img_pyramid[s], warped[s], wgt))
@@ -238,9 +246,7 @@ class Model_flow(nn.Module):
             if fused_sums:
                 # `loss = 0; loss += term(scale)` per loss, then fwd + bwd (:226-233), as one launch each way (ops.loss_combine)
                 packed = ops.loss_combine(pixel, ssim, smooth, consis)
-        if fused_sums:
-            pass
-        else:
+        if not fused_sums:
             packed = [sum(t[1:], t[0]) for t in (pixel, ssim, smooth, consis)]
             packed = [t[B:] + t[:B] for t in packed[:3]] + packed[3:]           # fwd + bwd (:226-227)
         loss_pack['loss_pixel'], loss_pack['loss_ssim'], loss_pack['loss_flow_smooth'], loss_pack['loss_flow_consis'] = packed

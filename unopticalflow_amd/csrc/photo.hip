@@ -7,6 +7,7 @@
 // partial per workgroup -> fixed-order finalize (bitwise reproducible, no float atomics).
 // Built with -ffp-contract=off: the elementwise algebra follows the reference op by op.
 #include "common.h"
+#include "multiscale.h"
 #include <stdlib.h>
 
 namespace {
@@ -21,39 +22,7 @@ __global__ void occ_weight_fwd_kernel(const float* __restrict__ img, const float
                                       float* __restrict__ diff_r, float* __restrict__ w_bwd,
                                       float* __restrict__ w_fwd, uint8_t* __restrict__ valid_bwd,
                                       uint8_t* __restrict__ valid_fwd, int B, int HW) {
-    const size_t n = (size_t)B * HW;
-    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-        const size_t b = t / HW, p = t - b * HW;
-        const size_t base = b * 3 * HW + p;
-        float dl = 0.f, dr = 0.f;
-        bool zl = true, zr = true;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float i = img[base + (size_t)c * HW];
-            const float l = from_l[base + (size_t)c * HW];
-            const float r = from_r[base + (size_t)c * HW];
-            dl = dl + fabsf(i - l);
-            dr = dr + fabsf(i - r);
-            zl = zl && (l == 0.f);
-            zr = zr && (r == 0.f);
-        }
-        dl = dl / 3.0f;                                   // :117-118  mean over the 3 channels
-        dr = dr / 3.0f;
-        const float vb = zl ? 0.f : 1.f;                  // :112  valid_bwd  <- img_from_l
-        const float vf = zr ? 0.f : 1.f;                  // :111  valid_fwd  <- img_from_r
-        const float mx = fmaxf(dl, dr);                   // :121  softmax over (diff_l, diff_r)
-        const float el = expf(dl - mx), er = expf(dr - mx);
-        const float den = el + er;
-        const float wl = 1.0f - el / den, wr = 1.0f - er / den;
-        const float tl = wl - 0.5f, tr = wr - 0.5f;       // :126
-        const float gl = 2.0f * expf(-(tl * tl) / 0.03f);
-        const float gr = 2.0f * expf(-(tr * tr) / 0.03f);
-        diff_l[t] = dl; diff_r[t] = dr;
-        w_bwd[t] = gl * vb;                               // :128
-        w_fwd[t] = gr * vf;                               // :129
-        if (valid_bwd) valid_bwd[t] = zl ? 0 : 1;
-        if (valid_fwd) valid_fwd[t] = zr ? 0 : 1;
-    }
+#include "bodies/occ_weight_fwd.inc"
 }
 
 // d mean_c|img - from| / d from  (torch: abs' = sign, with sign(0) = 0)
@@ -61,13 +30,7 @@ __global__ void occ_weight_fwd_kernel(const float* __restrict__ img, const float
 // the centre image, so the two directions run as one 2B launch)
 __global__ void absdiff_bwd_kernel(const float* __restrict__ img, const float* __restrict__ from,
                                    const float* __restrict__ gdiff, float* __restrict__ gfrom, int B, int HW, int img_b) {
-    const size_t n = (size_t)B * 3 * HW;
-    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-        const size_t b = t / ((size_t)3 * HW), p = t % HW;
-        const float d = img[t - (b - b % img_b) * 3 * HW] - from[t];
-        const float sg = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-        gfrom[t] = -(gdiff[b * HW + p] / 3.0f) * sg;
-    }
+#include "bodies/absdiff_bwd.inc"
 }
 
 #ifdef UNFLOW_LOSS_R5B
@@ -90,24 +53,7 @@ __global__ __launch_bounds__(256) void absdiff_bwd4_kernel(const float* __restri
 __global__ __launch_bounds__(256) void masked_mean_partial_kernel(const float* __restrict__ diff,
                                                                   const float* __restrict__ w,
                                                                   float* __restrict__ partials, int HW) {
-    __shared__ float red[8];
-    const int b = blockIdx.y;
-    float acc[2] = {0.f, 0.f};
-    const int p0 = blockIdx.x * TILE;
-#pragma unroll
-    for (int k = 0; k < TILE / 256; ++k) {
-        const int p = p0 + k * 256 + threadIdx.x;
-        if (p < HW) {
-            const float wv = w[(size_t)b * HW + p];
-            acc[0] += diff[(size_t)b * HW + p] * wv;
-            acc[1] += wv;
-        }
-    }
-    block_sum_256<2>(acc, red);
-    if (threadIdx.x == 0) {
-        float* o = partials + ((size_t)b * gridDim.x + blockIdx.x) * 2;
-        o[0] = acc[0]; o[1] = acc[1];
-    }
+#include "bodies/masked_mean_partial.inc"
 }
 
 // generic finalize for loss = (s0 / n0) / (s1 / n1 + 1e-12)
@@ -127,12 +73,7 @@ __global__ void ratio_finalize_kernel(const float* __restrict__ partials, int nb
 __global__ void masked_mean_bwd_kernel(const float* __restrict__ w, const float* __restrict__ sums,
                                        const float* __restrict__ gloss, float* __restrict__ gdiff,
                                        int B, int HW) {
-    const size_t n = (size_t)B * HW;
-    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-        const size_t b = t / HW;
-        const float k = gloss[b] / (float)HW / (sums[b * 2 + 1] / (float)HW + 1e-12f);
-        gdiff[t] = k * w[t];
-    }
+#include "bodies/masked_mean_bwd.inc"
 }
 
 #ifdef UNFLOW_LOSS_R5B
@@ -337,99 +278,14 @@ __device__ __forceinline__ float stage_edge_w(const SmoothStage& t, int j0, int 
 // grid = (tiles_x, tiles_y, B); partials[(b * tiles + tile) * 2] = {sum over the tile of wx |dx2|, of wy |dy2|}
 __global__ __launch_bounds__(256) void smooth2_fwd_tile_kernel(const float* __restrict__ flow, const float* __restrict__ img,
                                                                float* __restrict__ partials, int H, int W, int img_b) {
-    __shared__ SmoothStage t;
-    __shared__ float red[8];
-    // XCD-local tile order: the staged region is 68 x 12 positions for 64 x 8 pixels -- the ring is the neighbours' pixels, and only a
-    // shared L2 keeps it from being fetched from HBM once per tile
-    const int tiles = (int)(gridDim.x * gridDim.y);
-    int wi = xcd_remap((int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)), tiles * (int)gridDim.z);
-    const int b = wi / tiles; wi -= b * tiles;
-    const int tyi = wi / (int)gridDim.x, txi = wi - tyi * (int)gridDim.x;
-    const int x0 = txi * SM_TW, y0 = tyi * SM_TH;
-    const int HW = H * W;
-    smooth_stage(t, flow + (size_t)b * 2 * HW, img + (size_t)(b % img_b) * 3 * HW, HW, H, W, x0, y0);
-    __syncthreads();
-    float acc[2] = {0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < SM_TW * SM_TH / 256; ++k) {
-        const int idx = k * 256 + (int)threadIdx.x;
-        const int r = idx / SM_TW, c = idx - r * SM_TW;
-        const int y = y0 + r, x = x0 + c;
-        if (x >= W || y >= H) continue;
-        const int j = (r + 2) * SG_W + c + 2;
-        if (x + 2 < W) {                                 // dx2 at x, weight w_x[x+1]
-            const float wx = stage_edge_w(t, j + 1, j + 2);
-            acc[0] += wx * fabsf((t.f0[j + 2] - t.f0[j + 1]) - (t.f0[j + 1] - t.f0[j]));
-            acc[0] += wx * fabsf((t.f1[j + 2] - t.f1[j + 1]) - (t.f1[j + 1] - t.f1[j]));
-        }
-        if (y + 2 < H) {
-            const float wy = stage_edge_w(t, j + SG_W, j + 2 * SG_W);
-            acc[1] += wy * fabsf((t.f0[j + 2 * SG_W] - t.f0[j + SG_W]) - (t.f0[j + SG_W] - t.f0[j]));
-            acc[1] += wy * fabsf((t.f1[j + 2 * SG_W] - t.f1[j + SG_W]) - (t.f1[j + SG_W] - t.f1[j]));
-        }
-    }
-    block_sum_256<2>(acc, red);
-    if (threadIdx.x == 0) {
-        float* o = partials + ((size_t)b * tiles + (size_t)tyi * gridDim.x + txi) * 2;
-        o[0] = acc[0]; o[1] = acc[1];
-    }
+#include "bodies/smooth2_fwd_tile.inc"
 }
 
 // the backward of smooth2_bwd_tile_kernel with its S values computed from the staged tile
 __global__ __launch_bounds__(256) void smooth2_bwd_stage_kernel(const float* __restrict__ flow, const float* __restrict__ img,
                                                                 const float* __restrict__ gloss, float* __restrict__ gflow,
                                                                 int H, int W, int img_b) {
-    constexpr int NX = SM_TH * (SM_TW + 2), NY = (SM_TH + 2) * SM_TW;
-    __shared__ SmoothStage t;
-    __shared__ float2 s_x[NX], s_y[NY];
-    const int tiles = (int)(gridDim.x * gridDim.y);             // (XCD-local tile order, as the forward)
-    int wi = xcd_remap((int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)), tiles * (int)gridDim.z);
-    const int b = wi / tiles; wi -= b * tiles;
-    const int tyi = wi / (int)gridDim.x, txi = wi - tyi * (int)gridDim.x;
-    const int x0 = txi * SM_TW, y0 = tyi * SM_TH;
-    const int HW = H * W;
-    smooth_stage(t, flow + (size_t)b * 2 * HW, img + (size_t)(b % img_b) * 3 * HW, HW, H, W, x0, y0);
-    __syncthreads();
-    for (int i = threadIdx.x; i < NX + NY; i += 256) {
-        float2 v = make_float2(0.f, 0.f);
-        if (i < NX) {
-            const int r = i / (SM_TW + 2), c = i - r * (SM_TW + 2);
-            const int y = y0 + r, x = x0 - 2 + c;                    // dx2 starting at x, weight w_x[x+1]
-            if (y < H && x >= 0 && x + 2 < W) {
-                const int j = (r + 2) * SG_W + c;
-                const float w = stage_edge_w(t, j + 1, j + 2);
-                v = make_float2(w * sgn((t.f0[j + 2] - t.f0[j + 1]) - (t.f0[j + 1] - t.f0[j])),
-                                w * sgn((t.f1[j + 2] - t.f1[j + 1]) - (t.f1[j + 1] - t.f1[j])));
-            }
-            s_x[i] = v;
-        } else {
-            const int k = i - NX;
-            const int r = k / SM_TW, c = k - r * SM_TW;
-            const int y = y0 - 2 + r, x = x0 + c;
-            if (x < W && y >= 0 && y + 2 < H) {
-                const int j = r * SG_W + c + 2;
-                const float w = stage_edge_w(t, j + SG_W, j + 2 * SG_W);
-                v = make_float2(w * sgn((t.f0[j + 2 * SG_W] - t.f0[j + SG_W]) - (t.f0[j + SG_W] - t.f0[j])),
-                                w * sgn((t.f1[j + 2 * SG_W] - t.f1[j + SG_W]) - (t.f1[j + SG_W] - t.f1[j])));
-            }
-            s_y[k] = v;
-        }
-    }
-    __syncthreads();
-    const float kx = gloss[b] / (2.0f * (2.0f * (float)H * (float)(W - 2))) / 20.0f;
-    const float ky = gloss[b] / (2.0f * (2.0f * (float)(H - 2) * (float)W)) / 20.0f;
-#pragma unroll
-    for (int k = 0; k < SM_TW * SM_TH / 256; ++k) {
-        const int idx = k * 256 + (int)threadIdx.x;
-        const int r = idx / SM_TW, c = idx - r * SM_TW;
-        const int y = y0 + r, x = x0 + c;
-        if (x >= W || y >= H) continue;
-        const float2 xa = s_x[r * (SM_TW + 2) + c], xb = s_x[r * (SM_TW + 2) + c + 1], xc = s_x[r * (SM_TW + 2) + c + 2];      // starts x-2, x-1, x
-        const float2 ya = s_y[r * SM_TW + c], yb = s_y[(r + 1) * SM_TW + c], yc = s_y[(r + 2) * SM_TW + c];                    // starts y-2, y-1, y
-        const size_t o = (size_t)b * 2 * HW + (size_t)y * W + x;
-        gflow[o] = kx * ((xa.x - 2.f * xb.x) + xc.x) + ky * ((ya.x - 2.f * yb.x) + yc.x);
-        gflow[o + HW] = kx * ((xa.y - 2.f * xb.y) + xc.y) + ky * ((ya.y - 2.f * yb.y) + yc.y);
-    }
+#include "bodies/smooth2_bwd_stage.inc"
 }
 
 // gather form of the backward: pixel q collects the three second differences it takes part in.
@@ -485,51 +341,13 @@ __global__ __launch_bounds__(256) void consis_partial_kernel(const float* __rest
                                                              const float* __restrict__ fb,
                                                              const float* __restrict__ w_fwd,
                                                              float* __restrict__ partials, int HW) {
-    __shared__ float red[8];
-    const int b = blockIdx.y;
-    const float* f = ff + (size_t)b * 2 * HW;
-    const float* g = fb + (size_t)b * 2 * HW;
-    float acc[2] = {0.f, 0.f};
-    const int p0 = blockIdx.x * TILE;
-#pragma unroll
-    for (int k = 0; k < TILE / 256; ++k) {
-        const int p = p0 + k * 256 + threadIdx.x;
-        if (p < HW) {
-            const float fu = f[p], fv = f[HW + p], gu = g[p], gv = g[HW + p];
-            const float nf = sqrtf(fu * fu + fv * fv) + 1e-12f;
-            const float ng = sqrtf(gu * gu + gv * gv) + 1e-12f;
-            const float occ = 1.0f - w_fwd[(size_t)b * HW + p];
-            acc[0] += fabsf(fu / nf + gu / ng) * occ + fabsf(fv / nf + gv / ng) * occ;
-            acc[1] += occ;
-        }
-    }
-    block_sum_256<2>(acc, red);
-    if (threadIdx.x == 0) {
-        float* o = partials + ((size_t)b * gridDim.x + blockIdx.x) * 2;
-        o[0] = acc[0]; o[1] = acc[1];
-    }
+#include "bodies/consis_partial.inc"
 }
 
 __global__ void consis_bwd_kernel(const float* __restrict__ ff, const float* __restrict__ fb,
                                   const float* __restrict__ w_fwd, const float* __restrict__ sums,
                                   const float* __restrict__ gloss, float* __restrict__ gflow, int B, int HW) {
-    const size_t n = (size_t)B * HW;
-    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-        const size_t b = t / HW, p = t - b * HW;
-        const float* f = ff + b * 2 * HW;
-        const float* g = fb + b * 2 * HW;
-        const float fu = f[p], fv = f[HW + p], gu = g[p], gv = g[HW + p];
-        const float n0 = sqrtf(fu * fu + fv * fv), nf = n0 + 1e-12f;
-        const float ng = sqrtf(gu * gu + gv * gv) + 1e-12f;
-        const float occ = 1.0f - w_fwd[t];
-        const float k = gloss[b] / (2.0f * (float)HW) / (sums[b * 2 + 1] / (float)HW + 1e-12f) * occ;
-        const float tu = k * sgn(fu / nf + gu / ng), tv = k * sgn(fv / nf + gv / ng);
-        // f_hat = f / (|f| + eps):  d f_hat_c / d f_j = delta_cj / nf - f_c f_j / (nf^2 |f|)
-        const float dot = tu * fu + tv * fv;
-        const float r = (n0 > 0.f) ? dot / (nf * nf * n0) : 0.f;
-        gflow[b * 2 * HW + p] = tu / nf - r * fu;
-        gflow[b * 2 * HW + HW + p] = tv / nf - r * fv;
-    }
+#include "bodies/consis_bwd.inc"
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -589,6 +407,81 @@ __global__ void weighted_mean_sum_bwd_kernel(MeanGrads out, int K, int B, const 
     if (b >= B) return;
     const float g = *gloss / (float)B;
     for (int k = 0; k < K; ++k) out.g[k][b] = out.w[k] * g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One launch over the scales (csrc/multiscale.h): the bodies above once more, behind a table of per-scale arguments.
+// ---------------------------------------------------------------------------------------------
+struct OccMsArgs { const float *img, *from_l, *from_r; float *diff_l, *diff_r, *w_bwd, *w_fwd; int HW; };
+__global__ void occ_weight_fwd_ms_kernel(MsTable<OccMsArgs> ms_table_, int B) {
+    UNFLOW_MS_PROLOGUE(ms_table_);
+    const float* __restrict__ img = ms_a_.img; const float* __restrict__ from_l = ms_a_.from_l; const float* __restrict__ from_r = ms_a_.from_r;
+    float* __restrict__ diff_l = ms_a_.diff_l; float* __restrict__ diff_r = ms_a_.diff_r;
+    float* __restrict__ w_bwd = ms_a_.w_bwd; float* __restrict__ w_fwd = ms_a_.w_fwd;
+    uint8_t* __restrict__ valid_bwd = nullptr; uint8_t* __restrict__ valid_fwd = nullptr;      // (the train step does not take the masks)
+    const int HW = ms_a_.HW;
+#include "bodies/occ_weight_fwd.inc"
+}
+
+struct AbsdiffMsArgs { const float *img, *from, *gdiff; float* gfrom; int HW; };
+__global__ void absdiff_bwd_ms_kernel(MsTable<AbsdiffMsArgs> ms_table_, int B, int img_b) {
+    UNFLOW_MS_PROLOGUE(ms_table_);
+    const float* __restrict__ img = ms_a_.img; const float* __restrict__ from = ms_a_.from; const float* __restrict__ gdiff = ms_a_.gdiff;
+    float* __restrict__ gfrom = ms_a_.gfrom;
+    const int HW = ms_a_.HW;
+#include "bodies/absdiff_bwd.inc"
+}
+
+struct MeanMsArgs { const float *diff, *w; float* partials; int HW; };
+__global__ __launch_bounds__(256) void masked_mean_partial_ms_kernel(MsTable<MeanMsArgs> ms_table_) {
+    UNFLOW_MS_PROLOGUE(ms_table_);
+    const float* __restrict__ diff = ms_a_.diff; const float* __restrict__ w = ms_a_.w; float* __restrict__ partials = ms_a_.partials;
+    const int HW = ms_a_.HW;
+#include "bodies/masked_mean_partial.inc"
+}
+
+struct MeanBwdMsArgs { const float *w, *sums, *gloss; float* gdiff; int HW; };
+__global__ void masked_mean_bwd_ms_kernel(MsTable<MeanBwdMsArgs> ms_table_, int B) {
+    UNFLOW_MS_PROLOGUE(ms_table_);
+    const float* __restrict__ w = ms_a_.w; const float* __restrict__ sums = ms_a_.sums; const float* __restrict__ gloss = ms_a_.gloss;
+    float* __restrict__ gdiff = ms_a_.gdiff;
+    const int HW = ms_a_.HW;
+#include "bodies/masked_mean_bwd.inc"
+}
+
+struct SmoothMsArgs { const float *flow, *img; float* partials; int H, W; };
+__global__ __launch_bounds__(256) void smooth2_fwd_tile_ms_kernel(MsTable<SmoothMsArgs> ms_table_, int img_b) {
+    UNFLOW_MS_PROLOGUE(ms_table_);
+    const float* __restrict__ flow = ms_a_.flow; const float* __restrict__ img = ms_a_.img; float* __restrict__ partials = ms_a_.partials;
+    const int H = ms_a_.H, W = ms_a_.W;
+#include "bodies/smooth2_fwd_tile.inc"
+}
+
+struct SmoothBwdMsArgs { const float *flow, *img, *gloss; float* gflow; int H, W; };
+__global__ __launch_bounds__(256) void smooth2_bwd_stage_ms_kernel(MsTable<SmoothBwdMsArgs> ms_table_, int img_b) {
+    UNFLOW_MS_PROLOGUE(ms_table_);
+    const float* __restrict__ flow = ms_a_.flow; const float* __restrict__ img = ms_a_.img; const float* __restrict__ gloss = ms_a_.gloss;
+    float* __restrict__ gflow = ms_a_.gflow;
+    const int H = ms_a_.H, W = ms_a_.W;
+#include "bodies/smooth2_bwd_stage.inc"
+}
+
+struct ConsisMsArgs { const float *ff, *fb, *w_fwd; float* partials; int HW; };
+__global__ __launch_bounds__(256) void consis_partial_ms_kernel(MsTable<ConsisMsArgs> ms_table_) {
+    UNFLOW_MS_PROLOGUE(ms_table_);
+    const float* __restrict__ ff = ms_a_.ff; const float* __restrict__ fb = ms_a_.fb; const float* __restrict__ w_fwd = ms_a_.w_fwd;
+    float* __restrict__ partials = ms_a_.partials;
+    const int HW = ms_a_.HW;
+#include "bodies/consis_partial.inc"
+}
+
+struct ConsisBwdMsArgs { const float *ff, *fb, *w_fwd, *sums, *gloss; float* gflow; int HW; };
+__global__ void consis_bwd_ms_kernel(MsTable<ConsisBwdMsArgs> ms_table_, int B) {
+    UNFLOW_MS_PROLOGUE(ms_table_);
+    const float* __restrict__ ff = ms_a_.ff; const float* __restrict__ fb = ms_a_.fb; const float* __restrict__ w_fwd = ms_a_.w_fwd;
+    const float* __restrict__ sums = ms_a_.sums; const float* __restrict__ gloss = ms_a_.gloss; float* __restrict__ gflow = ms_a_.gflow;
+    const int HW = ms_a_.HW;
+#include "bodies/consis_bwd.inc"
 }
 
 inline int flat_blocks(size_t n) {
@@ -899,5 +792,131 @@ extern "C" int unflow_consis_bwd(const float* fwd_flow, const float* bwd_flow, c
     hipStream_t s = (hipStream_t)stream;
     UNFLOW_LAUNCH(consis_bwd_kernel, dim3(flat_blocks((size_t)B * H * W)), dim3(256), 0, s, fwd_flow, bwd_flow,
                        w_fwd, sums, gloss, gflow, B, H * W);
+    return unflow_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// The loss entries above, ONE launch for n <= 4 scales each (csrc/multiscale.h).  Every array argument is a HOST array with one
+// entry per scale; B / img_batch are common to the scales.  The forward entries stop after the first stage of the per-sample
+// reductions (what the single-scale entries do with loss == NULL): unflow_loss_finalize_batch finishes them, with
+// unflow_loss_partial_blocks partial sums per sample at a scale -- the same grids, the same partial sums and the same bits as n
+// single-scale calls.  -22 for shapes the single-scale entries serve by another kernel (B > 65535, H or W < 3 in the smoothness
+// backward, odd W / unaligned tensors in the SSIM pair): call those per scale.
+// ---------------------------------------------------------------------------------------------
+#define UNFLOW_MS_REQUIRE_N(n) UNFLOW_REQUIRE((n) > 0 && (n) <= MS_MAX)
+
+// stacked layout of the train step: warped = (from_l | from_r) [2B,3,H,W] against the B centre images -> diff = (diff_l | diff_r),
+// wgt = (w_bwd | w_fwd) [2B,1,H,W]  (model_flow_paper.py:108-132)
+extern "C" int unflow_occ_weight_fwd_ms(int n, const float* const* img, const float* const* warped, float* const* diff,
+                                        float* const* wgt, const int* H, const int* W, int B, void* stream) {
+    UNFLOW_REQUIRE(img && warped && diff && wgt && H && W && B > 0);
+    UNFLOW_MS_REQUIRE_N(n);
+    MsTable<OccMsArgs> t = {};
+    for (int k = 0; k < n; ++k) {
+        UNFLOW_REQUIRE(img[k] && warped[k] && diff[k] && wgt[k] && H[k] > 0 && W[k] > 0);
+        const int HW = H[k] * W[k];
+        t.a[k] = OccMsArgs{img[k], warped[k], warped[k] + (size_t)B * 3 * HW, diff[k], diff[k] + (size_t)B * HW, wgt[k], wgt[k] + (size_t)B * HW, HW};
+        UNFLOW_REQUIRE(ms_grid_add(t.grid, dim3(flat_blocks((size_t)B * HW))));
+    }
+    UNFLOW_LAUNCH(occ_weight_fwd_ms_kernel, dim3(ms_grid_blocks(t.grid)), dim3(256), 0, (hipStream_t)stream, t, B);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_absdiff_bwd_ms(int n, const float* const* img, const float* const* from, const float* const* gdiff,
+                                     float* const* gfrom, const int* H, const int* W, int B, int img_batch, void* stream) {
+    UNFLOW_REQUIRE(img && from && gdiff && gfrom && H && W && B > 0 && img_batch > 0 && B % img_batch == 0);
+    UNFLOW_MS_REQUIRE_N(n);
+    MsTable<AbsdiffMsArgs> t = {};
+    for (int k = 0; k < n; ++k) {
+        UNFLOW_REQUIRE(img[k] && from[k] && gdiff[k] && gfrom[k] && H[k] > 0 && W[k] > 0);
+        t.a[k] = AbsdiffMsArgs{img[k], from[k], gdiff[k], gfrom[k], H[k] * W[k]};
+        UNFLOW_REQUIRE(ms_grid_add(t.grid, dim3(flat_blocks((size_t)B * 3 * H[k] * W[k]))));
+    }
+    UNFLOW_LAUNCH(absdiff_bwd_ms_kernel, dim3(ms_grid_blocks(t.grid)), dim3(256), 0, (hipStream_t)stream, t, B, img_batch);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_masked_mean_fwd_ms(int n, const float* const* diff, const float* const* w, float* const* partials,
+                                         const int* H, const int* W, int B, void* stream) {
+    UNFLOW_REQUIRE(diff && w && partials && H && W && B > 0 && B <= 65535);
+    UNFLOW_MS_REQUIRE_N(n);
+    MsTable<MeanMsArgs> t = {};
+    for (int k = 0; k < n; ++k) {
+        UNFLOW_REQUIRE(diff[k] && w[k] && partials[k] && H[k] > 0 && W[k] > 0);
+        t.a[k] = MeanMsArgs{diff[k], w[k], partials[k], H[k] * W[k]};
+        UNFLOW_REQUIRE(ms_grid_add(t.grid, dim3(ceil_div(H[k] * W[k], TILE), B)));
+    }
+    UNFLOW_LAUNCH(masked_mean_partial_ms_kernel, dim3(ms_grid_blocks(t.grid)), dim3(256), 0, (hipStream_t)stream, t);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_masked_mean_bwd_ms(int n, const float* const* w, const float* const* sums, const float* const* gloss,
+                                         float* const* gdiff, const int* H, const int* W, int B, void* stream) {
+    UNFLOW_REQUIRE(w && sums && gloss && gdiff && H && W && B > 0);
+    UNFLOW_MS_REQUIRE_N(n);
+    MsTable<MeanBwdMsArgs> t = {};
+    for (int k = 0; k < n; ++k) {
+        UNFLOW_REQUIRE(w[k] && sums[k] && gloss[k] && gdiff[k] && H[k] > 0 && W[k] > 0);
+        t.a[k] = MeanBwdMsArgs{w[k], sums[k], gloss[k], gdiff[k], H[k] * W[k]};
+        UNFLOW_REQUIRE(ms_grid_add(t.grid, dim3(flat_blocks((size_t)B * H[k] * W[k]))));
+    }
+    UNFLOW_LAUNCH(masked_mean_bwd_ms_kernel, dim3(ms_grid_blocks(t.grid)), dim3(256), 0, (hipStream_t)stream, t, B);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_smooth2_fwd_ms(int n, const float* const* flow, const float* const* img, float* const* partials,
+                                     const int* H, const int* W, int B, int img_batch, void* stream) {
+    UNFLOW_REQUIRE(flow && img && partials && H && W && B > 0 && B <= 65535 && img_batch > 0 && B % img_batch == 0);
+    UNFLOW_MS_REQUIRE_N(n);
+    MsTable<SmoothMsArgs> t = {};
+    for (int k = 0; k < n; ++k) {
+        UNFLOW_REQUIRE(flow[k] && img[k] && partials[k] && H[k] > 0 && W[k] > 0);
+        t.a[k] = SmoothMsArgs{flow[k], img[k], partials[k], H[k], W[k]};
+        UNFLOW_REQUIRE(ms_grid_add(t.grid, dim3(ceil_div(W[k], SM_TW), ceil_div(H[k], SM_TH), B)));
+    }
+    UNFLOW_LAUNCH(smooth2_fwd_tile_ms_kernel, dim3(ms_grid_blocks(t.grid)), dim3(256), 0, (hipStream_t)stream, t, img_batch);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_smooth2_bwd_ms(int n, const float* const* flow, const float* const* img, const float* const* gloss,
+                                     float* const* gflow, const int* H, const int* W, int B, int img_batch, void* stream) {
+    UNFLOW_REQUIRE(flow && img && gloss && gflow && H && W && B > 0 && B <= 65535 && img_batch > 0 && B % img_batch == 0);
+    UNFLOW_MS_REQUIRE_N(n);
+    MsTable<SmoothBwdMsArgs> t = {};
+    for (int k = 0; k < n; ++k) {
+        UNFLOW_REQUIRE(flow[k] && img[k] && gloss[k] && gflow[k] && H[k] >= 3 && W[k] >= 3);
+        t.a[k] = SmoothBwdMsArgs{flow[k], img[k], gloss[k], gflow[k], H[k], W[k]};
+        UNFLOW_REQUIRE(ms_grid_add(t.grid, dim3(ceil_div(W[k], SM_TW), ceil_div(H[k], SM_TH), B)));
+    }
+    UNFLOW_LAUNCH(smooth2_bwd_stage_ms_kernel, dim3(ms_grid_blocks(t.grid)), dim3(256), 0, (hipStream_t)stream, t, img_batch);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_consis_fwd_ms(int n, const float* const* fwd_flow, const float* const* bwd_flow, const float* const* w_fwd,
+                                    float* const* partials, const int* H, const int* W, int B, void* stream) {
+    UNFLOW_REQUIRE(fwd_flow && bwd_flow && w_fwd && partials && H && W && B > 0 && B <= 65535);
+    UNFLOW_MS_REQUIRE_N(n);
+    MsTable<ConsisMsArgs> t = {};
+    for (int k = 0; k < n; ++k) {
+        UNFLOW_REQUIRE(fwd_flow[k] && bwd_flow[k] && w_fwd[k] && partials[k] && H[k] > 0 && W[k] > 0);
+        t.a[k] = ConsisMsArgs{fwd_flow[k], bwd_flow[k], w_fwd[k], partials[k], H[k] * W[k]};
+        UNFLOW_REQUIRE(ms_grid_add(t.grid, dim3(ceil_div(H[k] * W[k], TILE), B)));
+    }
+    UNFLOW_LAUNCH(consis_partial_ms_kernel, dim3(ms_grid_blocks(t.grid)), dim3(256), 0, (hipStream_t)stream, t);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_consis_bwd_ms(int n, const float* const* fwd_flow, const float* const* bwd_flow, const float* const* w_fwd,
+                                    const float* const* sums, const float* const* gloss, float* const* gflow, const int* H,
+                                    const int* W, int B, void* stream) {
+    UNFLOW_REQUIRE(fwd_flow && bwd_flow && w_fwd && sums && gloss && gflow && H && W && B > 0);
+    UNFLOW_MS_REQUIRE_N(n);
+    MsTable<ConsisBwdMsArgs> t = {};
+    for (int k = 0; k < n; ++k) {
+        UNFLOW_REQUIRE(fwd_flow[k] && bwd_flow[k] && w_fwd[k] && sums[k] && gloss[k] && gflow[k] && H[k] > 0 && W[k] > 0);
+        t.a[k] = ConsisBwdMsArgs{fwd_flow[k], bwd_flow[k], w_fwd[k], sums[k], gloss[k], gflow[k], H[k] * W[k]};
+        UNFLOW_REQUIRE(ms_grid_add(t.grid, dim3(flat_blocks((size_t)B * H[k] * W[k]))));
+    }
+    UNFLOW_LAUNCH(consis_bwd_ms_kernel, dim3(ms_grid_blocks(t.grid)), dim3(256), 0, (hipStream_t)stream, t, B);
     return unflow_launch_status();
 }

@@ -17,6 +17,7 @@
 //   a = gS*dS/dmu_y, b = gS*dS/dE[yy], c = gS*dS/dE[xy]
 // whose 3x3 box sum gives  d/dy_q = (A + 2*y_q*B + x_q*C) / 9.
 #include "common.h"
+#include "multiscale.h"
 
 namespace {
 
@@ -445,76 +446,7 @@ template <int RS, bool EXACT>
 __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_FWD_WAVES))) void ssim2_fwd_kernel(const float* __restrict__ img, const float* __restrict__ warped,
                                                         const float* __restrict__ wgt, float* __restrict__ partials,
                                                         int H, int W, int img_groups) {
-    __shared__ float red[6];
-    const int lane = threadIdx.x & 63;
-    const int ch = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform: the plane addresses stay scalar
-    // work item = (sample, strip, row chunk), the chunks of a strip consecutive and consecutive items on one XCD: a chunk's four
-    // halo rows are its vertical neighbours' rows, and only an L2 that both use keeps them from being fetched from HBM twice
-    const int nsx = strips2(W), per = (int)gridDim.x;           // per sample: nsx * chunks
-    const int item = xcd_remap((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
-    const int grp = item / per, tile = item - grp * per;
-    const int nch = per / nsx;
-    const int sx = tile / nch, cy = tile - sx * nch;
-    const int x0 = sx * S2_COLS - 2 + 2 * lane;
-    const int ys = cy * RS, ye = min(ys + RS, H);
-    const bool pin = (x0 >= 0 && x0 < W);                       // (W even: the pair is inside or outside as a whole)
-    const bool outl = pin && lane >= 1 && lane <= 62;
-    const int xc = min(max(x0, 0), W - 2);
-    const size_t plane = (size_t)H * W;
-    const float* ip = img + ((size_t)(grp % img_groups) * 3 + ch) * plane;
-    const float* wp = warped + ((size_t)grp * 3 + ch) * plane;
-    const float* mp = wgt + (size_t)grp * plane;
-    const f2 z = {0.f, 0.f};
-    constexpr int NS = EXACT ? 5 : 4;
-    f2 a[NS], b[NS];
-#pragma unroll
-    for (int q = 0; q < NS; ++q) { a[q] = z; b[q] = z; }
-    f2 acc0 = z, acc1 = z;
-    const f2 keep = {outl ? 1.0f : 0.0f, outl ? 1.0f : 0.0f};
-    constexpr int NR = RS + 2;                                   // input rows ys-1 .. ye
-    Row2 buf[3];
-    buf[0] = load_row2(ip, wp, mp, ys - 1, ys - 1 >= 0, H, W, xc, pin);
-    if (SSIM2_PF > 1) buf[1] = load_row2(ip, wp, mp, ys, true, H, W, xc, pin);
-#pragma unroll 1
-    for (int k0 = 0; k0 < NR; k0 += 3) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int r = ys - 1 + k0 + j;
-            const int rn = r + SSIM2_PF;                         // requested SSIM2_PF rows ahead
-            buf[(j + SSIM2_PF) % 3] = load_row2(ip, wp, mp, rn, rn < H && rn <= ye, H, W, xc, pin);
-            const Row2 v = buf[j];
-            const f2 xs = v.x * v.m, ysv = v.y * v.m;
-            if (ch == 0 && r >= ys && r < ye) acc1 += v.m * keep;
-            f2 fin[NS];
-            if constexpr (EXACT) feed_row<true>(a, b, xs, ysv, fin);
-            else feed_row4(a, b, xs, ysv, fin);
-            const int ro = r - 1;                                // the row whose windows are now complete
-            if (ro >= ys && ro < ye) {
-                f2 ssim;
-                if constexpr (EXACT) {
-                    const Stats2 st = pair_stats(fin);
-                    const f2 num = st.n1 * st.n2, den = st.d1 * st.d2;
-                    ssim.x = num.x / den.x; ssim.y = num.y / den.y;          // IEEE quotients, as ssim.py:20
-                } else {
-                    const Factors2 st = pair_factors(fin);
-                    ssim = (st.a1 * st.a2) * rcp_refined(st.b1 * st.b2);
-                }
-                const f2 one = {1.0f, 1.0f}, half = {0.5f, 0.5f};
-                f2 t = (one - ssim) * half;                      // == / 2.0f exactly
-                t = __builtin_elementwise_min(__builtin_elementwise_max(t, z), one);
-                acc0 += t * keep;
-            }
-        }
-    }
-    const float s0 = wave_sum(acc0.x + acc0.y);
-    const float s1 = wave_sum(acc1.x + acc1.y);
-    if (lane == 0) { red[ch * 2] = s0; red[ch * 2 + 1] = s1; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float* p = partials + ((size_t)grp * per + tile) * 2;
-        p[0] = (red[0] + red[2]) + red[4];
-        p[1] = red[1];
-    }
+#include "bodies/ssim2_fwd.inc"
 }
 
 // grid = (strips2(W) * ceil(H / RS), B); block = 192: wave c = channel c.  Rows ys-2 .. ye+1 stream through; row r completes
@@ -524,82 +456,39 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_BWD_W
                                                         const float* __restrict__ wgt, const float* __restrict__ sums,
                                                         const float* __restrict__ gloss, float* __restrict__ gwarped,
                                                         int H, int W, int img_b) {
-    const int lane = threadIdx.x & 63;
-    const int ch = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nsx = strips2(W), per = (int)gridDim.x;           // (work-item order: see the forward kernel)
-    const int item = xcd_remap((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
-    const int bidx = item / per, tile = item - bidx * per;
-    const int nch = per / nsx;
-    const int sx = tile / nch, cy = tile - sx * nch;
-    const int x0 = sx * S2_COLS - 2 + 2 * lane;
-    const int ys = cy * RS, ye = min(ys + RS, H);
-    const bool pin = (x0 >= 0 && x0 < W);
-    const bool outl = pin && lane >= 1 && lane <= 62;
-    const int xc = min(max(x0, 0), W - 2);
-    const size_t plane = (size_t)H * W;
-    const float* ip = img + ((size_t)(bidx % img_b) * 3 + ch) * plane;
-    const float* wp = warped + ((size_t)bidx * 3 + ch) * plane;
-    const float* mp = wgt + (size_t)bidx * plane;
-    float* gp = gwarped + ((size_t)bidx * 3 + ch) * plane;
-    const float hw = (float)H * (float)W;
-    // d loss[b] / d clamp-sum, times d clamp / d SSIM = -1/2 inside the clamp range; 0 for a pair outside the image
-    const float kb = pin ? gloss[bidx] / (3.0f * hw) / (sums[bidx * 2 + 1] / hw + 1e-12f) * -0.5f : 0.f;
-    const f2 z = {0.f, 0.f};
-    f2 a[4], b[4], t0[3], t1[3];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { a[q] = z; b[q] = z; }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) { t0[q] = z; t1[q] = z; }
-    constexpr int NR = RS + 4;                                   // input rows ys-2 .. ye+1
-    Row2 buf[3];
-    f2 kx[3], ky[3], km[3];                                      // weighted x, y and the weight of the last three rows
-    buf[0] = load_row2(ip, wp, mp, ys - 2, ys - 2 >= 0, H, W, xc, pin);
-    if (SSIM2_PF > 1) buf[1] = load_row2(ip, wp, mp, ys - 1, ys - 1 >= 0, H, W, xc, pin);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) { kx[q] = z; ky[q] = z; km[q] = z; }
-#pragma unroll 1
-    for (int k0 = 0; k0 < NR; k0 += 3) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int r = ys - 2 + k0 + j;
-            const int rn = r + SSIM2_PF;
-            buf[(j + SSIM2_PF) % 3] = load_row2(ip, wp, mp, rn, rn >= 0 && rn < H && rn <= ye + 1, H, W, xc, pin);
-            const Row2 v = buf[j];
-            const f2 xs = v.x * v.m, ysv = v.y * v.m;
-            kx[j] = xs; ky[j] = ysv; km[j] = v.m;
-            f2 fin[4];
-            feed_row4(a, b, xs, ysv, fin);
-            const int rs = r - 1;                                // statistics row: rows outside the image have none
-            const float kr = (rs >= 0 && rs < H) ? kb : 0.f;
-            // d SSIM / d(Sy, Syy, Sxy) in sum space (see pair_factors): with inv = 1 / (B1 B2), r1 = 1 / B1, r2 = 1 / B2
-            //   d/dSy  = 2 Sx (A2 - A1) inv - 2 Sy ssim (r1 - r2),   d/dSyy = -9 ssim r2,   d/dSxy = 18 A1 inv
-            // and d loss / d y_q = sum over the windows that hold q of (cSy + 2 y_q cSyy + x_q cSxy): no division by 9 anywhere
-            const Factors2 st = pair_factors(fin);
-            const f2 inv = rcp_refined(st.b1 * st.b2);           // one reciprocal per pixel; 1/B1 = B2 inv, 1/B2 = B1 inv
-            const f2 r1 = st.b2 * inv, r2 = st.b1 * inv;
-            const f2 ssim = st.a1 * st.a2 * inv;
-            // clamp((1 - ssim) / 2, 0, 1) passes gradient on [0, 1], i.e. for ssim in [-1, 1]
-            f2 kbv;
-            kbv.x = (ssim.x <= 1.0f && ssim.x >= -1.0f) ? kr : 0.f;
-            kbv.y = (ssim.y <= 1.0f && ssim.y >= -1.0f) ? kr : 0.f;
-            const f2 two = {2.0f, 2.0f}, m18 = {-18.0f, -18.0f}, p18 = {18.0f, 18.0f};
-            const f2 ca = (two * kbv) * (st.sx * (st.a2 - st.a1) * inv - st.sy * ssim * (r1 - r2));
-            const f2 cb = (m18 * kbv) * (ssim * r2);             // (the 2 of 2 y_q cSyy folded in: -9 * 2)
-            const f2 cc = (p18 * kbv) * (st.a1 * inv);
-            // 3x3 box sum of the coefficients: over x here, over y through the running pair (t1 = rows r-3, r-2; t0 = row r-2)
-            const f2 ha = (pair_left(ca) + ca) + pair_right(ca);
-            const f2 hb = (pair_left(cb) + cb) + pair_right(cb);
-            const f2 hc = (pair_left(cc) + cc) + pair_right(cc);
-            const f2 A = t1[0] + ha, Bq = t1[1] + hb, Cq = t1[2] + hc;
-            t1[0] = t0[0] + ha; t1[1] = t0[1] + hb; t1[2] = t0[2] + hc;
-            t0[0] = ha; t0[1] = hb; t0[2] = hc;
-            const int ro = r - 2;                                // gradient row: its x, y, weight sit two slots back
-            if (ro >= ys && ro < ye) {
-                const int o = (j + 1) % 3;
-                const f2 gy = __builtin_elementwise_fma(kx[o], Cq, __builtin_elementwise_fma(ky[o], Bq, A)) * km[o];
-                if (outl) *reinterpret_cast<f2*>(gp + (unsigned)(ro * W + x0)) = gy;
-            }
-        }
+#include "bodies/ssim2_bwd.inc"
+}
+
+// ---- one launch over the scales (csrc/multiscale.h): the two bodies above behind a table of per-scale arguments; a scale's rows per
+// wave (8 or 16, by its height) pick the instantiation of the body, block-uniformly ----
+struct Ssim2MsArgs { const float *img, *warped, *wgt; float* partials; int H, W, rs; };
+template <bool EXACT>
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_FWD_WAVES))) void ssim2_fwd_ms_kernel(MsTable<Ssim2MsArgs> ms_table_, int img_groups) {
+    UNFLOW_MS_PROLOGUE(ms_table_);
+    const float* __restrict__ img = ms_a_.img; const float* __restrict__ warped = ms_a_.warped; const float* __restrict__ wgt = ms_a_.wgt;
+    float* __restrict__ partials = ms_a_.partials;
+    const int H = ms_a_.H, W = ms_a_.W;
+    if (ms_a_.rs == 16) {
+        constexpr int RS = 16;
+#include "bodies/ssim2_fwd.inc"
+    } else {
+        constexpr int RS = 8;
+#include "bodies/ssim2_fwd.inc"
+    }
+}
+
+struct Ssim2BwdMsArgs { const float *img, *warped, *wgt, *sums, *gloss; float* gwarped; int H, W, rs; };
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_BWD_WAVES))) void ssim2_bwd_ms_kernel(MsTable<Ssim2BwdMsArgs> ms_table_, int img_b) {
+    UNFLOW_MS_PROLOGUE(ms_table_);
+    const float* __restrict__ img = ms_a_.img; const float* __restrict__ warped = ms_a_.warped; const float* __restrict__ wgt = ms_a_.wgt;
+    const float* __restrict__ sums = ms_a_.sums; const float* __restrict__ gloss = ms_a_.gloss; float* __restrict__ gwarped = ms_a_.gwarped;
+    const int H = ms_a_.H, W = ms_a_.W;
+    if (ms_a_.rs == 16) {
+        constexpr int RS = 16;
+#include "bodies/ssim2_bwd.inc"
+    } else {
+        constexpr int RS = 8;
+#include "bodies/ssim2_bwd.inc"
     }
 }
 
@@ -763,5 +652,40 @@ extern "C" int unflow_ssim_map_bwd(const float* x, const float* y, const float* 
     dim3 grid(ceil_div(H * W, 256), B * C);
     UNFLOW_LAUNCH(ssim_map_bwd_coef_kernel, grid, dim3(256), 0, s, x, y, gmap, scratch, H, W, n);
     UNFLOW_LAUNCH(ssim_map_bwd_gather_kernel, grid, dim3(256), 0, s, x, y, (const float*)scratch, gx, gy, H, W, n);
+    return unflow_launch_status();
+}
+
+// ---- the SSIM loss pair, ONE launch for n <= 4 scales (csrc/multiscale.h; the conventions of the `_ms` entries in photo.hip).  Serves
+// what the column-pair kernels serve (even widths, 8-byte aligned tensors) with 8 or 16 rows per wave; -22 otherwise: call per scale.
+extern "C" int unflow_ssim_loss_fwd_ms(int n, const float* const* img, const float* const* warped, const float* const* w,
+                                       float* const* partials, const int* H, const int* W, int B, int img_batch, void* stream) {
+    UNFLOW_REQUIRE(img && warped && w && partials && H && W && n > 0 && n <= MS_MAX && B > 0 && B <= 65535 && img_batch > 0 && B % img_batch == 0);
+    MsTable<Ssim2MsArgs> t = {};
+    for (int k = 0; k < n; ++k) {
+        UNFLOW_REQUIRE(img[k] && warped[k] && w[k] && partials[k] && H[k] > 0 && W[k] > 0 && ssim2_ok(img[k], warped[k], w[k], w[k], W[k]));
+        const int rs = ssim2_rows(H[k]);
+        UNFLOW_REQUIRE(rs == 8 || rs == 16);
+        t.a[k] = Ssim2MsArgs{img[k], warped[k], w[k], partials[k], H[k], W[k], rs};
+        UNFLOW_REQUIRE(ms_grid_add(t.grid, dim3(ssim2_blocks(H[k], W[k]), B)));
+    }
+    UNFLOW_LAUNCH((ssim2_fwd_ms_kernel<SSIM2_EXACT>), dim3(ms_grid_blocks(t.grid)), dim3(192), 0, (hipStream_t)stream, t, img_batch);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_ssim_loss_bwd_ms(int n, const float* const* img, const float* const* warped, const float* const* w,
+                                       const float* const* sums, const float* const* gloss, float* const* gwarped, const int* H,
+                                       const int* W, int B, int img_batch, void* stream) {
+    UNFLOW_REQUIRE(img && warped && w && sums && gloss && gwarped && H && W && n > 0 && n <= MS_MAX && B > 0 && B <= 65535 && img_batch > 0 &&
+                   B % img_batch == 0);
+    MsTable<Ssim2BwdMsArgs> t = {};
+    for (int k = 0; k < n; ++k) {
+        UNFLOW_REQUIRE(img[k] && warped[k] && w[k] && sums[k] && gloss[k] && gwarped[k] && H[k] > 0 && W[k] > 0 &&
+                       ssim2_ok(img[k], warped[k], w[k], gwarped[k], W[k]));
+        const int rs = ssim2_rows(H[k]);
+        UNFLOW_REQUIRE(rs == 8 || rs == 16);
+        t.a[k] = Ssim2BwdMsArgs{img[k], warped[k], w[k], sums[k], gloss[k], gwarped[k], H[k], W[k], rs};
+        UNFLOW_REQUIRE(ms_grid_add(t.grid, dim3(ssim2_blocks(H[k], W[k]), B)));
+    }
+    UNFLOW_LAUNCH(ssim2_bwd_ms_kernel, dim3(ms_grid_blocks(t.grid)), dim3(192), 0, (hipStream_t)stream, t, img_batch);
     return unflow_launch_status();
 }

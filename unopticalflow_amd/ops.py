@@ -14,7 +14,7 @@ import torch
 from . import _lib
 
 __all__ = ['corr', 'warp_flow', 'warp_flow_masked', 'warp_corr', 'occ_weight', 'occ_weight_stacked', 'masked_mean', 'ssim_loss',
-           'ssim_map', 'smooth2_loss', 'consis_loss', 'bias_leaky_relu_', 'bias_leaky_relu_into', 'upsample_bilinear_scaled', 'loss_combine', 'weighted_mean_sum', 'flow_head', 'img_pyramid']
+           'ssim_map', 'smooth2_loss', 'consis_loss', 'multiscale_losses', 'multiscale_supported', 'bias_leaky_relu_', 'bias_leaky_relu_into', 'upsample_bilinear_scaled', 'loss_combine', 'weighted_mean_sum', 'flow_head', 'img_pyramid']
 
 
 def _ptr(t):
@@ -758,6 +758,273 @@ class _Consis(torch.autograd.Function):
 def consis_loss(fwd_flow, bwd_flow, w_fwd):
     """One scale of compute_loss_flow_consis (model_flow_paper.py:183-193) -> [B]; grad to fwd_flow."""
     return _Consis.apply(fwd_flow, bwd_flow.detach(), w_fwd.detach())
+
+
+# ------------------------------------------------------------------------------------------
+# the five losses of Model_flow.forward's scale loop (model_flow_paper.py:224-235), each as ONE launch over the scales per
+# direction of the pass (csrc/multiscale.h, C ABI 11): per scale the launch runs the single-scale entry's workgroups with its
+# kernel body -- the per-scale ops above give the same bits, these give them in 5 + 5 launches instead of 15 + 15
+# ------------------------------------------------------------------------------------------
+def _ptrs(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _ints(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def multiscale_supported(imgs, warped):
+    """True when the `_ms` entries serve these scales (what the single-scale fast paths serve: even widths -- the SSIM column pairs --,
+    maps of at least 3 x 3 -- the smoothness tiles --, at most 4 scales)."""
+    return (0 < len(imgs) <= 4 and all(t.is_cuda and t.shape[-1] % 2 == 0 and t.shape[-1] >= 3 and t.shape[-2] >= 3 for t in imgs)
+            and all(w.shape[0] <= 65535 for w in warped))
+
+
+def _register_sums(jobs):
+    """jobs of one `_ms` forward: finished with everything else inside ``with deferred_loss_sums``, at once otherwise."""
+    for j in jobs:
+        deferred_loss_sums.add(*j)
+    if not deferred_loss_sums.enabled:
+        deferred_loss_sums.flush()
+
+
+class _OccWeightMS(torch.autograd.Function):
+    """_OccWeight2 over n scales: (imgs..., warped...) -> (diffs..., weights...)."""
+
+    @staticmethod
+    def forward(ctx, n, *ts):
+        dev = _dev(*ts)
+        imgs = [t.contiguous() for t in ts[:n]]
+        warped = [t.contiguous() for t in ts[n:]]
+        B = imgs[0].shape[0]
+        diffs, wgts = [], []
+        for i, w in zip(imgs, warped):
+            assert i.shape[1] == 3 and i.shape[0] == B and w.shape[0] == 2 * B and w.shape[1:] == i.shape[1:]
+            diffs.append(torch.empty((2 * B, 1) + tuple(i.shape[2:]), dtype=torch.float32, device=dev))
+            wgts.append(torch.empty((2 * B, 1) + tuple(i.shape[2:]), dtype=torch.float32, device=dev))
+        H, W = [i.shape[2] for i in imgs], [i.shape[3] for i in imgs]
+        with _on(dev):
+            _call('unflow_occ_weight_fwd_ms', n, _ptrs(imgs), _ptrs(warped), _ptrs(diffs), _ptrs(wgts), _ints(H), _ints(W), B, _stream(),
+                  nbytes=sum(B * h * w * 4 * 13 for h, w in zip(H, W)), shape=(n, B, 3, H[0], W[0]))
+        ctx.save_for_backward(*imgs, *warped)
+        ctx.n = n
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(*wgts)                           # weight is .data (model_flow_paper.py:122)
+        return (*diffs, *wgts)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n = ctx.n
+        imgs, warped = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        B = imgs[0].shape[0]
+        live = [k for k in range(n) if gs[k] is not None and ctx.needs_input_grad[1 + n + k]]
+        out = [None] * n
+        if live:
+            g = [gs[k].contiguous() for k in live]
+            for k in live:
+                out[k] = torch.empty_like(warped[k])
+            H, W = [imgs[k].shape[2] for k in live], [imgs[k].shape[3] for k in live]
+            with _on(imgs[0].device):
+                _call('unflow_absdiff_bwd_ms', len(live), _ptrs([imgs[k] for k in live]), _ptrs([warped[k] for k in live]), _ptrs(g),
+                      _ptrs([out[k] for k in live]), _ints(H), _ints(W), 2 * B, B, _stream(),
+                      nbytes=sum(4 * B * h * w * (3 + 2 * 7) for h, w in zip(H, W)), shape=(len(live), 2 * B, 3, H[0], W[0]))
+        return (None, *([None] * n), *out)
+
+
+class _MaskedMeanMS(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, n, *ts):
+        dev = _dev(*ts)
+        diffs = [t.contiguous() for t in ts[:n]]
+        ws = [t.contiguous() for t in ts[n:]]
+        B = diffs[0].shape[0]
+        H, W = [d.shape[2] for d in diffs], [d.shape[3] for d in diffs]
+        losses = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(n)]
+        sums = [torch.empty((B, 2), dtype=torch.float32, device=dev) for _ in range(n)]
+        parts = [_partials(B, h, w, dev) for h, w in zip(H, W)]
+        with _on(dev):
+            _call('unflow_masked_mean_fwd_ms', n, _ptrs(diffs), _ptrs(ws), _ptrs(parts), _ints(H), _ints(W), B, _stream(),
+                  nbytes=sum(4 * B * h * w * 2 for h, w in zip(H, W)), shape=(n, B, 1, H[0], W[0]))
+        jobs = []
+        for k in range(n):
+            hw = _f32(float(H[k]) * float(W[k]))
+            jobs.append((parts[k], losses[k], sums[k], 0, H[k], W[k], 0, hw, hw))
+        _register_sums(jobs)
+        ctx.save_for_backward(*ws, *sums)
+        ctx.n = n
+        ctx.set_materialize_grads(False)
+        return tuple(losses)
+
+    @staticmethod
+    def backward(ctx, *gl):
+        n = ctx.n
+        ws, sums = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        live = [k for k in range(n) if gl[k] is not None]
+        out = [None] * n
+        if live:
+            B = ws[0].shape[0]
+            g = [gl[k].contiguous() for k in live]
+            for k in live:
+                out[k] = torch.empty_like(ws[k])
+            H, W = [ws[k].shape[2] for k in live], [ws[k].shape[3] for k in live]
+            with _on(ws[0].device):
+                _call('unflow_masked_mean_bwd_ms', len(live), _ptrs([ws[k] for k in live]), _ptrs([sums[k] for k in live]), _ptrs(g),
+                      _ptrs([out[k] for k in live]), _ints(H), _ints(W), B, _stream(),
+                      nbytes=sum(4 * B * h * w * 2 for h, w in zip(H, W)), shape=(len(live), B, 1, H[0], W[0]))
+        return (None, *out, *([None] * n))
+
+
+class _SsimLossMS(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, n, *ts):
+        dev = _dev(*ts)
+        imgs = [t.contiguous() for t in ts[:n]]
+        warped = [t.contiguous() for t in ts[n:2 * n]]
+        ws = [t.contiguous() for t in ts[2 * n:]]
+        B, ib = warped[0].shape[0], imgs[0].shape[0]
+        assert B % ib == 0 and all(w.shape[0] == B for w in ws)
+        H, W = [t.shape[2] for t in warped], [t.shape[3] for t in warped]
+        losses = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(n)]
+        sums = [torch.empty((B, 2), dtype=torch.float32, device=dev) for _ in range(n)]
+        parts = [_partials(B, h, w, dev) for h, w in zip(H, W)]
+        with _on(dev):
+            _call('unflow_ssim_loss_fwd_ms', n, _ptrs(imgs), _ptrs(warped), _ptrs(ws), _ptrs(parts), _ints(H), _ints(W), B, ib, _stream(),
+                  nbytes=sum(4 * B * h * w * 7 for h, w in zip(H, W)), shape=(n, B, 3, H[0], W[0]))
+        jobs = []
+        for k in range(n):
+            hw = _f32(float(H[k]) * float(W[k]))
+            jobs.append((parts[k], losses[k], sums[k], 1, H[k], W[k], 0, _f32(3.0 * hw), hw, True))
+        _register_sums(jobs)
+        ctx.save_for_backward(*imgs, *warped, *ws, *sums)
+        ctx.n = n
+        ctx.set_materialize_grads(False)
+        return tuple(losses)
+
+    @staticmethod
+    def backward(ctx, *gl):
+        n = ctx.n
+        t = ctx.saved_tensors
+        imgs, warped, ws, sums = t[:n], t[n:2 * n], t[2 * n:3 * n], t[3 * n:]
+        live = [k for k in range(n) if gl[k] is not None]
+        out = [None] * n
+        if live:
+            B, ib = warped[0].shape[0], imgs[0].shape[0]
+            g = [gl[k].contiguous() for k in live]
+            for k in live:
+                out[k] = torch.empty_like(warped[k])
+            H, W = [warped[k].shape[2] for k in live], [warped[k].shape[3] for k in live]
+            pick = lambda seq: _ptrs([seq[k] for k in live])
+            with _on(imgs[0].device):
+                _call('unflow_ssim_loss_bwd_ms', len(live), pick(imgs), pick(warped), pick(ws), pick(sums), _ptrs(g), pick(out),
+                      _ints(H), _ints(W), B, ib, _stream(),
+                      nbytes=sum(4 * B * h * w * 10 for h, w in zip(H, W)), shape=(len(live), B, 3, H[0], W[0]))
+        return (None, *([None] * n), *out, *([None] * n))
+
+
+class _Smooth2MS(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, n, *ts):
+        dev = _dev(*ts)
+        flows = [t.contiguous() for t in ts[:n]]
+        imgs = [t.contiguous() for t in ts[n:]]
+        B, ib = flows[0].shape[0], imgs[0].shape[0]
+        assert B % ib == 0
+        H, W = [t.shape[2] for t in flows], [t.shape[3] for t in flows]
+        losses = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(n)]
+        parts = [_partials(B, h, w, dev) for h, w in zip(H, W)]
+        with _on(dev):
+            _call('unflow_smooth2_fwd_ms', n, _ptrs(flows), _ptrs(imgs), _ptrs(parts), _ints(H), _ints(W), B, ib, _stream(),
+                  nbytes=sum(4 * h * w * (2 * B + 3 * ib) for h, w in zip(H, W)), shape=(n, B, 2, H[0], W[0]))
+        jobs = []
+        for k in range(n):
+            nx = _f32(_f32(2.0 * float(H[k])) * float(W[k] - 2))
+            ny = _f32(_f32(2.0 * float(H[k] - 2)) * float(W[k]))
+            jobs.append((parts[k], losses[k], None, 2, H[k], W[k], 1, nx, ny))
+        _register_sums(jobs)
+        ctx.save_for_backward(*flows, *imgs)
+        ctx.n = n
+        ctx.set_materialize_grads(False)
+        return tuple(losses)
+
+    @staticmethod
+    def backward(ctx, *gl):
+        n = ctx.n
+        flows, imgs = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        live = [k for k in range(n) if gl[k] is not None]
+        out = [None] * n
+        if live:
+            B, ib = flows[0].shape[0], imgs[0].shape[0]
+            g = [gl[k].contiguous() for k in live]
+            for k in live:
+                out[k] = torch.empty_like(flows[k])
+            H, W = [flows[k].shape[2] for k in live], [flows[k].shape[3] for k in live]
+            with _on(flows[0].device):
+                _call('unflow_smooth2_bwd_ms', len(live), _ptrs([flows[k] for k in live]), _ptrs([imgs[k] for k in live]), _ptrs(g),
+                      _ptrs([out[k] for k in live]), _ints(H), _ints(W), B, ib, _stream(),
+                      nbytes=sum(4 * h * w * (4 * B + 3 * ib) for h, w in zip(H, W)), shape=(len(live), B, 2, H[0], W[0]))
+        return (None, *out, *([None] * n))
+
+
+class _ConsisMS(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, n, *ts):
+        dev = _dev(*ts)
+        ff = [t.contiguous() for t in ts[:n]]
+        fb = [t.contiguous() for t in ts[n:2 * n]]
+        ws = [t.contiguous() for t in ts[2 * n:]]
+        B = ff[0].shape[0]
+        H, W = [t.shape[2] for t in ff], [t.shape[3] for t in ff]
+        losses = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(n)]
+        sums = [torch.empty((B, 2), dtype=torch.float32, device=dev) for _ in range(n)]
+        parts = [_partials(B, h, w, dev) for h, w in zip(H, W)]
+        with _on(dev):
+            _call('unflow_consis_fwd_ms', n, _ptrs(ff), _ptrs(fb), _ptrs(ws), _ptrs(parts), _ints(H), _ints(W), B, _stream(),
+                  nbytes=sum(4 * B * h * w * 5 for h, w in zip(H, W)), shape=(n, B, 2, H[0], W[0]))
+        jobs = []
+        for k in range(n):
+            hw = _f32(float(H[k]) * float(W[k]))
+            jobs.append((parts[k], losses[k], sums[k], 3, H[k], W[k], 0, _f32(2.0 * hw), hw))
+        _register_sums(jobs)
+        ctx.save_for_backward(*ff, *fb, *ws, *sums)
+        ctx.n = n
+        ctx.set_materialize_grads(False)
+        return tuple(losses)
+
+    @staticmethod
+    def backward(ctx, *gl):
+        n = ctx.n
+        t = ctx.saved_tensors
+        ff, fb, ws, sums = t[:n], t[n:2 * n], t[2 * n:3 * n], t[3 * n:]
+        live = [k for k in range(n) if gl[k] is not None]
+        out = [None] * n
+        if live:
+            B = ff[0].shape[0]
+            g = [gl[k].contiguous() for k in live]
+            for k in live:
+                out[k] = torch.empty_like(ff[k])
+            H, W = [ff[k].shape[2] for k in live], [ff[k].shape[3] for k in live]
+            pick = lambda seq: _ptrs([seq[k] for k in live])
+            with _on(ff[0].device):
+                _call('unflow_consis_bwd_ms', len(live), pick(ff), pick(fb), pick(ws), pick(sums), _ptrs(g), pick(out), _ints(H), _ints(W),
+                      B, _stream(), nbytes=sum(4 * B * h * w * 7 for h, w in zip(H, W)), shape=(len(live), B, 2, H[0], W[0]))
+        return (None, *out, *([None] * 2 * n))
+
+
+def multiscale_losses(imgs, warped, flows_lr, flows_fwd, flows_bwd):
+    """The scale loop of Model_flow.forward (model_flow_paper.py:224-235) with every loss as ONE launch over the scales:
+    imgs[s] [B,3,H,W] centre pyramid, warped[s] [2B,3,H,W] = (from_l | from_r), flows_lr[s] [2B,2,H,W] = (bwd | fwd) flows,
+    flows_fwd[s] / flows_bwd[s] [B,2,H,W] -> (pixel, ssim, smooth, consis): lists of per-scale [2B] / [2B] / [2B] / [B] losses, the
+    values of occ_weight_stacked + masked_mean + ssim_loss + smooth2_loss + consis_loss per scale, bit for bit."""
+    n = len(imgs)
+    B = imgs[0].shape[0]
+    imgs = [i.detach() for i in imgs]
+    ow = _OccWeightMS.apply(n, *imgs, *warped)
+    diffs, wgts = ow[:n], [w.detach() for w in ow[n:]]
+    pixel = _MaskedMeanMS.apply(n, *diffs, *wgts)
+    ssim = _SsimLossMS.apply(n, *imgs, *warped, *wgts)
+    smooth = _Smooth2MS.apply(n, *flows_lr, *imgs)
+    consis = _ConsisMS.apply(n, *flows_fwd, *[f.detach() for f in flows_bwd], *[w[B:] for w in wgts])
+    return list(pixel), list(ssim), list(smooth), list(consis)
 
 
 def _ptr_array(tensors):
