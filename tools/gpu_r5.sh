@@ -111,6 +111,22 @@ PY
     python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $out/ab_loss_shipped.json 2>> $out/ab.err
     UNFLOW_LIB_PATH=$V python3 tools/bench_with_lib.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $out/ab_loss_lossr5b.json 2>> $out/ab.err
     line $out/ab_loss_shipped.json $out/ab_loss_lossr5b.json ;;
+  multiscale)
+    # one launch per loss over the three scales (csrc/multiscale.h, written after the lease closed): its bit-identity tests, then the step A/B
+    timeout 900 python3 -m pytest tests/test_zz_round5_gpu.py -q -m gpu -p no:cacheprovider -k "multiscale" > $out/multiscale_tests.log 2>&1; echo "multiscale tests rc=$?"; tail -4 $out/multiscale_tests.log
+    for v in 0 1; do python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --multiscale-losses $v > $out/ab_multiscale_losses_$v.json 2>> $out/ab.err; done
+    line $out/ab_multiscale_losses_0.json $out/ab_multiscale_losses_1.json
+    python3 - <<'PY'
+import json
+for v in (0, 1):
+    try:
+        d = json.loads(open('gpurun_out/r5/ab_multiscale_losses_%d.json' % v).read().strip().splitlines()[-1])
+        l = d['roofline']['losses']
+        print('multiscale_losses=%d: %.1f pairs/s, loss section %.1f us in %d launches, frac %.3f' % (v, d['value'], l['us_per_step'], l['launches_per_step'], l['frac']))
+    except Exception as e:
+        print('multiscale_losses=%d: no line (%s)' % (v, e))
+PY
+    ;;
   final) bash tools/gpu_r5.sh suite headline configs ranks8 profile_fp32 profile_bf16 traffic corr8 capi ;;
   *) echo "unknown recipe $r" ;;
 esac
