@@ -336,7 +336,7 @@ def main():
     for _ in range(warm):
         trainer.step(inputs)
     CW = ('unflow_corr_fwd', 'unflow_corr_bwd', 'unflow_warp_fwd', 'unflow_warp_fwd_table', 'unflow_warp_bwd', 'unflow_warp_bwd_det', 'unflow_warp_bwd_fused',
-          'unflow_warp_corr_fwd', 'unflow_warp_corr_bwd')
+          'unflow_warp_corr_fwd', 'unflow_warp_corr_bwd', 'unflow_warp_fwd_ms', 'unflow_warp_bwd_ms')
     # the second timed set: the occlusion-aware loss kernels (north_star names the SSIM window reduction and the occlusion-mask
     # ops next to corr / warp) -> roofline.losses
     LOSSES = ('unflow_ssim_loss_fwd', 'unflow_ssim_loss_bwd', 'unflow_occ_weight_fwd', 'unflow_absdiff_bwd', 'unflow_masked_mean_fwd',

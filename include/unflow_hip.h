@@ -225,6 +225,13 @@ int unflow_consis_fwd_ms(int n, const float* const* fwd_flow, const float* const
 int unflow_consis_bwd_ms(int n, const float* const* fwd_flow, const float* const* bwd_flow, const float* const* w_fwd,
                          const float* const* sums, const float* const* gloss, float* const* gflow, const int* H, const int* W,
                          int B, void* stream);
+/* the masked image warps of Model_flow.warp_flow_pyramid (model_flow_paper.py:62-66, net_utils.py:47-52), one launch over the scales
+ * each way: src[k] [B,C,H,W] with C <= 4, flow[k] [B,2,H,W] -> out[k] = warp * mask[k], mask[k] [B,1,H,W] uint8 (required); the backward
+ * writes the flow gradient only (unflow_warp_bwd with gsrc = NULL: the image pyramids carry no gradient). */
+int unflow_warp_fwd_ms(int n, const float* const* src, const float* const* flow, float* const* out, uint8_t* const* mask,
+                       const int* H, const int* W, int B, int C, int align_corners, void* stream);
+int unflow_warp_bwd_ms(int n, const float* const* src, const float* const* flow, const float* const* gout, const uint8_t* const* mask,
+                       float* const* gflow, const int* H, const int* W, int B, int C, int align_corners, void* stream);
 
 /* ---- conv() epilogue: Conv2d bias + LeakyReLU(0.1), core/networks/structures/net_utils.py:7-11 ----
  * y [N,C,H,W] is a bias-free convolution output, updated in place: y = leaky_relu(y + bias[c]). */

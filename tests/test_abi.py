@@ -107,6 +107,7 @@ ROUND5_DEVICE_CODE = {
                           # csrc/multiscale.h, never run: the single-scale kernels' bodies (csrc/bodies/*.inc) behind a table of scales; off by default
                           'occ_weight_fwd_ms_kernel', 'absdiff_bwd_ms_kernel', 'masked_mean_partial_ms_kernel', 'masked_mean_bwd_ms_kernel',
                           'smooth2_fwd_tile_ms_kernel', 'smooth2_bwd_stage_ms_kernel', 'consis_partial_ms_kernel', 'consis_bwd_ms_kernel'}},
+    'warp.hip': {'new': {'warp_fwd_ms_kernel', 'warp_bwd_ms_kernel'}},                                # the masked image warps of a pyramid; never run, off by default
     'ssim.hip': {'new': {'ssim2_fwd_ms_kernel<false>', 'ssim2_bwd_ms_kernel'},
                  'changed': {'ssim2_fwd_kernel<8, false>', 'ssim2_fwd_kernel<16, false>', 'ssim2_fwd_kernel<32, false>',
                              'ssim2_bwd_kernel<8>', 'ssim2_bwd_kernel<16>', 'ssim2_bwd_kernel<32>'}},     # pair_factors: fma forms
@@ -196,6 +197,9 @@ def test_multiscale_entries_reject_what_they_do_not_serve():
     assert lib.unflow_smooth2_fwd_ms(1, ptrs(ok), ptrs(ok), ptrs(ok), ints(8), ints(8), 65536, 65536, None) == -22
     assert lib.unflow_consis_fwd_ms(1, ptrs(ok), ptrs(ok), ptrs(ok), ptrs(ok), ints(8), ints(0), 2, None) == -22
     assert lib.unflow_consis_bwd_ms(1, ptrs(ok), ptrs(ok), ptrs(ok), ptrs(ok), ptrs(ok), ptrs(ok), ints(8), ints(8), 0, None) == -22
+    assert lib.unflow_warp_fwd_ms(1, ptrs(ok), ptrs(ok), ptrs(ok), ptrs(ok), ints(8), ints(8), 2, 5, 0, None) == -22          # C > 4: feature maps go per level
+    assert lib.unflow_warp_fwd_ms(1, ptrs(ok), ptrs(ok), ptrs(ok), ptrs(0), ints(8), ints(8), 2, 3, 0, None) == -22           # the mask is not optional here
+    assert lib.unflow_warp_bwd_ms(2, ptrs(ok, ok), ptrs(ok, ok), ptrs(ok, ok), ptrs(ok, ok), ptrs(ok, 0), ints(8, 4), ints(8, 4), 2, 3, 0, None) == -22
 
 
 def test_multiscale_workgroup_table_covers_every_scale_once():

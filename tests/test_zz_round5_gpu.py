@@ -187,3 +187,26 @@ def test_multiscale_losses_in_the_model(ops):
     for k in packs[0]:
         assert torch.equal(packs[0][k], packs[1][k]), k
     assert abs(norms[0] - norms[1]) <= 1e-3 * norms[0], norms
+
+
+@pytest.mark.parametrize('ac', [False, True])
+def test_multiscale_image_warps_are_the_same_bits(ops, ac):
+    """ops.warp_flow_masked_pyramid (C ABI 11: unflow_warp_fwd_ms / unflow_warp_bwd_ms) against ops.warp_flow(use_mask=True) per scale:
+    warped images, the flow gradients and -- the integer half of the parity bar -- the masks, bit for bit; a ragged width (W = 100: a
+    36-pixel last row segment) and flows that leave the image."""
+    B, n = 3, 3
+    for (h, w) in ((64, 208), (40, 100)):
+        hs, ws = [h >> s for s in range(n)], [w >> s for s in range(n)]
+        imgs = [dev(rnd(101 + s, (B, 3, hs[s], ws[s]), uniform=True)) for s in range(n)]
+        flows0 = [dev(rnd(104 + s, (B, 2, hs[s], ws[s]), 6.0 / (1 << s))) for s in range(n)]
+        gout = [dev(rnd(107 + s, (B, 3, hs[s], ws[s]))) for s in range(n)]
+        fa = [f.clone().requires_grad_() for f in flows0]
+        fb = [f.clone().requires_grad_() for f in flows0]
+        per = [ops.warp_flow_masked(imgs[s], fa[s], align_corners=ac) for s in range(n)]
+        sum((o * g).sum() for (o, _), g in zip(per, gout)).backward()
+        ms = ops._WarpMaskedMS.apply(n, ac, *imgs, *fb)
+        sum((o * g).sum() for o, g in zip(ms[:n], gout)).backward()
+        for s in range(n):
+            assert torch.equal(per[s][0], ms[s]) and torch.equal(per[s][1], ms[n + s]) and torch.equal(fa[s].grad, fb[s].grad), (h, w, s)
+            assert 0 < int(per[s][1].sum()) < per[s][1].numel()               # (both mask values occur)
+        assert all(torch.equal(a, b) for a, b in zip(ops.warp_flow_masked_pyramid(imgs, flows0, ac), [p[0] for p in per]))

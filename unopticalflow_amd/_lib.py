@@ -77,6 +77,8 @@ SIGNATURES = {
     'unflow_smooth2_bwd_ms': [_I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     'unflow_consis_fwd_ms': [_I, _P, _P, _P, _P, _P, _P, _I, _P],
     'unflow_consis_bwd_ms': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    'unflow_warp_fwd_ms': [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    'unflow_warp_bwd_ms': [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     'unflow_adam_multi': [_P, _P, _I, _P, _I, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P],
     'unflow_loss_combine_fwd': [_P, _I, _I, _P, _P],
     'unflow_loss_combine_bwd': [_P, _I, _P, _P],

@@ -18,6 +18,7 @@
 // near-coalesced because flow is smooth); threadIdx.y strides the channel loop so small pyramid
 // levels still fill the chip, and the per-pixel tap set-up is shared by a lane's channels.
 #include "common.h"
+#include "multiscale.h"
 #include "warp_taps.h"
 
 namespace {
@@ -27,28 +28,7 @@ template <int NY, bool MASKED>
 __global__ void warp_fwd_kernel(const float* __restrict__ src, const float* __restrict__ flow,
                                 float* __restrict__ out, uint8_t* __restrict__ mask,
                                 int C, int H, int W, int ac) {
-    // (an XCD-local order of the (row segment, row, sample) work items was measured here in round 4 and LOST: image warps 30.0 -> 32.5 us
-    // forward, 36.0 -> 38.5 backward -- unlike the tile kernels these workgroups share little: one row of taps with one neighbour)
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
-    if (x >= W) return;
-    const size_t plane = (size_t)H * W, pix = (size_t)y * W + x;
-    const float u = flow[((size_t)b * 2) * plane + pix];
-    const float v = flow[((size_t)b * 2 + 1) * plane + pix];
-    const Taps t = make_taps(u, v, x, y, H, W, ac);
-    const float keep = (!MASKED || t.mask) ? 1.f : 0.f;
-    if (MASKED && threadIdx.y == 0) mask[(size_t)b * plane + pix] = t.mask ? 1 : 0;
-    const float* sp = src + (size_t)b * C * plane;
-    float* op = out + (size_t)b * C * plane + pix;
-#pragma unroll 4
-    for (int c = threadIdx.y; c < C; c += NY) {
-        const float* p = sp + (size_t)c * plane;
-        // same accumulation order as ATen: nw, ne, sw, se
-        float r = p[t.o_nw] * t.nw;
-        r = fmaf(p[t.o_ne], t.ne, r);
-        r = fmaf(p[t.o_sw], t.sw, r);
-        r = fmaf(p[t.o_se], t.se, r);
-        op[(size_t)c * plane] = r * keep;
-    }
+#include "bodies/warp_fwd.inc"
 }
 
 // gsrc (optional) is scatter-added; gflow is reduced over the channel phases through LDS and
@@ -58,74 +38,31 @@ __global__ void warp_bwd_kernel(const float* __restrict__ src, const float* __re
                                 const float* __restrict__ gout, const uint8_t* __restrict__ mask,
                                 float* __restrict__ gsrc, float* __restrict__ gflow,
                                 int C, int H, int W, int ac) {
-    __shared__ float red[2][NY][64];
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
-    const bool live = (x < W);
-    const size_t plane = (size_t)H * W, pix = (size_t)y * W + (live ? x : 0);
-    float gix = 0.f, giy = 0.f;
-    {
-        // dead lanes (x >= W) run the loop too, with keep == false: the in-wave shuffles below need every lane
-        const float u = live ? flow[((size_t)b * 2) * plane + pix] : 0.f;
-        const float v = live ? flow[((size_t)b * 2 + 1) * plane + pix] : 0.f;
-        const Taps t = make_taps(u, v, live ? x : 0, y, H, W, ac);
-        const bool keep = live && (!MASKED || (mask[(size_t)b * plane + pix] != 0));
-        // Scatter-add of the source gradient.  With a locally smooth flow, lane l's right-hand taps (ne, se) hit
-        // the same source pixels as lane l+1's left-hand taps (nw, sw): the pair is summed in-wave (one DPP
-        // shuffle per row) and issued as ONE atomic by lane l+1, which halves the float atomics -- the op runs
-        // at the chip-wide atomic rate (~1.3 TB/s of added bytes), not at HBM rate.
-        const int lane = threadIdx.x;                      // blockDim.x == 64: one wave per threadIdx.y
-        const int my_nw = (keep && t.v_nw) ? t.o_nw : -1, my_sw = (keep && t.v_sw) ? t.o_sw : -1;
-        const int my_ne = (keep && t.v_ne) ? t.o_ne : -2, my_se = (keep && t.v_se) ? t.o_se : -2;
-        const int left_ne = __shfl_up(my_ne, 1, 64), left_se = __shfl_up(my_se, 1, 64);
-        // take over the left neighbour's ne / se contribution when it targets my nw / sw pixel
-        const bool take_n = WITH_GSRC && lane > 0 && left_ne == my_nw && my_nw >= 0;
-        const bool take_s = WITH_GSRC && lane > 0 && left_se == my_sw && my_sw >= 0;
-        const bool give_n = __shfl_down((int)take_n, 1, 64) && lane < 63;   // my ne is handled by lane+1
-        const bool give_s = __shfl_down((int)take_s, 1, 64) && lane < 63;
-        {
-            const float* sp = src + (size_t)b * C * plane;
-            const float* gp = gout + (size_t)b * C * plane + pix;
-            float* dp = WITH_GSRC ? gsrc + (size_t)b * C * plane : nullptr;
-#pragma unroll 4
-            for (int c = threadIdx.y; c < C; c += NY) {
-                const float* p = sp + (size_t)c * plane;
-                const float g = keep ? gp[(size_t)c * plane] : 0.f;
-                if (keep) {
-                    const float a = t.v_nw ? p[t.o_nw] : 0.f, bq = t.v_ne ? p[t.o_ne] : 0.f;
-                    const float cq = t.v_sw ? p[t.o_sw] : 0.f, dq = t.v_se ? p[t.o_se] : 0.f;
-                    gix += g * ((bq - a) * t.s + (dq - cq) * t.n);
-                    giy += g * ((cq - a) * t.e + (dq - bq) * t.w);
-                }
-                if (WITH_GSRC) {
-                    float* d = dp + (size_t)c * plane;
-                    const float c_ne = g * t.ne, c_se = g * t.se;           // all lanes shuffle (no divergence here)
-                    const float from_n = __shfl_up(c_ne, 1, 64), from_s = __shfl_up(c_se, 1, 64);
-                    if (my_nw >= 0) atomicAdd(d + my_nw, g * t.nw + (take_n ? from_n : 0.f));
-                    if (my_sw >= 0) atomicAdd(d + my_sw, g * t.sw + (take_s ? from_s : 0.f));
-                    if (my_ne >= 0 && !give_n) atomicAdd(d + my_ne, c_ne);
-                    if (my_se >= 0 && !give_s) atomicAdd(d + my_se, c_se);
-                }
-            }
-        }
-    }
-    if (NY > 1) {
-        red[0][threadIdx.y][threadIdx.x] = gix;
-        red[1][threadIdx.y][threadIdx.x] = giy;
-        __syncthreads();
-        if (threadIdx.y != 0) return;
-        gix = 0.f; giy = 0.f;
-#pragma unroll
-        for (int k = 0; k < NY; ++k) { gix += red[0][k][threadIdx.x]; giy += red[1][k][threadIdx.x]; }
-    }
-    if (!live) return;
-    // d(ix)/d(g) = W/2 (or (W-1)/2); d(g)/d(v) = 2/max(W-1,1)   (net_utils.py:42-43 in reverse)
-    const float mx = ac ? (float)(W - 1) * 0.5f : (float)W * 0.5f;
-    const float my = ac ? (float)(H - 1) * 0.5f : (float)H * 0.5f;
-    const float dx = (float)(W > 1 ? W - 1 : 1), dy = (float)(H > 1 ? H - 1 : 1);
-    gflow[((size_t)b * 2) * plane + pix] = (gix * mx) / dx * 2.0f;
-    gflow[((size_t)b * 2 + 1) * plane + pix] = (giy * my) / dy * 2.0f;
+#include "bodies/warp_bwd.inc"
 }
 
+
+// ---- the masked image warps of Model_flow.warp_flow_pyramid (model_flow_paper.py:62-66, net_utils.py:47-52) as ONE launch over
+// the scales (csrc/multiscale.h): the two bodies above at one channel phase (C <= 4), with the mask, without a source gradient ----
+struct WarpMsArgs { const float *src, *flow; float* out; uint8_t* mask; int H, W; };
+__global__ void warp_fwd_ms_kernel(MsTable<WarpMsArgs> ms_table_, int C, int ac) {
+    UNFLOW_MS_PROLOGUE(ms_table_);
+    constexpr int NY = 1; constexpr bool MASKED = true;
+    const float* __restrict__ src = ms_a_.src; const float* __restrict__ flow = ms_a_.flow;
+    float* __restrict__ out = ms_a_.out; uint8_t* __restrict__ mask = ms_a_.mask;
+    const int H = ms_a_.H, W = ms_a_.W;
+#include "bodies/warp_fwd.inc"
+}
+
+struct WarpBwdMsArgs { const float *src, *flow, *gout; const uint8_t* mask; float* gflow; int H, W; };
+__global__ void warp_bwd_ms_kernel(MsTable<WarpBwdMsArgs> ms_table_, int C, int ac) {
+    UNFLOW_MS_PROLOGUE(ms_table_);
+    constexpr int NY = 1; constexpr bool MASKED = true, WITH_GSRC = false;
+    const float* __restrict__ src = ms_a_.src; const float* __restrict__ flow = ms_a_.flow; const float* __restrict__ gout = ms_a_.gout;
+    const uint8_t* __restrict__ mask = ms_a_.mask; float* __restrict__ gsrc = nullptr; float* __restrict__ gflow = ms_a_.gflow;
+    const int H = ms_a_.H, W = ms_a_.W;
+#include "bodies/warp_bwd.inc"
+}
 
 // ---------------------------------------------------------------------------------------------
 // Feature-map warp through LDS tiles (pyramid levels: many channels, smooth flow).
@@ -1518,4 +1455,34 @@ extern "C" int unflow_warp_bwd_det(const float* src, const float* flow, const fl
                                    float* gsrc, float* gflow, int B, int C, int H, int W, int align_corners,
                                    void* stream) {
     return warp_bwd_impl(src, flow, gout, mask, gsrc, gflow, B, C, H, W, align_corners, stream, 1);
+}
+
+// ---- (ABI 11) the masked image warps of a pyramid, ONE launch over n <= 4 scales each way (the conventions of the `_ms` loss entries,
+// photo.hip): src[k] [B,C,H,W] with C <= 4, flow[k] [B,2,H,W] -> out[k] = warp * mask, mask[k] [B,1,H,W] uint8; the backward writes the
+// flow gradient only (the images carry none).  Per scale the grid and the kernel body of unflow_warp_fwd / unflow_warp_bwd(gsrc = NULL).
+extern "C" int unflow_warp_fwd_ms(int n, const float* const* src, const float* const* flow, float* const* out, uint8_t* const* mask,
+                                  const int* H, const int* W, int B, int C, int align_corners, void* stream) {
+    UNFLOW_REQUIRE(src && flow && out && mask && H && W && n > 0 && n <= MS_MAX && B > 0 && B <= 65535 && C > 0 && C <= 4);
+    MsTable<WarpMsArgs> t = {};
+    for (int k = 0; k < n; ++k) {
+        UNFLOW_REQUIRE(src[k] && flow[k] && out[k] && mask[k] && H[k] > 0 && H[k] <= 65535 && W[k] > 0);
+        t.a[k] = WarpMsArgs{src[k], flow[k], out[k], mask[k], H[k], W[k]};
+        UNFLOW_REQUIRE(ms_grid_add(t.grid, dim3(ceil_div(W[k], 64), H[k], B)));
+    }
+    UNFLOW_LAUNCH(warp_fwd_ms_kernel, dim3(ms_grid_blocks(t.grid)), dim3(64, 1), 0, (hipStream_t)stream, t, C, align_corners ? 1 : 0);
+    return unflow_launch_status();
+}
+
+extern "C" int unflow_warp_bwd_ms(int n, const float* const* src, const float* const* flow, const float* const* gout,
+                                  const uint8_t* const* mask, float* const* gflow, const int* H, const int* W, int B, int C,
+                                  int align_corners, void* stream) {
+    UNFLOW_REQUIRE(src && flow && gout && mask && gflow && H && W && n > 0 && n <= MS_MAX && B > 0 && B <= 65535 && C > 0 && C <= 4);
+    MsTable<WarpBwdMsArgs> t = {};
+    for (int k = 0; k < n; ++k) {
+        UNFLOW_REQUIRE(src[k] && flow[k] && gout[k] && mask[k] && gflow[k] && H[k] > 0 && H[k] <= 65535 && W[k] > 0);
+        t.a[k] = WarpBwdMsArgs{src[k], flow[k], gout[k], mask[k], gflow[k], H[k], W[k]};
+        UNFLOW_REQUIRE(ms_grid_add(t.grid, dim3(ceil_div(W[k], 64), H[k], B)));
+    }
+    UNFLOW_LAUNCH(warp_bwd_ms_kernel, dim3(ms_grid_blocks(t.grid)), dim3(64, 1), 0, (hipStream_t)stream, t, C, align_corners ? 1 : 0);
+    return unflow_launch_status();
 }

@@ -14,7 +14,7 @@ import torch
 from . import _lib
 
 __all__ = ['corr', 'warp_flow', 'warp_flow_masked', 'warp_corr', 'occ_weight', 'occ_weight_stacked', 'masked_mean', 'ssim_loss',
-           'ssim_map', 'smooth2_loss', 'consis_loss', 'multiscale_losses', 'multiscale_supported', 'bias_leaky_relu_', 'bias_leaky_relu_into', 'upsample_bilinear_scaled', 'loss_combine', 'weighted_mean_sum', 'flow_head', 'img_pyramid']
+           'ssim_map', 'smooth2_loss', 'consis_loss', 'multiscale_losses', 'multiscale_supported', 'warp_flow_masked_pyramid', 'bias_leaky_relu_', 'bias_leaky_relu_into', 'upsample_bilinear_scaled', 'loss_combine', 'weighted_mean_sum', 'flow_head', 'img_pyramid']
 
 
 def _ptr(t):
@@ -1008,6 +1008,60 @@ class _ConsisMS(torch.autograd.Function):
                 _call('unflow_consis_bwd_ms', len(live), pick(ff), pick(fb), pick(ws), pick(sums), _ptrs(g), pick(out), _ints(H), _ints(W),
                       B, _stream(), nbytes=sum(4 * B * h * w * 7 for h, w in zip(H, W)), shape=(len(live), B, 2, H[0], W[0]))
         return (None, *out, *([None] * 2 * n))
+
+
+class _WarpMaskedMS(torch.autograd.Function):
+    """warp_flow(img, flow, use_mask=True) (net_utils.py:16-54) over the n scales of an image pyramid in one launch each way."""
+
+    @staticmethod
+    def forward(ctx, n, align_corners, *ts):
+        dev = _dev(*ts)
+        imgs = [t.contiguous() for t in ts[:n]]
+        flows = [t.contiguous() for t in ts[n:]]
+        B, C = imgs[0].shape[:2]
+        for x, f in zip(imgs, flows):
+            _check_flow_shape(x, f)
+            assert x.shape[:2] == (B, C)
+        H, W = [t.shape[2] for t in imgs], [t.shape[3] for t in imgs]
+        outs = [torch.empty_like(x) for x in imgs]
+        masks = [torch.empty((B, 1, h, w), dtype=torch.uint8, device=dev) for h, w in zip(H, W)]
+        with _on(dev):
+            _call('unflow_warp_fwd_ms', n, _ptrs(imgs), _ptrs(flows), _ptrs(outs), _ptrs(masks), _ints(H), _ints(W), B, C, int(align_corners),
+                  _stream(), nbytes=sum(B * h * w * (8 * C + 8 + 1) for h, w in zip(H, W)), shape=(n, B, C, H[0], W[0]))
+        ctx.save_for_backward(*imgs, *flows, *masks)
+        ctx.n, ctx.ac = n, int(align_corners)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(*masks)
+        return (*outs, *masks)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n = ctx.n
+        t = ctx.saved_tensors
+        imgs, flows, masks = t[:n], t[n:2 * n], t[2 * n:]
+        if any(ctx.needs_input_grad[2 + k] for k in range(n)):
+            raise RuntimeError('warp_flow_masked_pyramid: the image pyramids are detached (model_flow_paper.py:58); no source gradient is defined here')
+        live = [k for k in range(n) if gs[k] is not None and ctx.needs_input_grad[2 + n + k]]
+        out = [None] * n
+        if live:
+            B, C = imgs[0].shape[:2]
+            g = [gs[k].contiguous() for k in live]
+            for k in live:
+                out[k] = torch.empty_like(flows[k])
+            H, W = [imgs[k].shape[2] for k in live], [imgs[k].shape[3] for k in live]
+            pick = lambda seq: _ptrs([seq[k] for k in live])
+            with _on(imgs[0].device):
+                _call('unflow_warp_bwd_ms', len(live), pick(imgs), pick(flows), _ptrs(g), pick(masks), pick(out), _ints(H), _ints(W), B, C,
+                      ctx.ac, _stream(), nbytes=sum(4 * B * h * w * (2 * C + 4) for h, w in zip(H, W)), shape=(len(live), B, C, H[0], W[0]))
+        return (None, None, *([None] * n), *out)
+
+
+def warp_flow_masked_pyramid(imgs, flows, align_corners=False):
+    """Model_flow.warp_flow_pyramid (model_flow_paper.py:62-66): warp_flow(img, flow, use_mask=True) at every scale of an image pyramid
+    (C <= 4, detached images) as one launch each way -> the list of masked warped images; values of ops.warp_flow per scale, bit for bit."""
+    n = len(imgs)
+    res = _WarpMaskedMS.apply(n, bool(align_corners), *[i.detach() for i in imgs], *flows)
+    return list(res[:n])
 
 
 def multiscale_losses(imgs, warped, flows_lr, flows_fwd, flows_bwd):
