@@ -101,6 +101,7 @@ def parse():
     ap.add_argument('--graph', type=int, default=-1, help='1: replay the step as a hipGraph; 0: eager (per-launch events INSIDE the timed steps); default: replay.  Under replay the roofline legs are taken over the same number of EAGER steps (at most 20) right behind the timed region: a captured graph cannot carry per-launch event pairs')
     ap.add_argument('--channels-last', type=int, default=-1, help='memory format of the conv stacks: 1 channels_last (NHWC), 0 NCHW; default: 1 when the shipped MIOpen find-db is in use, else 0 (cfg.channels_last)')
     ap.add_argument('--weight-shadows', type=int, default=1, help='bf16 only; 0: autocast casts every convolution weight per call instead of one multi-tensor cast per pass (A/B; cfg.weight_shadows)')
+    ap.add_argument('--fused-levels', default='', help="decoder levels (e.g. '5' or '4,5') whose warp + cost volume run as the one fused kernel (cfg.fused_warp_corr_levels); --fused 1 = all four")
     ap.add_argument('--fused', type=int, default=0, help='1: warp + cost volume of each decoder level as one kernel (cfg.fused_warp_corr)')
     ap.add_argument('--dup-centre', type=int, default=1, help='0: torch.cat((c, c)) of the centre features instead of the hand-off that writes them twice (A/B; Model_flow.dup_centre)')
     ap.add_argument('--fused-head', type=int, default=1, help='0: ATen bias add, re-layout copy and residual add behind the flow heads instead of unflow_flow_head_* (A/B; PWC_tf.fused_head)')
@@ -282,7 +283,7 @@ def main():
     cl = measured_picks if args.channels_last < 0 else bool(args.channels_last)
     cfg = types.SimpleNamespace(mode='flow', dataset='kitti_depth', num_scales=3, h_flow_consist_alpha=3.0,
                                 h_flow_consist_beta=0.05, w_ssim=0.85, w_flow_smooth=10.0, w_flow_consis=0.01,
-                                lr=1e-4, align_corners=False, precision=args.precision, weight_shadows=bool(args.weight_shadows), fused_warp_corr=bool(args.fused),
+                                lr=1e-4, align_corners=False, precision=args.precision, weight_shadows=bool(args.weight_shadows), fused_warp_corr=bool(args.fused), fused_warp_corr_levels=(args.fused_levels or None),
                                 channels_last=cl)
     torch.manual_seed(1234)                       # same random init on every rank
     model = get_model('flow')(cfg).to(dev)

@@ -196,3 +196,13 @@ def test_conv_split_emulation_helpers():
         for a, b in zip(gs, gr):
             assert float((a - b).abs().max() / b.abs().max()) < 4 * tol
     assert torch.equal(conv(inp), ref)                                # the patch is gone after the block
+
+
+def test_fused_warp_corr_levels_are_a_config_key():
+    """cfg.fused_warp_corr_levels picks the decoder levels whose warp + cost volume run as the fused kernel (bench.py --fused-levels);
+    cfg.fused_warp_corr keeps meaning all four, the default none."""
+    from oracle import ref_cpu as R
+    from unopticalflow_amd import get_model
+    for kw, want in ((dict(fused_warp_corr_levels='4,5'), {4, 5}), (dict(fused_warp_corr_levels=5), {5}), (dict(fused_warp_corr_levels=(3, 5)), {3, 5}),
+                     (dict(fused_warp_corr=True), {2, 3, 4, 5}), (dict(), set())):
+        assert get_model('flow')(R.default_cfg(**kw)).pwc_model.fused_levels == want, kw

@@ -210,3 +210,22 @@ def test_multiscale_image_warps_are_the_same_bits(ops, ac):
             assert torch.equal(per[s][0], ms[s]) and torch.equal(per[s][1], ms[n + s]) and torch.equal(fa[s].grad, fb[s].grad), (h, w, s)
             assert 0 < int(per[s][1].sum()) < per[s][1].numel()               # (both mask values occur)
         assert all(torch.equal(a, b) for a, b in zip(ops.warp_flow_masked_pyramid(imgs, flows0, ac), [p[0] for p in per]))
+
+
+def test_fused_warp_corr_at_level_5_only(ops):
+    """cfg.fused_warp_corr_levels = '5': only the 8 x 26 level takes the fused warp + cost-volume kernel (the op of
+    test_fused_warp_corr_model_matches_golden, chosen per level) -- same losses as the two-kernel path to 1e-5."""
+    from unopticalflow_amd import get_model
+    x = R.synthetic_triplets(2, 256, 832, seed=0, structured=True).cuda()
+    packs = []
+    for lv in (None, '5'):
+        model = get_model('flow')(R.default_cfg(fused_warp_corr_levels=lv)).cuda()
+        model.load_state_dict(R.seeded_state_dict(model, 1234, 0.25))
+        ops.kernel_timer.enable(('unflow_warp_corr_fwd',))
+        with torch.no_grad():
+            packs.append({k: v.clone() for k, v in model(x).items()})
+        torch.cuda.synchronize()
+        ops.kernel_timer.disable()
+        assert sum(r['launches'] for r in ops.kernel_timer.rows()) == (1 if lv else 0)       # (both flow directions ride one 2B pass of the decoder)
+    for k in packs[0]:
+        close(packs[1][k], packs[0][k], rtol=1e-5, what=k)

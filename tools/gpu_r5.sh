@@ -127,6 +127,13 @@ for v in (0, 1):
         print('multiscale_losses=%d: no line (%s)' % (v, e))
 PY
     ;;
+  fused_levels)
+    # the fused warp + cost-volume kernel at the small levels only (it lost at levels 2-4; level 5 was never measured alone)
+    for lv in none 5 4,5; do
+      a=""; [ $lv != none ] && a="--fused-levels $lv"
+      python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline $a > $out/ab_fused_levels_$lv.json 2>> $out/ab.err
+    done
+    line $out/ab_fused_levels_*.json ;;
   final) bash tools/gpu_r5.sh suite headline configs ranks8 profile_fp32 profile_bf16 traffic corr8 capi ;;
   *) echo "unknown recipe $r" ;;
 esac

@@ -51,6 +51,9 @@ class Model_flow(nn.Module):
         self.fpyramid = FeaturePyramid(channels_last=self.channels_last)
         self.pwc_model = PWC_tf(align_corners=self.align_corners, fused_warp_corr=bool(getattr(cfg, 'fused_warp_corr', False)),
                                 channels_last=self.channels_last)
+        lv = getattr(cfg, 'fused_warp_corr_levels', None)        # e.g. '5' or (4, 5): only those levels take the fused warp + cost-volume kernel
+        if lv:
+            self.pwc_model.fused_levels = frozenset(int(v) for v in (str(lv).split(',') if isinstance(lv, (str, int)) else lv))
         if cfg.mode == 'depth' or cfg.mode == 'flowposenet':
             # Stage 2 training
             for param in self.fpyramid.parameters():

@@ -35,6 +35,9 @@ class PWC_tf(nn.Module):
         # slower below it -- the cost-volume kernel is LDS/VALU-bound, so the warp stage adds to the bound resource --
         # hence off by default.
         self.fused_warp_corr = bool(fused_warp_corr)
+        # decoder levels whose warp + cost volume run as the ONE fused kernel (ops.warp_corr): all four with fused_warp_corr, or a chosen few --
+        # the fused kernel lost at levels 2-4 (VALU-bound there) but was never measured alone at level 5 (8 x 26: latency-bound launches)
+        self.fused_levels = frozenset((2, 3, 4, 5)) if self.fused_warp_corr else frozenset()
         self.leakyRELU = nn.LeakyReLU(0.1)
         self.align_corners = align_corners
         nd = (2 * md + 1) ** 2
@@ -143,7 +146,7 @@ class PWC_tf(nn.Module):
         level_flow = {}
         for lvl in (5, 4, 3, 2):
             up = self._up(flow, (2 * flow.shape[2], 2 * flow.shape[3]), 2.0)         # F.interpolate(flow, scale_factor=2.0, 'bilinear') * 2.0 (pwc_tf.py:119)
-            if self.fused_warp_corr and self.corr == self.corr_naive:      # (a user-supplied self.corr keeps the two-op path)
+            if lvl in self.fused_levels and self.corr == self.corr_naive:   # (a user-supplied self.corr keeps the two-op path)
                 cv = ops.warp_corr(f1[lvl].float(), f2[lvl].float(), up.float(), 4, self.align_corners)
             else:
                 cv = self.corr(f1[lvl], self.warp(f2[lvl], up))
