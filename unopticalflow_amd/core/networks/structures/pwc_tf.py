@@ -36,7 +36,7 @@ class PWC_tf(nn.Module):
         # hence off by default.
         self.fused_warp_corr = bool(fused_warp_corr)
         # decoder levels whose warp + cost volume run as the ONE fused kernel (ops.warp_corr): all four with fused_warp_corr, or a chosen few --
-        # the fused kernel lost at levels 2-4 (VALU-bound there) but was never measured alone at level 5 (8 x 26: latency-bound launches)
+        # (the fused kernel lost with levels 2-4 all fused; single levels were never measured alone -- level 5's width 26 is not a multiple of 4: not served)
         self.fused_levels = frozenset((2, 3, 4, 5)) if self.fused_warp_corr else frozenset()
         self.leakyRELU = nn.LeakyReLU(0.1)
         self.align_corners = align_corners
