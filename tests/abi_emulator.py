@@ -177,6 +177,79 @@ class Emulator:
             f32(gflow[k], B, 2, H[k], W[k]).copy_(f.grad)
 
 
+    # ---- the single-scale entries of the same operators: the `_ms` emulation at n = 1, plus the immediate second stage when `loss` is given
+    @staticmethod
+    def _one(*v):
+        return [[x] for x in v]
+
+    def _finish(self, op, partials, loss, sums, B, H, W, kind, n0, n1):
+        if loss:
+            nblk = self.lib.unflow_loss_partial_blocks(op, H, W, B, 1)
+            self.unflow_loss_finalize_batch([partials], [loss], [sums], [nblk], [B], [kind], [n0], [n1], 1, None)
+
+    def unflow_occ_weight_fwd(self, img, from_l, from_r, diff_l, diff_r, w_bwd, w_fwd, valid_bwd, valid_fwd, B, H, W, stream):
+        i = f32(img, B, 3, H, W)
+        d_l, d_r, w_b, w_f, v_b, v_f = R.diff_weight(i, f32(from_l, B, 3, H, W), f32(from_r, B, 3, H, W))
+        for dst, src in ((diff_l, d_l), (diff_r, d_r), (w_bwd, w_b), (w_fwd, w_f)):
+            f32(dst, B, 1, H, W).copy_(src)
+        for dst, src in ((valid_bwd, v_b), (valid_fwd, v_f)):
+            if _addr(dst):
+                u8(dst, B, 1, H, W).copy_(src.to(torch.uint8))
+
+    def unflow_absdiff_bwd(self, img, frm, gdiff, gfrom, B, H, W, img_batch, stream):
+        self.unflow_absdiff_bwd_ms(1, *self._one(img, frm, gdiff, gfrom, H, W), B, img_batch, stream)
+
+    def unflow_masked_mean_fwd(self, diff, w, loss, sums, partials, B, H, W, stream):
+        self.unflow_masked_mean_fwd_ms(1, *self._one(diff, w, partials, H, W), B, stream)
+        self._finish(0, partials, loss, sums, B, H, W, 0, float(H * W), float(H * W))
+
+    def unflow_masked_mean_bwd(self, w, sums, gloss, gdiff, B, H, W, stream):
+        self.unflow_masked_mean_bwd_ms(1, *self._one(w, sums, gloss, gdiff, H, W), B, stream)
+
+    def unflow_ssim_loss_fwd(self, img, warped, w, loss, sums, partials, B, H, W, img_batch, stream):
+        self.unflow_ssim_loss_fwd_ms(1, *self._one(img, warped, w, partials, H, W), B, img_batch, stream)
+        self._finish(1, partials, loss, sums, B, H, W, 0, 3.0 * H * W, float(H * W))
+
+    def unflow_ssim_loss_bwd(self, img, warped, w, sums, gloss, gwarped, B, H, W, img_batch, stream):
+        self.unflow_ssim_loss_bwd_ms(1, *self._one(img, warped, w, sums, gloss, gwarped, H, W), B, img_batch, stream)
+
+    def unflow_smooth2_fwd(self, flow, img, loss, partials, B, H, W, img_batch, stream):
+        self.unflow_smooth2_fwd_ms(1, *self._one(flow, img, partials, H, W), B, img_batch, stream)
+        self._finish(2, partials, loss, None, B, H, W, 1, 2.0 * H * (W - 2), 2.0 * (H - 2) * W)
+
+    def unflow_smooth2_bwd(self, flow, img, gloss, gflow, B, H, W, img_batch, stream):
+        self.unflow_smooth2_bwd_ms(1, *self._one(flow, img, gloss, gflow, H, W), B, img_batch, stream)
+
+    def unflow_consis_fwd(self, ff, fb, w, loss, sums, partials, B, H, W, stream):
+        self.unflow_consis_fwd_ms(1, *self._one(ff, fb, w, partials, H, W), B, stream)
+        self._finish(3, partials, loss, sums, B, H, W, 0, 2.0 * H * W, float(H * W))
+
+    def unflow_consis_bwd(self, ff, fb, w, sums, gloss, gflow, B, H, W, stream):
+        self.unflow_consis_bwd_ms(1, *self._one(ff, fb, w, sums, gloss, gflow, H, W), B, stream)
+
+    # masked image warps only (mask given, no source gradient): what Model_flow.warp_flow_pyramid asks for
+    def unflow_warp_fwd(self, src, flow, out, mask, B, C, H, W, align_corners, stream):
+        assert _addr(mask), 'abi_emulator: only the masked image warp is emulated'
+        self.unflow_warp_fwd_ms(1, *self._one(src, flow, out, mask, H, W), B, C, align_corners, stream)
+
+    def unflow_warp_bwd(self, src, flow, gout, mask, gsrc, gflow, B, C, H, W, align_corners, stream):
+        assert _addr(mask) and not _addr(gsrc), 'abi_emulator: only the masked image warp (no source gradient) is emulated'
+        self.unflow_warp_bwd_ms(1, *self._one(src, flow, gout, mask, gflow, H, W), B, C, align_corners, stream)
+
+    # ---- int unflow_img_pyramid(img, half, quarter, planes, H, W, stream): 2x2 and 4x4 box means
+    def unflow_img_pyramid(self, img, half, quarter, planes, H, W, stream):
+        x = f32(img, 1, planes, H, W)
+        f32(half, 1, planes, H // 2, W // 2).copy_(torch.nn.functional.adaptive_avg_pool2d(x, [H // 2, W // 2]))
+        f32(quarter, 1, planes, H // 4, W // 4).copy_(torch.nn.functional.adaptive_avg_pool2d(x, [H // 4, W // 4]))
+
+    # ---- int unflow_weighted_mean_sum_fwd(terms[K], weights[K], K, B, loss, stream) / _bwd(gloss, weights, K, B, grads[K], stream)
+    def unflow_weighted_mean_sum_fwd(self, terms, weights, K, B, loss, stream):
+        f32(loss, 1).copy_(sum(weights[k] * f32(terms[k], B).mean() for k in range(K)).reshape(1))
+
+    def unflow_weighted_mean_sum_bwd(self, gloss, weights, K, B, grads, stream):
+        for k in range(K):
+            f32(grads[k], B).copy_((f32(gloss, 1) * weights[k] / B).expand(B))
+
 @contextlib.contextmanager
 def patched(ops):
     """Inside the block ``ops`` accepts CPU tensors and its C calls go to the emulator (yielded: ``.calls`` lists the entry names)."""

@@ -117,3 +117,38 @@ def test_masked_image_warp_pyramid_wiring():
     with patched(ops):
         with pytest.raises(ValueError):
             ops.warp_flow_masked_pyramid(imgs, [flows0[0], flows0[1], flows0[1]])
+
+
+def test_model_loss_section_wiring(monkeypatch):
+    """Model_flow.forward from the flows on -- image pyramids, masked warps, the scale loop, loss_combine -- through the emulator, with and
+    without `multiscale_losses`, against the reference's own sequence (model_flow_paper.py:214-235) evaluated by the oracle on the same
+    flows: the (left | right) / (bwd | fwd) stacking, the per-scale operands and the association of the sums are what is being checked."""
+    from unopticalflow_amd import get_model, ops
+    B, H, W = 2, 32, 48
+    cfg = R.default_cfg()
+    inputs = R.synthetic_triplets(B, H, W, seed=3)
+    # flows as the decoder would hand them over: [2B,2,h,w] = (centre->left | centre->right) at scales 0..3
+    flows0 = [_rnd(60 + s, (2 * B, 2, H >> s, W >> s), 2.0 / (1 << s)) for s in range(4)]
+    imgl, img, imgr = inputs[:, :, :H], inputs[:, :, H:2 * H], inputs[:, :, 2 * H:]
+    fr = [f.clone().requires_grad_() for f in flows0]
+    pyr_l, pyr_c, pyr_r = R.img_pyramid(imgl, 3), R.img_pyramid(img, 3), R.img_pyramid(imgr, 3)
+    warped = [torch.cat((R.warp_flow(pl, f[:B], True), R.warp_flow(pr, f[B:], True))) for pl, pr, f in zip(pyr_l, pyr_r, fr)]
+    ref = _oracle_pack(pyr_c, warped, fr[:3], B)
+    gl = [_rnd(70 + k, (B,)) for k in range(4)]
+    sum((p * g).sum() for p, g in zip(ref, gl)).backward()
+    monkeypatch.setattr(ops, 'multiscale_supported', lambda imgs, warped: 0 < len(imgs) <= 4 and all(t.shape[-1] % 2 == 0 for t in imgs))
+    for ms in (False, True):
+        model = get_model('flow')(cfg)
+        model.multiscale_losses = ms
+        fl = [f.clone().requires_grad_() for f in flows0]
+        monkeypatch.setattr(model, '_flows', lambda *a, **k: fl)
+        with patched(ops) as emu:
+            pack = model(inputs)
+            sum((pack[k] * g).sum() for k, g in zip(('loss_pixel', 'loss_ssim', 'loss_flow_smooth', 'loss_flow_consis'), gl)).backward()
+        assert ('unflow_warp_fwd_ms' in emu.calls) == ms and ('unflow_ssim_loss_fwd_ms' in emu.calls) == ms and ('unflow_ssim_loss_fwd' in emu.calls) != ms
+        for k, r in zip(('loss_pixel', 'loss_ssim', 'loss_flow_smooth', 'loss_flow_consis'), ref):
+            assert pack[k].shape == (B,)
+            np.testing.assert_allclose(pack[k].detach().numpy(), r.detach().numpy(), rtol=2e-5, atol=1e-7, err_msg='%s (multiscale_losses=%s)' % (k, ms))
+        for s in range(3):
+            np.testing.assert_allclose(fl[s].grad.numpy(), fr[s].grad.numpy(), rtol=2e-4, atol=2e-6 * float(fr[s].grad.abs().max()), err_msg='flow gradient, scale %d' % s)
+        assert fl[3].grad is None                                           # the reference builds a fourth scale and never uses it (num_scales = 3)

@@ -82,7 +82,7 @@ class Model_flow(nn.Module):
 
     def warp_flow_pyramid(self, img_pyramid, flow_pyramid):
         n = min(len(img_pyramid), len(flow_pyramid))
-        if (self.multiscale_losses and 0 < n <= 4 and img_pyramid[0].is_cuda and img_pyramid[0].shape[1] <= 4
+        if (self.multiscale_losses and ops.multiscale_supported(img_pyramid[:n], flow_pyramid[:n]) and img_pyramid[0].shape[1] <= 4
                 and not any(i.requires_grad for i in img_pyramid[:n])):
             # one launch over the scales each way (ops.warp_flow_masked_pyramid; same bits)
             return ops.warp_flow_masked_pyramid(img_pyramid[:n], flow_pyramid[:n], align_corners=self.align_corners)
