@@ -15,6 +15,10 @@
 #   instep_ab    bench.py --corr-bwd {auto, mfma, fp32} and --deferred-loss-sums {1, 0}: in-step A/B of this round's switches
 #   loss_pending the loss-kernel changes written after the lease closed (-DUNFLOW_LOSS_R5B, libunflow_hip_tuning_lossr5b.so built on the
 #                build host): the loss tests against that library, kernel-exact loss times and the bench line, each next to the shipped one
+#   multiscale   one launch per loss / image warp over the scales (ABI 11): its bit-identity tests, then bench --multiscale-losses 0 / 1
+#   fused_levels bench --fused-levels 4 / 3,4: the fused warp + cost-volume kernel at chosen decoder levels only
+#   reopen       what to run FIRST when the lease comes back, most valuable first, so that a cut-off call still leaves the important half:
+#                suite, multiscale, mfma_harness, headline, ranks8, profile_fp32, traffic, loss_pending, fused_levels, configs, profile_bf16, corr8, capi
 #   final        everything that gets recorded for one source state: suite, headline, configs, ranks8, profile_fp32, profile_bf16, traffic, corr8, capi
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/r5
@@ -134,6 +138,7 @@ PY
       python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline $a > $out/ab_fused_levels_$lv.json 2>> $out/ab.err
     done
     line $out/ab_fused_levels_*.json ;;
+  reopen) bash tools/gpu_r5.sh suite multiscale mfma_harness headline ranks8 profile_fp32 traffic loss_pending fused_levels configs profile_bf16 corr8 capi ;;
   final) bash tools/gpu_r5.sh suite headline configs ranks8 profile_fp32 profile_bf16 traffic corr8 capi ;;
   *) echo "unknown recipe $r" ;;
 esac
