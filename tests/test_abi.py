@@ -202,6 +202,22 @@ def test_multiscale_entries_reject_what_they_do_not_serve():
     assert lib.unflow_warp_bwd_ms(2, ptrs(ok, ok), ptrs(ok, ok), ptrs(ok, ok), ptrs(ok, ok), ptrs(ok, 0), ints(8, 4), ints(8, 4), 2, 3, 0, None) == -22
 
 
+def test_every_shared_body_is_included_by_a_single_scale_and_a_multi_scale_kernel():
+    """The `_ms` kernels' claim to the single-scale kernels' bits rests on both including the SAME body file (csrc/bodies/*.inc) and on
+    the single-scale kernel being nothing but that body: every body file is included at least twice, once by a kernel whose whole
+    definition is the include, and the other includers are `_ms` kernels that open with UNFLOW_MS_PROLOGUE."""
+    csrc = os.path.join(ROOT, 'unopticalflow_amd', 'csrc')
+    bodies = sorted(f for f in os.listdir(os.path.join(csrc, 'bodies')) if f.endswith('.inc'))
+    assert len(bodies) == 12
+    text = ''.join(open(os.path.join(csrc, f)).read() for f in ('photo.hip', 'ssim.hip', 'warp.hip'))
+    for b in bodies:
+        inc = '#include "bodies/%s"' % b
+        assert text.count(inc) >= 2, b
+        assert re.search(r'\) \{\n' + re.escape(inc) + r'\n\}\n', text), 'no kernel that is only ' + inc         # the single-scale kernel
+        ms = re.findall(r'void (\w+_ms_kernel)\(MsTable<\w+> ms_table_[^)]*\) \{\n    UNFLOW_MS_PROLOGUE\(ms_table_\);(?:(?!\n\}\n).)*?' + re.escape(inc), text, flags=re.S)
+        assert len(ms) >= 1, 'no _ms kernel includes ' + b
+
+
 def test_multiscale_workgroup_table_covers_every_scale_once():
     """csrc/multiscale.h restated: ms_grid_add pads a scale's workgroup range to a multiple of 8 and ms_locate maps a linear workgroup id
     to (scale, virtual blockIdx).  For the grids of the train step's ten loss kernels: every (scale, x, y, z) of the per-scale grids is
