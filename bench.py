@@ -109,6 +109,7 @@ def parse():
     ap.add_argument('--fused-upsample', type=int, default=1, help='0: F.interpolate + multiply for the flow up-sampling instead of unflow_upsample_scaled_* (A/B; PWC_tf.fused_upsample)')
     ap.add_argument('--fill-cat', type=int, default=1, help='0: channels_last decoder with torch.cat inputs instead of epilogue-filled cat buffers (A/B; PWC_tf.fill_cat_buffers)')
     ap.add_argument('--fused-warp-bwd', type=int, default=1, help='0: zero-fill + scatter for the feature-map warps\' backward instead of the one-pass gather (A/B; ops.fused_warp_bwd)')
+    ap.add_argument('--split-handoff', type=int, default=0, help='1: the pyramid hand-off returns both decoder inputs itself (Model_flow.split_handoff: no split, no gradient concatenation; A/B)')
     ap.add_argument('--multiscale-losses', type=int, default=0, help='1: every loss of the scale loop as one launch over the three scales (A/B; Model_flow.multiscale_losses, off until GPU-validated)')
     ap.add_argument('--deferred-loss-sums', type=int, default=1, help='0: one second-stage launch per loss reduction instead of one per forward pass (A/B; Model_flow.deferred_loss_sums)')
     ap.add_argument('--corr-bwd', default='auto', choices=['auto', 'fp32', 'mfma'], help='cost-volume backward arithmetic (ops.set_corr_backward): mfma = the matrix-core form at d = 4 too (A/B)')
@@ -293,6 +294,7 @@ def main():
     model.fused_loss_sums = bool(args.fused_loss_sums)
     model.deferred_loss_sums = bool(args.deferred_loss_sums)
     model.multiscale_losses = bool(args.multiscale_losses)
+    model.split_handoff = bool(args.split_handoff)
     model.dup_centre = bool(args.dup_centre)
     trainer = FlowTrainer(cfg, model, distributed=(world > 1 or args.force_ddp), use_graph=bool(args.graph),
                           single_rank_collectives=args.force_ddp, gc_freeze_after=2 if args.gc_freeze else None)
@@ -330,6 +332,7 @@ def main():
             model.fused_loss_sums = bool(args.fused_loss_sums)
             model.deferred_loss_sums = bool(args.deferred_loss_sums)
             model.multiscale_losses = bool(args.multiscale_losses)
+            model.split_handoff = bool(args.split_handoff)
             model.dup_centre = bool(args.dup_centre)
             trainer = FlowTrainer(cfg, model, distributed=(world > 1 or args.force_ddp), use_graph=False,
                                   single_rank_collectives=args.force_ddp, gc_freeze_after=2 if args.gc_freeze else None)

@@ -242,6 +242,19 @@ class Emulator:
         f32(half, 1, planes, H // 2, W // 2).copy_(torch.nn.functional.adaptive_avg_pool2d(x, [H // 2, W // 2]))
         f32(quarter, 1, planes, H // 4, W // 4).copy_(torch.nn.functional.adaptive_avg_pool2d(x, [H // 4, W // 4]))
 
+    # ---- int unflow_to_nchw_dup(in NHWC [Bin][HW][C], out NCHW [Bin + dup][C][HW], C, Bin, dup, HW, stream) and the gradient's way back,
+    # int unflow_to_nhwc_fold(g NCHW [Bout + dup][C][HW], out NHWC [Bout][HW][C], C, Bout, dup, HW, stream)
+    def unflow_to_nchw_dup(self, src, out, C, Bin, dup, HW, stream):
+        x = f32(src, Bin, HW, C).permute(0, 2, 1)
+        f32(out, Bin + dup, C, HW).copy_(torch.cat((x, x[Bin - dup:]), 0) if dup else x)
+
+    def unflow_to_nhwc_fold(self, g, out, C, Bout, dup, HW, stream):
+        gg = f32(g, Bout + dup, C, HW)
+        r = gg[:Bout].clone()
+        if dup:
+            r[Bout - dup:] += gg[Bout:]
+        f32(out, Bout, HW, C).copy_(r.permute(0, 2, 1))
+
     # ---- int unflow_weighted_mean_sum_fwd(terms[K], weights[K], K, B, loss, stream) / _bwd(gloss, weights, K, B, grads[K], stream)
     def unflow_weighted_mean_sum_fwd(self, terms, weights, K, B, loss, stream):
         f32(loss, 1).copy_(sum(weights[k] * f32(terms[k], B).mean() for k in range(K)).reshape(1))

@@ -152,3 +152,32 @@ def test_model_loss_section_wiring(monkeypatch):
         for s in range(3):
             np.testing.assert_allclose(fl[s].grad.numpy(), fr[s].grad.numpy(), rtol=2e-4, atol=2e-6 * float(fr[s].grad.abs().max()), err_msg='flow gradient, scale %d' % s)
         assert fl[3].grad is None                                           # the reference builds a fourth scale and never uses it (num_scales = 3)
+
+
+def test_pyramid_handoff_as_two_tensors():
+    """ops.to_nchw_split: the (left | right), (centre | centre) decoder inputs straight out of the hand-off kernel, and both gradients
+    back through the fold kernel from where they are -- against `cat` + `split` in plain torch, values and gradient, with either half
+    unused, and with no duplicated tail."""
+    from unopticalflow_amd import ops
+    Bp = 2                                                                  # pairs: the batch is (left | right | centre) = 3 * Bp samples
+    for (C, H, W, head, dup) in ((5, 4, 6, 2 * Bp, Bp), (3, 2, 3, 2, 0), (4, 3, 5, 0, 3), (2, 2, 2, 6, 0)):
+        B = 3 * Bp
+        x0 = _rnd(80 + C, (B, C, H, W)).contiguous(memory_format=torch.channels_last)
+        ga, gb = _rnd(81, (head, C, H, W)), _rnd(82, (B - head + dup, C, H, W))
+        for use in ('both', 'head', 'tail'):
+            xr = x0.clone().requires_grad_()
+            full = torch.cat((xr, xr[B - dup:]), 0) if dup else xr
+            ra, rb = full.contiguous().split((head, B - head + dup))
+            x = x0.clone(memory_format=torch.channels_last).requires_grad_()
+            with patched(ops) as emu:
+                a, b = ops.to_nchw_split(x, head, dup)
+                assert a.is_contiguous() and b.is_contiguous() and a.shape == ra.shape and b.shape == rb.shape
+                assert torch.equal(a, ra) and torch.equal(b, rb)
+                if (use == 'head' and head == 0) or (use == 'tail' and B - head + dup == 0):
+                    continue
+                loss = lambda p, q: ((p * ga).sum() if use != 'tail' else 0) + ((q * gb).sum() if use != 'head' else 0)
+                loss(a, b).backward()
+                loss(ra, rb).backward()
+                assert emu.calls[0] == 'unflow_to_nchw_dup' and set(emu.calls[1:]) <= {'unflow_to_nhwc_fold'} and len(emu.calls) <= 3
+            assert x.grad.is_contiguous(memory_format=torch.channels_last) or x.grad.numel() == 0
+            np.testing.assert_allclose(x.grad.numpy(), xr.grad.numpy(), rtol=0, atol=1e-6, err_msg=str((C, H, W, head, dup, use)))

@@ -230,3 +230,34 @@ def test_fused_warp_corr_at_level_4_only(ops):
         assert sum(r['launches'] for r in ops.kernel_timer.rows()) == (1 if lv else 0)       # (both flow directions ride one 2B pass of the decoder)
     for k in packs[0]:
         close(packs[1][k], packs[0][k], rtol=1e-5, what=k)
+
+
+def test_pyramid_handoff_as_two_tensors_on_the_gpu(ops):
+    """ops.to_nchw_split (validated kernels behind a new autograd node; wiring checked on the CPU in tests/test_ops_plumbing_cpu.py):
+    values and the gradient against cat + split in torch at a pyramid level's shape, fp32 and bf16; and Model_flow.split_handoff gives
+    the same loss pack as the split it replaces."""
+    Bp, C, H, W = 4, 64, 32, 104
+    B = 3 * Bp
+    for dt, tol in ((torch.float32, 0.0), (torch.bfloat16, 1e-2)):
+        x0 = dev(rnd(120, (B, C, H, W))).to(dt).contiguous(memory_format=torch.channels_last)
+        ga, gb = dev(rnd(121, (2 * Bp, C, H, W))), dev(rnd(122, (2 * Bp, C, H, W)))
+        xr = x0.clone().requires_grad_()
+        ra, rb = torch.cat((xr, xr[B - Bp:]), 0).float().contiguous().split((2 * Bp, 2 * Bp))
+        ((ra * ga).sum() + (rb * gb).sum()).backward()
+        x = x0.clone(memory_format=torch.channels_last).requires_grad_()
+        a, b = ops.to_nchw_split(x, 2 * Bp, Bp)
+        ((a * ga).sum() + (b * gb).sum()).backward()
+        assert torch.equal(a, ra) and torch.equal(b, rb)
+        close(x.grad.float(), xr.grad.float(), rtol=tol, atol=tol * float(xr.grad.float().abs().max()) + (0 if tol else 1e-6), what=str(dt))
+    from unopticalflow_amd import get_model
+    inputs = R.synthetic_triplets(2, 128, 192, seed=5, structured=True).cuda()
+    packs = []
+    for sh in (False, True):
+        model = get_model('flow')(R.default_cfg(channels_last=True)).cuda()
+        model.load_state_dict(R.seeded_state_dict(model, 1234, 0.25))
+        model.split_handoff = sh
+        pack = model(inputs)
+        sum(v.mean() for v in pack.values()).backward()
+        packs.append({k: v.detach().clone() for k, v in pack.items()})
+    for k in packs[0]:
+        assert torch.equal(packs[0][k], packs[1][k]), k

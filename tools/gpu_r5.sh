@@ -117,9 +117,11 @@ PY
     line $out/ab_loss_shipped.json $out/ab_loss_lossr5b.json ;;
   multiscale)
     # one launch per loss over the three scales (csrc/multiscale.h, written after the lease closed): its bit-identity tests, then the step A/B
-    timeout 900 python3 -m pytest tests/test_zz_round5_gpu.py -q -m gpu -p no:cacheprovider -k "multiscale" > $out/multiscale_tests.log 2>&1; echo "multiscale tests rc=$?"; tail -4 $out/multiscale_tests.log
+    timeout 900 python3 -m pytest tests/test_zz_round5_gpu.py -q -m gpu -p no:cacheprovider -k "multiscale or handoff" > $out/multiscale_tests.log 2>&1; echo "multiscale tests rc=$?"; tail -4 $out/multiscale_tests.log
     for v in 0 1; do python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --multiscale-losses $v > $out/ab_multiscale_losses_$v.json 2>> $out/ab.err; done
-    line $out/ab_multiscale_losses_0.json $out/ab_multiscale_losses_1.json
+    python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --split-handoff 1 > $out/ab_split_handoff_1.json 2>> $out/ab.err
+    python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --split-handoff 1 --multiscale-losses 1 > $out/ab_split_handoff_1_multiscale_1.json 2>> $out/ab.err
+    line $out/ab_multiscale_losses_0.json $out/ab_multiscale_losses_1.json $out/ab_split_handoff_1.json $out/ab_split_handoff_1_multiscale_1.json
     python3 - <<'PY'
 import json
 for v in (0, 1):

@@ -48,6 +48,9 @@ class Model_flow(nn.Module):
         # bodies, same bits, 30 loss launches -> 10.  Off until its GPU tests have run (written after the round-5 GPU lease closed); bench.py
         # --multiscale-losses 1 / tests/test_zz_round5_gpu.py switch it on
         self.multiscale_losses = bool(getattr(cfg, 'multiscale_losses', False))
+        # the pyramid hand-off returns (left | right) and (centre | centre) as two tensors (ops.to_nchw_split): no `split`, whose backward copies every
+        # level's gradient into one buffer again (125 us/step of ATen copies in the round-4 trace).  Validated kernels, new autograd node: off until measured
+        self.split_handoff = bool(getattr(cfg, 'split_handoff', False))
         self.fpyramid = FeaturePyramid(channels_last=self.channels_last)
         self.pwc_model = PWC_tf(align_corners=self.align_corners, fused_warp_corr=bool(getattr(cfg, 'fused_warp_corr', False)),
                                 channels_last=self.channels_last)
@@ -186,11 +189,11 @@ class Model_flow(nn.Module):
             # [4B, ...] per level: (left | right | centre | centre) -- the hand-off out of the conv stack writes the centre features
             # twice (FeaturePyramid dup_tail), so both decoder inputs are views and the two gradients of the centre features meet
             # in the hand-off's backward kernel
-            feats = self.fpyramid(frames, dup_tail=B if self.dup_centre else 0)
+            feats = self.fpyramid(frames, dup_tail=B if self.dup_centre else 0, split_head=2 * B if (self.dup_centre and self.split_handoff) else 0)
             # the decoder never reads pyramid level 1 (pwc_tf.py:108-179 uses c12..c16 / c22..c26): nothing built for it.
             # split (not slices): its backward is one cat, a slice's is a zero-fill + copy + add of the whole map
             if self.dup_centre:
-                parts = [f.split((2 * B, 2 * B)) for f in feats[1:]]         # (left | right), (centre | centre)
+                parts = [f if isinstance(f, tuple) else f.split((2 * B, 2 * B)) for f in feats[1:]]         # (left | right), (centre | centre)
             else:
                 parts = [f.split((2 * B, B)) for f in feats[1:]]
                 parts = [(lr, torch.cat((c, c), 0)) for lr, c in parts]

@@ -25,9 +25,11 @@ class FeaturePyramid(nn.Module):
         if self.channels_last:
             weights_to_channels_last(self)
 
-    def forward(self, img, dup_tail=0):
+    def forward(self, img, dup_tail=0, split_head=0):
         """``dup_tail`` = d: every returned level (but the unused first) carries d extra samples, copies of its last d -- the train
-        step's (left | right | centre) batch comes back as (left | right | centre | centre), both decoder inputs as views."""
+        step's (left | right | centre) batch comes back as (left | right | centre | centre), both decoder inputs as views.
+        ``split_head`` = h > 0 (channels_last stacks only): those levels come back as PAIRS (first h samples, the rest) straight from
+        the hand-off (ops.to_nchw_split) -- the caller's split, without the gradient concatenation it costs on the way back."""
         cl = self.channels_last and img.is_cuda and img.dtype == torch.float32      # (under bf16 autocast the convs then produce bf16 NHWC)
         outs, t, last = [], (img.contiguous(memory_format=CL) if cl else img), len(_CHANNELS) - 1
         for lvl in range(len(_CHANNELS)):
@@ -38,7 +40,7 @@ class FeaturePyramid(nn.Module):
                 t = out = getattr(self, 'conv%d' % (2 * lvl + 2))(t)
             # level 1 is never read by the decoder (pwc_tf.py:108-179): it stays as it is
             if cl and lvl > 0:
-                out = ops.to_nchw(out, dup_tail)
+                out = ops.to_nchw_split(out, split_head, dup_tail) if split_head else ops.to_nchw(out, dup_tail)
             elif dup_tail and lvl > 0:
                 out = torch.cat((out, out[out.shape[0] - dup_tail:]), 0)
             outs.append(out)

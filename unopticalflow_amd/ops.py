@@ -1458,6 +1458,62 @@ class _ToNCHW(torch.autograd.Function):
         return out, None
 
 
+class _ToNCHWSplit(torch.autograd.Function):
+    """_ToNCHW whose output batch comes back as TWO tensors -- the first ``head`` samples and the rest (with the duplicated tail) -- both
+    views of the one buffer the forward kernel fills.  What it saves is in the backward: a caller that splits _ToNCHW's result makes
+    autograd concatenate the two gradients into one buffer again (a copy of every pyramid level's gradient per step); here each
+    gradient goes through the fold kernel from where it is -- two launches of unflow_to_nhwc_fold on the two halves of the result."""
+
+    @staticmethod
+    def forward(ctx, x, head, dup):
+        B, C, H, W = x.shape
+        ctx.half = x.dtype == torch.bfloat16
+        ctx.meta = (B, head, dup)
+        out = torch.empty((B + dup, C, H, W), dtype=torch.float32, device=x.device)
+        with _on(x.device):
+            _call('unflow_to_nchw_dup_bf16' if ctx.half else 'unflow_to_nchw_dup', _ptr(x), _ptr(out), C, B, dup, H * W, _stream(),
+                  nbytes=(2 if ctx.half else 4) * x.numel() + 4 * out.numel(), shape=(B + dup, C, H, W))
+        return out[:head], out[head:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        B, head, dup = ctx.meta
+        g = ga if ga is not None else gb
+        if g is None:
+            return None, None, None
+        C, H, W = g.shape[1:]
+        out = torch.empty((B, C, H, W), dtype=torch.bfloat16 if ctx.half else torch.float32, device=g.device, memory_format=torch.channels_last)
+        entry = 'unflow_to_nhwc_fold_bf16' if ctx.half else 'unflow_to_nhwc_fold'
+        esz = 2 if ctx.half else 4
+        # NHWC is sample-major: out[:head] and out[head:] are contiguous pieces of the one gradient buffer
+        for piece, first, count, d in ((ga, 0, head, 0), (gb, head, B - head, dup)):
+            if count == 0:
+                continue
+            dst = ctypes.c_void_p(out.data_ptr() + first * C * H * W * esz)
+            if piece is None:                            # (that half was not used: its gradient is zero)
+                out[first:first + count].zero_()
+                continue
+            piece = piece.float().contiguous()
+            with _on(g.device):
+                _call(entry, _ptr(piece), dst, C, count, d, H * W, _stream(), nbytes=4 * piece.numel() + esz * count * C * H * W, shape=(count, C, H, W))
+        return out, None, None
+
+
+def to_nchw_split(x, head, dup_tail=0):
+    """``to_nchw(x, dup_tail).split((head, rest))`` without the gradient concatenation a split costs on the way back: returns
+    (y[:head], y[head:]) of the fp32 NCHW form y of the channels_last activation x (with its last ``dup_tail`` samples repeated)."""
+    head, dup_tail = int(head), int(dup_tail)
+    if not (0 <= dup_tail <= x.shape[0] - head and 0 <= head <= x.shape[0]):
+        raise ValueError('to_nchw_split: head %d, dup_tail %d for a batch of %d' % (head, dup_tail, x.shape[0]))
+    if x.dtype not in (torch.float32, torch.bfloat16) or not _is_nhwc(x):
+        return to_nchw(x, dup_tail).split((head, x.shape[0] - head + dup_tail))
+    if x.dtype == torch.float32:
+        _dev(x)
+    elif not x.is_cuda:
+        raise RuntimeError('unopticalflow_amd ops run on an MI355X (HIP) device only; got a %s tensor. There is no CPU fallback.' % x.device)
+    return _ToNCHWSplit.apply(x, head, dup_tail)
+
+
 def cat_channels_last(tensors, dtype=torch.float32):
     """``torch.cat(tensors, 1).contiguous(memory_format=torch.channels_last)`` for up to three fp32 NCHW tensors in ONE
     pass (the decoder input of pwc_tf.py:113 at the border of the channels_last conv stack).  ``dtype=torch.bfloat16``: the
