@@ -48,14 +48,15 @@ def test_multiscale_losses_wiring_against_the_oracle():
     fl_ref = [t.clone().requires_grad_() for t in flows0]
     ref = _oracle_pack(imgs, wp_ref, fl_ref, B)
     sum((p * g).sum() for p, g in zip(ref, gl)).backward()
-    for deferred in (True, False):
+    for deferred, stacked in ((True, False), (False, False), (True, True)):
         wp = [t.clone().requires_grad_() for t in warped0]
         fl = [t.clone().requires_grad_() for t in flows0]
         halves = [f.split(B) for f in fl]
         fb, ff = [x[0] for x in halves], [x[1] for x in halves]
         with patched(ops) as emu:
             with (ops.deferred_loss_sums if deferred else __import__('contextlib').nullcontext()):
-                pixel, ssim, smooth, consis = ops.multiscale_losses(imgs, wp, fl, ff, fb)
+                # stacked: the consistency term finds its halves in flows_lr by offset (what Model_flow.forward uses: no split nodes in the graph)
+                pixel, ssim, smooth, consis = ops.multiscale_losses(imgs, wp, fl) if stacked else ops.multiscale_losses(imgs, wp, fl, ff, fb)
                 assert [tuple(t.shape) for t in pixel + ssim + smooth] == [(2 * B,)] * 9 and [tuple(t.shape) for t in consis] == [(B,)] * 3
                 packed = ops.loss_combine(pixel, ssim, smooth, consis)
             fwd_calls = list(emu.calls)

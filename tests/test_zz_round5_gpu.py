@@ -138,7 +138,7 @@ def test_multiscale_losses_are_the_same_bits(ops, B, h, w):
     gl = [dev(rnd(90 + k, (B,))) for k in range(4)]
     assert ops.multiscale_supported(imgs, warped0)
     res = {}
-    for form in ('per scale', 'one launch', 'one launch, sums at once'):
+    for form in ('per scale', 'one launch', 'one launch, halves by offset', 'one launch, sums at once'):
         wp = [t.clone().requires_grad_() for t in warped0]
         fl = [t.clone().requires_grad_() for t in flows0]
         halves = [f.split(B) for f in fl]
@@ -152,6 +152,8 @@ def test_multiscale_losses_are_the_same_bits(ops, B, h, w):
                     diff, wgt = ops.occ_weight_stacked(imgs[s], wp[s])
                     pixel.append(ops.masked_mean(diff, wgt)); ssim.append(ops.ssim_loss(imgs[s], wp[s], wgt))
                     smooth.append(ops.smooth2_loss(fl[s], imgs[s])); consis.append(ops.consis_loss(ff[s], fb[s], wgt[B:]))
+            elif form.endswith('by offset'):                              # (what Model_flow.forward uses: no split nodes behind the consistency term)
+                pixel, ssim, smooth, consis = ops.multiscale_losses(imgs, wp, fl)
             else:
                 pixel, ssim, smooth, consis = ops.multiscale_losses(imgs, wp, fl, ff, fb)
             packed = ops.loss_combine(pixel, ssim, smooth, consis)
@@ -164,7 +166,8 @@ def test_multiscale_losses_are_the_same_bits(ops, B, h, w):
                      [t.clone() for t in pixel + ssim + smooth + consis], launches, {r['entry'] for r in rows})
     assert res['per scale'][1] == 10 * n + 1 and res['one launch'][1] == 11, (res['per scale'][1], res['one launch'][1])
     assert all(e.endswith('_ms') or e in ('unflow_loss_finalize_batch', 'unflow_loss_combine_fwd', 'unflow_loss_combine_bwd') for e in res['one launch'][2])
-    for form in ('one launch', 'one launch, sums at once'):
+    assert res['one launch, halves by offset'][1] == 11
+    for form in ('one launch', 'one launch, halves by offset', 'one launch, sums at once'):
         for k, (a, b) in enumerate(zip(res['per scale'][0], res[form][0])):
             assert torch.equal(a, b), (form, k, float((a - b).abs().max()))
 

@@ -246,8 +246,7 @@ class Model_flow(nn.Module):
         with (ops.deferred_loss_sums if (fused_sums and self.deferred_loss_sums and images.is_cuda) else contextlib.nullcontext()):
             one_launch_per_loss = self.multiscale_losses and ops.multiscale_supported(img_pyramid[:n], warped[:n])
             if one_launch_per_loss:
-                pixel, ssim, smooth, consis = ops.multiscale_losses(img_pyramid[:n], warped[:n], flows_lr[:n], optical_flows_fwd[:n],
-                                                                    optical_flows_bwd[:n])
+                pixel, ssim, smooth, consis = ops.multiscale_losses(img_pyramid[:n], warped[:n], flows_lr[:n])     # (the halves by offset: no split nodes)
             for s in (() if one_launch_per_loss else range(n)):
                 diff, wgt = ops.occ_weight_stacked(img_pyramid[s], warped[s])       # (diff_bwd | diff_fwd), (weight_bwd | weight_fwd)
                 pixel.append(ops.masked_mean(diff, wgt))

@@ -1010,6 +1010,65 @@ class _ConsisMS(torch.autograd.Function):
         return (None, *out, *([None] * 2 * n))
 
 
+class _ConsisStackedMS(torch.autograd.Function):
+    """_ConsisMS on the decoder's STACKED operands: flows[s] [2B,2,H,W] = (centre->left | centre->right), wgt[s] [2B,1,H,W] = (w_bwd | w_fwd).
+    The halves are pointer offsets here instead of `split` nodes in the graph, whose backward costs a zero-fill and a concatenation per
+    scale (model_flow_paper.py:183-193: the gradient goes to the forward flow only, the backward flow is detached): the result is a
+    [2B,...] gradient whose first half is zero."""
+
+    @staticmethod
+    def forward(ctx, n, *ts):
+        dev = _dev(*ts)
+        flows = [t.contiguous() for t in ts[:n]]
+        ws = [t.contiguous() for t in ts[n:]]
+        B = flows[0].shape[0] // 2
+        assert all(f.shape[0] == 2 * B and w.shape[0] == 2 * B for f, w in zip(flows, ws))
+        H, W = [t.shape[2] for t in flows], [t.shape[3] for t in flows]
+        losses = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(n)]
+        sums = [torch.empty((B, 2), dtype=torch.float32, device=dev) for _ in range(n)]
+        parts = [_partials(B, h, w, dev) for h, w in zip(H, W)]
+        ptr = lambda addrs: (ctypes.c_void_p * n)(*addrs)
+        ff = ptr([f.data_ptr() + 4 * B * 2 * h * w for f, h, w in zip(flows, H, W)])       # the forward half
+        fb = ptr([f.data_ptr() for f in flows])
+        wf = ptr([t.data_ptr() + 4 * B * h * w for t, h, w in zip(ws, H, W)])              # weight_fwd
+        with _on(dev):
+            _call('unflow_consis_fwd_ms', n, ff, fb, wf, _ptrs(parts), _ints(H), _ints(W), B, _stream(),
+                  nbytes=sum(4 * B * h * w * 5 for h, w in zip(H, W)), shape=(n, B, 2, H[0], W[0]))
+        jobs = []
+        for k in range(n):
+            hw = _f32(float(H[k]) * float(W[k]))
+            jobs.append((parts[k], losses[k], sums[k], 3, H[k], W[k], 0, _f32(2.0 * hw), hw))
+        _register_sums(jobs)
+        ctx.save_for_backward(*flows, *ws, *sums)
+        ctx.n = n
+        ctx.set_materialize_grads(False)
+        return tuple(losses)
+
+    @staticmethod
+    def backward(ctx, *gl):
+        n = ctx.n
+        t = ctx.saved_tensors
+        flows, ws, sums = t[:n], t[n:2 * n], t[2 * n:]
+        live = [k for k in range(n) if gl[k] is not None]
+        out = [None] * n
+        if live:
+            B = flows[0].shape[0] // 2
+            g = [gl[k].contiguous() for k in live]
+            H, W = [flows[k].shape[2] for k in live], [flows[k].shape[3] for k in live]
+            for k in live:
+                out[k] = torch.empty_like(flows[k])
+                out[k][:B].zero_()                           # d / d(backward flow) = 0: it is detached in the reference (:186)
+            ptr = lambda addrs: (ctypes.c_void_p * len(live))(*addrs)
+            ff = ptr([flows[k].data_ptr() + 4 * B * 2 * h * w for k, h, w in zip(live, H, W)])
+            fb = ptr([flows[k].data_ptr() for k in live])
+            wf = ptr([ws[k].data_ptr() + 4 * B * h * w for k, h, w in zip(live, H, W)])
+            go = ptr([out[k].data_ptr() + 4 * B * 2 * h * w for k, h, w in zip(live, H, W)])
+            with _on(flows[0].device):
+                _call('unflow_consis_bwd_ms', len(live), ff, fb, wf, _ptrs([sums[k] for k in live]), _ptrs(g), go, _ints(H), _ints(W),
+                      B, _stream(), nbytes=sum(4 * B * h * w * 7 for h, w in zip(H, W)), shape=(len(live), B, 2, H[0], W[0]))
+        return (None, *out, *([None] * n))
+
+
 class _WarpMaskedMS(torch.autograd.Function):
     """warp_flow(img, flow, use_mask=True) (net_utils.py:16-54) over the n scales of an image pyramid in one launch each way."""
 
@@ -1064,11 +1123,13 @@ def warp_flow_masked_pyramid(imgs, flows, align_corners=False):
     return list(res[:n])
 
 
-def multiscale_losses(imgs, warped, flows_lr, flows_fwd, flows_bwd):
+def multiscale_losses(imgs, warped, flows_lr, flows_fwd=None, flows_bwd=None):
     """The scale loop of Model_flow.forward (model_flow_paper.py:224-235) with every loss as ONE launch over the scales:
-    imgs[s] [B,3,H,W] centre pyramid, warped[s] [2B,3,H,W] = (from_l | from_r), flows_lr[s] [2B,2,H,W] = (bwd | fwd) flows,
-    flows_fwd[s] / flows_bwd[s] [B,2,H,W] -> (pixel, ssim, smooth, consis): lists of per-scale [2B] / [2B] / [2B] / [B] losses, the
-    values of occ_weight_stacked + masked_mean + ssim_loss + smooth2_loss + consis_loss per scale, bit for bit."""
+    imgs[s] [B,3,H,W] centre pyramid, warped[s] [2B,3,H,W] = (from_l | from_r), flows_lr[s] [2B,2,H,W] = (bwd | fwd) flows
+    -> (pixel, ssim, smooth, consis): lists of per-scale [2B] / [2B] / [2B] / [B] losses, the values of occ_weight_stacked + masked_mean +
+    ssim_loss + smooth2_loss + consis_loss per scale, bit for bit.  flows_fwd[s] / flows_bwd[s] [B,2,H,W]: the halves of flows_lr as tensors
+    of their own (a caller that has split them already); None: the consistency term takes its halves from flows_lr by offset, and no
+    `split` node -- a concatenation per scale on the way back -- enters the graph."""
     n = len(imgs)
     B = imgs[0].shape[0]
     imgs = [i.detach() for i in imgs]
@@ -1077,7 +1138,10 @@ def multiscale_losses(imgs, warped, flows_lr, flows_fwd, flows_bwd):
     pixel = _MaskedMeanMS.apply(n, *diffs, *wgts)
     ssim = _SsimLossMS.apply(n, *imgs, *warped, *wgts)
     smooth = _Smooth2MS.apply(n, *flows_lr, *imgs)
-    consis = _ConsisMS.apply(n, *flows_fwd, *[f.detach() for f in flows_bwd], *[w[B:] for w in wgts])
+    if flows_fwd is None:
+        consis = _ConsisStackedMS.apply(n, *flows_lr, *wgts)
+    else:
+        consis = _ConsisMS.apply(n, *flows_fwd, *[f.detach() for f in flows_bwd], *[w[B:] for w in wgts])
     return list(pixel), list(ssim), list(smooth), list(consis)
 
 
