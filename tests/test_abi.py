@@ -202,6 +202,33 @@ def test_multiscale_entries_reject_what_they_do_not_serve():
     assert lib.unflow_warp_bwd_ms(2, ptrs(ok, ok), ptrs(ok, ok), ptrs(ok, ok), ptrs(ok, ok), ptrs(ok, 0), ints(8, 4), ints(8, 4), 2, 3, 0, None) == -22
 
 
+def test_no_wide_buffer_store_names_a_scalar_offset():
+    """hipcc (ROCm 7.2) skips the "VMEM store of more than 64 bits -> VALU write of the store data" hazard when the store's soffset is an
+    SGPR, and gfx950 then stores what the following instruction puts into those registers (found the hard way in round 5:
+    profiles/r5_corr_bwd_mfma.md, finding 1; the matrix-core kernel folds its channel-group offset into the vector offset since).
+    Guard for every kernel the library ships: no buffer_store_dwordx3 / x4 with a register soffset."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    try:
+        import isa_hashes
+    finally:
+        sys.path.pop(0)
+    csrc = os.path.join(ROOT, 'unopticalflow_amd', 'csrc')
+    wide = bad = 0
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith('.hip'):
+            continue
+        for k, ins in isa_hashes.isa_streams(os.path.join(csrc, f)).items():
+            for line in ins:
+                m = re.match(r'buffer_store_dwordx[34]\s+(\S+),\s*(\S+),\s*(s\[\d+:\d+\]),\s*(\S+)', line)
+                if m:
+                    wide += 1
+                    if re.match(r's\d+|s\[', m.group(4)):
+                        bad += 1
+                        print(f, k, line)
+    assert wide > 50 and bad == 0, (wide, bad)
+
+
 def test_every_shared_body_is_included_by_a_single_scale_and_a_multi_scale_kernel():
     """The `_ms` kernels' claim to the single-scale kernels' bits rests on both including the SAME body file (csrc/bodies/*.inc) and on
     the single-scale kernel being nothing but that body: every body file is included at least twice, once by a kernel whose whole

@@ -56,16 +56,26 @@ def kernel_streams(asm_text):
     return out
 
 
+_STREAMS = {}
+
+
+def isa_streams(src, hipcc=HIPCC, extra=()):
+    """{mangled kernel name: [instruction lines]} of one source file compiled with the build's flags (cached per process)."""
+    key = (os.path.abspath(src), os.path.getmtime(src), tuple(extra))
+    if key not in _STREAMS:
+        with tempfile.TemporaryDirectory() as d:
+            asm = os.path.join(d, 'k.s')
+            cmd = [hipcc, *build_flags(), '--cuda-device-only', '-S', src, '-o', asm, *extra]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(r.stderr[-2000:])
+            _STREAMS[key] = kernel_streams(open(asm).read())
+    return _STREAMS[key]
+
+
 def isa_hashes(src, hipcc=HIPCC, extra=()):
-    with tempfile.TemporaryDirectory() as d:
-        asm = os.path.join(d, 'k.s')
-        cmd = [hipcc, *build_flags(), '--cuda-device-only', '-S', src, '-o', asm, *extra]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(r.stderr[-2000:])
-        text = open(asm).read()
     return {k: {'sha16': hashlib.sha256('\n'.join(v).encode()).hexdigest()[:16], 'instructions': len(v)}
-            for k, v in kernel_streams(text).items()}
+            for k, v in isa_streams(src, hipcc, extra).items()}
 
 
 def demangle(names):
