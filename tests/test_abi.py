@@ -229,6 +229,33 @@ def test_no_wide_buffer_store_names_a_scalar_offset():
     assert wide > 50 and bad == 0, (wide, bad)
 
 
+def test_matrix_core_backward_waits_are_counted():
+    """The second hipcc finding of round 5 (profiles/r5_corr_bwd_mfma.md): the s_waitcnt pass takes the weaker of the loop pre-header's
+    and the back edge's view of what is in flight, and an unpinned request group turns every first use in the loop into `vmcnt(0)` -- a
+    full drain of the loads the design keeps in flight.  Guard: in corr_bwd_mf_kernel no loop that issues MFMAs waits for vmcnt(0)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    try:
+        import isa_hashes
+    finally:
+        sys.path.pop(0)
+    st = isa_hashes.isa_streams(os.path.join(ROOT, 'unopticalflow_amd', 'csrc', 'corr.hip'))
+    names = isa_hashes.demangle(list(st))
+    checked = 0
+    for k, ins in st.items():
+        if 'corr_bwd_mf_kernel' not in names[k]:
+            continue
+        labels = {l[:-1]: i for i, l in enumerate(ins) if l.endswith(':')}
+        for i, l in enumerate(ins):
+            m = re.match(r's_c?branch\w*\s+(\.LBB_\d+)', l)
+            if m and labels.get(m.group(1), i) < i:                          # a back edge: ins[target:i] is a loop body
+                body = ins[labels[m.group(1)]:i]
+                if any('v_mfma' in x for x in body):
+                    checked += 1
+                    assert not [x for x in body if x.startswith('s_waitcnt') and 'vmcnt(0)' in x], (names[k], labels[m.group(1)], i)
+    assert checked >= 8
+
+
 def test_every_shared_body_is_included_by_a_single_scale_and_a_multi_scale_kernel():
     """The `_ms` kernels' claim to the single-scale kernels' bits rests on both including the SAME body file (csrc/bodies/*.inc) and on
     the single-scale kernel being nothing but that body: every body file is included at least twice, once by a kernel whose whole
