@@ -35,6 +35,21 @@ def test_library_builds_loads_and_exports_every_header_symbol():
     assert lib.unflow_abi_version() == _lib.ABI_VERSION
 
 
+def test_variant_libraries_in_the_tree_are_not_stale():
+    """Variant builds (libunflow_hip_tuning*.so: tools/ and the gpu_r5.sh A/B recipes load them through UNFLOW_LIB_PATH) travel to the GPU
+    box with the tree: one that was built before the header grew would fail there, not here.  Every one present exports every symbol
+    the header declares and reports the header's ABI version."""
+    pkg = os.path.join(ROOT, 'unopticalflow_amd')
+    from unopticalflow_amd import _lib
+    decls = _header_decls()
+    for f in sorted(os.listdir(pkg)):
+        if f.startswith('libunflow_hip_tuning') and f.endswith('.so'):
+            lib = ctypes.CDLL(os.path.join(pkg, f))
+            missing = [n for n in decls if not hasattr(lib, n)]
+            assert not missing, (f, missing)
+            assert lib.unflow_abi_version() == _lib.ABI_VERSION, f
+
+
 def test_argument_validation_without_gpu():
     from unopticalflow_amd import _lib
     lib = _lib.load()
