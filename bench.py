@@ -232,13 +232,49 @@ def measured_traffic(entry, shape, path=None):
     if path is None or not os.path.exists(path):
         return None, 'no PMC file'
     d = json.load(open(path))
-    if d.get('sources_sha16') != sources_sha16():
-        return None, 'PMC file %s was measured on other kernel sources (%s != %s)' % (os.path.basename(path), d.get('sources_sha16'), sources_sha16())
     key = '%s %s' % (entry, list(shape) if shape else None)
     v = d.get('entries', {}).get(key)
+    if d.get('sources_sha16') != sources_sha16():
+        # other sources -- but the same MACHINE CODE?  The file names the kernels that served the entry and (kernel_isa) the hash of each
+        # one's instruction stream in the measured build; if hipcc emits byte-identical kernels from today's sources the measurement stands
+        # (a comment or a pruned template parameter changes the source hash, not the traffic)
+        same, why = _kernels_unchanged(d, v)
+        if not same:
+            return None, 'PMC file %s was measured on other kernel sources (%s != %s; %s)' % (os.path.basename(path), d.get('sources_sha16'), sources_sha16(), why)
+        return int(v['hbm_bytes_per_launch']), 'profiles/%s (measured on sources %s; the kernels serving this entry are byte-identical in this build: %s)' % (
+            os.path.basename(path), d['sources_sha16'], why)
     if v is None:
         return None, 'no PMC entry for %s' % key
     return int(v['hbm_bytes_per_launch']), 'profiles/%s (sources %s)' % (os.path.basename(path), d['sources_sha16'])
+
+
+def _kernels_unchanged(pmc, entry_row):
+    """(True, 'kernel sha16, ...') when every kernel that served `entry_row` in the PMC capture has, compiled from today's sources with
+    the build's flags and the same hipcc, the instruction-stream hash the capture's sources gave (tools/isa_hashes.py)."""
+    isa = (pmc.get('kernel_isa') or {})
+    if entry_row is None or not isa.get('kernels'):
+        return False, 'no per-kernel hashes in the file'
+    try:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import isa_hashes
+        if isa_hashes.hipcc_version() != isa.get('hipcc') or ' '.join(isa_hashes.build_flags()) != isa.get('flags'):
+            return False, 'another compiler or other flags'
+        seen = []
+        for k in entry_row.get('kernels', {}):
+            ref = isa['kernels'].get(k)
+            if ref is None:
+                return False, 'no hash for %s' % k
+            now = isa_hashes.isa_hashes(os.path.join(ROOT, 'unopticalflow_amd', 'csrc', ref['file']))
+            names = isa_hashes.demangle(list(now))
+            got = {isa_hashes.short_name(names[m]): v['sha16'] for m, v in now.items()}.get(k)
+            if got != ref['sha16']:
+                return False, '%s differs (%s != %s)' % (k, got, ref['sha16'])
+            seen.append('%s %s' % (k, got))
+        return bool(seen), ', '.join(seen)
+    except Exception as e:                                     # noqa: BLE001  (no hipcc on the box, ...: the traffic stays null)
+        return False, 'ISA comparison unavailable (%s: %s)' % (type(e).__name__, e)
+    finally:
+        sys.path.pop(0)
 
 
 def main():

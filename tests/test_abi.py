@@ -271,6 +271,25 @@ def test_matrix_core_backward_waits_are_counted():
     assert checked >= 8
 
 
+def test_pmc_traffic_carries_over_to_byte_identical_kernels(tmp_path):
+    """bench.py's `roofline.traffic` comes from a committed rocprofv3 --pmc capture.  The capture names the kernels that served each entry
+    and the hash of each one's instruction stream; a later build is served by it exactly when hipcc still emits those kernels byte for
+    byte (the round-5 sources differ from the capture's in comments and pruned templates only: the level-2 cost-volume backward keeps its
+    measured 211.3 MB) -- and not otherwise (the SSIM kernels changed: null), nor when a hash in the file does not match."""
+    import json
+    import bench
+    got, note = bench.measured_traffic('unflow_corr_bwd', [16, 32, 64, 208])
+    assert got == 211299925 and 'byte-identical' in note and 'corr_bwd_rs_mixed_kernel<4, 16, 2>' in note, (got, note)
+    got, note = bench.measured_traffic('unflow_ssim_loss_fwd', [16, 3, 256, 832])
+    assert got is None and 'differs' in note, (got, note)
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r4_pmc_traffic.json')))
+    d['kernel_isa']['kernels']['corr_bwd_rs_mixed_kernel<4, 16, 2>']['sha16'] = '0' * 16
+    p = tmp_path / 'tampered.json'
+    p.write_text(json.dumps(d))
+    got, note = bench.measured_traffic('unflow_corr_bwd', [16, 32, 64, 208], path=str(p))
+    assert got is None and 'differs' in note
+
+
 def test_every_shared_body_is_included_by_a_single_scale_and_a_multi_scale_kernel():
     """The `_ms` kernels' claim to the single-scale kernels' bits rests on both including the SAME body file (csrc/bodies/*.inc) and on
     the single-scale kernel being nothing but that body: every body file is included at least twice, once by a kernel whose whole
