@@ -16,6 +16,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import sources_sha16   # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
 
 ENTRIES = [('unflow_corr_bwd', 'L2'), ('unflow_corr_fwd', 'L2'), ('unflow_warp_bwd_fused', 'L2'), ('unflow_warp_bwd', 'L2'), ('unflow_warp_fwd', 'L2'),
            ('unflow_corr_bwd', 'L3'), ('unflow_warp_bwd', 'L3'), ('unflow_ssim_loss_fwd', 'S0'), ('unflow_ssim_loss_bwd', 'S0')]
@@ -65,8 +66,22 @@ def main():
                                'kernels': {k: {'fetch_kb': round(sum(v) / REPS, 1), 'write_kb': round(sum(write.get(k, [0])) / REPS, 1)}
                                            for k, v in fetch.items()}}
         print(key, res['entries'][key]['hbm_bytes_per_launch'], flush=True)
-        os.makedirs(os.path.join(ROOT, 'gpurun_out', 'r4'), exist_ok=True)       # (after every entry: a late failure keeps what was measured)
-        json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'r4', 'r4_pmc_traffic.json'), 'w'), indent=1)
+        rnd = os.environ.get('UNFLOW_ROUND', 'r5')
+        os.makedirs(os.path.join(ROOT, 'gpurun_out', rnd), exist_ok=True)        # (after every entry: a late failure keeps what was measured)
+        json.dump(res, open(os.path.join(ROOT, 'gpurun_out', rnd, rnd + '_pmc_traffic.json'), 'w'), indent=1)
+    # the hash of every measured kernel's instruction stream: bench.py keeps serving this capture to later builds whose kernels for an
+    # entry are byte-identical (bench._kernels_unchanged)
+    try:
+        import isa_hashes
+        where = {}
+        for f, ks in isa_hashes.tree_hashes(ROOT).items():
+            for k, v in ks.items():
+                where.setdefault(k, {'file': f, 'sha16': v['sha16']})
+        res['kernel_isa'] = {'hipcc': isa_hashes.hipcc_version(), 'flags': ' '.join(isa_hashes.build_flags()),
+                             'kernels': {k: where[k] for e in res['entries'].values() for k in e['kernels'] if k in where}}
+        json.dump(res, open(os.path.join(ROOT, 'gpurun_out', rnd, rnd + '_pmc_traffic.json'), 'w'), indent=1)
+    except Exception as e:                                          # noqa: BLE001
+        print('kernel ISA hashes not recorded: %s' % e, flush=True)
 
 
 if __name__ == '__main__':
