@@ -297,7 +297,7 @@ def test_every_shared_body_is_included_by_a_single_scale_and_a_multi_scale_kerne
     csrc = os.path.join(ROOT, 'unopticalflow_amd', 'csrc')
     bodies = sorted(f for f in os.listdir(os.path.join(csrc, 'bodies')) if f.endswith('.inc'))
     assert len(bodies) == 12
-    text = ''.join(open(os.path.join(csrc, f)).read() for f in ('photo.hip', 'ssim.hip', 'warp.hip'))
+    text = ''.join(open(os.path.join(csrc, f)).read() for f in ('photo.hip', 'ssim.hip', 'warp.hip', 'ms_flat_photo.h', 'ms_flat_warp.h'))
     for b in bodies:
         inc = '#include "bodies/%s"' % b
         assert text.count(inc) >= 2, b

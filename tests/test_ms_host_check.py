@@ -1,0 +1,78 @@
+"""The flat `_ms` kernels of csrc/multiscale.h EXECUTED on the build host (tests/host_check/ms_flat_check.cpp compiles the shipped
+definitions -- csrc/ms_flat_photo.h, csrc/ms_flat_warp.h, csrc/multiscale.h, csrc/bodies/*.inc -- with g++ and runs every workgroup and
+lane): one launch over three scales leaves, bit for bit, what three single-scale launches leave (checked inside the program), and what it
+leaves is what the oracle computes (checked here).  Five of the twelve `_ms` kernels can run this way (no LDS, barrier or wave shuffle in
+their bodies); all twelve share the prologue and the workgroup table this executes."""
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+from oracle import ref_cpu as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _v(n, seed, scale=1.0, shift=0.0):
+    i = np.arange(n, dtype=np.uint64) + np.uint64(seed)
+    a = ((i * np.uint64(2654435761)) % np.uint64(2001)).astype(np.float32) / np.float32(1000.0) - np.float32(1.0)
+    return torch.from_numpy(a * np.float32(scale) + np.float32(shift))
+
+
+def test_flat_ms_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
+    exe, out = str(tmp_path / 'ms_flat_check'), str(tmp_path / 'out.bin')
+    r = subprocess.run(['g++', '-O1', '-std=c++17', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'),
+                        os.path.join(ROOT, 'tests', 'host_check', 'ms_flat_check.cpp'), '-o', exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe, out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'OK: 0 mismatches' in r.stdout, r.stdout[-2000:]          # one launch over the scales == three launches, bit for bit
+    raw = open(out, 'rb').read()
+    pos = [0]
+
+    def take(shape, dtype=np.float32):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        a = np.frombuffer(raw[pos[0]:pos[0] + n], dtype=dtype).reshape(shape)
+        pos[0] += n
+        return torch.from_numpy(a.copy())
+
+    n, B = 3, 2
+    Hs, Ws = (12, 6, 5), (70, 36, 17)
+    S = []
+    for s in range(n):
+        H, W = Hs[s], Ws[s]
+        hw = H * W
+        img = _v(B * 3 * hw, 11 + s, 0.5, 0.5).view(B, 3, H, W)
+        warped = _v(2 * B * 3 * hw, 101 + s, 0.5, 0.5).view(2 * B, 3, H, W).clone()
+        flat = warped.view(-1)
+        for c in range(3):
+            flat[c * hw:c * hw + hw // 3] = 0.0
+        S.append(dict(H=H, W=W, hw=hw, img=img, warped=warped, flow=_v(B * 2 * hw, 201 + s, 4.0).view(B, 2, H, W),
+                      gdiff=_v(2 * B * hw, 301 + s).view(2 * B, 1, H, W), sums=_v(2 * B * 2, 401 + s, 0.25, 0.75 * hw).view(2 * B, 2),
+                      gloss=_v(2 * B, 501 + s), ff=_v(B * 2 * hw, 601 + s, 3.0).view(B, 2, H, W), fb=_v(B * 2 * hw, 701 + s, 3.0).view(B, 2, H, W),
+                      w=_v(B * hw, 801 + s, 1.0, 1.0).view(B, 1, H, W)))
+    close = lambda a, b, what, tol=2e-6: np.testing.assert_allclose(a.numpy(), b.detach().numpy(), rtol=1e-5, atol=tol * max(float(b.abs().max()), 1e-30), err_msg=what)
+    for s, q in enumerate(S):                                              # the masked image warp (align_corners=False) and its binary mask
+        wout, mask = take((B, 3, q['H'], q['W'])), take((B, 1, q['H'], q['W']), np.uint8)
+        assert torch.equal(mask, R.warp_mask(q['img'].shape, q['flow'])), 'mask, scale %d' % s            # the integer half of the parity bar
+        assert 0 < int(mask.sum()) < mask.numel()
+        close(wout, R.warp_flow(q['img'], q['flow'], True), 'warped image, scale %d' % s)
+    for s, q in enumerate(S):
+        H, W, hw = q['H'], q['W'], q['hw']
+        diff, wgt = take((2 * B, 1, H, W)), take((2 * B, 1, H, W))
+        gfrom, gmm, gflow = take((2 * B, 3, H, W)), take((2 * B, 1, H, W)), take((B, 2, H, W))
+        d_l, d_r, w_b, w_f, _, _ = R.diff_weight(q['img'], q['warped'][:B], q['warped'][B:])
+        close(diff, torch.cat((d_l, d_r)), 'diff, scale %d' % s)
+        close(wgt, torch.cat((w_b, w_f)), 'occlusion weight, scale %d' % s, tol=5e-6)
+        assert float(wgt[0, 0].view(-1)[:hw // 3].abs().max()) == 0.0                               # the all-zero region is invalid: weight 0
+        f = q['warped'].clone().requires_grad_()
+        torch.abs(q['img'].repeat(2, 1, 1, 1) - f).mean(1, True).backward(q['gdiff'])
+        close(gfrom, f.grad, '|.| backward, scale %d' % s)
+        k = q['gloss'] / hw / (q['sums'][:, 1] / hw + 1e-12)
+        close(gmm, k.view(-1, 1, 1, 1) * wgt, 'masked-mean backward, scale %d' % s)
+        a = q['ff'].clone().requires_grad_()
+        occ = 1 - q['w']
+        num = (torch.abs(R.flow_normalization(a) + R.flow_normalization(q['fb'])) * occ).sum((1, 2, 3)) / (2.0 * hw)
+        (num / (q['sums'][:B, 1] / hw + 1e-12)).backward(q['gloss'][:B])
+        close(gflow, a.grad, 'consistency backward, scale %d' % s, tol=1e-5)
+    assert pos[0] == len(raw)

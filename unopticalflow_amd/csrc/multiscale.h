@@ -9,7 +9,9 @@
 // A scale's range of workgroups starts at a multiple of 8, so `id mod 8` -- the XCD a workgroup lands on, which xcd_remap() relies
 // on -- is the same for the virtual id as for the real one.
 #pragma once
+#ifndef UNFLOW_HOST_CHECK        // (tests/host_check/ms_flat_check.cpp compiles this header and the flat `_ms` kernels with g++: no HIP there)
 #include "common.h"
+#endif
 
 // what a `_ms` kernel declares as LOCALS named blockIdx / gridDim in front of the included body (they shadow the built-ins)
 struct VDim { unsigned x, y, z; };

@@ -412,25 +412,7 @@ __global__ void weighted_mean_sum_bwd_kernel(MeanGrads out, int K, int B, const 
 // ---------------------------------------------------------------------------------------------
 // One launch over the scales (csrc/multiscale.h): the bodies above once more, behind a table of per-scale arguments.
 // ---------------------------------------------------------------------------------------------
-struct OccMsArgs { const float *img, *from_l, *from_r; float *diff_l, *diff_r, *w_bwd, *w_fwd; int HW; };
-__global__ void occ_weight_fwd_ms_kernel(MsTable<OccMsArgs> ms_table_, int B) {
-    UNFLOW_MS_PROLOGUE(ms_table_);
-    const float* __restrict__ img = ms_a_.img; const float* __restrict__ from_l = ms_a_.from_l; const float* __restrict__ from_r = ms_a_.from_r;
-    float* __restrict__ diff_l = ms_a_.diff_l; float* __restrict__ diff_r = ms_a_.diff_r;
-    float* __restrict__ w_bwd = ms_a_.w_bwd; float* __restrict__ w_fwd = ms_a_.w_fwd;
-    uint8_t* __restrict__ valid_bwd = nullptr; uint8_t* __restrict__ valid_fwd = nullptr;      // (the train step does not take the masks)
-    const int HW = ms_a_.HW;
-#include "bodies/occ_weight_fwd.inc"
-}
-
-struct AbsdiffMsArgs { const float *img, *from, *gdiff; float* gfrom; int HW; };
-__global__ void absdiff_bwd_ms_kernel(MsTable<AbsdiffMsArgs> ms_table_, int B, int img_b) {
-    UNFLOW_MS_PROLOGUE(ms_table_);
-    const float* __restrict__ img = ms_a_.img; const float* __restrict__ from = ms_a_.from; const float* __restrict__ gdiff = ms_a_.gdiff;
-    float* __restrict__ gfrom = ms_a_.gfrom;
-    const int HW = ms_a_.HW;
-#include "bodies/absdiff_bwd.inc"
-}
+#include "ms_flat_photo.h"      // occ_weight_fwd, absdiff_bwd, masked_mean_bwd, consis_bwd (also compiled for the host by the tests)
 
 struct MeanMsArgs { const float *diff, *w; float* partials; int HW; };
 __global__ __launch_bounds__(256) void masked_mean_partial_ms_kernel(MsTable<MeanMsArgs> ms_table_) {
@@ -438,15 +420,6 @@ __global__ __launch_bounds__(256) void masked_mean_partial_ms_kernel(MsTable<Mea
     const float* __restrict__ diff = ms_a_.diff; const float* __restrict__ w = ms_a_.w; float* __restrict__ partials = ms_a_.partials;
     const int HW = ms_a_.HW;
 #include "bodies/masked_mean_partial.inc"
-}
-
-struct MeanBwdMsArgs { const float *w, *sums, *gloss; float* gdiff; int HW; };
-__global__ void masked_mean_bwd_ms_kernel(MsTable<MeanBwdMsArgs> ms_table_, int B) {
-    UNFLOW_MS_PROLOGUE(ms_table_);
-    const float* __restrict__ w = ms_a_.w; const float* __restrict__ sums = ms_a_.sums; const float* __restrict__ gloss = ms_a_.gloss;
-    float* __restrict__ gdiff = ms_a_.gdiff;
-    const int HW = ms_a_.HW;
-#include "bodies/masked_mean_bwd.inc"
 }
 
 struct SmoothMsArgs { const float *flow, *img; float* partials; int H, W; };
@@ -473,15 +446,6 @@ __global__ __launch_bounds__(256) void consis_partial_ms_kernel(MsTable<ConsisMs
     float* __restrict__ partials = ms_a_.partials;
     const int HW = ms_a_.HW;
 #include "bodies/consis_partial.inc"
-}
-
-struct ConsisBwdMsArgs { const float *ff, *fb, *w_fwd, *sums, *gloss; float* gflow; int HW; };
-__global__ void consis_bwd_ms_kernel(MsTable<ConsisBwdMsArgs> ms_table_, int B) {
-    UNFLOW_MS_PROLOGUE(ms_table_);
-    const float* __restrict__ ff = ms_a_.ff; const float* __restrict__ fb = ms_a_.fb; const float* __restrict__ w_fwd = ms_a_.w_fwd;
-    const float* __restrict__ sums = ms_a_.sums; const float* __restrict__ gloss = ms_a_.gloss; float* __restrict__ gflow = ms_a_.gflow;
-    const int HW = ms_a_.HW;
-#include "bodies/consis_bwd.inc"
 }
 
 inline int flat_blocks(size_t n) {

@@ -44,15 +44,7 @@ __global__ void warp_bwd_kernel(const float* __restrict__ src, const float* __re
 
 // ---- the masked image warps of Model_flow.warp_flow_pyramid (model_flow_paper.py:62-66, net_utils.py:47-52) as ONE launch over
 // the scales (csrc/multiscale.h): the two bodies above at one channel phase (C <= 4), with the mask, without a source gradient ----
-struct WarpMsArgs { const float *src, *flow; float* out; uint8_t* mask; int H, W; };
-__global__ void warp_fwd_ms_kernel(MsTable<WarpMsArgs> ms_table_, int C, int ac) {
-    UNFLOW_MS_PROLOGUE(ms_table_);
-    constexpr int NY = 1; constexpr bool MASKED = true;
-    const float* __restrict__ src = ms_a_.src; const float* __restrict__ flow = ms_a_.flow;
-    float* __restrict__ out = ms_a_.out; uint8_t* __restrict__ mask = ms_a_.mask;
-    const int H = ms_a_.H, W = ms_a_.W;
-#include "bodies/warp_fwd.inc"
-}
+#include "ms_flat_warp.h"        // warp_fwd_ms_kernel (also compiled for the host by the tests)
 
 struct WarpBwdMsArgs { const float *src, *flow, *gout; const uint8_t* mask; float* gflow; int H, W; };
 __global__ void warp_bwd_ms_kernel(MsTable<WarpBwdMsArgs> ms_table_, int C, int ac) {

@@ -9,7 +9,9 @@
 //   w = ix-floor(ix), e = 1-w, n = iy-floor(iy), s = 1-n; taps nw=s*e ne=s*w sw=n*e se=n*w
 //   mask = (((nw'+ne')+sw')+se') >= 0.9999f   with out-of-image taps' weights zeroed
 #pragma once
+#ifndef UNFLOW_HOST_CHECK        // (tests/host_check/ms_flat_check.cpp compiles this header with g++ behind a few one-line stand-ins)
 #include "common.h"
+#endif
 
 namespace {
 
