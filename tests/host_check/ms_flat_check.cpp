@@ -2,9 +2,9 @@
 //
 // The kernels whose bodies are plain grid-stride loops -- no LDS, no barrier, no wave shuffle: occlusion weights, |.| backward, masked-mean
 // backward, consistency backward, masked image warp forward -- are ordinary C++ once threadIdx / blockIdx / blockDim / gridDim are
-// variables.  This program compiles the very definitions the library ships (csrc/ms_flat_photo.h, csrc/ms_flat_warp.h: table structs,
-// UNFLOW_MS_PROLOGUE / ms_locate / ms_grid_add, the hook-up of a scale's arguments to the body's parameter names, csrc/bodies/*.inc) with
-// g++, executes every workgroup and lane of a launch in a loop, and does the same with the single-scale kernels (the same body files
+// variables.  This program compiles the very definitions the library ships -- the C entries (csrc/ms_flat_*_entries.h: argument checks,
+// per-scale pointer arithmetic, launch geometry), the kernels (csrc/ms_flat_photo.h, ms_flat_warp.h: table structs, UNFLOW_MS_PROLOGUE /
+// ms_locate / ms_grid_add, the hook-up of a scale's arguments to the body's parameter names) and the bodies (csrc/bodies/*.inc) -- with g++, executes every workgroup and lane of a launch in a loop, and does the same with the single-scale kernels (the same body files
 // behind the real coordinates).  It checks that the one launch over three scales leaves bit for bit what three single-scale launches
 // leave, and writes the results to a file that the Python test compares with the oracle.
 //
@@ -33,6 +33,13 @@ static inline float __fmul_rn(float a, float b) { return a * b; }
 static inline float __fdiv_rn(float a, float b) { return a / b; }
 static inline float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }      // photo.hip
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }                          // common.h
+// ... and what the C entries use: argument checks as in common.h, a launch that runs every workgroup and lane here
+#define UNFLOW_EINVAL (-22)
+#define UNFLOW_REQUIRE(cond) do { if (!(cond)) return UNFLOW_EINVAL; } while (0)
+typedef void* hipStream_t;
+static inline int unflow_launch_status() { return 0; }
+template <class K, class... A> static void launch(K kernel, dim3 grid, dim3 block, A... args);
+#define UNFLOW_LAUNCH(kernel, grid, block, shmem, stream, ...) launch(kernel, grid, block, __VA_ARGS__)
 
 #include "multiscale.h"
 #include "warp_taps.h"
@@ -63,7 +70,13 @@ void warp_fwd_kernel(const float* __restrict__ src, const float* __restrict__ fl
                      int C, int H, int W, int ac) {
 #include "bodies/warp_fwd.inc"
 }
+inline int flat_blocks(size_t n) { size_t b = (n + 255) / 256; return (int)(b < 8192 ? (b ? b : 1) : 8192); }   // photo.hip
 }  // namespace
+
+// the C entries themselves (photo.hip / warp.hip include the same two headers at file scope)
+#define UNFLOW_MS_REQUIRE_N(n) UNFLOW_REQUIRE((n) > 0 && (n) <= MS_MAX)
+#include "ms_flat_photo_entries.h"
+#include "ms_flat_warp_entries.h"
 
 // every workgroup and every lane of a launch, one after the other (legal for kernels without barriers or cross-lane traffic)
 template <class K, class... A>
@@ -81,8 +94,6 @@ static std::vector<float> gen(size_t n, size_t seed, float scale = 1.f, float sh
     for (size_t i = 0; i < n; ++i) a[i] = v(i + seed) * scale + shift;
     return a;
 }
-static inline int flat_blocks(size_t n) { size_t b = (n + 255) / 256; return (int)(b < 8192 ? (b ? b : 1) : 8192); }   // photo.hip
-
 static int failures = 0;
 static void same(const char* what, int s, const void* a, const void* b, size_t bytes) {
     if (memcmp(a, b, bytes) != 0) { printf("MISMATCH %s scale %d\n", what, s); ++failures; }
@@ -90,7 +101,7 @@ static void same(const char* what, int s, const void* a, const void* b, size_t b
 
 int main(int argc, char** argv) {
     const int n = 3, B = 2, C = 3;
-    const int Hs[n] = {12, 6, 5}, Ws[n] = {70, 36, 17};                // (70 = one full 64-lane row segment + a ragged one; 17 x 5 = odd everything)
+    static const int Hs[n] = {12, 6, 5}, Ws[n] = {70, 36, 17};                // (70 = one full 64-lane row segment + a ragged one; 17 x 5 = odd everything)
     FILE* f = argc > 1 ? fopen(argv[1], "wb") : nullptr;
     auto dump = [&](const std::vector<float>& a) { if (f) fwrite(a.data(), 4, a.size(), f); };
     auto dump8 = [&](const std::vector<uint8_t>& a) { if (f) fwrite(a.data(), 1, a.size(), f); };
@@ -120,52 +131,26 @@ int main(int argc, char** argv) {
         q.wout.assign(B * 3 * hw, -7.f); q.wout1 = q.wout;
         q.mask.assign(B * hw, 9); q.mask1 = q.mask;
     }
-    // ---- one launch over the scales: the host code of the `_ms` entries (photo.hip, warp.hip), then every workgroup of the launch
-    {
-        MsTable<OccMsArgs> t = {};
-        for (int s = 0; s < n; ++s) {
-            Scale& q = S[s];
-            t.a[s] = OccMsArgs{q.img.data(), q.warped.data(), q.warped.data() + (size_t)B * 3 * q.HW, q.diff.data(), q.diff.data() + (size_t)B * q.HW,
-                               q.wgt.data(), q.wgt.data() + (size_t)B * q.HW, q.HW};
-            if (!ms_grid_add(t.grid, dim3(flat_blocks((size_t)B * q.HW)))) return 2;
-        }
-        launch(occ_weight_fwd_ms_kernel, dim3(ms_grid_blocks(t.grid)), dim3(256), t, B);
+    // ---- one launch over the scales, through the C entries as the ctypes binding calls them (host arrays of per-scale pointers / sizes)
+    const float *img[n], *warped[n], *gdiff[n], *sums[n], *gloss[n], *ff[n], *fb[n], *win[n], *wgt_c[n], *flow_img[n];
+    float *diff[n], *wgt[n], *gfrom[n], *gmm[n], *gflow[n], *wout[n];
+    uint8_t* mask[n];
+    for (int s = 0; s < n; ++s) {
+        Scale& q = S[s];
+        img[s] = q.img.data(); warped[s] = q.warped.data(); gdiff[s] = q.gdiff.data(); sums[s] = q.sums.data(); gloss[s] = q.gloss.data();
+        ff[s] = q.ff.data(); fb[s] = q.fb.data(); win[s] = q.wgt_in.data(); wgt_c[s] = q.wgt.data(); flow_img[s] = q.flow_img.data();
+        diff[s] = q.diff.data(); wgt[s] = q.wgt.data(); gfrom[s] = q.gfrom.data(); gmm[s] = q.gmm.data(); gflow[s] = q.gflow.data();
+        wout[s] = q.wout.data(); mask[s] = q.mask.data();
     }
-    {
-        MsTable<AbsdiffMsArgs> t = {};
-        for (int s = 0; s < n; ++s) {
-            Scale& q = S[s];
-            t.a[s] = AbsdiffMsArgs{q.img.data(), q.warped.data(), q.gdiff.data(), q.gfrom.data(), q.HW};
-            if (!ms_grid_add(t.grid, dim3(flat_blocks((size_t)2 * B * 3 * q.HW)))) return 2;
-        }
-        launch(absdiff_bwd_ms_kernel, dim3(ms_grid_blocks(t.grid)), dim3(256), t, 2 * B, B);
-    }
-    {
-        MsTable<MeanBwdMsArgs> t = {};
-        for (int s = 0; s < n; ++s) {
-            Scale& q = S[s];
-            t.a[s] = MeanBwdMsArgs{q.wgt.data(), q.sums.data(), q.gloss.data(), q.gmm.data(), q.HW};
-            if (!ms_grid_add(t.grid, dim3(flat_blocks((size_t)2 * B * q.HW)))) return 2;
-        }
-        launch(masked_mean_bwd_ms_kernel, dim3(ms_grid_blocks(t.grid)), dim3(256), t, 2 * B);
-    }
-    {
-        MsTable<ConsisBwdMsArgs> t = {};
-        for (int s = 0; s < n; ++s) {
-            Scale& q = S[s];
-            t.a[s] = ConsisBwdMsArgs{q.ff.data(), q.fb.data(), q.wgt_in.data(), q.sums.data(), q.gloss.data(), q.gflow.data(), q.HW};
-            if (!ms_grid_add(t.grid, dim3(flat_blocks((size_t)B * q.HW)))) return 2;
-        }
-        launch(consis_bwd_ms_kernel, dim3(ms_grid_blocks(t.grid)), dim3(256), t, B);
-    }
+    if (unflow_occ_weight_fwd_ms(n, img, warped, diff, wgt, Hs, Ws, B, nullptr) != 0) return 2;
+    if (unflow_absdiff_bwd_ms(n, img, warped, gdiff, gfrom, Hs, Ws, 2 * B, B, nullptr) != 0) return 2;
+    if (unflow_masked_mean_bwd_ms(n, wgt_c, sums, gloss, gmm, Hs, Ws, 2 * B, nullptr) != 0) return 2;
+    if (unflow_consis_bwd_ms(n, ff, fb, win, sums, gloss, gflow, Hs, Ws, B, nullptr) != 0) return 2;
+    // (and what they must refuse, as tests/test_abi.py asks the built library)
+    if (unflow_occ_weight_fwd_ms(0, img, warped, diff, wgt, Hs, Ws, B, nullptr) != UNFLOW_EINVAL || unflow_occ_weight_fwd_ms(5, img, warped, diff, wgt, Hs, Ws, B, nullptr) != UNFLOW_EINVAL ||
+        unflow_absdiff_bwd_ms(n, img, warped, gdiff, gfrom, Hs, Ws, 3, 2, nullptr) != UNFLOW_EINVAL) { printf("argument checks\n"); ++failures; }
     for (int ac = 0; ac < 2; ++ac) {
-        MsTable<WarpMsArgs> t = {};
-        for (int s = 0; s < n; ++s) {
-            Scale& q = S[s];
-            t.a[s] = WarpMsArgs{q.img.data(), q.flow_img.data(), q.wout.data(), q.mask.data(), q.H, q.W};
-            if (!ms_grid_add(t.grid, dim3(ceil_div(q.W, 64), q.H, B))) return 2;
-        }
-        launch(warp_fwd_ms_kernel, dim3(ms_grid_blocks(t.grid)), dim3(64, 1), t, C, ac);
+        if (unflow_warp_fwd_ms(n, img, flow_img, wout, mask, Hs, Ws, B, C, ac, nullptr) != 0) return 2;
         for (int s = 0; s < n; ++s) {
             Scale& q = S[s];
             launch(warp_fwd_kernel<1, true>, dim3(ceil_div(q.W, 64), q.H, B), dim3(64, 1), q.img.data(), q.flow_img.data(), q.wout1.data(), q.mask1.data(), C, q.H, q.W, ac);

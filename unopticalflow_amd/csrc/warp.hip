@@ -1452,18 +1452,7 @@ extern "C" int unflow_warp_bwd_det(const float* src, const float* flow, const fl
 // ---- (ABI 11) the masked image warps of a pyramid, ONE launch over n <= 4 scales each way (the conventions of the `_ms` loss entries,
 // photo.hip): src[k] [B,C,H,W] with C <= 4, flow[k] [B,2,H,W] -> out[k] = warp * mask, mask[k] [B,1,H,W] uint8; the backward writes the
 // flow gradient only (the images carry none).  Per scale the grid and the kernel body of unflow_warp_fwd / unflow_warp_bwd(gsrc = NULL).
-extern "C" int unflow_warp_fwd_ms(int n, const float* const* src, const float* const* flow, float* const* out, uint8_t* const* mask,
-                                  const int* H, const int* W, int B, int C, int align_corners, void* stream) {
-    UNFLOW_REQUIRE(src && flow && out && mask && H && W && n > 0 && n <= MS_MAX && B > 0 && B <= 65535 && C > 0 && C <= 4);
-    MsTable<WarpMsArgs> t = {};
-    for (int k = 0; k < n; ++k) {
-        UNFLOW_REQUIRE(src[k] && flow[k] && out[k] && mask[k] && H[k] > 0 && H[k] <= 65535 && W[k] > 0);
-        t.a[k] = WarpMsArgs{src[k], flow[k], out[k], mask[k], H[k], W[k]};
-        UNFLOW_REQUIRE(ms_grid_add(t.grid, dim3(ceil_div(W[k], 64), H[k], B)));
-    }
-    UNFLOW_LAUNCH(warp_fwd_ms_kernel, dim3(ms_grid_blocks(t.grid)), dim3(64, 1), 0, (hipStream_t)stream, t, C, align_corners ? 1 : 0);
-    return unflow_launch_status();
-}
+#include "ms_flat_warp_entries.h"       // unflow_warp_fwd_ms
 
 extern "C" int unflow_warp_bwd_ms(int n, const float* const* src, const float* const* flow, const float* const* gout,
                                   const uint8_t* const* mask, float* const* gflow, const int* H, const int* W, int B, int C,
