@@ -156,7 +156,7 @@ int main(int argc, char** argv) {
             launch(warp_fwd_kernel<1, true>, dim3(ceil_div(q.W, 64), q.H, B), dim3(64, 1), q.img.data(), q.flow_img.data(), q.wout1.data(), q.mask1.data(), C, q.H, q.W, ac);
             same(ac ? "warp fwd (align_corners)" : "warp fwd", s, q.wout.data(), q.wout1.data(), q.wout.size() * 4);
             same(ac ? "warp mask (align_corners)" : "warp mask", s, q.mask.data(), q.mask1.data(), q.mask.size());
-            if (ac == 0) { dump(q.wout); dump8(q.mask); }
+            dump(q.wout); dump8(q.mask);                                   // (both align_corners settings go to the file)
         }
     }
     // ---- the same work as single-scale launches, and the comparison
@@ -176,6 +176,11 @@ int main(int argc, char** argv) {
         for (const auto* a : {&q.diff, &q.wgt, &q.gfrom, &q.gmm, &q.gflow})
             for (float x : *a) if (x == -7.f) { printf("UNWRITTEN element, scale %d\n", s); ++failures; break; }
         dump(q.diff); dump(q.wgt); dump(q.gfrom); dump(q.gmm); dump(q.gflow);
+        // the validity masks of compute_diff_weight (model_flow_paper.py:111-112: bit-exact target #2) come out of the single-scale kernel only
+        std::vector<uint8_t> vb((size_t)B * hw, 9), vf((size_t)B * hw, 9);
+        launch(occ_weight_fwd_kernel, dim3(flat_blocks((size_t)B * hw)), dim3(256), q.img.data(), q.warped.data(), q.warped.data() + (size_t)B * 3 * hw,
+               q.diff1.data(), q.diff1.data() + (size_t)B * hw, q.wgt1.data(), q.wgt1.data() + (size_t)B * hw, vb.data(), vf.data(), B, q.HW);
+        dump8(vb); dump8(vf);
     }
     if (f) fclose(f);
     printf("%s: %d mismatches\n", failures ? "FAILED" : "OK", failures);

@@ -52,11 +52,12 @@ def test_flat_ms_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
                       gloss=_v(2 * B, 501 + s), ff=_v(B * 2 * hw, 601 + s, 3.0).view(B, 2, H, W), fb=_v(B * 2 * hw, 701 + s, 3.0).view(B, 2, H, W),
                       w=_v(B * hw, 801 + s, 1.0, 1.0).view(B, 1, H, W)))
     close = lambda a, b, what, tol=2e-6: np.testing.assert_allclose(a.numpy(), b.detach().numpy(), rtol=1e-5, atol=tol * max(float(b.abs().max()), 1e-30), err_msg=what)
-    for s, q in enumerate(S):                                              # the masked image warp (align_corners=False) and its binary mask
-        wout, mask = take((B, 3, q['H'], q['W'])), take((B, 1, q['H'], q['W']), np.uint8)
-        assert torch.equal(mask, R.warp_mask(q['img'].shape, q['flow'])), 'mask, scale %d' % s            # the integer half of the parity bar
-        assert 0 < int(mask.sum()) < mask.numel()
-        close(wout, R.warp_flow(q['img'], q['flow'], True), 'warped image, scale %d' % s)
+    for ac in (False, True):                                               # the masked image warp and its binary mask, both grid_sample conventions
+        for s, q in enumerate(S):
+            wout, mask = take((B, 3, q['H'], q['W'])), take((B, 1, q['H'], q['W']), np.uint8)
+            assert torch.equal(mask, R.warp_mask(q['img'].shape, q['flow'], ac)), 'mask, scale %d' % s    # bit-exact target #1 (net_utils.py:47-51)
+            assert 0 < int(mask.sum()) < mask.numel()
+            close(wout, R.warp_flow(q['img'], q['flow'], True, ac), 'warped image, scale %d' % s)
     for s, q in enumerate(S):
         H, W, hw = q['H'], q['W'], q['hw']
         diff, wgt = take((2 * B, 1, H, W)), take((2 * B, 1, H, W))
@@ -75,4 +76,38 @@ def test_flat_ms_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
         num = (torch.abs(R.flow_normalization(a) + R.flow_normalization(q['fb'])) * occ).sum((1, 2, 3)) / (2.0 * hw)
         (num / (q['sums'][:B, 1] / hw + 1e-12)).backward(q['gloss'][:B])
         close(gflow, a.grad, 'consistency backward, scale %d' % s, tol=1e-5)
+        vb, vf = take((B, 1, H, W), np.uint8), take((B, 1, H, W), np.uint8)
+        _, _, _, _, rb, rf = R.diff_weight(q['img'], q['warped'][:B], q['warped'][B:])
+        assert torch.equal(vb, rb.to(torch.uint8)) and torch.equal(vf, rf.to(torch.uint8)), 'validity masks, scale %d' % s   # bit-exact target #2 (:111-112)
+        assert int(vb.sum()) < vb.numel()                                                  # (the all-zero region is in the bwd direction)
     assert pos[0] == len(raw)
+
+
+def test_input_stage_kernel_runs_on_the_host_bit_exact(tmp_path):
+    """csrc/prepare.hip itself, compiled with g++ and executed lane by lane (tests/host_check/prepare_check.cpp), against
+    oracle/prepare_cpu.py: the byte / integer arithmetic of the input stage (cv2's fixed-point 8-bit resize, flip, / 255, BGR planes) is
+    bit-exact on the build host too -- KITTI's native sizes, up- and down-scaling, odd sizes, leftover rows, flips, RGB-decoded sources."""
+    import struct
+    from oracle.prepare_cpu import prepare_triplet
+    exe = str(tmp_path / 'prepare_check')
+    r = subprocess.run(['g++', '-O1', '-std=c++17', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'),
+                        os.path.join(ROOT, 'tests', 'host_check', 'prepare_check.cpp'), '-o', exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rng = np.random.default_rng(11)
+    for (H, W), swap in (((64, 128), 0), ((32, 52), 1)):
+        sizes = [(375, 1242), (370, 1226), (H, W), (2 * H, 2 * W), (40, 50), (H + 1, 3 * W + 7)]
+        images = [rng.integers(0, 256, (3 * h + (i % 3), w, 3), dtype=np.uint8) for i, (h, w) in enumerate(sizes)]
+        flips = [bool(i & 1) for i in range(len(images))]
+        fin, fout = str(tmp_path / 'in.bin'), str(tmp_path / 'out.bin')
+        with open(fin, 'wb') as f:
+            f.write(struct.pack('4i', len(images), H, W, swap))
+            for im, fl in zip(images, flips):
+                f.write(struct.pack('3i', im.shape[0], im.shape[1], int(fl)))
+            for im in images:
+                f.write(np.ascontiguousarray(im).tobytes())
+        r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and 'OK' in r.stdout, (r.stdout, r.stderr)
+        out = np.fromfile(fout, dtype=np.float32).reshape(len(images), 3, 3 * H, W)
+        for i, im in enumerate(images):
+            src = im[:, :, ::-1] if swap else im                              # swap_rb: an RGB-decoded source lands in cv2's BGR planes
+            np.testing.assert_array_equal(out[i], prepare_triplet(src, (H, W), flips[i]), err_msg='image %d, %dx%d' % (i, H, W))

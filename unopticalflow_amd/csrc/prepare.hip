@@ -12,7 +12,9 @@
 //
 // One lane produces 4 adjacent output pixels of one row for the 3 channels (three 16-byte stores, one per
 // plane); source bytes are gathered through L2/TA (each source byte is touched by ~1.5 lanes).
+#ifndef UNFLOW_HOST_CHECK        // (tests/host_check/prepare_check.cpp compiles this file with g++ behind a few one-line stand-ins and runs it)
 #include "common.h"
+#endif
 
 namespace {
 
