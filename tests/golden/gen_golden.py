@@ -165,6 +165,56 @@ def gen_losses():
     save('g1_losses.npz', out)
 
 
+# ------------------------------------------------------------------ G5: the loss section of forward() over three scales
+def gen_loss_section():
+    """model_flow_paper.py:227-251 as the reference runs it -- image pyramids, warp_flow_pyramid with masks, compute_diff_weight and the
+    four losses summed over num_scales = 3 -- from GIVEN flows (4 scales, as PWC_tf returns them), on a triplet whose frames carry the
+    regions where SSIM's window sums cancel hardest: saturated flat patches (1.0 against 1.0, 1 - 1/255, 0.95), dark flat patches, a
+    step edge, plus a black occluder.  Outputs: the four [B] losses, the masked warped images, the gradients w.r.t. all flows."""
+    cfg = R.default_cfg()
+    m = get_model('flow')(cfg)
+    B, H, W = 2, 64, 96
+    rng = np.random.default_rng(900)
+    base = rng.random((B, 3, H, W), dtype=np.float32)
+    frames = [np.clip(base + 0.05 * rng.standard_normal((B, 3, H, W)).astype(np.float32), 0, 1) for _ in range(3)]      # left, centre, right
+    hq, wq = H // 4, W // 4
+    for k, dy in enumerate((0.0, 1.0 / 255.0, 0.05)):
+        frames[1][:, :, :hq, k * wq:(k + 1) * wq] = 1.0
+        frames[0][:, :, :hq, k * wq:(k + 1) * wq] = np.float32(1.0 - dy)
+        frames[2][:, :, :hq, k * wq:(k + 1) * wq] = np.float32(1.0 - dy)
+    for f in frames:
+        f[:, :, hq:2 * hq, :wq] = 0.0                                     # dark, equal in all three (also: invalid where warped to 0)
+    frames[1][:, :, hq:2 * hq, wq:2 * wq] = 2.0 / 255.0
+    frames[0][:, :, hq:2 * hq, wq:2 * wq] = 0.0
+    frames[1][:, :, 2 * hq:, 2 * wq:] = 0.25; frames[1][:, :, 2 * hq:, 3 * wq:] = 0.9      # a step edge in the centre frame only
+    imgl, img, imgr = (torch.from_numpy(f) for f in frames)
+    flows_b = [rnd(910 + s, (B, 2, H >> s, W >> s), 2.0 / (1 << s)).requires_grad_() for s in range(4)]       # centre -> left
+    flows_f = [rnd(920 + s, (B, 2, H >> s, W >> s), 2.0 / (1 << s)).requires_grad_() for s in range(4)]       # centre -> right
+    n = len(flows_f)
+    pl, pc, pr = m.generate_img_pyramid(imgl, n), m.generate_img_pyramid(img, n), m.generate_img_pyramid(imgr, n)
+    from_l = m.warp_flow_pyramid(pl, flows_b)
+    from_r = m.warp_flow_pyramid(pr, flows_f)
+    d_b, d_f, w_b, w_f = m.compute_diff_weight(from_l, pc, from_r)
+    loss_pixel = m.compute_loss_with_mask(d_f, w_f) + m.compute_loss_with_mask(d_b, w_b)
+    loss_ssim = m.compute_loss_ssim(pc, from_r, w_f) + m.compute_loss_ssim(pc, from_l, w_b)
+    loss_smooth = m.compute_loss_flow_smooth(flows_f, pc) + m.compute_loss_flow_smooth(flows_b, pc)
+    loss_consis = m.compute_loss_flow_consis(flows_f, flows_b, w_f)
+    gl = [rnd(930 + k, (B,)) for k in range(4)]
+    sum((l * g).sum() for l, g in zip((loss_pixel, loss_ssim, loss_smooth, loss_consis), gl)).backward()
+    out = {'imgl': npy(imgl), 'img': npy(img), 'imgr': npy(imgr),
+           'loss_pixel': npy(loss_pixel), 'loss_ssim': npy(loss_ssim), 'loss_flow_smooth': npy(loss_smooth), 'loss_flow_consis': npy(loss_consis)}
+    for k in range(4):
+        out['gl%d' % k] = npy(gl[k])
+    for s in range(4):
+        out['flow_b%d' % s], out['flow_f%d' % s] = npy(flows_b[s]), npy(flows_f[s])
+    for s in range(3):
+        out['from_l%d' % s], out['from_r%d' % s] = npy(from_l[s]), npy(from_r[s])
+        out['w_bwd%d' % s], out['w_fwd%d' % s] = npy(w_b[s]), npy(w_f[s])
+        out['g_flow_b%d' % s], out['g_flow_f%d' % s] = npy(flows_b[s].grad), npy(flows_f[s].grad)
+    assert flows_b[3].grad is None and flows_f[3].grad is None          # the fourth scale is built and never used (num_scales = 3)
+    save('g5_loss_section.npz', out)
+
+
 # ------------------------------------------------------------------ G2 / G3: modules
 def grad_stats(model):
     names, s, a = [], [], []
@@ -303,10 +353,14 @@ if __name__ == '__main__':
     if sys.argv[1:] == ['eval']:
         gen_eval()
         sys.exit(0)
+    if sys.argv[1:] == ['loss_section']:
+        gen_loss_section()
+        sys.exit(0)
     torch.manual_seed(0)
     gen_corr()
     gen_warp()
     gen_losses()
+    gen_loss_section()
     gen_module('g2_module_128.npz', 2, 128, 128, steps=3, full_flows=True, mask_flow_scales=(0, 1, 2, 3), full_grads=True)
     gen_module('g3_kitti_256x832.npz', 1, 256, 832, steps=1, full_flows=False, mask_flow_scales=(1, 2, 3))
     gen_eval()

@@ -182,3 +182,30 @@ def test_pyramid_handoff_as_two_tensors():
                 assert emu.calls[0] == 'unflow_to_nchw_dup' and set(emu.calls[1:]) <= {'unflow_to_nhwc_fold'} and len(emu.calls) <= 3
             assert x.grad.is_contiguous(memory_format=torch.channels_last) or x.grad.numel() == 0
             np.testing.assert_allclose(x.grad.numpy(), xr.grad.numpy(), rtol=0, atol=1e-6, err_msg=str((C, H, W, head, dup, use)))
+
+
+def test_model_loss_section_against_the_reference_fixture(monkeypatch, golden):
+    """The same path against g5_loss_section.npz -- the REFERENCE's own run of model_flow_paper.py:227-251 from given flows, on frames with
+    saturated / dark flat patches: Model_flow.forward's Python (both launch forms) on the reference's inputs gives the reference's four
+    losses and flow gradients (the arithmetic behind the C entries is the oracle's here; tests -m gpu run the same comparison on the kernels)."""
+    from unopticalflow_amd import get_model, ops
+    g = golden('g5_loss_section.npz')
+    T = torch.from_numpy
+    imgl, img, imgr = T(g['imgl']), T(g['img']), T(g['imgr'])
+    B = img.shape[0]
+    inputs = torch.cat((imgl, img, imgr), 2)                                  # [B,3,3H,W]: left, centre, right stacked on H
+    monkeypatch.setattr(ops, 'multiscale_supported', lambda imgs, warped: 0 < len(imgs) <= 4 and all(t.shape[-1] % 2 == 0 for t in imgs))
+    for ms in (False, True):
+        model = get_model('flow')(R.default_cfg())
+        model.multiscale_losses = ms
+        fl = [torch.cat((T(g['flow_b%d' % s]), T(g['flow_f%d' % s]))).requires_grad_() for s in range(4)]      # (centre->left | centre->right)
+        monkeypatch.setattr(model, '_flows', lambda *a, **k: fl)
+        with patched(ops):
+            pack = model(inputs)
+            sum((pack[k] * T(g['gl%d' % i])).sum() for i, k in enumerate(('loss_pixel', 'loss_ssim', 'loss_flow_smooth', 'loss_flow_consis'))).backward()
+        for k in ('loss_pixel', 'loss_ssim', 'loss_flow_smooth', 'loss_flow_consis'):
+            np.testing.assert_allclose(pack[k].detach().numpy(), g[k], rtol=1e-5, err_msg='%s (multiscale_losses=%s)' % (k, ms))
+        for s in range(3):
+            ref = np.concatenate((g['g_flow_b%d' % s], g['g_flow_f%d' % s]))
+            np.testing.assert_allclose(fl[s].grad.numpy(), ref, rtol=1e-4, atol=2e-6 * float(np.abs(ref).max()), err_msg='flow gradient, scale %d' % s)
+        assert fl[3].grad is None

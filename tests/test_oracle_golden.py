@@ -184,3 +184,34 @@ def test_state_dict_layout():
     assert tuple(sd['pwc_model.dc_conv1.0.weight'].shape) == (128, 34, 3, 3)
     assert tuple(sd['pwc_model.dc_conv7.weight'].shape) == (2, 32, 3, 3)
     assert sum(v.numel() for v in sd.values()) == 5134324
+
+
+def test_loss_section_over_three_scales(golden):
+    """g5_loss_section.npz: the reference's own run of model_flow_paper.py:227-251 from given flows -- image pyramids, masked warps,
+    compute_diff_weight, the four losses summed over num_scales = 3 -- on frames with saturated / dark flat patches and a step edge (where
+    SSIM's window sums cancel hardest).  Pins the oracle's multi-scale association, its masked warps bit for bit where the mask is
+    concerned, and every flow gradient; the fourth scale is built and unused."""
+    g = golden('g5_loss_section.npz')
+    imgl, img, imgr = T(g['imgl']), T(g['img']), T(g['imgr'])
+    B = img.shape[0]
+    fb = [T(g['flow_b%d' % s]).requires_grad_() for s in range(4)]
+    ff = [T(g['flow_f%d' % s]).requires_grad_() for s in range(4)]
+    pl, pc, pr = R.img_pyramid(imgl, 4), R.img_pyramid(img, 4), R.img_pyramid(imgr, 4)
+    lp = ls = lsm = lc = 0
+    for s in range(3):
+        from_l, from_r = R.warp_flow(pl[s], fb[s], True), R.warp_flow(pr[s], ff[s], True)
+        close(from_l, g['from_l%d' % s], atol=1e-6); close(from_r, g['from_r%d' % s], atol=1e-6)
+        d_l, d_r, w_b, w_f, _, _ = R.diff_weight(pc[s], from_l, from_r)
+        close(w_b, g['w_bwd%d' % s], atol=2e-6); close(w_f, g['w_fwd%d' % s], atol=2e-6)
+        assert np.array_equal(w_b.numpy() != 0, g['w_bwd%d' % s] != 0) and np.array_equal(w_f.numpy() != 0, g['w_fwd%d' % s] != 0)
+        lp = lp + R.masked_l1(d_r, w_f) + R.masked_l1(d_l, w_b)
+        ls = ls + R.ssim_loss(pc[s], from_r, w_f) + R.ssim_loss(pc[s], from_l, w_b)
+        lsm = lsm + R.grad2_error(ff[s] / 20.0, pc[s]) + R.grad2_error(fb[s] / 20.0, pc[s])
+        lc = lc + R.consis_loss(ff[s], fb[s], w_f)
+    for v, k in ((lp, 'loss_pixel'), (ls, 'loss_ssim'), (lsm, 'loss_flow_smooth'), (lc, 'loss_flow_consis')):
+        close(v, g[k], rtol=1e-5)
+    sum((l * T(g['gl%d' % k])).sum() for k, l in enumerate((lp, ls, lsm, lc))).backward()
+    for s in range(3):
+        for t, k in ((fb[s], 'g_flow_b%d' % s), (ff[s], 'g_flow_f%d' % s)):
+            close(t.grad, g[k], rtol=1e-4, atol=1e-6 * float(np.abs(g[k]).max()))
+    assert fb[3].grad is None and ff[3].grad is None

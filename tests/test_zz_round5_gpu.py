@@ -287,3 +287,30 @@ def test_pyramid_handoff_as_two_tensors_on_the_gpu(ops):
         packs.append({k: v.detach().clone() for k, v in pack.items()})
     for k in packs[0]:
         assert torch.equal(packs[0][k], packs[1][k]), k
+
+
+@pytest.mark.parametrize('ms', [False, True])
+def test_loss_section_against_the_reference_fixture(ops, golden, monkeypatch, request, ms):
+    """g5_loss_section.npz -- the REFERENCE's own run of model_flow_paper.py:227-251 from given flows, on frames with saturated / dark
+    flat patches and a step edge -- against Model_flow.forward from the flows on, i.e. the HIP image pyramid, masked warps, occlusion
+    weights and the four loss kernels with their backward passes, in both launch forms: losses at 1e-4 rel (north_star's bar), the
+    masked warped images, flow gradients at 1e-4 + 2e-6 of the largest."""
+    if ms and _ran_in_a_child(request):
+        return
+    from unopticalflow_amd import get_model
+    g = golden('g5_loss_section.npz')
+    imgl, img, imgr = (dev(g[k]) for k in ('imgl', 'img', 'imgr'))
+    inputs = torch.cat((imgl, img, imgr), 2)
+    model = get_model('flow')(R.default_cfg()).cuda()
+    model.multiscale_losses = ms
+    fl = [torch.cat((dev(g['flow_b%d' % s]), dev(g['flow_f%d' % s]))).requires_grad_() for s in range(4)]
+    monkeypatch.setattr(model, '_flows', lambda *a, **k: fl)
+    pack = model(inputs)
+    keys = ('loss_pixel', 'loss_ssim', 'loss_flow_smooth', 'loss_flow_consis')
+    sum((pack[k] * dev(g['gl%d' % i])).sum() for i, k in enumerate(keys)).backward()
+    for k in keys:
+        close(pack[k], g[k], rtol=1e-4, what='%s (multiscale_losses=%s)' % (k, ms))
+    for s in range(3):
+        ref = np.concatenate((g['g_flow_b%d' % s], g['g_flow_f%d' % s]))
+        close(fl[s].grad, ref, rtol=1e-4, atol=2e-6 * float(np.abs(ref).max()), what='flow gradient, scale %d' % s)
+    assert fl[3].grad is None
