@@ -1,0 +1,126 @@
+// A workgroup of a HIP kernel as real threads of the build host (TEST INFRASTRUCTURE: csrc/common.h includes this file instead of the HIP
+// headers when it is compiled with -DUNFLOW_HOST_CHECK -I tests/host_check).
+//
+// What the loss kernels (csrc/photo.hip) use of the HIP dialect is small: threadIdx / blockIdx / blockDim / gridDim, __shared__ arrays,
+// __syncthreads(), the 64-lane butterfly __shfl_xor of wave_sum(), and the launch macros.  Here a lane is a fiber with a stack of its own, a workgroup's lanes
+// run interleaved and meet at a real barrier, __shared__ is `static`, and __shfl_xor exchanges
+// through a per-workgroup array between two barriers -- every lane of a workgroup calls it at the same point, exactly as the kernels
+// already require of __syncthreads().  Workgroups run one after the other.  (Lanes are FIBERS of one OS thread -- ucontext -- run in lane
+// order from barrier to barrier: deterministic, and a barrier costs a context switch instead of a futex.)  The kernels' own reduction helpers (common.h: wave_sum,
+// block_sum_256, sum_partials) are compiled UNCHANGED on top of this, so even the order of their additions is the device's.
+#pragma once
+#include <algorithm>
+#include <ucontext.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __device__
+#define __global__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+static inline float2 make_float2(float a, float b) { return float2{a, b}; }
+static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+using std::max;
+using std::min;
+
+static dim3 threadIdx;                                            // the running lane's (set on every switch)
+static dim3 blockIdx, blockDim, gridDim;                       // one workgroup at a time: shared by its lanes
+
+namespace hip_on_host {
+static float xchg[1024];
+static unsigned lane_id = 0;                                  // the running lane's linear id inside the workgroup
+}  // namespace hip_on_host
+
+namespace hip_on_host { struct WgBarrier; void sync(); }
+static inline void __syncthreads() { hip_on_host::sync(); }
+static inline float __shfl_xor(float v, int mask, int width = 64) {
+    (void)width;
+    hip_on_host::xchg[hip_on_host::lane_id] = v;
+    __syncthreads();
+    const float r = hip_on_host::xchg[hip_on_host::lane_id ^ (unsigned)mask];       // (mask < 64: the partner is in the same wave)
+    __syncthreads();
+    return r;
+}
+
+// lane i <- lane i -/+ delta of the same 64-lane wave; a lane without a source keeps its own value (HIP's __shfl_up / __shfl_down)
+template <class T> static inline T hip_on_host_shift(T v, int delta) {
+    static_assert(sizeof(T) == 4, "32-bit values");
+    float f; memcpy(&f, &v, 4);
+    hip_on_host::xchg[hip_on_host::lane_id] = f;
+    __syncthreads();
+    const int lane = (int)(hip_on_host::lane_id & 63u), src = lane + delta;
+    const float r = (src >= 0 && src < 64) ? hip_on_host::xchg[(hip_on_host::lane_id & ~63u) + (unsigned)src] : f;
+    __syncthreads();
+    T out; memcpy(&out, &r, 4);
+    return out;
+}
+template <class T> static inline T __shfl_up(T v, unsigned delta, int width = 64) { (void)width; return hip_on_host_shift(v, -(int)delta); }
+template <class T> static inline T __shfl_down(T v, unsigned delta, int width = 64) { (void)width; return hip_on_host_shift(v, (int)delta); }
+// the two scalar built-ins the SSIM kernels name: a wave-uniform value is itself; the hardware reciprocal (1 ulp) is the IEEE one here
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+
+// ---- the runtime names the entry points use
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline int hipGetLastError() { return 0; }
+static inline int hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
+static inline int hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
+
+namespace hip_on_host {
+struct Lane { ucontext_t ctx; std::vector<char> stack; dim3 tid; bool done = false, at_barrier = false; };
+static std::vector<Lane> lanes;
+static ucontext_t scheduler;
+static std::function<void()> body;
+static void lane_entry() { body(); lanes[lane_id].done = true; swapcontext(&lanes[lane_id].ctx, &scheduler); }
+
+template <class K, class... A>
+static void launch(K kernel, dim3 grid, dim3 block, A... args) {
+    const unsigned n = block.x * block.y * block.z;
+    gridDim = grid; blockDim = block;
+    body = [&] { kernel(args...); };
+    lanes.resize(n);
+    for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) {
+        blockIdx = dim3(bx, by, bz);
+        for (unsigned t = 0; t < n; ++t) {
+            Lane& l = lanes[t];
+            l.stack.resize(256 * 1024);
+            l.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+            l.done = l.at_barrier = false;
+            getcontext(&l.ctx);
+            l.ctx.uc_stack.ss_sp = l.stack.data(); l.ctx.uc_stack.ss_size = l.stack.size(); l.ctx.uc_link = &scheduler;
+            makecontext(&l.ctx, lane_entry, 0);
+        }
+        // lanes in order, each until its next barrier (or its end); when every lane still alive waits at the barrier, all go on
+        for (bool any = true; any;) {
+            any = false;
+            for (unsigned t = 0; t < n; ++t) {
+                Lane& l = lanes[t];
+                if (l.done || l.at_barrier) continue;
+                lane_id = t; threadIdx = l.tid;
+                swapcontext(&scheduler, &l.ctx);
+                any = true;
+            }
+            bool waiting = false;
+            for (auto& l : lanes) waiting |= (!l.done && l.at_barrier);
+            if (waiting) { for (auto& l : lanes) l.at_barrier = false; any = true; }
+        }
+    }
+}
+void sync() { const unsigned me = lane_id; lanes[me].at_barrier = true; swapcontext(&lanes[me].ctx, &scheduler); lane_id = me; threadIdx = lanes[me].tid; }
+}  // namespace hip_on_host
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hip_on_host::launch(kernel, grid, block, __VA_ARGS__)
+#define hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, start, stop, flags, ...) hip_on_host::launch(kernel, grid, block, __VA_ARGS__)

@@ -1,7 +1,11 @@
 // Shared device helpers for the gfx950 kernels of libunflow_hip.so.
 #pragma once
+#ifdef UNFLOW_HOST_CHECK            // tests/host_check/: this header and the loss kernels compiled with g++, lanes as threads of the build host
+#include "hip_on_host.h"
+#else
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#endif
 #include <stdint.h>
 #include "../../include/unflow_hip.h"
 

@@ -308,12 +308,22 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define SSIM2_ROWS 0             // output rows per wave: 0 = by map height (16 from 128 rows up, else 8)
 #endif
 
+#ifdef UNFLOW_HOST_CHECK
+#define UNFLOW_WAVES_PER_EU(n)
+#else
+#define UNFLOW_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+#endif
+#ifdef UNFLOW_HOST_CHECK            // (tests/host_check/ssim_check.cpp: lanes are fibers of the build host, the wave shift an exchange between them)
+__device__ __forceinline__ float from_lane_below(float v) { const float r = __shfl_up(v, 1, 64); return (threadIdx.x & 63) == 0 ? 0.f : r; }
+__device__ __forceinline__ float from_lane_above(float v) { const float r = __shfl_down(v, 1, 64); return (threadIdx.x & 63) == 63 ? 0.f : r; }
+#else
 __device__ __forceinline__ float from_lane_below(float v) {       // lane i <- lane i-1 (0 into lane 0)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float from_lane_above(float v) {       // lane i <- lane i+1 (0 into lane 63)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
+#endif
 // the column pair one to the left / right of this lane's pair
 __device__ __forceinline__ f2 pair_left(f2 c) { f2 r; r.x = from_lane_below(c.y); r.y = c.x; return r; }
 __device__ __forceinline__ f2 pair_right(f2 c) { f2 r; r.x = c.y; r.y = from_lane_above(c.x); return r; }
@@ -443,7 +453,7 @@ __device__ __forceinline__ f2 rcp_refined(f2 d) {                 // 1/d: v_rcp_
 
 // grid = (strips2(W) * ceil(H / RS), B); block = 192: wave c = channel c of the tile.
 template <int RS, bool EXACT>
-__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_FWD_WAVES))) void ssim2_fwd_kernel(const float* __restrict__ img, const float* __restrict__ warped,
+__global__ __launch_bounds__(192) UNFLOW_WAVES_PER_EU(SSIM2_FWD_WAVES) void ssim2_fwd_kernel(const float* __restrict__ img, const float* __restrict__ warped,
                                                         const float* __restrict__ wgt, float* __restrict__ partials,
                                                         int H, int W, int img_groups) {
 #include "bodies/ssim2_fwd.inc"
@@ -452,7 +462,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_FWD_W
 // grid = (strips2(W) * ceil(H / RS), B); block = 192: wave c = channel c.  Rows ys-2 .. ye+1 stream through; row r completes
 // the statistics of row r-1 (-> coefficient row r-1, summed over x-1..x+1) and with them the gradient of row r-2.
 template <int RS>
-__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_BWD_WAVES))) void ssim2_bwd_kernel(const float* __restrict__ img, const float* __restrict__ warped,
+__global__ __launch_bounds__(192) UNFLOW_WAVES_PER_EU(SSIM2_BWD_WAVES) void ssim2_bwd_kernel(const float* __restrict__ img, const float* __restrict__ warped,
                                                         const float* __restrict__ wgt, const float* __restrict__ sums,
                                                         const float* __restrict__ gloss, float* __restrict__ gwarped,
                                                         int H, int W, int img_b) {
@@ -463,7 +473,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_BWD_W
 // wave (8 or 16, by its height) pick the instantiation of the body, block-uniformly ----
 struct Ssim2MsArgs { const float *img, *warped, *wgt; float* partials; int H, W, rs; };
 template <bool EXACT>
-__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_FWD_WAVES))) void ssim2_fwd_ms_kernel(MsTable<Ssim2MsArgs> ms_table_, int img_groups) {
+__global__ __launch_bounds__(192) UNFLOW_WAVES_PER_EU(SSIM2_FWD_WAVES) void ssim2_fwd_ms_kernel(MsTable<Ssim2MsArgs> ms_table_, int img_groups) {
     UNFLOW_MS_PROLOGUE(ms_table_);
     const float* __restrict__ img = ms_a_.img; const float* __restrict__ warped = ms_a_.warped; const float* __restrict__ wgt = ms_a_.wgt;
     float* __restrict__ partials = ms_a_.partials;
@@ -478,7 +488,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_FWD_W
 }
 
 struct Ssim2BwdMsArgs { const float *img, *warped, *wgt, *sums, *gloss; float* gwarped; int H, W, rs; };
-__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(SSIM2_BWD_WAVES))) void ssim2_bwd_ms_kernel(MsTable<Ssim2BwdMsArgs> ms_table_, int img_b) {
+__global__ __launch_bounds__(192) UNFLOW_WAVES_PER_EU(SSIM2_BWD_WAVES) void ssim2_bwd_ms_kernel(MsTable<Ssim2BwdMsArgs> ms_table_, int img_b) {
     UNFLOW_MS_PROLOGUE(ms_table_);
     const float* __restrict__ img = ms_a_.img; const float* __restrict__ warped = ms_a_.warped; const float* __restrict__ wgt = ms_a_.wgt;
     const float* __restrict__ sums = ms_a_.sums; const float* __restrict__ gloss = ms_a_.gloss; float* __restrict__ gwarped = ms_a_.gwarped;
