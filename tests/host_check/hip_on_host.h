@@ -5,12 +5,11 @@
 // __syncthreads(), the 64-lane butterfly __shfl_xor of wave_sum(), and the launch macros.  Here a lane is a fiber with a stack of its own, a workgroup's lanes
 // run interleaved and meet at a real barrier, __shared__ is `static`, and __shfl_xor exchanges
 // through a per-workgroup array between two barriers -- every lane of a workgroup calls it at the same point, exactly as the kernels
-// already require of __syncthreads().  Workgroups run one after the other.  (Lanes are FIBERS of one OS thread -- ucontext -- run in lane
-// order from barrier to barrier: deterministic, and a barrier costs a context switch instead of a futex.)  The kernels' own reduction helpers (common.h: wave_sum,
+// already require of __syncthreads().  Workgroups run one after the other.  (Lanes are FIBERS of one OS thread -- a stack each, a 15-instruction
+// register switch -- run in lane order from barrier to barrier: deterministic, and a barrier costs a switch, not a system call.)  The kernels' own reduction helpers (common.h: wave_sum,
 // block_sum_256, sum_partials) are compiled UNCHANGED on top of this, so even the order of their additions is the device's.
 #pragma once
 #include <algorithm>
-#include <ucontext.h>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -44,14 +43,30 @@ static unsigned lane_id = 0;                                  // the running lan
 
 namespace hip_on_host { struct WgBarrier; void sync(); }
 static inline void __syncthreads() { hip_on_host::sync(); }
-static inline float __shfl_xor(float v, int mask, int width = 64) {
+template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) {
+    static_assert(sizeof(T) == 4, "32-bit values");
     (void)width;
-    hip_on_host::xchg[hip_on_host::lane_id] = v;
+    memcpy(&hip_on_host::xchg[hip_on_host::lane_id], &v, 4);
     __syncthreads();
-    const float r = hip_on_host::xchg[hip_on_host::lane_id ^ (unsigned)mask];       // (mask < 64: the partner is in the same wave)
+    T r; memcpy(&r, &hip_on_host::xchg[hip_on_host::lane_id ^ (unsigned)mask], 4);   // (mask < 64: the partner is in the same wave)
     __syncthreads();
     return r;
 }
+// barrier + OR over the workgroup's predicates
+namespace hip_on_host { static int or_acc = 0; }
+static inline int __syncthreads_or(int p) {
+    __syncthreads();                                              // (nobody still reads the previous result)
+    hip_on_host::or_acc = 0;
+    __syncthreads();
+    if (p) hip_on_host::or_acc = 1;
+    __syncthreads();
+    return hip_on_host::or_acc;
+}
+// the explicitly rounded operations of warp_taps.h (built with -ffp-contract=off: no fused forms sneak in)
+static inline float __fadd_rn(float a, float b) { return a + b; }
+static inline float __fsub_rn(float a, float b) { return a - b; }
+static inline float __fmul_rn(float a, float b) { return a * b; }
+static inline float __fdiv_rn(float a, float b) { return a / b; }
 
 // lane i <- lane i -/+ delta of the same 64-lane wave; a lane without a source keeps its own value (HIP's __shfl_up / __shfl_down)
 template <class T> static inline T hip_on_host_shift(T v, int delta) {
@@ -71,6 +86,12 @@ template <class T> static inline T __shfl_down(T v, unsigned delta, int width = 
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 
+// scheduling fences mean nothing here; LDS-DMA (global_load_lds_dwordx4: lane l of a wave moves `size` bytes from ITS global address to the
+// wave's LDS base + l * size) is a memcpy; a float atomic is a plain add (fibers never run concurrently)
+#define __builtin_amdgcn_sched_barrier(x)
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) memcpy((char*)(l) + (hip_on_host::lane_id & 63u) * (size), (const void*)(g), (size))
+static inline float atomicAdd(float* p, float v) { const float old = *p; *p = old + v; return old; }
+
 // ---- the runtime names the entry points use
 typedef void* hipStream_t;
 typedef void* hipEvent_t;
@@ -80,12 +101,42 @@ static inline int hipGetLastError() { return 0; }
 static inline int hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
 static inline int hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 
+// a fiber switch without system calls (ucontext's swapcontext saves the signal mask: a syscall per switch): callee-saved registers on the
+// old stack, stack pointers exchanged (x86-64 System V)
+extern "C" void hip_on_host_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl hip_on_host_switch
+.type hip_on_host_switch,@function
+hip_on_host_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+)");
+
 namespace hip_on_host {
-struct Lane { ucontext_t ctx; std::vector<char> stack; dim3 tid; bool done = false, at_barrier = false; };
+struct Lane { void* sp = nullptr; std::vector<char> stack; dim3 tid; bool done = false, at_barrier = false; };
 static std::vector<Lane> lanes;
-static ucontext_t scheduler;
+static void* scheduler_sp = nullptr;
 static std::function<void()> body;
-static void lane_entry() { body(); lanes[lane_id].done = true; swapcontext(&lanes[lane_id].ctx, &scheduler); }
+static void lane_entry() {
+    body();
+    lanes[lane_id].done = true;
+    hip_on_host_switch(&lanes[lane_id].sp, scheduler_sp);
+    abort();                                                   // (a finished lane is never resumed)
+}
 
 template <class K, class... A>
 static void launch(K kernel, dim3 grid, dim3 block, A... args) {
@@ -93,16 +144,21 @@ static void launch(K kernel, dim3 grid, dim3 block, A... args) {
     gridDim = grid; blockDim = block;
     body = [&] { kernel(args...); };
     lanes.resize(n);
+    for (unsigned t = 0; t < n; ++t) {
+        if (lanes[t].stack.size() < 192 * 1024) lanes[t].stack.resize(192 * 1024);
+        lanes[t].tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+    }
     for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) {
         blockIdx = dim3(bx, by, bz);
         for (unsigned t = 0; t < n; ++t) {
             Lane& l = lanes[t];
-            l.stack.resize(256 * 1024);
-            l.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
             l.done = l.at_barrier = false;
-            getcontext(&l.ctx);
-            l.ctx.uc_stack.ss_sp = l.stack.data(); l.ctx.uc_stack.ss_size = l.stack.size(); l.ctx.uc_link = &scheduler;
-            makecontext(&l.ctx, lane_entry, 0);
+            // a fresh stack whose first `ret` enters lane_entry with the alignment of a call: [r15 r14 r13 r12 rbx rbp][lane_entry] below a 16-byte boundary + 8
+            uintptr_t top = ((uintptr_t)(l.stack.data() + l.stack.size()) & ~(uintptr_t)15) - 8;
+            void** sp = (void**)top;
+            *--sp = (void*)&lane_entry;
+            for (int r = 0; r < 6; ++r) *--sp = nullptr;
+            l.sp = sp;
         }
         // lanes in order, each until its next barrier (or its end); when every lane still alive waits at the barrier, all go on
         for (bool any = true; any;) {
@@ -111,7 +167,7 @@ static void launch(K kernel, dim3 grid, dim3 block, A... args) {
                 Lane& l = lanes[t];
                 if (l.done || l.at_barrier) continue;
                 lane_id = t; threadIdx = l.tid;
-                swapcontext(&scheduler, &l.ctx);
+                hip_on_host_switch(&scheduler_sp, l.sp);
                 any = true;
             }
             bool waiting = false;
@@ -120,7 +176,7 @@ static void launch(K kernel, dim3 grid, dim3 block, A... args) {
         }
     }
 }
-void sync() { const unsigned me = lane_id; lanes[me].at_barrier = true; swapcontext(&lanes[me].ctx, &scheduler); lane_id = me; threadIdx = lanes[me].tid; }
+void sync() { const unsigned me = lane_id; lanes[me].at_barrier = true; hip_on_host_switch(&lanes[me].sp, scheduler_sp); lane_id = me; threadIdx = lanes[me].tid; }
 }  // namespace hip_on_host
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hip_on_host::launch(kernel, grid, block, __VA_ARGS__)
 #define hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, start, stop, flags, ...) hip_on_host::launch(kernel, grid, block, __VA_ARGS__)
