@@ -92,6 +92,59 @@ template <class T> static inline T __shfl_down(T v, unsigned delta, int width = 
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) memcpy((char*)(l) + (hip_on_host::lane_id & 63u) * (size), (const void*)(g), (size))
 static inline float atomicAdd(float* p, float v) { const float old = *p; *p = old + v; return old; }
 
+// ---- what the matrix-core cost-volume backward (csrc/corr_mfma.h) names
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+// a buffer descriptor: base + size in bytes; an access that does not lie inside [0, size) reads zeros / writes nothing (the hardware's range check,
+// which the kernels use as their predicate: offset 0x40000000 = "outside")
+namespace hip_on_host { struct Rsrc { char* base; unsigned bytes; }; }
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, num, flags) (hip_on_host::Rsrc{(char*)(p), (unsigned)(num)})
+namespace hip_on_host {
+template <int N> static inline void buf_load(const Rsrc& r, int voff, int soff, void* dst) {
+    const unsigned long long o = (unsigned long long)(unsigned)voff + (unsigned)soff;
+    if (o + N <= r.bytes) memcpy(dst, r.base + o, N); else memset(dst, 0, N);
+}
+template <int N> static inline void buf_store(const Rsrc& r, int voff, int soff, const void* src) {
+    const unsigned long long o = (unsigned long long)(unsigned)voff + (unsigned)soff;
+    if (o + N <= r.bytes) memcpy(r.base + o, src, N);
+}
+}  // namespace hip_on_host
+#if defined(__clang__)
+typedef unsigned hip_on_host_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned hip_on_host_v2u __attribute__((ext_vector_type(2)));
+typedef float hip_on_host_v4f __attribute__((ext_vector_type(4)));
+typedef __bf16 hip_on_host_bf16x8 __attribute__((ext_vector_type(8)));
+static inline unsigned hip_on_host_load_b32(const hip_on_host::Rsrc& r, int v, int s) { unsigned x; hip_on_host::buf_load<4>(r, v, s, &x); return x; }
+static inline hip_on_host_v2u hip_on_host_load_b64(const hip_on_host::Rsrc& r, int v, int s) { hip_on_host_v2u x; hip_on_host::buf_load<8>(r, v, s, &x); return x; }
+static inline hip_on_host_v4u hip_on_host_load_b128(const hip_on_host::Rsrc& r, int v, int s) { hip_on_host_v4u x; hip_on_host::buf_load<16>(r, v, s, &x); return x; }
+static inline void hip_on_host_store_b128(hip_on_host_v4u d, const hip_on_host::Rsrc& r, int v, int s) { hip_on_host::buf_store<16>(r, v, s, &d); }
+#define __builtin_amdgcn_raw_buffer_load_b32(r, v, s, aux) hip_on_host_load_b32(r, v, s)
+#define __builtin_amdgcn_raw_buffer_load_b64(r, v, s, aux) hip_on_host_load_b64(r, v, s)
+#define __builtin_amdgcn_raw_buffer_load_b128(r, v, s, aux) hip_on_host_load_b128(r, v, s)
+#define __builtin_amdgcn_raw_buffer_store_b128(d, r, v, s, aux) hip_on_host_store_b128(d, r, v, s)
+// v_mfma_f32_16x16x32_bf16, one wave: D[row][col] = sum_k A[row][k] B[k][col] + C[row][col] with the lane layouts of the CDNA4 ISA --
+// A: lane l holds row l & 15, k = 8 (l >> 4) .. + 7;  B: lane l holds column l & 15, the same k;  C / D: lane l holds column l & 15, rows
+// 4 (l >> 4) .. + 3.  Products of bf16 values are exact in fp32; they are added here in k order, in fp32 (the hardware's order is its own:
+// results can differ from the device's in the last bits, not in what is multiplied with what).
+namespace hip_on_host { static float mf_a[256][8], mf_b[256][8]; }
+static inline hip_on_host_v4f hip_on_host_mfma_16x16x32_bf16(hip_on_host_bf16x8 a, hip_on_host_bf16x8 b, hip_on_host_v4f c) {
+    const unsigned me = hip_on_host::lane_id, wave0 = me & ~63u, l = me & 63u;
+    for (int e = 0; e < 8; ++e) { hip_on_host::mf_a[me][e] = (float)a[e]; hip_on_host::mf_b[me][e] = (float)b[e]; }
+    __syncthreads();
+    hip_on_host_v4f d = c;
+    const unsigned col = l & 15u;
+    for (int reg = 0; reg < 4; ++reg) {
+        const unsigned row = 4u * (l >> 4) + (unsigned)reg;
+        float acc = c[reg];
+        for (int k = 0; k < 32; ++k) acc += hip_on_host::mf_a[wave0 + row + 16u * (unsigned)(k >> 3)][k & 7] * hip_on_host::mf_b[wave0 + col + 16u * (unsigned)(k >> 3)][k & 7];
+        d[reg] = acc;
+    }
+    __syncthreads();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) hip_on_host_mfma_16x16x32_bf16(a, b, c)
+#endif
+
 // ---- the runtime names the entry points use
 typedef void* hipStream_t;
 typedef void* hipEvent_t;

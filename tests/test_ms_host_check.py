@@ -290,3 +290,50 @@ def test_warp_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
             close(take((B, C, H, W)), x.grad, what + ' source gradient (one pass)', 1e-4, 2e-5 * float(x.grad.abs().max()) + 1e-7)
             close(take((B, 2, H, W)), fl.grad, what + ' flow gradient (one pass)', 1e-4, gf_tol)
     assert pos[0] == len(raw) and picked >= 1                               # (the level-2 launch took the one-pass form by itself)
+
+
+def test_matrix_core_backward_runs_on_the_host(tmp_path):
+    """The cost-volume backward on the matrix cores compiled for the host (ROCm clang++) and executed with lanes as fibers: the matrix
+    instruction as a function that gathers the wave's A / B fragments by the CDNA4 lane layouts, range-checked buffer accesses, LDS tables.
+    csrc/corr_mfma.h -- the shipped kernel, the default at d = 8 -- and tools/proto/corr_mfma2.h -- the pixel-pair prototype that has NEVER
+    run on a GPU -- against the oracle's autograd of corr_naive (pwc_tf.py:97-106) at the GPU test's bar (rtol 1e-4 + 1e-5 of the largest
+    gradient): both radii, ragged last segments, a partial channel group, chunks that do not divide the rows, one row chunk and several."""
+    import struct
+    clang = '/opt/rocm/lib/llvm/bin/clang++'
+    if not os.path.exists(clang):
+        import pytest
+        pytest.skip('needs clang (vector extensions, __bf16): no ROCm clang++ here')
+    exe = str(tmp_path / 'mfma_check')
+    r = subprocess.run([clang, '-O2', '-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-Wno-unknown-attributes', '-Wno-unknown-pragmas', '-Wno-pass-failed',
+                        '-I', os.path.join(ROOT, 'tests', 'host_check'), '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'),
+                        os.path.join(ROOT, 'tests', 'host_check', 'mfma_check.cpp'), '-o', exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rng = np.random.default_rng(3)
+    shapes = [(4, 2, 32, 12, 48, 8), (4, 1, 48, 21, 100, 16), (4, 2, 16, 9, 36, 4), (8, 1, 32, 20, 48, 16), (8, 1, 16, 37, 44, 32)]       # R, B, C, H, W, rows per wave
+    cases = [(s, which) for which in (0, 1) for s in shapes]
+    data = []
+    fin, fout = str(tmp_path / 'in.bin'), str(tmp_path / 'out.bin')
+    with open(fin, 'wb') as f:
+        f.write(struct.pack('i', len(cases)))
+        for (R_, B, C, H, W, rows), which in cases:
+            DD = 2 * R_ + 1
+            f1, f2 = (torch.from_numpy(rng.uniform(-1, 1, (B, C, H, W)).astype(np.float32)) for _ in range(2))
+            g = torch.from_numpy((0.05 * rng.standard_normal((B, DD * DD, H, W))).astype(np.float32))
+            data.append((f1, f2, g))
+            f.write(struct.pack('7i', R_, B, C, H, W, rows, which))
+            for t in (f1, f2, g):
+                f.write(t.numpy().tobytes())
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and 'OK' in r.stdout, (r.stdout[-2000:], r.stderr[-500:])
+    raw = np.fromfile(fout, dtype=np.float32)
+    pos = 0
+    for ((R_, B, C, H, W, rows), which), (f1, f2, g) in zip(cases, data):
+        a, b = f1.clone().requires_grad_(), f2.clone().requires_grad_()
+        R.corr_naive(a, b, R_).backward(g)
+        n = B * C * H * W
+        for name, ref in (('gf1', a.grad), ('gf2', b.grad)):
+            got = raw[pos:pos + n].reshape(B, C, H, W)
+            pos += n
+            np.testing.assert_allclose(got, ref.numpy(), rtol=1e-4, atol=1e-5 * float(ref.abs().max()),
+                                       err_msg='%s, %s, R=%d [%d,%d,%d,%d] rows %d' % (name, 'corr_mfma2.h' if which else 'corr_mfma.h', R_, B, C, H, W, rows))
+    assert pos == raw.size

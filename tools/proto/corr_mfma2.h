@@ -42,6 +42,7 @@ __device__ __forceinline__ void corr_bwd_mf2_body(lds_byte* __restrict__ tab, co
     const auto ors = __builtin_amdgcn_make_buffer_rsrc(out + ((size_t)b * Ctot + c_begin) * plane, 0, (int)((size_t)C * plane * 4), 0x00020000);
 
     for (int o = lane * 16; o < K::WAVE_LDS; o += 64 * 16) *(__attribute__((address_space(3))) v4u_t*)(tab + o) = v4u_t{0u, 0u, 0u, 0u};
+    UNFLOW_WAVE_LOCKSTEP();                                   // (corr_mfma.h: nothing on the device)
 
     const int r_begin = max(ya - R, 0), r_end = min(ybp - 1 + R, H - 1);
     const int xg0 = 16 * S + 2 * p;
@@ -174,6 +175,7 @@ __device__ __forceinline__ void corr_bwd_mf2_body(lds_byte* __restrict__ tab, co
                 }
                 if (q8 == 0) write_pair(wrow0, wrow1, __uint_as_float(rawB[NR8].x), 0.f, __uint_as_float(rawB[NR8].y), 0.f, MODE ? 0 : 2 * R, 0, false);
             }
+            UNFLOW_WAVE_LOCKSTEP();
             __builtin_amdgcn_sched_barrier(0);
             b_request(rawB, gbB, r + 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -193,6 +195,7 @@ __device__ __forceinline__ void corr_bwd_mf2_body(lds_byte* __restrict__ tab, co
                                __uint_as_float(rawA[rho][n].y), both ? __uint_as_float(rawA[rho][n + 1 < DD ? n + 1 : n].y) : 0.f, j0, j1, both);
                 }
             }
+            UNFLOW_WAVE_LOCKSTEP();
             __builtin_amdgcn_sched_barrier(0);
             a_request(rawA[rho], gbA[rho], rho, r + 1);
             __builtin_amdgcn_sched_barrier(0);

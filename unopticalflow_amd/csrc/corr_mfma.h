@@ -25,7 +25,19 @@
 // Results are deterministic (no atomics) but not bit-identical to the fp32 kernels.
 #pragma once
 #define UNFLOW_CORR_MFMA_INCLUDED 1
+#ifdef UNFLOW_HOST_CHECK            // (tests/host_check/mfma_check.cpp: this header compiled for the build host -- the matrix instruction, the buffer
+#include "common.h"                 // accesses and the LDS address space have host forms in tests/host_check/hip_on_host.h)
+#else
 #include "corr_ring.h"
+#endif
+
+// A wave executes its LDS accesses in program order for all 64 lanes at once: the table writes of a round are complete before any lane reads its
+// fragment, with no barrier.  Lanes that run one after the other (the host check) need the point marked; on the device it is nothing.
+#ifdef UNFLOW_HOST_CHECK
+#define UNFLOW_WAVE_LOCKSTEP() __syncthreads()
+#else
+#define UNFLOW_WAVE_LOCKSTEP()
+#endif
 
 namespace {
 
@@ -73,6 +85,7 @@ __device__ __forceinline__ void corr_bwd_mf_body(lds_byte* __restrict__ tab, con
 
     // zeros around the band, once (the band's own cells are rewritten by every round)
     for (int o = lane * 16; o < K::WAVE_LDS; o += 64 * 16) *(__attribute__((address_space(3))) v4u_t*)(tab + o) = v4u_t{0u, 0u, 0u, 0u};
+    UNFLOW_WAVE_LOCKSTEP();
 
     const int r_begin = max(ya - R, 0), r_end = min(ybp - 1 + R, H - 1);      // source rows that feed this chunk
     const int xg = 16 * S + xl;
@@ -200,6 +213,7 @@ __device__ __forceinline__ void corr_bwd_mf_body(lds_byte* __restrict__ tab, con
                 }
             }
             }
+            UNFLOW_WAVE_LOCKSTEP();
             __builtin_amdgcn_sched_barrier(0);
             g_request(graw[K_][rho], gb[K_][rho], rho, r + DEPTH);
             __builtin_amdgcn_sched_barrier(0);
