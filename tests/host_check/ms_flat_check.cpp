@@ -1,4 +1,4 @@
-// Runs the FLAT `_ms` kernels of csrc/multiscale.h ON THE BUILD HOST (test infrastructure; tests/test_ms_host_check.py builds and runs it).
+// Runs the FLAT `_ms` kernels of csrc/multiscale.h ON THE BUILD HOST (test infrastructure; tests/test_kernels_on_host.py builds and runs it).
 //
 // The kernels whose bodies are plain grid-stride loops -- no LDS, no barrier, no wave shuffle: occlusion weights, |.| backward, masked-mean
 // backward, consistency backward, masked image warp forward -- are ordinary C++ once threadIdx / blockIdx / blockDim / gridDim are

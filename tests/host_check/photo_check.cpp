@@ -1,6 +1,6 @@
 // csrc/photo.hip -- the occlusion-weight, masked-mean, smoothness and consistency kernels with their C entries, single-scale and `_ms` --
 // compiled with g++ and EXECUTED on the build host, lanes as threads (tests/host_check/hip_on_host.h; TEST INFRASTRUCTURE,
-// tests/test_ms_host_check.py builds and runs it).  The program includes the shipped source file itself; LDS tiles, barriers and the
+// tests/test_kernels_on_host.py builds and runs it).  The program includes the shipped source file itself; LDS tiles, barriers and the
 // butterfly reductions of common.h run as written.
 //
 // It drives the entries as ops.py does for the three scales of a train step -- first stages, ONE unflow_loss_finalize_batch, backward

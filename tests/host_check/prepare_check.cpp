@@ -1,7 +1,7 @@
 // The input-stage kernel (csrc/prepare.hip: KITTI_Prepared.__getitem__ after the PNG decode, core/dataset/kitti_prepared.py:63-90,145-148 --
 // split, cv2's 8-bit INTER_LINEAR resize in fixed point, flip, / 255, HWC -> CHW) EXECUTED on the build host: this program includes the
 // shipped source file itself, compiled with g++, and runs every workgroup and lane of the launch unflow_prepare_triplets() makes
-// (test infrastructure; tests/test_ms_host_check.py compares the result with oracle/prepare_cpu.py byte for byte).
+// (test infrastructure; tests/test_kernels_on_host.py compares the result with oracle/prepare_cpu.py byte for byte).
 //
 // The kernel's one barrier separates the fill of a 256-entry table in LDS from its use; lanes run one after the other here, so each
 // workgroup is run twice -- the second pass finds the table complete and rewrites every output (the kernel is idempotent).

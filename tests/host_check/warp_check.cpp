@@ -1,6 +1,6 @@
 // csrc/warp.hip -- every warp kernel of the library (row-segment kernels, LDS-tile forward, tile / cell scatter backward, the one-pass gather
 // backward with its displacement table, the `_ms` image warps) with its C entries -- compiled with g++ and EXECUTED on the build host, lanes as
-// fibers (tests/host_check/hip_on_host.h; LDS-DMA is a memcpy, float atomics plain adds: TEST INFRASTRUCTURE, tests/test_ms_host_check.py).
+// fibers (tests/host_check/hip_on_host.h; LDS-DMA is a memcpy, float atomics plain adds: TEST INFRASTRUCTURE, tests/test_kernels_on_host.py).
 //
 //   warp_check in.bin out.bin
 // in : int32 ncases; per case int32 B, C, H, W, masked, align_corners; float src[B,C,H,W], flow[B,2,H,W], gout[B,C,H,W]

@@ -1,7 +1,7 @@
 // The `_ms` kernels (csrc/multiscale.h) of photo.hip's FLAT bodies -- grid-stride loops without LDS, barriers or wave shuffles -- in a
 // header of their own, so that tests/host_check/ms_flat_check.cpp can compile exactly these definitions (table structs, prologue, the
 // hook-up of a scale's arguments to the body's parameter names, the bodies themselves) with g++ and RUN them on the build host:
-// tests/test_ms_host_check.py compares them with the single-scale kernels run the same way, bit for bit, and with the oracle.
+// tests/test_kernels_on_host.py compares them with the single-scale kernels run the same way, bit for bit, and with the oracle.
 // Included by photo.hip inside its anonymous namespace, after `sgn`.
 #pragma once
 #include "multiscale.h"
