@@ -14,6 +14,24 @@ from oracle import ref_cpu as R
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _sanitized(build_cmd, run_args, tmp_path, name, always=True):
+    """The same program once more under AddressSanitizer + UndefinedBehaviorSanitizer (the CPU build is where sanitizers run: no GPU ASan on
+    this pool): every global-memory access of the executed kernels lands inside the buffers it was given (they are exactly-sized heap
+    blocks with red zones around them), every LDS access inside its array, no signed overflow / misaligned access / bad shift in the
+    index arithmetic.  `always` = False: only with UNFLOW_HOST_CHECK_SANITIZE=all (the long ones)."""
+    if not always and os.environ.get('UNFLOW_HOST_CHECK_SANITIZE') != 'all':
+        return
+    exe = str(tmp_path / (name + '_asan'))
+    cmd = [a for a in build_cmd if a not in ('-O2',)]
+    cmd = cmd[:1] + ['-O1', '-g', '-fsanitize=address,undefined', '-fno-omit-frame-pointer', '-fno-sanitize-recover=undefined'] + [a for a in cmd[1:] if a != '-O1']
+    cmd[cmd.index('-o') + 1] = exe
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS='detect_stack_use_after_return=0:detect_leaks=0')      # (the lanes' stacks are heap blocks switched by hand)
+    r = subprocess.run([exe] + list(run_args), capture_output=True, text=True, timeout=3000, env=env)
+    assert r.returncode == 0 and 'ERROR' not in r.stderr and 'runtime error' not in r.stderr, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def _v(n, seed, scale=1.0, shift=0.0):
     i = np.arange(n, dtype=np.uint64) + np.uint64(seed)
     a = ((i * np.uint64(2654435761)) % np.uint64(2001)).astype(np.float32) / np.float32(1000.0) - np.float32(1.0)
@@ -22,11 +40,13 @@ def _v(n, seed, scale=1.0, shift=0.0):
 
 def test_flat_ms_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
     exe, out = str(tmp_path / 'ms_flat_check'), str(tmp_path / 'out.bin')
-    r = subprocess.run(['g++', '-O1', '-std=c++17', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'),
-                        os.path.join(ROOT, 'tests', 'host_check', 'ms_flat_check.cpp'), '-o', exe], capture_output=True, text=True)
+    build = ['g++', '-O1', '-std=c++17', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'),
+                        os.path.join(ROOT, 'tests', 'host_check', 'ms_flat_check.cpp'), '-o', exe]
+    r = subprocess.run(build, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe, out], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'OK: 0 mismatches' in r.stdout, r.stdout[-2000:]          # one launch over the scales == three launches, bit for bit
+    _sanitized(build, [str(tmp_path / 'san.bin')], tmp_path, 'ms_flat_check')
     raw = open(out, 'rb').read()
     pos = [0]
 
@@ -90,8 +110,9 @@ def test_input_stage_kernel_runs_on_the_host_bit_exact(tmp_path):
     import struct
     from oracle.prepare_cpu import prepare_triplet
     exe = str(tmp_path / 'prepare_check')
-    r = subprocess.run(['g++', '-O1', '-std=c++17', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'),
-                        os.path.join(ROOT, 'tests', 'host_check', 'prepare_check.cpp'), '-o', exe], capture_output=True, text=True)
+    build = ['g++', '-O1', '-std=c++17', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'),
+                        os.path.join(ROOT, 'tests', 'host_check', 'prepare_check.cpp'), '-o', exe]
+    r = subprocess.run(build, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     rng = np.random.default_rng(11)
     for (H, W), swap in (((64, 128), 0), ((32, 52), 1)):
@@ -107,6 +128,7 @@ def test_input_stage_kernel_runs_on_the_host_bit_exact(tmp_path):
                 f.write(np.ascontiguousarray(im).tobytes())
         r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and 'OK' in r.stdout, (r.stdout, r.stderr)
+        _sanitized(build, [fin, str(tmp_path / 'san.bin')], tmp_path, 'prepare_check', always=False)
         out = np.fromfile(fout, dtype=np.float32).reshape(len(images), 3, 3 * H, W)
         for i, im in enumerate(images):
             src = im[:, :, ::-1] if swap else im                              # swap_rb: an RGB-decoded source lands in cv2's BGR planes
@@ -120,9 +142,9 @@ def test_loss_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
     loss over three scales leaves the bits of the scale-by-scale entries everywhere, partial sums included.  Here: what it leaves is what
     the oracle computes -- three losses per scale and every gradient."""
     exe, out = str(tmp_path / 'photo_check'), str(tmp_path / 'out.bin')
-    r = subprocess.run(['g++', '-O1', '-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-I', os.path.join(ROOT, 'tests', 'host_check'),
-                        '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'), os.path.join(ROOT, 'tests', 'host_check', 'photo_check.cpp'), '-o', exe],
-                       capture_output=True, text=True)
+    build = ['g++', '-O1', '-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-I', os.path.join(ROOT, 'tests', 'host_check'),
+                        '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'), os.path.join(ROOT, 'tests', 'host_check', 'photo_check.cpp'), '-o', exe]
+    r = subprocess.run(build, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe, out], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'OK: 0 mismatches' in r.stdout, r.stdout[-2000:]
@@ -130,13 +152,14 @@ def test_loss_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
     # the loss-kernel changes parked behind -DUNFLOW_LOSS_R5B (all loads of the smoothness staging issued before the first use; 16-byte forms of
     # the |.| and masked-mean backward): compiled in, the same program leaves the same bytes -- what remains open for them is their speed
     exe5, out5 = str(tmp_path / 'photo_check_r5b'), str(tmp_path / 'out_r5b.bin')
-    r = subprocess.run(['g++', '-O1', '-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-DUNFLOW_LOSS_R5B', '-I', os.path.join(ROOT, 'tests', 'host_check'),
-                        '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'), os.path.join(ROOT, 'tests', 'host_check', 'photo_check.cpp'), '-o', exe5],
-                       capture_output=True, text=True)
+    build5 = ['g++', '-O1', '-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-DUNFLOW_LOSS_R5B', '-I', os.path.join(ROOT, 'tests', 'host_check'),
+                        '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'), os.path.join(ROOT, 'tests', 'host_check', 'photo_check.cpp'), '-o', exe5]
+    r = subprocess.run(build5, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe5, out5], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'OK: 0 mismatches' in r.stdout, r.stdout[-2000:]
     assert open(out5, 'rb').read() == open(out, 'rb').read()
+    _sanitized(build, [str(tmp_path / 'san.bin')], tmp_path, 'photo_check')
     pos = [0]
 
     def take(*shape):
@@ -186,12 +209,14 @@ def test_ssim_kernels_run_on_the_host_on_flat_patches(tmp_path):
         import pytest
         pytest.skip('the SSIM kernels use clang vector extensions: no ROCm clang++ here')
     exe, out = str(tmp_path / 'ssim_check'), str(tmp_path / 'out.bin')
-    r = subprocess.run([clang, '-O1', '-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-Wno-unknown-attributes', '-Wno-unknown-pragmas', '-Wno-pass-failed',
+    build = [clang, '-O1', '-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-Wno-unknown-attributes', '-Wno-unknown-pragmas', '-Wno-pass-failed',
                         '-I', os.path.join(ROOT, 'tests', 'host_check'), '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'),
-                        os.path.join(ROOT, 'tests', 'host_check', 'ssim_check.cpp'), '-o', exe], capture_output=True, text=True)
+                        os.path.join(ROOT, 'tests', 'host_check', 'ssim_check.cpp'), '-o', exe]
+    r = subprocess.run(build, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe, out], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and 'OK: 0 mismatches' in r.stdout, r.stdout[-2000:]
+    _sanitized(build, [str(tmp_path / 'san.bin')], tmp_path, 'ssim_check')
     raw = np.fromfile(out, dtype=np.float32)
     pos = [0]
 
@@ -241,9 +266,9 @@ def test_warp_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
     bit for bit, for the five flow kinds of the GPU tests."""
     import struct
     exe = str(tmp_path / 'warp_check')
-    r = subprocess.run(['g++', '-O2', '-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-I', os.path.join(ROOT, 'tests', 'host_check'),
-                        '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'), os.path.join(ROOT, 'tests', 'host_check', 'warp_check.cpp'), '-o', exe],
-                       capture_output=True, text=True)
+    build = ['g++', '-O2', '-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-I', os.path.join(ROOT, 'tests', 'host_check'),
+                        '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'), os.path.join(ROOT, 'tests', 'host_check', 'warp_check.cpp'), '-o', exe]
+    r = subprocess.run(build, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     rng = np.random.default_rng(5)
     cases = []                                                              # (B, C, H, W, masked, ac, flow kind)
@@ -267,6 +292,7 @@ def test_warp_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
                 f.write(t.numpy().tobytes())
     r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and 'OK: 0 mismatches' in r.stdout, (r.stdout[-2000:], r.stderr[-500:])      # (the `_ms` image warps == the per-scale ones, bit for bit)
+    _sanitized(build, [fin, str(tmp_path / 'san.bin')], tmp_path, 'warp_check', always=False)      # (~100 s: UNFLOW_HOST_CHECK_SANITIZE=all)
     raw = open(fout, 'rb').read()
     pos = [0]
 
@@ -314,9 +340,10 @@ def test_matrix_core_backward_runs_on_the_host(tmp_path):
         import pytest
         pytest.skip('needs clang (vector extensions, __bf16): no ROCm clang++ here')
     exe = str(tmp_path / 'mfma_check')
-    r = subprocess.run([clang, '-O2', '-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-Wno-unknown-attributes', '-Wno-unknown-pragmas', '-Wno-pass-failed',
+    build = [clang, '-O2', '-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-Wno-unknown-attributes', '-Wno-unknown-pragmas', '-Wno-pass-failed',
                         '-I', os.path.join(ROOT, 'tests', 'host_check'), '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'),
-                        os.path.join(ROOT, 'tests', 'host_check', 'mfma_check.cpp'), '-o', exe], capture_output=True, text=True)
+                        os.path.join(ROOT, 'tests', 'host_check', 'mfma_check.cpp'), '-o', exe]
+    r = subprocess.run(build, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     rng = np.random.default_rng(3)
     shapes = [(4, 2, 32, 12, 48, 8), (4, 1, 48, 21, 100, 16), (4, 2, 16, 9, 36, 4), (8, 1, 32, 20, 48, 16), (8, 1, 16, 37, 44, 32)]       # R, B, C, H, W, rows per wave
@@ -335,6 +362,7 @@ def test_matrix_core_backward_runs_on_the_host(tmp_path):
                 f.write(t.numpy().tobytes())
     r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and 'OK' in r.stdout, (r.stdout[-2000:], r.stderr[-500:])
+    _sanitized(build, [fin, str(tmp_path / 'san.bin')], tmp_path, 'mfma_check')
     raw = np.fromfile(fout, dtype=np.float32)
     pos = 0
     for ((R_, B, C, H, W, rows), which), (f1, f2, g) in zip(cases, data):
