@@ -67,8 +67,9 @@ int unflow_corr_bwd(const float* f1, const float* f2, const float* gcv, float* g
 /* Which arithmetic unflow_corr_bwd uses where both exist (round 5; process-wide): 0 (default) = the matrix-core form -- banded
  * bf16 hi/lo split products, fp32 accumulation, ~4e-6 of the largest gradient away from the fp32 sums, deterministic -- where it
  * measured faster (d = 8 on maps of >= 8192 pixels with C % 16 == 0, W % 4 == 0); 1 = fp32 FMA kernels everywhere (the results of
- * ABI <= 9, bit for bit); 2 = the matrix-core form wherever the shape is served (d = 4 too).  Returns the previous mode, or
- * UNFLOW_EINVAL.  The reference has one arithmetic (ATen's fp32 sums, pwc_tf.py:97-106); both forms hold its 1e-4 bar. */
+ * ABI <= 9, bit for bit); 2 = the matrix-core form wherever the shape is served (d = 4 too); 3 = its pixel-pair variant (csrc/corr_mfma2.h:
+ * 11 instead of 27 gradient-load instructions per step at d = 4; same arithmetic; executed and checked on the build host, not measured on a
+ * GPU yet) wherever served.  Returns the previous mode, or UNFLOW_EINVAL.  The reference has one arithmetic (ATen's fp32 sums, pwc_tf.py:97-106); both forms hold its 1e-4 bar. */
 int unflow_corr_set_backward(int mode);
 
 /* ---- flow warp: warp_flow, core/networks/structures/net_utils.py:16-54 ----

@@ -103,7 +103,7 @@ def test_dma_ring_kernels_do_not_spill():
     assert len(names) == len(scratch) and names
     checked = 0
     for n, s in zip(names, scratch):
-        if 'ring_kernel' in n or 'ring_mixed_kernel' in n or 'gs_kernel' in n or 'rs_kernel' in n or 'rs_mixed_kernel' in n or 'mf_kernel' in n:      # (row-streamed backward: counted vmcnt behind its LDS-DMA too; matrix-core backward: two request sets in flight)
+        if 'ring_kernel' in n or 'ring_mixed_kernel' in n or 'gs_kernel' in n or 'rs_kernel' in n or 'rs_mixed_kernel' in n or 'mf_kernel' in n or 'mf2_kernel' in n:      # (row-streamed backward: counted vmcnt behind its LDS-DMA too; matrix-core backward: two request sets in flight)
             assert s == 0, (n, s)
             checked += 1
     assert checked >= 3      # ring<9 rows>, ring<3 rows>, group-split backward
@@ -113,7 +113,8 @@ def test_dma_ring_kernels_do_not_spill():
 # Every other kernel the library ships is, instruction for instruction, one that suite exercised.  What is listed here has its own
 # GPU evidence from round 5: see DESIGN.md section 7.
 ROUND5_DEVICE_CODE = {
-    'corr.hip': {'new': {'corr_bwd_mf_kernel<4, 2, 1, 1>', 'corr_bwd_mf_kernel<8, 2, 2, 1>'},        # csrc/corr_mfma.h
+    'corr.hip': {'new': {'corr_bwd_mf_kernel<4, 2, 1, 1>', 'corr_bwd_mf_kernel<8, 2, 2, 1>',         # csrc/corr_mfma.h
+                         'corr_bwd_mf2_kernel<4, 2, 1>', 'corr_bwd_mf2_kernel<8, 2, 1>'},            # csrc/corr_mfma2.h: never run on a GPU, mode 3 only
                  'renamed': {'corr_bwd_rs_kernel<4, 16, 8, 2>': 'corr_bwd_rs_kernel<4, 16, 8, 2, 0, 1, 1>',
                              'corr_bwd_rs_kernel<4, 8, 8, 2>': 'corr_bwd_rs_kernel<4, 8, 8, 2, 0, 1, 1>',
                              'corr_bwd_rs_kernel<8, 8, 8, 1>': 'corr_bwd_rs_kernel<8, 8, 8, 1, 0, 1, 1>'},
@@ -171,7 +172,8 @@ def test_round5_host_entry_points_without_gpu():
     from unopticalflow_amd import _lib
     lib = ctypes.CDLL(_lib.LIB_PATH)
     assert lib.unflow_corr_set_backward(2) == 0 and lib.unflow_corr_set_backward(1) == 2 and lib.unflow_corr_set_backward(0) == 1
-    assert lib.unflow_corr_set_backward(3) == -22 and lib.unflow_corr_set_backward(-1) == -22 and lib.unflow_corr_set_backward(0) == 0
+    assert lib.unflow_corr_set_backward(3) == 0 and lib.unflow_corr_set_backward(0) == 3                     # (3: the pixel-pair matrix-core form)
+    assert lib.unflow_corr_set_backward(4) == -22 and lib.unflow_corr_set_backward(-1) == -22 and lib.unflow_corr_set_backward(0) == 0
     cdiv = lambda a, b: (a + b - 1) // b
     for H, W in ((256, 832), (128, 416), (64, 208), (33, 57), (448, 1024), (1, 1)):
         per_sample = lib.unflow_partials_per_sample(H, W) // 2

@@ -331,7 +331,7 @@ def test_warp_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
 def test_matrix_core_backward_runs_on_the_host(tmp_path):
     """The cost-volume backward on the matrix cores compiled for the host (ROCm clang++) and executed with lanes as fibers: the matrix
     instruction as a function that gathers the wave's A / B fragments by the CDNA4 lane layouts, range-checked buffer accesses, LDS tables.
-    csrc/corr_mfma.h -- the shipped kernel, the default at d = 8 -- and tools/proto/corr_mfma2.h -- the pixel-pair prototype that has NEVER
+    csrc/corr_mfma.h -- the shipped kernel, the default at d = 8 -- and csrc/corr_mfma2.h -- the pixel-pair form (mode 3 of the switch) that has NEVER
     run on a GPU -- against the oracle's autograd of corr_naive (pwc_tf.py:97-106) at the GPU test's bar (rtol 1e-4 + 1e-5 of the largest
     gradient): both radii, ragged last segments, a partial channel group, chunks that do not divide the rows, one row chunk and several."""
     import struct

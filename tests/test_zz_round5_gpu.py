@@ -314,3 +314,28 @@ def test_loss_section_against_the_reference_fixture(ops, golden, monkeypatch, re
         ref = np.concatenate((g['g_flow_b%d' % s], g['g_flow_f%d' % s]))
         close(fl[s].grad, ref, rtol=1e-4, atol=2e-6 * float(np.abs(ref).max()), what='flow gradient, scale %d' % s)
     assert fl[3].grad is None
+
+
+@pytest.mark.parametrize('d,B,C,h,w', [(4, 16, 32, 64, 208), (4, 4, 48, 21, 100), (8, 12, 64, 32, 104), (8, 6, 16, 37, 44)])
+def test_corr_backward_pixel_pair_form(ops, request, d, B, C, h, w):
+    """ops.set_corr_backward('mfma2') (csrc/corr_mfma2.h: the pixel-pair variant of the matrix-core backward; executed and checked on the build
+    host, never on a GPU) against the oracle at the matrix-core test's bar, in a process of its own."""
+    if _ran_in_a_child(request):
+        return
+    f1c, f2c = rnd(61, (B, C, h, w)).requires_grad_(), rnd(62, (B, C, h, w)).requires_grad_()
+    cv_ref = R.corr_naive(f1c, f2c, d)
+    gout = rnd(63, tuple(cv_ref.shape), 0.05)
+    cv_ref.backward(gout)
+    amax = max(f1c.grad.abs().max().item(), f2c.grad.abs().max().item())
+    prev = ops.set_corr_backward('mfma2')
+    try:
+        runs = []
+        for _ in range(2):
+            f1, f2 = dev(f1c.detach()).requires_grad_(), dev(f2c.detach()).requires_grad_()
+            ops.corr(f1, f2, d).backward(dev(gout))
+            close(f1.grad, f1c.grad, rtol=1e-4, atol=1e-5 * amax, what='gf1')
+            close(f2.grad, f2c.grad, rtol=1e-4, atol=1e-5 * amax, what='gf2')
+            runs.append((f1.grad.clone(), f2.grad.clone()))
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])          # deterministic
+    finally:
+        ops.set_corr_backward(prev)

@@ -104,7 +104,7 @@ PY
     ;;
   mfma_sweep) UNFLOW_MICROBENCH_TUNING=1 timeout 600 python3 tools/microbench.py corr_bwd_mf 2>&1 | tee $out/corr_bwd_mf_tuning.txt | tail -60 ;;
   instep_ab)
-    for m in auto mfma fp32; do python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --corr-bwd $m > $out/ab_corr_bwd_$m.json 2>> $out/ab.err; done
+    for m in auto mfma mfma2 fp32; do python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --corr-bwd $m > $out/ab_corr_bwd_$m.json 2>> $out/ab.err; done
     for v in 1 0; do python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --deferred-loss-sums $v > $out/ab_deferred_loss_sums_$v.json 2>> $out/ab.err; done
     line $out/ab_*.json ;;
   loss_pending)

@@ -20,6 +20,7 @@
 #include "common.h"
 #include "corr_ring.h"
 #include "corr_mfma.h"
+#include "corr_mfma2.h"
 #include <atomic>
 #include <stdlib.h>
 #include <utility>
@@ -1592,6 +1593,9 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
                 // (59 vs 57 us), so it is taken only on request (unflow_corr_set_backward(2))
                 if (g_bwd_mfma_mode.load(std::memory_order_relaxed) == 2 && mfma_served(f1, f2, gcv, gf1, gf2, B, C, H, W, 4))
                     return launch_bwd_mf<4, 2, 1, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, mfma_rows(B, C, H, W, 2, 4), s);
+                // (3: the pixel-pair form of the same sums, corr_mfma2.h -- 11 instead of 27 load instructions per step; host-checked, NOT measured)
+                if (g_bwd_mfma_mode.load(std::memory_order_relaxed) == 3 && mfma_served(f1, f2, gcv, gf1, gf2, B, C, H, W, 4))
+                    return launch_bwd_mf2<4, 2, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, mfma_rows(B, C, H, W, 2, 4), s);
                 const bool ring_ok = (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0)     // LDS-DMA moves aligned 16-byte pieces
                                      && gs_offsets_fit(C, H, W, 4);
                 const int fb = forced_bwd();
@@ -1641,6 +1645,8 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
         case 8: variant = pick_variant(B, C, H, W);
                 // round 5: banded bf16x3 products on the matrix cores: level 2 149 us against 271 for the fp32 row-streamed kernel
                 // (tools/proto/corr_bwd_mfma.hip); ~4e-6 of the largest gradient away from the fp32 sums
+                if (g_bwd_mfma_mode.load(std::memory_order_relaxed) == 3 && mfma_served(f1, f2, gcv, gf1, gf2, B, C, H, W, 8))
+                    return launch_bwd_mf2<8, 2, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, mfma_rows(B, C, H, W, 2, 8), s);
                 if (g_bwd_mfma_mode.load(std::memory_order_relaxed) != 1 && mfma_served(f1, f2, gcv, gf1, gf2, B, C, H, W, 8))
                     return launch_bwd_mf<8, 2, 2, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, mfma_rows(B, C, H, W, 2, 8), s);
                 if (variant == 4 || (long)B * H * W < 8192) break;      // small maps: one lane per element (117 / 57 us at levels 5 / 6, tile kernel 283 / 378)
@@ -1658,6 +1664,6 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
 }
 
 extern "C" int unflow_corr_set_backward(int mode) {
-    if (mode < 0 || mode > 2) return UNFLOW_EINVAL;
+    if (mode < 0 || mode > 3) return UNFLOW_EINVAL;
     return g_bwd_mfma_mode.exchange(mode, std::memory_order_relaxed);
 }

@@ -1,4 +1,4 @@
-// PROTOTYPE (harness only, not in libunflow_hip.so): the matrix-core cost-volume backward of csrc/corr_mfma.h with TWO PIXELS PER LANE
+// NOT MEASURED YET (in libunflow_hip.so behind unflow_corr_set_backward(3) only): the matrix-core cost-volume backward of csrc/corr_mfma.h with TWO PIXELS PER LANE
 // in the upstream-gradient stage.  What the counters of the shipped form say (profiles/r5_corr_bwd_mfma.md): at d = 4 the
 // vector-memory path carries 27 dword-load instructions per source-row step and wave for 81 x 16 gradients -- four 64-byte pieces per
 // instruction -- and a second request set in flight does not help: throughput, not latency.  Here a lane is (pixel PAIR p, displacement
@@ -7,10 +7,10 @@
 // 9 + 2 = 11 load instructions per step at d = 4 (27), 34 + 3 = 37 at d = 8 (85), each moving 128-byte runs.  Everything else is the
 // shipped kernel: banded 16 x 32 A tables in per-wave LDS (eight of them per part now: 16.9 KB per wave at a 64-byte row stride),
 // B operand from global memory in the MFMA layout, accumulator slots that slide through C != D, no workgroup barrier.
-// Written after the GPU lease closed in round 5: the table arithmetic is checked lane by lane on the CPU (the emulation is quoted in
-// DESIGN.md section 7), the kernel itself has NOT run.
+// Written after the GPU lease closed in round 5: it has NOT run on a GPU; compiled for the host and executed lane by lane it holds the oracle at the
+// GPU test's bar (tests/test_kernels_on_host.py::test_matrix_core_backward_runs_on_the_host, also under ASan / UBSan).
 #pragma once
-#include "../../unopticalflow_amd/csrc/corr_mfma.h"
+#include "corr_mfma.h"
 
 namespace {
 
@@ -237,9 +237,9 @@ template <int R, int NCG, int SKIP = 1>
 int launch_bwd_mf2(const float* f1, const float* f2, const float* g, float* gf1, float* gf2,
                    int B, int C, int H, int W, int rows, hipStream_t s) {
     const int nseg = ceil_div(W, 16), nsb = ceil_div(nseg, 4), nchunk = ceil_div(H, rows), ngrp = ceil_div(C, NCG * 16);
-    hipLaunchKernelGGL((corr_bwd_mf2_kernel<R, NCG, SKIP>), dim3(nsb * nchunk * B * 2 * ngrp), dim3(256), 0, s,
-                       f1, f2, g, gf1, gf2, C, H, W, nseg, nsb, rows, nchunk, ngrp, 1.0f / C);
-    return (int)hipGetLastError();
+    UNFLOW_LAUNCH((corr_bwd_mf2_kernel<R, NCG, SKIP>), dim3(nsb * nchunk * B * 2 * ngrp), dim3(256), 0, s,
+                  f1, f2, g, gf1, gf2, C, H, W, nseg, nsb, rows, nchunk, ngrp, 1.0f / C);
+    return unflow_launch_status();
 }
 
 }  // namespace

@@ -328,14 +328,15 @@ class _Corr(torch.autograd.Function):
         return gf1, gf2, None
 
 
-CORR_BACKWARD_MODES = {'auto': 0, 'fp32': 1, 'mfma': 2}
+CORR_BACKWARD_MODES = {'auto': 0, 'fp32': 1, 'mfma': 2, 'mfma2': 3}
 
 
 def set_corr_backward(mode):
     """Which arithmetic the cost-volume backward uses where two exist (unflow_corr_set_backward; process-wide): 'auto' = the
     matrix-core form (banded bf16 hi/lo split products, fp32 accumulation; ~4e-6 of the largest gradient away from the fp32 sums,
     deterministic) where it measured faster (d = 8); 'fp32' = the fp32 FMA kernels everywhere; 'mfma' = the matrix-core form
-    wherever the shape is served.  Returns the previous mode's name."""
+    wherever the shape is served; 'mfma2' = its pixel-pair variant (csrc/corr_mfma2.h; checked on the build host, not measured yet) wherever served.
+    Returns the previous mode's name."""
     prev = _lib.load().unflow_corr_set_backward(CORR_BACKWARD_MODES[mode])
     if prev < 0:
         raise ValueError(mode)
