@@ -33,15 +33,15 @@ static inline float4 make_float4(float a, float b, float c, float d) { return fl
 using std::max;
 using std::min;
 
-static dim3 threadIdx;                                            // the running lane's (set on every switch)
-static dim3 blockIdx, blockDim, gridDim;                       // one workgroup at a time: shared by its lanes
+inline dim3 threadIdx;                                            // the running lane's (set on every switch)
+inline dim3 blockIdx, blockDim, gridDim;                       // one workgroup at a time: shared by its lanes
 
 namespace hip_on_host {
-static float xchg[1024];
-static unsigned lane_id = 0;                                  // the running lane's linear id inside the workgroup
+inline float xchg[1024];
+inline unsigned lane_id = 0;                                  // the running lane's linear id inside the workgroup
 }  // namespace hip_on_host
 
-namespace hip_on_host { struct WgBarrier; void sync(); }
+namespace hip_on_host { inline void sync(); }
 static inline void __syncthreads() { hip_on_host::sync(); }
 template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) {
     static_assert(sizeof(T) == 4, "32-bit values");
@@ -53,7 +53,7 @@ template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) {
     return r;
 }
 // barrier + OR over the workgroup's predicates
-namespace hip_on_host { static int or_acc = 0; }
+namespace hip_on_host { inline int or_acc = 0; }
 static inline int __syncthreads_or(int p) {
     __syncthreads();                                              // (nobody still reads the previous result)
     hip_on_host::or_acc = 0;
@@ -126,7 +126,7 @@ static inline void hip_on_host_store_b128(hip_on_host_v4u d, const hip_on_host::
 // A: lane l holds row l & 15, k = 8 (l >> 4) .. + 7;  B: lane l holds column l & 15, the same k;  C / D: lane l holds column l & 15, rows
 // 4 (l >> 4) .. + 3.  Products of bf16 values are exact in fp32; they are added here in k order, in fp32 (the hardware's order is its own:
 // results can differ from the device's in the last bits, not in what is multiplied with what).
-namespace hip_on_host { static float mf_a[256][8], mf_b[256][8]; }
+namespace hip_on_host { inline float mf_a[256][8], mf_b[256][8]; }
 static inline hip_on_host_v4f hip_on_host_mfma_16x16x32_bf16(hip_on_host_bf16x8 a, hip_on_host_bf16x8 b, hip_on_host_v4f c) {
     const unsigned me = hip_on_host::lane_id, wave0 = me & ~63u, l = me & 63u;
     for (int e = 0; e < 8; ++e) { hip_on_host::mf_a[me][e] = (float)a[e]; hip_on_host::mf_b[me][e] = (float)b[e]; }
@@ -145,6 +145,11 @@ static inline hip_on_host_v4f hip_on_host_mfma_16x16x32_bf16(hip_on_host_bf16x8 
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) hip_on_host_mfma_16x16x32_bf16(a, b, c)
 #endif
 
+// dynamic LDS (common.h: UNFLOW_DYNAMIC_LDS): one block of the size of a CU's LDS; raising a kernel's dynamic-LDS limit is a no-op
+namespace hip_on_host { alignas(16) inline unsigned char dynamic_lds[160 * 1024]; }
+#define hipFuncAttributeMaxDynamicSharedMemorySize 0
+static inline int hipFuncSetAttribute(const void*, int, int) { return 0; }
+
 // ---- the runtime names the entry points use
 typedef void* hipStream_t;
 typedef void* hipEvent_t;
@@ -159,7 +164,7 @@ static inline int hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms =
 extern "C" void hip_on_host_switch(void** save_sp, void* load_sp);
 asm(R"(
 .text
-.globl hip_on_host_switch
+.weak hip_on_host_switch
 .type hip_on_host_switch,@function
 hip_on_host_switch:
     pushq %rbp
@@ -181,10 +186,10 @@ hip_on_host_switch:
 
 namespace hip_on_host {
 struct Lane { void* sp = nullptr; std::vector<char> stack; dim3 tid; bool done = false, at_barrier = false; };
-static std::vector<Lane> lanes;
-static void* scheduler_sp = nullptr;
-static std::function<void()> body;
-static void lane_entry() {
+inline std::vector<Lane> lanes;
+inline void* scheduler_sp = nullptr;
+inline std::function<void()> body;
+inline void lane_entry() {
     body();
     lanes[lane_id].done = true;
     hip_on_host_switch(&lanes[lane_id].sp, scheduler_sp);
@@ -229,7 +234,7 @@ static void launch(K kernel, dim3 grid, dim3 block, A... args) {
         }
     }
 }
-void sync() { const unsigned me = lane_id; lanes[me].at_barrier = true; hip_on_host_switch(&lanes[me].sp, scheduler_sp); lane_id = me; threadIdx = lanes[me].tid; }
+inline void sync() { const unsigned me = lane_id; lanes[me].at_barrier = true; hip_on_host_switch(&lanes[me].sp, scheduler_sp); lane_id = me; threadIdx = lanes[me].tid; }
 }  // namespace hip_on_host
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hip_on_host::launch(kernel, grid, block, __VA_ARGS__)
 #define hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, start, stop, flags, ...) hip_on_host::launch(kernel, grid, block, __VA_ARGS__)

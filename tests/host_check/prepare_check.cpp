@@ -3,46 +3,13 @@
 // shipped source file itself, compiled with g++, and runs every workgroup and lane of the launch unflow_prepare_triplets() makes
 // (test infrastructure; tests/test_kernels_on_host.py compares the result with oracle/prepare_cpu.py byte for byte).
 //
-// The kernel's one barrier separates the fill of a 256-entry table in LDS from its use; lanes run one after the other here, so each
-// workgroup is run twice -- the second pass finds the table complete and rewrites every output (the kernel is idempotent).
+// Lanes are fibers (tests/host_check/hip_on_host.h): the kernel's one barrier -- between the fill of a 256-entry table in LDS and its use -- is real.
 //
-//   g++ -O1 -std=c++17 -ffp-contract=off -DUNFLOW_HOST_CHECK -I unopticalflow_amd/csrc tests/host_check/prepare_check.cpp -o prepare_check
+//   g++ -O1 -std=c++20 -ffp-contract=off -DUNFLOW_HOST_CHECK -I tests/host_check -I unopticalflow_amd/csrc tests/host_check/prepare_check.cpp -o prepare_check
 //   prepare_check in.bin out.bin      in: int32 B, H, W, swap_rb; per image int32 rows, cols, flip; then the images' bytes back to back
-#include <algorithm>
-#include <cmath>
-#include <cstdint>
-#include <cstdio>
-#include <cstring>
-#include <vector>
-
-#define __device__
-#define __global__
-#define __host__
-#define __forceinline__ inline
-#define __launch_bounds__(...)
-#define __shared__ static
-static inline void __syncthreads() {}
-struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
-static dim3 threadIdx, blockIdx, blockDim, gridDim;
-using std::max;
-using std::min;
-struct float4 { float x, y, z, w; };
-static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
-#define UNFLOW_EINVAL (-22)
-typedef void* hipStream_t;
-static inline int hipGetLastError() { return 0; }
-template <class K, class... A>
-static void launch(K kernel, dim3 grid, dim3 block, A... args) {
-    gridDim = grid; blockDim = block;
-    for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) {
-        blockIdx = dim3(bx, by, bz);
-        for (int pass = 0; pass < 2; ++pass)                                  // (see above: the table in LDS is complete for the second pass)
-            for (unsigned tx = 0; tx < block.x; ++tx) { threadIdx = dim3(tx, 0, 0); kernel(args...); }
-    }
-}
-#define UNFLOW_LAUNCH(kernel, grid, block, shmem, stream, ...) launch(kernel, grid, block, __VA_ARGS__)
-
 #include "prepare.hip"
+
+UnflowTimingArm& unflow_timing_arm() { static UnflowTimingArm arm = {nullptr, nullptr, false}; return arm; }      // photo.hip's: never armed here
 
 int main(int argc, char** argv) {
     if (argc < 3) return 2;

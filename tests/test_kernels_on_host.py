@@ -110,8 +110,8 @@ def test_input_stage_kernel_runs_on_the_host_bit_exact(tmp_path):
     import struct
     from oracle.prepare_cpu import prepare_triplet
     exe = str(tmp_path / 'prepare_check')
-    build = ['g++', '-O1', '-std=c++17', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'),
-                        os.path.join(ROOT, 'tests', 'host_check', 'prepare_check.cpp'), '-o', exe]
+    build = ['g++', '-O1', '-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-I', os.path.join(ROOT, 'tests', 'host_check'),
+             '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'), os.path.join(ROOT, 'tests', 'host_check', 'prepare_check.cpp'), '-o', exe]
     r = subprocess.run(build, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     rng = np.random.default_rng(11)

@@ -1,0 +1,152 @@
+"""The product's operators -- unopticalflow_amd/ops.py as it is -- on CPU tensors over the HOST-EXECUTED kernel library (tests/hostexec.py:
+the kernel source files compiled for the build host, lanes as fibers): Python wrapper, C entry and kernel source together, against the
+oracle and the reference's fixtures, without a GPU.  The `-m gpu` tests make the same comparisons on the device build."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+import hostexec
+
+T = torch.from_numpy
+
+
+def rnd(seed, shape, scale=1.0, uniform=False):
+    rng = np.random.default_rng(seed)
+    a = rng.random(shape, dtype=np.float32) if uniform else rng.standard_normal(shape).astype(np.float32)
+    return T(a * np.float32(scale))
+
+
+def close(a, b, rtol=1e-4, atol=1e-6, what=''):
+    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().numpy() if torch.is_tensor(b) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from unopticalflow_amd import ops as _ops
+    return _ops
+
+
+def test_multiscale_losses_are_the_same_bits_and_the_oracles_values(ops):
+    """tests/test_zz_round5_gpu.py::test_multiscale_losses_are_the_same_bits, here: every loss of the scale loop as one launch over the scales
+    (ops.multiscale_losses, C ABI 11) against the scale-by-scale operators -- bit for bit in losses and every gradient, inside and outside
+    deferred_loss_sums, halves by offset or as tensors -- and both against the oracle."""
+    B, n = 2, 3
+    h, w = 24, 72
+    hs, ws = [h >> s for s in range(n)], [w >> s for s in range(n)]
+    imgs = [rnd(71 + s, (B, 3, hs[s], ws[s]), uniform=True) for s in range(n)]
+    warped0 = [torch.cat(((imgs[s] + rnd(74 + s, (B, 3, hs[s], ws[s]), 0.1)).clamp(0, 1), (imgs[s] + rnd(77 + s, (B, 3, hs[s], ws[s]), 0.1)).clamp(0, 1))) for s in range(n)]
+    for s in range(n):
+        warped0[s][:B, :, 1:5, 2:9] = 0.0
+    flows0 = [rnd(80 + s, (2 * B, 2, hs[s], ws[s]), 3.0 / (1 << s)) for s in range(n)]
+    gl = [rnd(90 + k, (B,)) for k in range(4)]
+    res = {}
+    with hostexec.patched(ops):
+        for form in ('per scale', 'one launch', 'one launch, halves by offset', 'one launch, sums at once'):
+            wp = [t.clone().requires_grad_() for t in warped0]
+            fl = [t.clone().requires_grad_() for t in flows0]
+            halves = [f.split(B) for f in fl]
+            fb, ff = [x[0] for x in halves], [x[1] for x in halves]
+            with (__import__('contextlib').nullcontext() if form.endswith('at once') else ops.deferred_loss_sums):
+                if form == 'per scale':
+                    pixel, ssim, smooth, consis = [], [], [], []
+                    for s in range(n):
+                        diff, wgt = ops.occ_weight_stacked(imgs[s], wp[s])
+                        pixel.append(ops.masked_mean(diff, wgt)); ssim.append(ops.ssim_loss(imgs[s], wp[s], wgt))
+                        smooth.append(ops.smooth2_loss(fl[s], imgs[s])); consis.append(ops.consis_loss(ff[s], fb[s], wgt[B:]))
+                elif form.endswith('by offset'):
+                    pixel, ssim, smooth, consis = ops.multiscale_losses(imgs, wp, fl)
+                else:
+                    pixel, ssim, smooth, consis = ops.multiscale_losses(imgs, wp, fl, ff, fb)
+                packed = ops.loss_combine(pixel, ssim, smooth, consis)
+            sum((p * g).sum() for p, g in zip(packed, gl)).backward()
+            res[form] = [t.clone() for t in packed] + [t.grad.clone() for t in wp] + [t.grad.clone() for t in fl] + [t.clone() for t in pixel + ssim + smooth + consis]
+    for form in list(res)[1:]:
+        for k, (a, b) in enumerate(zip(res['per scale'], res[form])):
+            assert torch.equal(a, b), (form, k, float((a - b).abs().max()))
+    # ... and the oracle (model_flow_paper.py:224-235 on the stacked operands)
+    wp = [t.clone().requires_grad_() for t in warped0]
+    fl = [t.clone().requires_grad_() for t in flows0]
+    lp = ls = lsm = lc = 0
+    for img, w_, f_ in zip(imgs, wp, fl):
+        d_l, d_r, w_b, w_f, _, _ = R.diff_weight(img, w_[:B], w_[B:])
+        lp = lp + R.masked_l1(d_r, w_f) + R.masked_l1(d_l, w_b)
+        ls = ls + R.ssim_loss(img, w_[B:], w_f) + R.ssim_loss(img, w_[:B], w_b)
+        lsm = lsm + R.grad2_error(f_[B:] / 20.0, img) + R.grad2_error(f_[:B] / 20.0, img)
+        lc = lc + R.consis_loss(f_[B:], f_[:B], w_f)
+    sum((p * g).sum() for p, g in zip((lp, ls, lsm, lc), gl)).backward()
+    got = res['one launch, halves by offset']
+    for k, (a, b) in enumerate(zip(got[:4], (lp, ls, lsm, lc))):
+        close(a, b, rtol=1e-4, what='loss %d' % k)
+    for s in range(n):
+        close(got[4 + s], wp[s].grad, rtol=1e-4, atol=2e-5 * float(wp[s].grad.abs().max()), what='warped gradient %d' % s)
+        close(got[4 + n + s], fl[s].grad, rtol=1e-4, atol=2e-5 * float(fl[s].grad.abs().max()), what='flow gradient %d' % s)
+
+
+@pytest.mark.parametrize('cl,switches', [(False, {}), (True, {}), (True, {'multiscale_losses': True, 'split_handoff': True})])
+@pytest.mark.parametrize('ac', [0, 1])
+def test_module_128_golden_on_host_kernels(golden, ops, ac, cl, switches):
+    """tests/test_hip_model.py::test_module_128_golden on the CPU tier: the product's Model_flow over the host-executed kernel sources (convolutions:
+    torch's CPU conv2d) against g2_module_128.npz, the REFERENCE's own run of BASELINE config 1 -- features, flows at four scales, the inference
+    flow, the image warps' validity masks, the four losses, the total, the gradient norm, every gradient tensor's L1 norm, three full gradient
+    tensors, and three Adam steps -- at the GPU test's bars, for both grid_sample conventions, both memory formats of the conv stacks, and with
+    the round-5 switches that have not run on a GPU yet (one launch per loss over the scales, the hand-off as two tensors)."""
+    from unopticalflow_amd import get_model, generate_loss_weights_dict
+    g = golden('g2_module_128.npz')
+    tag = '_ac%d' % ac
+    cfg = R.default_cfg(align_corners=bool(ac), channels_last=cl)
+    model = get_model('flow')(cfg)
+    model.load_state_dict(R.seeded_state_dict(model, 1234, float(g['flow_gain'])))
+    for k, v in switches.items():
+        setattr(model, k, v)
+    weights = generate_loss_weights_dict(cfg)
+    B, H, W = int(g['B']), int(g['H']), int(g['W'])
+    x = R.synthetic_triplets(B, H, W, seed=0, structured=True)
+    imgl, img, imgr = x[:, :, :H], x[:, :, H:2 * H], x[:, :, 2 * H:]
+    with hostexec.patched(ops):
+        with torch.no_grad():
+            feats = model.fpyramid(img)
+            close(feats[4], g['feat5' + tag], rtol=1e-4, atol=1e-5); close(feats[5], g['feat6' + tag], rtol=1e-4, atol=1e-5)
+            stacked = model._flows(imgl, img, imgr)
+            fb, ff = [f[:B] for f in stacked], [f[B:] for f in stacked]
+            for s in range(4):
+                st = 1 if s >= 1 else 8
+                scale = np.abs(g['flow_fwd%d%s' % (s, tag)]).max()
+                close(ff[s][:, :, ::st, ::st], g['flow_fwd%d%s' % (s, tag)], rtol=1e-4, atol=1e-4 * scale)
+                close(fb[s][:, :, ::st, ::st], g['flow_bwd%d%s' % (s, tag)], rtol=1e-4, atol=1e-4 * scale)
+            inf = model.inference_flow(img, imgr)
+            close(inf[:, :, ::8, ::8], g['inference_flow' + tag], rtol=1e-4, atol=1e-4 * np.abs(g['inference_flow' + tag]).max())
+            pyr_r = model.generate_img_pyramid(imgr, 4)
+            for s in range(3):
+                _, m = ops.warp_flow_masked(pyr_r[s], ff[s], align_corners=bool(ac))
+                ref_bits = np.unpackbits(g['mask_fwd%d%s' % (s, tag)])[: m.numel()].reshape(m.shape)
+                assert (m.numpy() != ref_bits).mean() <= 1e-3
+        opt = torch.optim.Adam([{'params': [p for p in model.parameters() if p.requires_grad], 'lr': cfg.lr}])
+        for it in range(3):
+            opt.zero_grad()
+            pack = model(x)
+            loss = sum(weights[k] * pack[k].mean() for k in pack)
+            loss.backward()
+            if it == 0:
+                for k in pack:
+                    close(pack[k], g[k + tag], rtol=1e-4, what=k)
+                close(loss, g['total' + tag], rtol=1e-4)
+                gn = float(np.sqrt(sum((p.grad.double() ** 2).sum().item() for p in model.parameters())))
+                np.testing.assert_allclose(gn, float(g['grad_norm' + tag]), rtol=5e-4)
+                ga = np.array([p.grad.double().abs().sum().item() for p in model.parameters()])
+                gmax = np.array([p.grad.abs().max().item() for p in model.parameters()])
+                ref_ga = g['grad_abs' + tag]
+                bad = np.abs(ga - ref_ga) > 2e-3 * ref_ga + 2e-3 * gmax
+                assert not bad.any(), [(n, a, b) for (n, _), a, b, z in zip(model.named_parameters(), ga, ref_ga, bad) if z]
+                if ac == 0:
+                    named = dict(model.named_parameters())
+                    for name, tol in (('fpyramid.conv1.0.weight', 1e-3), ('pwc_model.conv2_0.0.weight', 2e-3), ('pwc_model.dc_conv7.weight', 1e-3)):
+                        ref_g = g['gradfull_' + name + tag]
+                        close(named[name].grad, ref_g, rtol=0, atol=tol * np.abs(ref_g).max(), what='grad ' + name)
+            opt.step()
+            np.testing.assert_allclose(loss.item(), g['loss_step%d%s' % (it, tag)], rtol=1e-4 if it == 0 else 2e-3)
+            if it in (0, 2):
+                pa = np.array([p.detach().double().abs().sum().item() for p in model.parameters()])
+                np.testing.assert_allclose(pa, g['param_abs_step%d%s' % (it + 1, tag)], rtol=5e-4)

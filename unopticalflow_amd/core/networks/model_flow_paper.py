@@ -243,7 +243,7 @@ class Model_flow(nn.Module):
         fused_sums = self.fused_loss_sums and n <= 4
         # round 5: the second stage of the 4 x n per-sample reductions below is ONE launch in front of loss_combine (its only reader)
         # instead of one per reduction -- ops.deferred_loss_sums, same bits
-        with (ops.deferred_loss_sums if (fused_sums and self.deferred_loss_sums and images.is_cuda) else contextlib.nullcontext()):
+        with (ops.deferred_loss_sums if (fused_sums and self.deferred_loss_sums and ops.on_device(images)) else contextlib.nullcontext()):
             one_launch_per_loss = self.multiscale_losses and ops.multiscale_supported(img_pyramid[:n], warped[:n])
             if one_launch_per_loss:
                 pixel, ssim, smooth, consis = ops.multiscale_losses(img_pyramid[:n], warped[:n], flows_lr[:n])     # (the halves by offset: no split nodes)

@@ -30,7 +30,7 @@ class FeaturePyramid(nn.Module):
         step's (left | right | centre) batch comes back as (left | right | centre | centre), both decoder inputs as views.
         ``split_head`` = h > 0 (channels_last stacks only): those levels come back as PAIRS (first h samples, the rest) straight from
         the hand-off (ops.to_nchw_split) -- the caller's split, without the gradient concatenation it costs on the way back."""
-        cl = self.channels_last and img.is_cuda and img.dtype == torch.float32      # (under bf16 autocast the convs then produce bf16 NHWC)
+        cl = self.channels_last and ops.on_device(img) and img.dtype == torch.float32      # (under bf16 autocast the convs then produce bf16 NHWC)
         outs, t, last = [], (img.contiguous(memory_format=CL) if cl else img), len(_CHANNELS) - 1
         for lvl in range(len(_CHANNELS)):
             t = getattr(self, 'conv%d' % (2 * lvl + 1))(t)

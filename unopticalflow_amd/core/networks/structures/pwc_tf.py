@@ -55,7 +55,7 @@ class PWC_tf(nn.Module):
             weights_to_channels_last(self)
 
     def _cl(self, x):
-        return self.channels_last and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
+        return self.channels_last and ops.on_device(x) and x.dtype in (torch.float32, torch.bfloat16)
 
     def _cat(self, parts):
         """The decoder input torch.cat(parts, 1) (pwc_tf.py:113): written directly in channels_last order when the conv
@@ -72,7 +72,7 @@ class PWC_tf(nn.Module):
         the reference's torch expression for what the kernel does not take (a non-integer ratio; host tensors in module-level tests --
         the model as a whole has no CPU path: its cost volume, warp and loss operators refuse host tensors)."""
         h, w = flow.shape[2], flow.shape[3]
-        if self.fused_upsample and flow.is_cuda and flow.dtype == torch.float32 and size[0] % h == 0 and size[1] % w == 0 and size[0] >= h and size[1] >= w:
+        if self.fused_upsample and ops.on_device(flow) and flow.dtype == torch.float32 and size[0] % h == 0 and size[1] % w == 0 and size[0] >= h and size[1] >= w:
             return ops.upsample_bilinear_scaled(flow, size, mul)
         return F.interpolate(flow * mul, list(size), mode='bilinear') if mul == 4.0 else F.interpolate(flow, list(size), mode='bilinear') * mul
 

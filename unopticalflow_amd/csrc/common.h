@@ -11,6 +11,13 @@
 
 #define UNFLOW_WAVE 64
 
+// a kernel's dynamic LDS array (`extern __shared__ T name[]`; on the build host -- tests/host_check/ -- one static block stands for it)
+#ifdef UNFLOW_HOST_CHECK
+#define UNFLOW_DYNAMIC_LDS(T, name) T* name = reinterpret_cast<T*>(hip_on_host::dynamic_lds)
+#else
+#define UNFLOW_DYNAMIC_LDS(T, name) extern __shared__ T name[]
+#endif
+
 #define UNFLOW_REQUIRE(cond) do { if (!(cond)) return UNFLOW_EINVAL; } while (0)
 
 static inline int unflow_launch_status() { return (int)hipGetLastError(); }

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void bias_leaky_bwd_nhwc_kernel(const float* _
                                                                   long long gps, const float* __restrict__ gout2, long long gps2,
                                                                   float* __restrict__ gin, float* __restrict__ partials,
                                                                   long long P, int C, int rows, float slope) {
-    extern __shared__ float red[];                 // [rows][C]
+    UNFLOW_DYNAMIC_LDS(float, red);                 // [rows][C]
     const int quads = C >> 2;
     const int q = threadIdx.x % quads, r = threadIdx.x / quads;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -253,7 +253,7 @@ __device__ __forceinline__ void nhwc_store(unsigned short* p, float v) {
 // the gradient of a hand-off that duplicated its last samples (split_nhwc_kernel with Bin < gridDim.y)
 template <typename T>
 __global__ __launch_bounds__(256) void cat_nhwc_fwd_kernel(Planes3 src, T* __restrict__ dst, int HW, int C, int fold) {
-    extern __shared__ float tile[];                   // [C][LG_LD]
+    UNFLOW_DYNAMIC_LDS(float, tile);                   // [C][LG_LD]
     const int b = blockIdx.y, p0 = blockIdx.x * LG_PIX, npx = min(LG_PIX, HW - p0);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int c0 = wave; c0 < C; c0 += 4 * LG_UNROLL) {
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void cat_nhwc_fwd_kernel(Planes3 src, T* __res
 // decoder directions, model_flow_paper.py:198-201 run twice -> one hand-off writes them twice instead of a torch.cat((c, c)))
 template <typename T>
 __global__ __launch_bounds__(256) void split_nhwc_kernel(const T* __restrict__ srcp, PlanesOut3 dst, int HW, int C, int Bin) {
-    extern __shared__ float tile[];
+    UNFLOW_DYNAMIC_LDS(float, tile);
     const int b = blockIdx.y, p0 = blockIdx.x * LG_PIX, npx = min(LG_PIX, HW - p0);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sb = b < Bin ? b : b - ((int)gridDim.y - Bin);

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void bias_leaky_bwd_nhwc_bf16_kernel(const uns
                                                                        const unsigned short* __restrict__ gout2, long long gps2,
                                                                        unsigned short* __restrict__ gin, float* __restrict__ partials,
                                                                        long long P, int C, int rows, float slope) {
-    extern __shared__ float red[];                 // [rows][C]
+    UNFLOW_DYNAMIC_LDS(float, red);                 // [rows][C]
     const int quads = C >> 2;
     const int q = threadIdx.x % quads, r = threadIdx.x / quads;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};

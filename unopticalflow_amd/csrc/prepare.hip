@@ -12,9 +12,7 @@
 //
 // One lane produces 4 adjacent output pixels of one row for the 3 channels (three 16-byte stores, one per
 // plane); source bytes are gathered through L2/TA (each source byte is touched by ~1.5 lanes).
-#ifndef UNFLOW_HOST_CHECK        // (tests/host_check/prepare_check.cpp compiles this file with g++ behind a few one-line stand-ins and runs it)
 #include "common.h"
-#endif
 
 namespace {
 
@@ -93,5 +91,5 @@ extern "C" int unflow_prepare_triplets(const unsigned char* src, const long long
     const int quads = 3 * H * (W >> 2);
     dim3 grid((quads + 255) / 256, 1, B);
     UNFLOW_LAUNCH(prepare_triplets_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, offsets, dims, flip, dst, H, W, swap_rb);
-    return (int)hipGetLastError();
+    return unflow_launch_status();
 }

@@ -17,6 +17,13 @@ __all__ = ['corr', 'warp_flow', 'warp_flow_masked', 'warp_corr', 'occ_weight', '
            'ssim_map', 'smooth2_loss', 'consis_loss', 'multiscale_losses', 'multiscale_supported', 'warp_flow_masked_pyramid', 'bias_leaky_relu_', 'bias_leaky_relu_into', 'upsample_bilinear_scaled', 'loss_combine', 'weighted_mean_sum', 'flow_head', 'img_pyramid']
 
 
+def on_device(t):
+    """True for a tensor the kernels can take.  The model asks THIS (not ``t.is_cuda``) before it chooses a path that only exists as a
+    HIP kernel -- channels_last epilogues, fused up-sampling, deferred sums, one launch over the scales -- so that tests/hostexec.py can
+    route the same paths to the host-executed build of the kernel sources (it patches this function inside its ``with`` block)."""
+    return t.is_cuda
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
@@ -777,7 +784,7 @@ def _ints(vals):
 def multiscale_supported(imgs, warped):
     """True when the `_ms` entries serve these scales (what the single-scale fast paths serve: even widths -- the SSIM column pairs --,
     maps of at least 3 x 3 -- the smoothness tiles --, at most 4 scales)."""
-    return (0 < len(imgs) <= 4 and all(t.is_cuda and t.shape[-1] % 2 == 0 and t.shape[-1] >= 3 and t.shape[-2] >= 3 for t in imgs)
+    return (0 < len(imgs) <= 4 and all(on_device(t) and t.shape[-1] % 2 == 0 and t.shape[-1] >= 3 and t.shape[-2] >= 3 for t in imgs)
             and all(w.shape[0] <= 65535 for w in warped))
 
 
@@ -1644,7 +1651,7 @@ class _FlowHead(torch.autograd.Function):
 def flow_head(y, bias, residual=None):
     """``(y + bias.view(1, 2, 1, 1)).float().contiguous() [+ residual]`` for the bias-free output ``y`` [N,2,H,W] (channels_last, fp32
     or bf16) of a predict_flow convolution (pwc_tf.py:93-94,118,130,...): the fp32 NCHW flow in one pass each way."""
-    if y.dim() != 4 or y.shape[1] != 2 or y.dtype not in (torch.float32, torch.bfloat16) or not y.is_cuda:
+    if y.dim() != 4 or y.shape[1] != 2 or y.dtype not in (torch.float32, torch.bfloat16) or not on_device(y):
         raise ValueError('flow_head: a [N,2,H,W] fp32 / bf16 HIP tensor expected, got %s %s' % (tuple(y.shape), y.dtype))
     if not y.is_contiguous(memory_format=torch.channels_last):
         y = y.contiguous(memory_format=torch.channels_last)
