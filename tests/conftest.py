@@ -30,3 +30,35 @@ def golden():
             cache[name] = dict(np.load(os.path.join(GOLDEN, name)))
         return cache[name]
     return load
+
+
+if os.environ.get('UNFLOW_TESTS_ON_HOST') == '1':
+    # A REHEARSAL of the -m gpu tests without a GPU (test infrastructure, off unless asked for):
+    #     UNFLOW_TESTS_ON_HOST=1 python -m pytest tests/test_zz_round5_gpu.py -m gpu -k "..."
+    # runs the GPU tests' own code on CPU tensors over the host-executed build of the kernel sources (tests/hostexec.py) -- `.cuda()` and
+    # `.to('cuda')` keep the tensor where it is, every test body sits inside hostexec.patched(ops).  It finds mistakes in TEST code (shapes,
+    # expectations, argument order) before a GPU session pays for them, and re-checks the kernels' arithmetic; what only a device has --
+    # MIOpen's convolutions, launch counts under the kernel timer's events, the fast fp32 cost-volume kernels, hipGraphs, Adam -- it
+    # cannot answer, and tests that need those fail here by design.  Nothing in the default runs (`-m "not gpu"`, `-m gpu`) sees any of this.
+    import torch
+
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    _to = torch.Tensor.to
+
+    def _to_host(self, *a, **k):
+        a = tuple(x for x in a if not (isinstance(x, (str, torch.device)) and str(x).startswith('cuda')))
+        if str(k.get('device', '')).startswith('cuda'):
+            k.pop('device')
+        return _to(self, *a, **k) if (a or k) else self
+    torch.Tensor.to = _to_host
+    torch.cuda.is_available = lambda: True
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+
+    @pytest.fixture(autouse=True)
+    def _over_host_executed_kernels():
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        import hostexec
+        from unopticalflow_amd import ops
+        with hostexec.patched(ops):
+            yield

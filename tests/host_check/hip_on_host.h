@@ -156,7 +156,7 @@ typedef void* hipEvent_t;
 typedef int hipError_t;
 #define hipSuccess 0
 static inline int hipGetLastError() { return 0; }
-static inline int hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
+static inline int hipEventCreate(hipEvent_t* e) { static char token; *e = &token; return 0; }      // (non-null: an armed timing slot counts its launches, the time is 0)
 static inline int hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 
 // a fiber switch without system calls (ucontext's swapcontext saves the signal mask: a syscall per switch): callee-saved registers on the

@@ -1581,7 +1581,7 @@ def to_nchw_split(x, head, dup_tail=0):
         return to_nchw(x, dup_tail).split((head, x.shape[0] - head + dup_tail))
     if x.dtype == torch.float32:
         _dev(x)
-    elif not x.is_cuda:
+    elif not on_device(x):
         raise RuntimeError('unopticalflow_amd ops run on an MI355X (HIP) device only; got a %s tensor. There is no CPU fallback.' % x.device)
     return _ToNCHWSplit.apply(x, head, dup_tail)
 
@@ -1613,7 +1613,7 @@ def to_nchw(x, dup_tail=0):
         return torch.cat((x, x[x.shape[0] - dup_tail:]), 0) if dup_tail else x
     if x.dtype == torch.float32:
         _dev(x)
-    elif not x.is_cuda:
+    elif not on_device(x):
         raise RuntimeError('unopticalflow_amd ops run on an MI355X (HIP) device only; got a %s tensor. There is no CPU fallback.' % x.device)
     return _ToNCHW.apply(x, dup_tail)
 
