@@ -42,14 +42,17 @@ if os.environ.get('UNFLOW_TESTS_ON_HOST') == '1':
     # cannot answer, and tests that need those fail here by design.  Nothing in the default runs (`-m "not gpu"`, `-m gpu`) sees any of this.
     import torch
 
-    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.Tensor.cuda = lambda self, *a, **k: self.clone()          # (a copy, differentiable like the real host-to-device copy: no aliasing)
     _to = torch.Tensor.to
 
     def _to_host(self, *a, **k):
+        n = len(a) + len(k)
         a = tuple(x for x in a if not (isinstance(x, (str, torch.device)) and str(x).startswith('cuda')))
         if str(k.get('device', '')).startswith('cuda'):
             k.pop('device')
-        return _to(self, *a, **k) if (a or k) else self
+        moved = len(a) + len(k) < n
+        out = _to(self, *a, **k) if (a or k) else self
+        return out.clone() if (moved and out is self) else out
     torch.Tensor.to = _to_host
     torch.cuda.is_available = lambda: True
     torch.cuda.synchronize = lambda *a, **k: None
