@@ -85,8 +85,8 @@ def test_multiscale_losses_are_the_same_bits_and_the_oracles_values(ops):
         close(got[4 + n + s], fl[s].grad, rtol=1e-4, atol=2e-5 * float(fl[s].grad.abs().max()), what='flow gradient %d' % s)
 
 
-@pytest.mark.parametrize('cl,switches', [(False, {}), (True, {}), (True, {'multiscale_losses': True, 'split_handoff': True})])
-@pytest.mark.parametrize('ac', [0, 1])
+@pytest.mark.parametrize('ac,cl,switches', [(0, False, {}), (0, True, {}), (1, True, {}), (0, True, {'multiscale_losses': True, 'split_handoff': True}),
+                                            (1, False, {'multiscale_losses': True})])
 def test_module_128_golden_on_host_kernels(golden, ops, ac, cl, switches):
     """tests/test_hip_model.py::test_module_128_golden on the CPU tier: the product's Model_flow over the host-executed kernel sources (convolutions:
     torch's CPU conv2d) against g2_module_128.npz, the REFERENCE's own run of BASELINE config 1 -- features, flows at four scales, the inference
