@@ -197,3 +197,39 @@ def test_loss_section_fixture_kernels_vs_reference_vs_float64(golden, ops, monke
             err = float(np.abs(fl[s].grad.double().numpy() - truth[s]).max())
             assert err <= max(2.0 * ref_err, 1e-4 * big), (ms, s, err / big, ref_err / big)
         assert fl[3].grad is None
+
+
+def test_kitti_256x832_golden_on_host_kernels(golden, ops):
+    """tests/test_hip_model.py::test_kitti_256x832_golden on the CPU tier: the headline resolution (832x256, B = 1) against the reference's fixture
+    g3_kitti_256x832.npz over the host-executed kernel sources, channels_last conv stacks with one launch per loss over the scales: inference
+    flow, the four losses, the total, the gradient norm, the L1 norm of each of the 98 gradients, the parameters after one Adam step."""
+    from unopticalflow_amd import get_model, generate_loss_weights_dict
+    g = golden('g3_kitti_256x832.npz')
+    cfg = R.default_cfg(align_corners=False, channels_last=True)
+    model = get_model('flow')(cfg)
+    model.load_state_dict(R.seeded_state_dict(model, 1234, float(g['flow_gain'])))
+    model.multiscale_losses = True
+    weights = generate_loss_weights_dict(cfg)
+    x = R.synthetic_triplets(1, 256, 832, seed=0, structured=True)
+    with hostexec.patched(ops):
+        with torch.no_grad():
+            inf = model.inference_flow(x[:, :, 256:512], x[:, :, 512:])
+            ref = g['inference_flow_ac0']
+            close(inf[:, :, ::8, ::8], ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+        opt = torch.optim.Adam([{'params': [p for p in model.parameters() if p.requires_grad], 'lr': cfg.lr}])
+        opt.zero_grad()
+        pack = model(x)
+        for k in pack:
+            close(pack[k], g[k + '_ac0'], rtol=1e-4, what=k)
+        loss = sum(weights[k] * pack[k].mean() for k in pack)
+        close(loss, g['total_ac0'], rtol=1e-4)
+        loss.backward()
+    gn = float(np.sqrt(sum((p.grad.double() ** 2).sum().item() for p in model.parameters())))
+    np.testing.assert_allclose(gn, float(g['grad_norm_ac0']), rtol=5e-4)
+    ga = np.array([p.grad.double().abs().sum().item() for p in model.parameters()])
+    gmax = np.array([p.grad.abs().max().item() for p in model.parameters()])
+    bad = np.abs(ga - g['grad_abs_ac0']) > 2e-3 * g['grad_abs_ac0'] + 2e-3 * gmax
+    assert not bad.any(), [(n, a, b) for (n, _), a, b, z in zip(model.named_parameters(), ga, g['grad_abs_ac0'], bad) if z]
+    opt.step()
+    pa = np.array([p.detach().double().abs().sum().item() for p in model.parameters()])
+    np.testing.assert_allclose(pa, g['param_abs_step1_ac0'], rtol=5e-4)
