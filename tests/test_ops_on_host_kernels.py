@@ -233,3 +233,23 @@ def test_kitti_256x832_golden_on_host_kernels(golden, ops):
     opt.step()
     pa = np.array([p.detach().double().abs().sum().item() for p in model.parameters()])
     np.testing.assert_allclose(pa, g['param_abs_step1_ac0'], rtol=5e-4)
+
+
+@pytest.mark.parametrize('fixture,scales,acs', [('g2_module_128.npz', (0, 1, 2, 3), (0, 1)), ('g3_kitti_256x832.npz', (1, 2, 3), (0,))])
+def test_model_scale_masks_bit_exact_on_host_kernels(golden, ops, fixture, scales, acs):
+    """tests/test_hip_model.py::test_model_scale_masks_bit_exact on the CPU tier -- the integer half of north_star's parity bar: the
+    reference's OWN flows (fixture ``flowfull_*``) through the warp kernel's source, executed on the host; the uint8 validity masks equal
+    the reference's bit for bit at every pyramid scale, both directions, both grid_sample conventions; no mismatch allowance."""
+    g = golden(fixture)
+    with hostexec.patched(ops):
+        for ac in acs:
+            tag = '_ac%d' % ac
+            for s in scales:
+                for nm in ('fwd', 'bwd'):
+                    fl = T(g['flowfull_%s%d%s' % (nm, s, tag)])
+                    ones = torch.ones((fl.shape[0], 1) + tuple(fl.shape[2:]))
+                    out, m = ops.warp_flow_masked(ones, fl, align_corners=bool(ac))
+                    ref_bits = np.unpackbits(g['mask_%s%d%s' % (nm, s, tag)])[: m.numel()].reshape(m.shape)
+                    assert np.array_equal(m.numpy(), ref_bits), (fixture, nm, s, ac, int((m.numpy() != ref_bits).sum()))
+                    o = out.numpy()
+                    assert np.array_equal(o != 0, ref_bits != 0) and (o[ref_bits != 0] >= 0.9999).all()
