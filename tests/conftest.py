@@ -1,5 +1,6 @@
 import os
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -54,6 +55,12 @@ if os.environ.get('UNFLOW_TESTS_ON_HOST') == '1':
         out = _to(self, *a, **k) if (a or k) else self
         return out.clone() if (moved and out is self) else out
     torch.Tensor.to = _to_host
+    for _name in ('zeros', 'ones', 'empty', 'full', 'rand', 'randn', 'randint', 'arange', 'tensor', 'as_tensor', 'zeros_like', 'empty_like', 'ones_like'):
+        def _on_host(*a, _f=getattr(torch, _name), **k):              # torch.zeros(..., device='cuda') -> the same tensor in host memory
+            if str(k.get('device', '')).startswith('cuda'):
+                k.pop('device')
+            return _f(*a, **k)
+        setattr(torch, _name, _on_host)
     torch.cuda.is_available = lambda: True
     torch.cuda.synchronize = lambda *a, **k: None
     torch.nn.Module.cuda = lambda self, *a, **k: self
@@ -63,5 +70,23 @@ if os.environ.get('UNFLOW_TESTS_ON_HOST') == '1':
         sys.path.insert(0, os.path.join(ROOT, 'tests'))
         import hostexec
         from unopticalflow_amd import ops
-        with hostexec.patched(ops):
-            yield
+        spent = [0.0]
+        call = ops._call
+
+        def timed_call(*a, **k):                                    # time inside the host-executed kernels: what a GPU would NOT spend
+            t0 = time.perf_counter()
+            try:
+                return call(*a, **k)
+            finally:
+                spent[0] += time.perf_counter() - t0
+        ops._call = timed_call
+        t0 = time.perf_counter()
+        try:
+            with hostexec.patched(ops):
+                yield
+        finally:
+            ops._call = call
+            if os.environ.get('UNFLOW_REHEARSAL_TIMES'):             # one line per test: wall seconds, seconds outside the kernels (oracle + torch)
+                wall = time.perf_counter() - t0
+                with open(os.environ['UNFLOW_REHEARSAL_TIMES'], 'a') as f:
+                    f.write('%s\t%.2f\t%.2f\n' % (os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0], wall, wall - spent[0]))

@@ -3,27 +3,28 @@ fibers, tests/host_check/hip_on_host.h) behind the library's own C ABI -- TEST I
 a `with` block, so the product's Python (autograd wrappers, Model_flow) runs on CPU tensors with the REAL kernel sources underneath; the
 product itself never loads it (unopticalflow_amd/_lib.py knows nothing about it) and still has no CPU path.
 
-What is in it: photo.hip, ssim.hip, warp.hip, elementwise.hip, prepare.hip as they are, and the cost volume through its any-radius kernels +
-the matrix-core backward (hostexec_corr.cpp).  What is not: the fast fp32 cost-volume kernels, the fused warp + cost volume, the bf16
-epilogues, Adam -- calling those raises AttributeError (no such symbol)."""
+What is in it: every kernel source file of the library -- photo.hip, ssim.hip, warp.hip, corr.hip (the LDS-DMA ring kernels with their
+hand-issued LDS reads included), warp_corr.hip, elementwise.hip, elementwise_bf16.hip, prepare.hip, optim.hip -- as they are.  What the
+host cannot show: anything about timing (counted waits are no-ops: every load has landed when its call returns), occupancy or the
+hardware's own rounding of v_rcp / MFMA summation order.  UNFLOW_HOSTEXEC_DIR: build into (and load from) another directory."""
 import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'unopticalflow_amd', 'csrc')
-OUT = os.path.join(HERE, '_build')
+OUT = os.environ.get('UNFLOW_HOSTEXEC_DIR') or os.path.join(HERE, '_build')
 LIB = os.path.join(OUT, 'libunflow_hostexec.so')
 CLANG = '/opt/rocm/lib/llvm/bin/clang++'
 FLAGS = ['-O2', '-std=c++20', '-fPIC', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-Wno-unknown-attributes', '-Wno-unknown-pragmas', '-Wno-pass-failed',
          '-I', HERE, '-I', CSRC]
-SOURCES = [os.path.join(CSRC, f) for f in ('photo.hip', 'ssim.hip', 'warp.hip', 'elementwise.hip', 'prepare.hip')] + [os.path.join(HERE, 'hostexec_corr.cpp')]
+SOURCES = [os.path.join(CSRC, f) for f in ('photo.hip', 'ssim.hip', 'warp.hip', 'corr.hip', 'warp_corr.hip', 'elementwise.hip', 'elementwise_bf16.hip', 'prepare.hip', 'optim.hip')]
 
 
 def _deps():
     d = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.h', '.hip'))]
     d += [os.path.join(CSRC, 'bodies', f) for f in os.listdir(os.path.join(CSRC, 'bodies'))]
-    d += [os.path.join(HERE, f) for f in ('hip_on_host.h', 'hostexec_corr.cpp')] + [os.path.abspath(__file__), os.path.join(ROOT, 'include', 'unflow_hip.h')]
+    d += [os.path.join(HERE, 'hip_on_host.h')] + [os.path.abspath(__file__), os.path.join(ROOT, 'include', 'unflow_hip.h')]
     return d
 
 

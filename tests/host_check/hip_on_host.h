@@ -91,6 +91,16 @@ template <class T> static inline T __shfl_down(T v, unsigned delta, int width = 
 #define __builtin_amdgcn_sched_barrier(x)
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) memcpy((char*)(l) + (hip_on_host::lane_id & 63u) * (size), (const void*)(g), (size))
 static inline float atomicAdd(float* p, float v) { const float old = *p; *p = old + v; return old; }
+// the raw barrier is the barrier; a 32-bit LDS address (what the hand-issued ds_read / ds_write of the cost-volume kernels take) is the low
+// half of the host address of a static array: lds_at() puts the high half back (the library's statics lie within 2 GB of the anchor)
+#define __builtin_amdgcn_s_barrier() __syncthreads()
+namespace hip_on_host {
+inline char lds_anchor;
+static inline char* lds_at(unsigned addr, int /*bytes*/) {
+    const uintptr_t base = (uintptr_t)&lds_anchor;
+    return (char*)(base + (intptr_t)(int32_t)(addr - (uint32_t)base));
+}
+}  // namespace hip_on_host
 
 // ---- what the matrix-core cost-volume backward (csrc/corr_mfma.h) names
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
@@ -122,6 +132,10 @@ static inline void hip_on_host_store_b128(hip_on_host_v4u d, const hip_on_host::
 #define __builtin_amdgcn_raw_buffer_load_b64(r, v, s, aux) hip_on_host_load_b64(r, v, s)
 #define __builtin_amdgcn_raw_buffer_load_b128(r, v, s, aux) hip_on_host_load_b128(r, v, s)
 #define __builtin_amdgcn_raw_buffer_store_b128(d, r, v, s, aux) hip_on_host_store_b128(d, r, v, s)
+// LDS-DMA through a buffer descriptor (buffer_load_dwordx4 ... lds): lane l of a wave moves `size` bytes from the descriptor's range (zeros
+// from outside it) to the wave's LDS base + l * size
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, l, size, v, s, ioff, aux) \
+    hip_on_host::buf_load<(size)>(r, v, (s) + (ioff), (char*)(l) + (hip_on_host::lane_id & 63u) * (size))
 // v_mfma_f32_16x16x32_bf16, one wave: D[row][col] = sum_k A[row][k] B[k][col] + C[row][col] with the lane layouts of the CDNA4 ISA --
 // A: lane l holds row l & 15, k = 8 (l >> 4) .. + 7;  B: lane l holds column l & 15, the same k;  C / D: lane l holds column l & 15, rows
 // 4 (l >> 4) .. + 3.  Products of bf16 values are exact in fp32; they are added here in k order, in fp32 (the hardware's order is its own:
@@ -236,5 +250,12 @@ static void launch(K kernel, dim3 grid, dim3 block, A... args) {
 }
 inline void sync() { const unsigned me = lane_id; lanes[me].at_barrier = true; hip_on_host_switch(&lanes[me].sp, scheduler_sp); lane_id = me; threadIdx = lanes[me].tid; }
 }  // namespace hip_on_host
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hip_on_host::launch(kernel, grid, block, __VA_ARGS__)
-#define hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, start, stop, flags, ...) hip_on_host::launch(kernel, grid, block, __VA_ARGS__)
+// HIP_ON_HOST_TRACE=1: one line per launch on stderr -- the kernel as the launch site names it (template arguments as written there) and its grid
+namespace hip_on_host {
+inline void trace(const char* kernel, dim3 grid, dim3 block) {
+    static const bool on = getenv("HIP_ON_HOST_TRACE") != nullptr;
+    if (on) fprintf(stderr, "launch %s grid %u %u %u block %u\n", kernel, grid.x, grid.y, grid.z, block.x * block.y * block.z);
+}
+}  // namespace hip_on_host
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) (hip_on_host::trace(#kernel, grid, block), hip_on_host::launch(kernel, grid, block, __VA_ARGS__))
+#define hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, start, stop, flags, ...) (hip_on_host::trace(#kernel, grid, block), hip_on_host::launch(kernel, grid, block, __VA_ARGS__))

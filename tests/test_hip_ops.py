@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from oracle import ref_cpu as R
+from oracle_cache import corr_case
 
 pytestmark = pytest.mark.gpu
 
@@ -93,38 +94,32 @@ def test_corr_d8_full_pyramid(ops, C, h, w):
 def test_corr_large_map_paths(ops, B, C, h, w):
     """Shapes that take the LDS-DMA ring kernels (level 2 of the 832x256 B=8 step and of 1024x448 B=4;
     ragged ones with partial tiles, odd B; fewer channels than ring stages, C not a multiple of the
-    stage size) and the mid-size group kernels, vs the oracle."""
-    f1c, f2c = rnd(14, (B, C, h, w)).requires_grad_(), rnd(15, (B, C, h, w)).requires_grad_()
-    cv_ref = R.corr_naive(f1c, f2c, 4)
-    gout = rnd(16, tuple(cv_ref.shape))
-    cv_ref.backward(gout)
-    f1, f2 = dev(f1c.detach()).requires_grad_(), dev(f2c.detach()).requires_grad_()
+    stage size) and the mid-size group kernels, vs the oracle (evaluated once per case and session: tests/oracle_cache.py)."""
+    o = corr_case(4, B, C, h, w)
+    f1, f2 = dev(o['f1']).requires_grad_(), dev(o['f2']).requires_grad_()
     cv = ops.corr(f1, f2, 4)
-    close(cv, cv_ref, rtol=1e-5, atol=2e-6)
-    cv.backward(dev(gout))
+    close(cv, o['cv'], rtol=1e-5, atol=2e-6)
+    cv.backward(dev(o['gout']))
     # an fp32 sum of 81 products per channel in a different order than ATen's: the error scales with the largest
     # terms, not with the (possibly cancelled) result -- atol relative to the largest gradient (1e-6 of it; with C = 1
     # nothing is divided by C and the terms reach ~30)
-    amax = max(f1c.grad.abs().max().item(), f2c.grad.abs().max().item())
-    close(f1.grad, f1c.grad, rtol=1e-5, atol=max(5e-6, 1e-6 * amax))
-    close(f2.grad, f2c.grad, rtol=1e-5, atol=max(5e-6, 1e-6 * amax))
+    amax = max(o['gf1'].abs().max().item(), o['gf2'].abs().max().item())
+    close(f1.grad, o['gf1'], rtol=1e-5, atol=max(5e-6, 1e-6 * amax))
+    close(f2.grad, o['gf2'], rtol=1e-5, atol=max(5e-6, 1e-6 * amax))
 
 
 @pytest.mark.parametrize('B,C,h,w', [(16, 32, 64, 208), (5, 7, 100, 268), (3, 2, 40, 72), (12, 64, 32, 104), (16, 96, 16, 52)])
 def test_corr_d8_large_map_paths(ops, B, C, h, w):
     """d=8 (BASELINE config 5) at the batch the step uses (2B=16): the LDS-DMA ring forward with 17 displacement
     rows split over workgroups (4 or 3 rows each, the last group partial), ragged tiles, odd channel counts."""
-    f1c, f2c = rnd(17, (B, C, h, w)).requires_grad_(), rnd(18, (B, C, h, w)).requires_grad_()
-    cv_ref = R.corr_naive(f1c, f2c, 8)
-    gout = rnd(19, tuple(cv_ref.shape))
-    cv_ref.backward(gout)
-    f1, f2 = dev(f1c.detach()).requires_grad_(), dev(f2c.detach()).requires_grad_()
+    o = corr_case(8, B, C, h, w)
+    f1, f2 = dev(o['f1']).requires_grad_(), dev(o['f2']).requires_grad_()
     cv = ops.corr(f1, f2, 8)
-    close(cv, cv_ref, rtol=1e-5, atol=2e-6)
-    cv.backward(dev(gout))
-    amax = max(1.0, f1c.grad.abs().max().item(), f2c.grad.abs().max().item())      # (as in test_corr_d8_full_pyramid)
-    close(f1.grad, f1c.grad, rtol=1e-4, atol=1e-5 * amax)
-    close(f2.grad, f2c.grad, rtol=1e-4, atol=1e-5 * amax)
+    close(cv, o['cv'], rtol=1e-5, atol=2e-6)
+    cv.backward(dev(o['gout']))
+    amax = max(1.0, o['gf1'].abs().max().item(), o['gf2'].abs().max().item())      # (as in test_corr_d8_full_pyramid)
+    close(f1.grad, o['gf1'], rtol=1e-4, atol=1e-5 * amax)
+    close(f2.grad, o['gf2'], rtol=1e-4, atol=1e-5 * amax)
 
 
 @pytest.mark.parametrize('B,C,h,w', [(16, 128, 8, 26), (16, 196, 4, 13), (3, 5, 7, 11), (1, 2, 30, 34), (2, 1, 3, 3), (4, 128, 14, 32)])
@@ -152,25 +147,23 @@ def test_corr_backward_on_the_matrix_cores(ops, d, B, C, h, w):
     Bars: north_star's 1e-4 relative (+ 1e-5 of the largest gradient: a sum of (2d+1)^2 signed products cancels); the kernel is
     measured at ~4e-6 of the largest gradient from the fp32 sums.  Deterministic: two launches agree bit for bit; 'fp32' mode
     restores the fp32 kernels' bits."""
-    f1c, f2c = rnd(61, (B, C, h, w)).requires_grad_(), rnd(62, (B, C, h, w)).requires_grad_()
-    cv_ref = R.corr_naive(f1c, f2c, d)
-    gout = rnd(63, tuple(cv_ref.shape), 0.05)
-    cv_ref.backward(gout)
-    amax = max(f1c.grad.abs().max().item(), f2c.grad.abs().max().item())
+    o = corr_case(d, B, C, h, w)          # (the case of test_corr_large_map_paths / test_corr_d8_large_map_paths where the shapes coincide: one oracle evaluation)
+    f1c, f2c, gout = o['f1'], o['f2'], o['gout']
+    amax = max(o['gf1'].abs().max().item(), o['gf2'].abs().max().item())
     lib = __import__('unopticalflow_amd._lib', fromlist=['load']).load()
     prev = ops.set_corr_backward('mfma')
     try:
         runs = []
         for _ in range(2):
-            f1, f2 = dev(f1c.detach()).requires_grad_(), dev(f2c.detach()).requires_grad_()
+            f1, f2 = dev(f1c).requires_grad_(), dev(f2c).requires_grad_()
             ops.corr(f1, f2, d).backward(dev(gout))
-            close(f1.grad, f1c.grad, rtol=1e-4, atol=1e-5 * amax, what='gf1')
-            close(f2.grad, f2c.grad, rtol=1e-4, atol=1e-5 * amax, what='gf2')
+            close(f1.grad, o['gf1'], rtol=1e-4, atol=1e-5 * amax, what='gf1')
+            close(f2.grad, o['gf2'], rtol=1e-4, atol=1e-5 * amax, what='gf2')
             runs.append((f1.grad.clone(), f2.grad.clone()))
         assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
         # the split keeps ~16 bits per factor: clearly away from the fp32 kernels' bits, clearly inside a tenth of the bar
         assert ops.set_corr_backward('fp32') == 'mfma'
-        f1, f2 = dev(f1c.detach()).requires_grad_(), dev(f2c.detach()).requires_grad_()
+        f1, f2 = dev(f1c).requires_grad_(), dev(f2c).requires_grad_()
         ops.corr(f1, f2, d).backward(dev(gout))
         err = max((f1.grad - runs[0][0]).abs().max().item(), (f2.grad - runs[0][1]).abs().max().item())
         assert 0 < err < 1e-5 * amax, (err, amax)
@@ -353,9 +346,14 @@ def test_warp_backward_fused_at_the_step_shapes(ops):
         close(fa, res[False][0][1], rtol=1e-4, atol=2e-5 * max(fa.abs().max().item(), 1e-6))
 
 
-@pytest.mark.parametrize('kind', ['smooth', 'mixed', 'edge', 'outside', 'noise'])
-@pytest.mark.parametrize('C,h,w', [(32, 64, 208), (64, 32, 104), (96, 16, 52), (128, 8, 26), (196, 4, 12), (5, 23, 72), (3, 70, 260)])
-def test_warp_corr_fused_vs_oracle(ops, kind, C, h, w):
+# all five flow kinds at level 2 and at a ragged shape; the two kinds with the most out-of-map taps at the others (the fused operator is an option
+# of the model, not its default: 20 cases x 2 conventions of the oracle's 81-shift chain instead of 35 x 2)
+_FUSED_CASES = [(C, h, w, kind) for (C, h, w) in ((32, 64, 208), (5, 23, 72)) for kind in ('smooth', 'mixed', 'edge', 'outside', 'noise')] + \
+               [(C, h, w, kind) for (C, h, w) in ((64, 32, 104), (96, 16, 52), (128, 8, 26), (196, 4, 12), (3, 70, 260)) for kind in ('mixed', 'outside')]
+
+
+@pytest.mark.parametrize('C,h,w,kind', _FUSED_CASES)
+def test_warp_corr_fused_vs_oracle(ops, C, h, w, kind):
     """Fused warp + cost volume (pwc_tf.py:121-122) at the pyramid-level shapes and ragged ones, forward and backward,
     against the oracle's  corr_naive(f1, warp_flow(f2, flow))  for both grid_sample generations."""
     B = 3

@@ -375,3 +375,109 @@ def test_matrix_core_backward_runs_on_the_host(tmp_path):
             np.testing.assert_allclose(got, ref.numpy(), rtol=1e-4, atol=1e-5 * float(ref.abs().max()),
                                        err_msg='%s, %s, R=%d [%d,%d,%d,%d] rows %d' % (name, 'corr_mfma2.h' if which else 'corr_mfma.h', R_, B, C, H, W, rows))
     assert pos == raw.size
+
+
+# (kind, d, B, C, H, W, align_corners, backward mode) -> the kernels the library's dispatch must reach for it (launch-site names, HIP_ON_HOST_TRACE)
+_COST_VOLUME_CASES = [
+    ((0, 4, 10, 16, 64, 208, 0, 0), ('corr_fwd_ring_kernel', 'corr_bwd_rs_mixed_kernel')),        # level-2 class: all 81 displacements per workgroup; 64x8 + 16x32 tiles
+    ((0, 4, 9, 6, 64, 256, 0, 0), ('corr_fwd_ring_kernel', 'corr_bwd_rs_kernel')),                # the same class without a remainder column; a channel group that is not full
+    ((0, 4, 5, 8, 32, 208, 0, 0), ('corr_fwd_ringp_kernel', 'corr_bwd_gs_kernel')),               # level-3 class: two channel phases; group-split ring backward
+    ((0, 4, 2, 16, 16, 260, 0, 0), ('corr_fwd_ringp_kernel', 'corr_bwd_rs_kernel')),              # level-4 class: four channel phases; row-streamed, 8 channels per item
+    ((0, 4, 2, 64, 8, 26, 0, 0), ('corr_fwd_split_kernel', 'corr_bwd_small_kernel')),             # levels 5 / 6: channel slices per wave; whole-map backward
+    ((0, 4, 2, 6, 9, 13, 0, 0), ('corr_fwd_generic', 'corr_bwd_small_kernel')),
+    ((0, 4, 5, 8, 64, 130, 0, 0), ('corr_fwd_kernel', 'corr_bwd_kernel')),                        # W % 4 != 0: the register-staged tile kernels
+    ((0, 4, 17, 4, 64, 130, 0, 0), ('corr_fwd_kernel', 'corr_bwd_kernel')),
+    ((0, 8, 3, 16, 32, 104, 0, 1), ('corr_fwd_ring_kernel', 'corr_bwd_rs_kernel')),               # d = 8, fp32 backward on request (the default there is corr_mfma.h: test above)
+    ((0, 8, 5, 8, 64, 130, 0, 0), ('corr_fwd_kernel', 'corr_bwd_kernel')),
+    ((0, 8, 1, 4, 6, 7, 0, 0), ('corr_fwd_generic', 'corr_bwd_generic')),
+    ((0, 1, 2, 5, 9, 37, 0, 0), ('corr_fwd_kernel', 'corr_bwd_kernel')),
+    ((0, 2, 2, 5, 9, 37, 0, 0), ('corr_fwd_kernel', 'corr_bwd_kernel')),
+    ((0, 3, 1, 4, 7, 9, 0, 0), ('corr_fwd_generic', 'corr_bwd_generic')),                         # a radius no tuned kernel exists for
+    ((1, 4, 10, 5, 64, 208, 0, 0), ('warp_corr_fwd_kernel',)),                                    # fused warp + cost volume, 81 displacements per workgroup
+    ((1, 4, 3, 24, 16, 52, 1, 0), ('warp_corr_fwd_kernel',)),                                     # ... three displacement rows per workgroup, align_corners
+    ((1, 4, 2, 5, 23, 72, 0, 0), ('warp_corr_fwd_kernel',)),
+]
+
+
+def test_cost_volume_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
+    """csrc/corr.hip and csrc/warp_corr.hip THEMSELVES -- the tile kernels, the LDS-DMA ring kernels with their hand-issued ds_read_b64 /
+    ds_write_b64 (plain loads and stores at the same 32-bit LDS addresses on the host), the group-split and row-streamed backward, the
+    whole-map backward, the per-element kernels, the fused warp + cost volume -- through the C entry points and the library's own dispatch by
+    shape: every case reaches the kernel family it is meant for (launch trace), holds the oracle's `corr_naive` (after `warp_flow`) forward and
+    backward at the GPU tests' bars, and runs clean under AddressSanitizer + UBSan (every global and LDS access of every lane inside its
+    buffer).  What the host cannot show: the counted waits (every copy has landed when its call returns)."""
+    import struct
+    clang = '/opt/rocm/lib/llvm/bin/clang++'
+    if not os.path.exists(clang):
+        import pytest
+        pytest.skip('needs clang (vector extensions, __bf16): no ROCm clang++ here')
+    csrc = os.path.join(ROOT, 'unopticalflow_amd', 'csrc')
+    sources = [os.path.join(csrc, 'corr.hip'), os.path.join(csrc, 'warp_corr.hip'), os.path.join(csrc, 'warp.hip'), os.path.join(ROOT, 'tests', 'host_check', 'corr_check.cpp')]
+    common = ['-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-Wno-unknown-attributes', '-Wno-unknown-pragmas', '-Wno-pass-failed',
+              '-I', os.path.join(ROOT, 'tests', 'host_check'), '-I', csrc]
+    san = ['-O1', '-g', '-fsanitize=address,undefined', '-fno-omit-frame-pointer', '-fno-sanitize-recover=undefined']
+    # both programs (plain -O2 and AddressSanitizer + UBSan, see _sanitized) at once, a compiler process per translation unit
+    jobs = []
+    for tag, flags in (('plain', ['-O2']), ('san', san)):
+        for src in sources:
+            obj = str(tmp_path / ('%s_%s.o' % (tag, os.path.basename(src))))
+            jobs.append((tag, obj, subprocess.Popen([clang, *flags, *common, '-x', 'c++', '-c', src, '-o', obj], stderr=subprocess.PIPE, text=True)))
+    for tag, obj, pr in jobs:
+        err = pr.communicate()[1]
+        assert pr.returncode == 0, err[-3000:]
+    exe, exe_san = str(tmp_path / 'corr_check'), str(tmp_path / 'corr_check_asan')
+    subprocess.run([clang, '-o', exe] + [o for t, o, _ in jobs if t == 'plain'], check=True)
+    subprocess.run([clang, '-fsanitize=address,undefined', '-o', exe_san] + [o for t, o, _ in jobs if t == 'san'], check=True)
+    rng = np.random.default_rng(5)
+    data = []
+    fin, fout = str(tmp_path / 'in.bin'), str(tmp_path / 'out.bin')
+    with open(fin, 'wb') as f:
+        f.write(struct.pack('i', len(_COST_VOLUME_CASES)))
+        for (kind, d, B, C, H, W, ac, mode), _ in _COST_VOLUME_CASES:
+            DD = 2 * d + 1
+            f1, f2 = (torch.from_numpy(rng.uniform(-1, 1, (B, C, H, W)).astype(np.float32)) for _ in range(2))
+            # flows that leave the map on every side, sit on pixel centres in places and are smooth elsewhere
+            flow = torch.from_numpy((rng.uniform(-1, 1, (B, 2, 1, 1)) * 0.6 * max(H, W) * rng.uniform(0, 1, (B, 1, H, 1)) + rng.uniform(-2, 2, (B, 2, H, W))).astype(np.float32))
+            flow[:, :, ::3, ::5] = torch.round(flow[:, :, ::3, ::5])
+            g = torch.from_numpy((0.05 * rng.standard_normal((B, DD * DD, H, W))).astype(np.float32))
+            data.append((f1, f2, flow, g))
+            f.write(struct.pack('8i', kind, d, B, C, H, W, ac, mode))
+            for t in ((f1, f2, flow, g) if kind else (f1, f2, g)):
+                f.write(t.numpy().tobytes())
+    sanitized = subprocess.Popen([exe_san, fin, str(tmp_path / 'san.bin')], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                 env=dict(os.environ, ASAN_OPTIONS='detect_stack_use_after_return=0:detect_leaks=0'))       # (the lanes' stacks are heap blocks switched by hand)
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=3000, env=dict(os.environ, HIP_ON_HOST_TRACE='1'))
+    assert r.returncode == 0 and 'OK' in r.stdout, (r.stdout[-2000:], r.stderr[-500:])
+    launches = [l.split()[1] for l in r.stderr.splitlines() if l.startswith('launch ')]
+    so, se = sanitized.communicate(timeout=3000)
+    assert sanitized.returncode == 0 and 'OK' in so and 'ERROR' not in se and 'runtime error' not in se, (so[-1500:], se[-3000:])
+    assert open(fout, 'rb').read() == open(str(tmp_path / 'san.bin'), 'rb').read()              # -O1 and -O2, with and without instrumentation: the same bytes
+    raw = np.fromfile(fout, dtype=np.float32)
+    pos = 0
+    at = 0
+    for ((kind, d, B, C, H, W, ac, mode), want), (f1, f2, flow, g) in zip(_COST_VOLUME_CASES, data):
+        what = 'kind %d d=%d [%d,%d,%d,%d] ac %d' % (kind, d, B, C, H, W, ac)
+        # the case's launches: from its first forward kernel to the next case's
+        nxt = at + 1
+        while nxt < len(launches) and not any(launches[nxt].lstrip('(').startswith(p) for p in ('corr_fwd', 'warp_corr_fwd')):
+            nxt += 1
+        mine, at = launches[at:nxt], nxt
+        for k in want:
+            assert any(m.lstrip('(').startswith(k) for m in mine), (what, k, mine)
+        a, b, fl = f1.clone().requires_grad_(), f2.clone().requires_grad_(), flow.clone().requires_grad_()
+        ref = R.corr_naive(a, R.warp_flow(b, fl, False, bool(ac)) if kind else b, d)
+        ref.backward(g)
+        DD = 2 * d + 1
+        n, ng, nf = B * C * H * W, B * DD * DD * H * W, B * 2 * H * W
+        amax = max(float(a.grad.abs().max()), float(b.grad.abs().max()), 1e-6)
+        np.testing.assert_allclose(raw[pos:pos + ng].reshape(ref.shape), ref.detach().numpy(), rtol=1e-5, atol=2e-6, err_msg='cv ' + what)
+        pos += ng
+        np.testing.assert_allclose(raw[pos:pos + n].reshape(a.shape), a.grad.numpy(), rtol=1e-4, atol=max(5e-6, 2e-6 * amax), err_msg='gf1 ' + what)
+        pos += n
+        np.testing.assert_allclose(raw[pos:pos + n].reshape(a.shape), b.grad.numpy(), rtol=1e-4, atol=max(2e-5, 2e-6 * amax), err_msg='gf2 ' + what)
+        pos += n
+        if kind:
+            scale = max(float(fl.grad.abs().max()), 1e-6)
+            np.testing.assert_allclose(raw[pos:pos + nf].reshape(fl.shape), fl.grad.numpy(), rtol=1e-4, atol=2e-5 * scale, err_msg='gflow ' + what)
+            pos += nf
+    assert pos == raw.size and at == len(launches)

@@ -12,6 +12,7 @@ import torch
 from oracle import ref_cpu as R
 from test_hip_ops import T, close, dev, ops, rnd, _structured_flow      # noqa: F401  (``ops`` is the module-scoped fixture)
 from test_hip_ops import test_corr_backward_on_the_matrix_cores as _matrix_core_backward_case
+from oracle_cache import corr_case
 
 # strict=False: a pass is reported as XPASS, a failure as xfailed -- either way the first run on a GPU tells what holds without stopping a
 # ``-x`` run of the validated suite; the marker goes once they have run (a failure here says the TEST's bar or set-up needs a second look
@@ -358,19 +359,17 @@ def test_corr_backward_pixel_pair_form(ops, request, d, B, C, h, w):
     host, never on a GPU) against the oracle at the matrix-core test's bar, in a process of its own."""
     if _ran_in_a_child(request):
         return
-    f1c, f2c = rnd(61, (B, C, h, w)).requires_grad_(), rnd(62, (B, C, h, w)).requires_grad_()
-    cv_ref = R.corr_naive(f1c, f2c, d)
-    gout = rnd(63, tuple(cv_ref.shape), 0.05)
-    cv_ref.backward(gout)
-    amax = max(f1c.grad.abs().max().item(), f2c.grad.abs().max().item())
+    o = corr_case(d, B, C, h, w)          # (the oracle's answer for this case is on file from test_hip_ops.py's tests: tests/oracle_cache.py)
+    f1c, f2c, gout = o['f1'], o['f2'], o['gout']
+    amax = max(o['gf1'].abs().max().item(), o['gf2'].abs().max().item())
     prev = ops.set_corr_backward('mfma2')
     try:
         runs = []
         for _ in range(2):
-            f1, f2 = dev(f1c.detach()).requires_grad_(), dev(f2c.detach()).requires_grad_()
+            f1, f2 = dev(f1c).requires_grad_(), dev(f2c).requires_grad_()
             ops.corr(f1, f2, d).backward(dev(gout))
-            close(f1.grad, f1c.grad, rtol=1e-4, atol=1e-5 * amax, what='gf1')
-            close(f2.grad, f2c.grad, rtol=1e-4, atol=1e-5 * amax, what='gf2')
+            close(f1.grad, o['gf1'], rtol=1e-4, atol=1e-5 * amax, what='gf1')
+            close(f2.grad, o['gf2'], rtol=1e-4, atol=1e-5 * amax, what='gf2')
             runs.append((f1.grad.clone(), f2.grad.clone()))
         assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])          # deterministic
     finally:

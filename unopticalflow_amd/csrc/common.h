@@ -18,6 +18,18 @@
 #define UNFLOW_DYNAMIC_LDS(T, name) extern __shared__ T name[]
 #endif
 
+// hipcc idioms that mean nothing on the build host: keep a value in a vector / scalar register where it is (an empty asm the
+// optimiser cannot see through), drain this wave's LDS / scalar-memory counter
+#ifdef UNFLOW_HOST_CHECK
+#define UNFLOW_PIN_VGPR(x) ((void)(x))
+#define UNFLOW_PIN_SGPR(x) ((void)(x))
+#define UNFLOW_WAIT_LGKMCNT0()
+#else
+#define UNFLOW_PIN_VGPR(x) asm volatile("" : "+v"(x))
+#define UNFLOW_PIN_SGPR(x) asm volatile("" : "+s"(x))
+#define UNFLOW_WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+
 #define UNFLOW_REQUIRE(cond) do { if (!(cond)) return UNFLOW_EINVAL; } while (0)
 
 static inline int unflow_launch_status() { return (int)hipGetLastError(); }

@@ -114,7 +114,7 @@ struct RowReader {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             lds_cfloat* p = (lds_cfloat*)(first + (PX == 2 ? 2 * k : k));   // generic -> LDS address space
-            asm volatile("" : "+v"(p));
+            UNFLOW_PIN_VGPR(p);
             col[k] = p;
         }
     }
@@ -371,7 +371,7 @@ struct FwdSlots {
             else { r -= K::S2P; const int ly = r / TW4; gy = y0 + ly; gx = x0 + (r - ly * TW4) * 4; }
             const bool in = real & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
             off[it] = in ? ((unsigned)c * plane + (unsigned)(gy * W + gx)) * 4u : kOutOfRange;
-            asm volatile("" : "+v"(off[it]));       // materialise once; do not re-derive in the loop
+            UNFLOW_PIN_VGPR(off[it]);       // materialise once; do not re-derive in the loop
             from_f2[it] = ((it * 256 + wave * 64) % K::SC) < K::S2P;
         }
     }
@@ -613,7 +613,7 @@ __global__ __launch_bounds__((RingPCfg<R, CC, DG, PH>::THREADS)) void corr_fwd_r
         Step0::template run<CC>(acc, row, a, rows_addr + sb);
     }
     vm_wait<0>();                                            // the all-zero tail stages: no LDS-DMA in flight beyond here
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    UNFLOW_WAIT_LGKMCNT0();
     __syncthreads();
 
     // partial cost volumes of phases 1 .. PH-1 -> phase 0, one phase at a time through the idle rings
@@ -692,7 +692,11 @@ __device__ __forceinline__ void slab_read(v2f (&q)[N], unsigned addr, std::integ
 }
 template <int OFF>
 __device__ __forceinline__ void lds_write_b64(unsigned addr, v2f v) {
+#ifdef UNFLOW_HOST_CHECK
+    memcpy(hip_on_host::lds_at(addr + OFF, 8), &v, 8);
+#else
     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+#endif
 }
 template <int GL, int CC, int... Cs>
 __device__ __forceinline__ void slab_write(unsigned addr, const v2f (&v)[CC], std::integer_sequence<int, Cs...>) {
@@ -727,9 +731,9 @@ struct GsWeights {
 #pragma unroll
         for (int ii = 0; ii < 3; ++ii) {
 #pragma unroll
-            for (int k = 0; k < R; ++k) { asm volatile("" : "+v"(p0[ii][k])); asm volatile("" : "+v"(p1[ii][k])); }
-            asm volatile("" : "+v"(s0[ii]));
-            asm volatile("" : "+v"(s1[ii]));
+            for (int k = 0; k < R; ++k) { UNFLOW_PIN_VGPR(p0[ii][k]); UNFLOW_PIN_VGPR(p1[ii][k]); }
+            UNFLOW_PIN_VGPR(s0[ii]);
+            UNFLOW_PIN_VGPR(s1[ii]);
         }
     }
 };
@@ -835,7 +839,7 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC, TYB>::THREADS)) void corr_bwd_gs_k
         const int gy = y0 - R + ly, gx = x0 - R + (r - ly * (LW / 4)) * 4;
         const bool in = (c < CC) && gy >= 0 && gy < H && gx >= 0 && gx < W;
         slotB[it] = in ? ((unsigned)c * (unsigned)plane + (unsigned)(gy * W + gx)) * 4u : kOut;
-        asm volatile("" : "+v"(slotB[it]));      // materialise once; do not re-derive in the loop
+        UNFLOW_PIN_VGPR(slotB[it]);      // materialise once; do not re-derive in the loop
     }
     auto issue = [&](int stage_idx) {
         float* dst = ring + (stage_idx % K::NS) * K::STAGE;
@@ -963,7 +967,7 @@ __global__ __launch_bounds__((BwdGsCfg<R, CC, TYB>::THREADS)) void corr_bwd_gs_k
                 pv[c].y = acc[c][1].x + acc[c][1].y;
             }
             slab_write<GL, CC>(wa, pv, std::make_integer_sequence<int, CC>{});
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slab written before the next barrier
+            UNFLOW_WAIT_LGKMCNT0();      // slab written before the next barrier
         }
         STAMP(4);
     }
@@ -1160,7 +1164,7 @@ __device__ __forceinline__ void corr_bwd_rs_body(float* __restrict__ tile, int t
     for (int k = 0; k < AHEAD; ++k) request_row(raw[k], min(k, DD - 1));
 
     // this wave's pieces of the tile have landed (the weights may still fly)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * DD > 63 ? 63 : AHEAD * DD) : "memory");
+    vm_wait<(AHEAD * DD > 63 ? 63 : AHEAD * DD)>();
     __builtin_amdgcn_s_barrier();                    // ... and everyone else's.  The waves do not meet again.
 
     v2f acc[CH][2];
@@ -1270,7 +1274,7 @@ __global__ __launch_bounds__(256, 3) void corr_bwd_small_kernel(const float* __r
                                                              float* __restrict__ gf2, int C, int H, int W, int pxl,
                                                              int cch, float inv_c) {
     constexpr int DD = 2 * R + 1;
-    extern __shared__ float planes[];                  // cch x (H+2R) x (W+2R), zero padded
+    UNFLOW_DYNAMIC_LDS(float, planes);                 // cch x (H+2R) x (W+2R), zero padded
     const int mode = blockIdx.z & 1, b = blockIdx.z >> 1;
     const float* __restrict__ F = mode ? f1 : f2;
     float* __restrict__ out = mode ? gf2 : gf1;

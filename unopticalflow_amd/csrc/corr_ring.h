@@ -7,6 +7,23 @@
 
 namespace {
 
+#ifdef UNFLOW_HOST_CHECK
+// On the build host (tests/host_check/: lanes as fibers) LDS is ordinary static memory: the address-space typedefs are plain pointers, a
+// 32-bit "LDS address" is the low half of the host address (hip_on_host::lds_at() finds the object again), the hand-issued reads and
+// writes are plain loads and stores, and the counted waits mean nothing -- every load has landed when its call returns.
+typedef const float lds_cfloat;
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef const v2f lds_cfloat2;
+typedef const float gfloat;
+typedef const void* gas_ptr;
+typedef void* lds_ptr;
+inline __attribute__((aligned(16))) float kZeroLine[4] = {0.f, 0.f, 0.f, 0.f};
+static inline gfloat* zero_line() { return kZeroLine; }
+template <int OFF>
+static inline v2f lds_read_b64(unsigned addr) { v2f v; memcpy(&v, hip_on_host::lds_at(addr + OFF, 8), 8); return v; }
+template <int N> static inline void lds_wait() {}
+template <int N> static inline void vm_wait() {}
+#else
 typedef __attribute__((address_space(3))) const float lds_cfloat;
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const v2f lds_cfloat2;
@@ -20,7 +37,7 @@ __device__ __attribute__((aligned(16))) float kZeroLine[4] = {0.f, 0.f, 0.f, 0.f
 typedef __attribute__((address_space(1))) const float gfloat;       // explicit global address space: a laundered generic
 __device__ __forceinline__ gfloat* zero_line() {                     // pointer would turn every load behind it into flat_load
     gfloat* z = (gfloat*)kZeroLine;
-    asm volatile("" : "+s"(z));
+    UNFLOW_PIN_SGPR(z);
     return z;
 }
 
@@ -45,6 +62,8 @@ __device__ __forceinline__ void lds_wait() {
 
 template <int N>
 __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+#endif
 
 // the lane's own f1 pixels of the stage's CC channels (channel stride CH_BYTES)
 template <int CH_BYTES, int CC, int... Cs>

@@ -25,11 +25,22 @@ namespace {
 template <int OFF0, int OFF1>
 __device__ __forceinline__ v2f lds_read2_b32(unsigned addr) {
     v2f v;
+#ifdef UNFLOW_HOST_CHECK            // (tests/host_check/: the two dwords at addr + 4 OFF0 and addr + 4 OFF1, plain loads)
+    float lo, hi;
+    memcpy(&lo, hip_on_host::lds_at(addr + 4 * OFF0, 4), 4);
+    memcpy(&hi, hip_on_host::lds_at(addr + 4 * OFF1, 4), 4);
+    v = v2f{lo, hi};
+#else
     asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(OFF0), "n"(OFF1));
+#endif
     return v;
 }
 __device__ __forceinline__ void lds_write_b32(unsigned addr, float v) {
+#ifdef UNFLOW_HOST_CHECK
+    memcpy(hip_on_host::lds_at(addr, 4), &v, 4);
+#else
     asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+#endif
 }
 
 __device__ __forceinline__ int wave_min_i32(int v) {
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(256, (FusedCfg<R, CC, DG, NS, SWX, SWH>::WAVES)) vo
         else { r -= K::S2; const int ly = r / (K::TW / 4); gy = y0t + ly; gx = x0t + (r - ly * (K::TW / 4)) * 4; }
         const bool in = (c < CC) && gy >= 0 && gy < H && gx >= 0 && gx < W && (!win || (fits && !empty));
         soff[it] = in ? gy * W + gx : -1;
-        asm volatile("" : "+v"(soff[it]));                   // materialise once; the channel / source are re-derived per stage
+        UNFLOW_PIN_VGPR(soff[it]);                   // materialise once; the channel / source are re-derived per stage
     }
     const float* base1 = f1 + (size_t)b * C * plane;
     const float* base2 = f2 + (size_t)b * C * plane;
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(256, (FusedCfg<R, CC, DG, NS, SWX, SWH>::WAVES)) vo
                 }
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's part of the warped tile is written ...
+        UNFLOW_WAIT_LGKMCNT0();   // this wave's part of the warped tile is written ...
         __builtin_amdgcn_s_barrier();                        // ... and everyone else's
 
         // ---- cost-volume stage: CC*DG row-steps as one software pipeline over the warped tile

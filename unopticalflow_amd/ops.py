@@ -1310,7 +1310,7 @@ def _bias_leaky_backward(ctx, ga, gb):
 def _bias_leaky_forward(ctx, y, bias, slope):
     half = y.dtype == torch.bfloat16                  # bf16 conv-stack option: bf16 activation, fp32 bias
     _dev(None if half else y, bias)
-    if half and (not y.is_cuda or y.device != bias.device):
+    if half and (not on_device(y) or y.device != bias.device):
         raise RuntimeError('bias_leaky_relu_: activation and bias must be on the same HIP device')
     N, C, H, W = y.shape
     nhwc = _is_nhwc(y)
