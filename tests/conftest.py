@@ -39,7 +39,7 @@ if os.environ.get('UNFLOW_TESTS_ON_HOST') == '1':
     # runs the GPU tests' own code on CPU tensors over the host-executed build of the kernel sources (tests/hostexec.py) -- `.cuda()` and
     # `.to('cuda')` keep the tensor where it is, every test body sits inside hostexec.patched(ops).  It finds mistakes in TEST code (shapes,
     # expectations, argument order) before a GPU session pays for them, and re-checks the kernels' arithmetic; what only a device has --
-    # MIOpen's convolutions, launch counts under the kernel timer's events, the fast fp32 cost-volume kernels, hipGraphs, Adam -- it
+    # MIOpen's convolutions (torch's CPU convolutions stand in), the kernel timer's events, hipGraphs, a second process's GPU -- it
     # cannot answer, and tests that need those fail here by design.  Nothing in the default runs (`-m "not gpu"`, `-m gpu`) sees any of this.
     import torch
 

@@ -3,8 +3,8 @@
 ``with hostexec.patched(ops):`` points the binding at tests/host_check/_build/libunflow_hostexec.so (tests/host_check/build_hostexec.py: the
 kernel source files of csrc/ compiled for the build host, lanes as fibers) and lets the autograd wrappers take CPU tensors: the product's
 Python and the REAL kernel sources, end to end, without a GPU.  Outside the block everything is as it was -- the product has no CPU path
-and never learns of this library (tests/test_abi.py::test_no_cpu_fallback still holds).  Entry points the host library does not have
-(the fast fp32 cost-volume kernels' siblings, the fused warp + cost volume, bf16 epilogues, Adam) raise AttributeError when called."""
+and never learns of this library (tests/test_abi.py::test_no_cpu_fallback still holds).  The host library holds every kernel file of csrc/
+(the fp32 cost-volume kernels with their LDS-DMA rings, the fused warp + cost volume, bf16 epilogues and Adam included)."""
 import contextlib
 import ctypes
 import os
