@@ -14,6 +14,20 @@ from oracle import ref_cpu as R
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+_san_builds = {}
+
+
+def _sanitized_build_started(build_cmd, tmp_path, name, always=True):
+    """Start the sanitized build of a check program NOW, next to the plain one's build and run (_sanitized() then waits for it)."""
+    if not always and os.environ.get('UNFLOW_HOST_CHECK_SANITIZE') != 'all':
+        return
+    exe = str(tmp_path / (name + '_asan'))
+    cmd = [a for a in build_cmd if a not in ('-O2',)]
+    cmd = cmd[:1] + ['-O1', '-g', '-fsanitize=address,undefined', '-fno-omit-frame-pointer', '-fno-sanitize-recover=undefined'] + [a for a in cmd[1:] if a != '-O1']
+    cmd[cmd.index('-o') + 1] = exe
+    _san_builds[exe] = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
 def _sanitized(build_cmd, run_args, tmp_path, name, always=True):
     """The same program once more under AddressSanitizer + UndefinedBehaviorSanitizer (the CPU build is where sanitizers run: no GPU ASan on
     this pool): every global-memory access of the executed kernels lands inside the buffers it was given (they are exactly-sized heap
@@ -22,11 +36,11 @@ def _sanitized(build_cmd, run_args, tmp_path, name, always=True):
     if not always and os.environ.get('UNFLOW_HOST_CHECK_SANITIZE') != 'all':
         return
     exe = str(tmp_path / (name + '_asan'))
-    cmd = [a for a in build_cmd if a not in ('-O2',)]
-    cmd = cmd[:1] + ['-O1', '-g', '-fsanitize=address,undefined', '-fno-omit-frame-pointer', '-fno-sanitize-recover=undefined'] + [a for a in cmd[1:] if a != '-O1']
-    cmd[cmd.index('-o') + 1] = exe
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-3000:]
+    if exe not in _san_builds:
+        _sanitized_build_started(build_cmd, tmp_path, name)
+    pr = _san_builds.pop(exe)
+    err = pr.communicate()[1]
+    assert pr.returncode == 0, err[-3000:]
     env = dict(os.environ, ASAN_OPTIONS='detect_stack_use_after_return=0:detect_leaks=0')      # (the lanes' stacks are heap blocks switched by hand)
     r = subprocess.run([exe] + list(run_args), capture_output=True, text=True, timeout=3000, env=env)
     assert r.returncode == 0 and 'ERROR' not in r.stderr and 'runtime error' not in r.stderr, (r.stdout[-1500:], r.stderr[-3000:])
@@ -42,6 +56,7 @@ def test_flat_ms_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
     exe, out = str(tmp_path / 'ms_flat_check'), str(tmp_path / 'out.bin')
     build = ['g++', '-O1', '-std=c++17', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'),
                         os.path.join(ROOT, 'tests', 'host_check', 'ms_flat_check.cpp'), '-o', exe]
+    _sanitized_build_started(build, tmp_path, 'ms_flat_check')
     r = subprocess.run(build, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe, out], capture_output=True, text=True, timeout=300)
@@ -144,6 +159,7 @@ def test_loss_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
     exe, out = str(tmp_path / 'photo_check'), str(tmp_path / 'out.bin')
     build = ['g++', '-O1', '-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-I', os.path.join(ROOT, 'tests', 'host_check'),
                         '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'), os.path.join(ROOT, 'tests', 'host_check', 'photo_check.cpp'), '-o', exe]
+    _sanitized_build_started(build, tmp_path, 'photo_check')
     r = subprocess.run(build, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe, out], capture_output=True, text=True, timeout=600)
@@ -212,6 +228,7 @@ def test_ssim_kernels_run_on_the_host_on_flat_patches(tmp_path):
     build = [clang, '-O1', '-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-Wno-unknown-attributes', '-Wno-unknown-pragmas', '-Wno-pass-failed',
                         '-I', os.path.join(ROOT, 'tests', 'host_check'), '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'),
                         os.path.join(ROOT, 'tests', 'host_check', 'ssim_check.cpp'), '-o', exe]
+    _sanitized_build_started(build, tmp_path, 'ssim_check')
     r = subprocess.run(build, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe, out], capture_output=True, text=True, timeout=900)
@@ -343,6 +360,7 @@ def test_matrix_core_backward_runs_on_the_host(tmp_path):
     build = [clang, '-O2', '-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-Wno-unknown-attributes', '-Wno-unknown-pragmas', '-Wno-pass-failed',
                         '-I', os.path.join(ROOT, 'tests', 'host_check'), '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'),
                         os.path.join(ROOT, 'tests', 'host_check', 'mfma_check.cpp'), '-o', exe]
+    _sanitized_build_started(build, tmp_path, 'mfma_check')
     r = subprocess.run(build, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     rng = np.random.default_rng(3)

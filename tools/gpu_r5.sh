@@ -18,7 +18,7 @@
 #   multiscale   one launch per loss / image warp over the scales (ABI 11): its bit-identity tests, then bench --multiscale-losses 0 / 1
 #   fused_levels bench --fused-levels 4 / 3,4: the fused warp + cost-volume kernel at chosen decoder levels only
 #   reopen       what to run FIRST when the lease comes back, most valuable first, so that a cut-off call still leaves the important half:
-#                suite, multiscale, mfma_harness, headline, ranks8, profile_fp32, traffic, loss_pending, fused_levels, configs, profile_bf16, corr8, capi
+#                suite, multiscale, mfma_harness, headline, instep_ab (incl. the never-run --corr-bwd mfma2), ranks8, profile_fp32, traffic, loss_pending, fused_levels, configs, profile_bf16, corr8, capi
 #   final        everything that gets recorded for one source state: suite, headline, configs, ranks8, profile_fp32, profile_bf16, traffic, corr8, capi
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/r5
@@ -140,7 +140,7 @@ PY
       python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline $a > $out/ab_fused_levels_$lv.json 2>> $out/ab.err
     done
     line $out/ab_fused_levels_*.json ;;
-  reopen) bash tools/gpu_r5.sh suite multiscale mfma_harness headline ranks8 profile_fp32 traffic loss_pending fused_levels configs profile_bf16 corr8 capi ;;
+  reopen) bash tools/gpu_r5.sh suite multiscale mfma_harness headline instep_ab ranks8 profile_fp32 traffic loss_pending fused_levels configs profile_bf16 corr8 capi ;;
   final) bash tools/gpu_r5.sh suite headline configs ranks8 profile_fp32 profile_bf16 traffic corr8 capi ;;
   *) echo "unknown recipe $r" ;;
 esac
