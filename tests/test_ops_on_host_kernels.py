@@ -42,8 +42,15 @@ def test_multiscale_losses_are_the_same_bits_and_the_oracles_values(ops):
         warped0[s][:B, :, 1:5, 2:9] = 0.0
     flows0 = [rnd(80 + s, (2 * B, 2, hs[s], ws[s]), 3.0 / (1 << s)) for s in range(n)]
     gl = [rnd(90 + k, (B,)) for k in range(4)]
-    res = {}
-    with hostexec.patched(ops):
+    res, moved, launches = {}, {}, {}
+    call = ops._call
+
+    def counting(name, *a, nbytes=0, shape=None):                  # the algorithmic bytes an entry declares (bench.py's roofline.losses sums them)
+        moved[form] = moved.get(form, 0) + nbytes
+        launches[form] = launches.get(form, 0) + 1
+        return call(name, *a, nbytes=nbytes, shape=shape)
+    with hostexec.patched(ops), pytest.MonkeyPatch.context() as mp:
+        mp.setattr(ops, '_call', counting)
         for form in ('per scale', 'one launch', 'one launch, halves by offset', 'one launch, sums at once'):
             wp = [t.clone().requires_grad_() for t in warped0]
             fl = [t.clone().requires_grad_() for t in flows0]
@@ -66,6 +73,9 @@ def test_multiscale_losses_are_the_same_bits_and_the_oracles_values(ops):
     for form in list(res)[1:]:
         for k, (a, b) in enumerate(zip(res['per scale'], res[form])):
             assert torch.equal(a, b), (form, k, float((a - b).abs().max()))
+        # one launch over the scales declares the bytes of the launches it replaces: the loss section's roofline fraction moves with its TIME only
+        assert moved[form] == moved['per scale'], (form, moved)
+    assert launches['one launch'] < launches['per scale'] and launches['one launch'] <= 14, launches
     # ... and the oracle (model_flow_paper.py:224-235 on the stacked operands)
     wp = [t.clone().requires_grad_() for t in warped0]
     fl = [t.clone().requires_grad_() for t in flows0]
@@ -244,12 +254,19 @@ def test_model_scale_masks_bit_exact_on_host_kernels(golden, ops, fixture, scale
     with hostexec.patched(ops):
         for ac in acs:
             tag = '_ac%d' % ac
+            per_scale = {}
             for s in scales:
                 for nm in ('fwd', 'bwd'):
                     fl = T(g['flowfull_%s%d%s' % (nm, s, tag)])
                     ones = torch.ones((fl.shape[0], 1) + tuple(fl.shape[2:]))
                     out, m = ops.warp_flow_masked(ones, fl, align_corners=bool(ac))
+                    per_scale[nm, s] = (ones, fl, out)
                     ref_bits = np.unpackbits(g['mask_%s%d%s' % (nm, s, tag)])[: m.numel()].reshape(m.shape)
                     assert np.array_equal(m.numpy(), ref_bits), (fixture, nm, s, ac, int((m.numpy() != ref_bits).sum()))
                     o = out.numpy()
                     assert np.array_equal(o != 0, ref_bits != 0) and (o[ref_bits != 0] >= 0.9999).all()
+            # ... and as ONE launch over the scales (ops.warp_flow_masked_pyramid, the `_ms` warp kernel): the same bytes
+            for nm in ('fwd', 'bwd'):
+                outs = ops.warp_flow_masked_pyramid([per_scale[nm, s][0] for s in scales], [per_scale[nm, s][1] for s in scales], align_corners=bool(ac))
+                for s, o in zip(scales, outs):
+                    assert torch.equal(o, per_scale[nm, s][2]), (fixture, nm, s, ac)
