@@ -63,6 +63,7 @@ if os.environ.get('UNFLOW_TESTS_ON_HOST') == '1':
         setattr(torch, _name, _on_host)
     torch.cuda.is_available = lambda: True
     torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.is_current_stream_capturing = lambda: False
     torch.nn.Module.cuda = lambda self, *a, **k: self
 
     @pytest.fixture(autouse=True)

@@ -270,3 +270,23 @@ def test_model_scale_masks_bit_exact_on_host_kernels(golden, ops, fixture, scale
                 outs = ops.warp_flow_masked_pyramid([per_scale[nm, s][0] for s in scales], [per_scale[nm, s][1] for s in scales], align_corners=bool(ac))
                 for s, o in zip(scales, outs):
                     assert torch.equal(o, per_scale[nm, s][2]), (fixture, nm, s, ac)
+
+
+def test_gpu_op_tests_rehearsed_on_host_kernels():
+    """The `-m gpu` operator tests' OWN code on the CPU tier: the node ids of tests/rehearsed_on_host.txt (110 of tests/test_hip_ops.py and
+    tests/test_zz_round5_gpu.py: the reference's golden fixtures for cost volume, warp and losses, masks bit for bit, the oracle comparisons of
+    every operator family at small shapes, bf16 epilogues, the round-5 tests that have never seen a GPU) run in a child pytest with
+    UNFLOW_TESTS_ON_HOST=1 (tests/conftest.py): CPU tensors, the product's ops.py, the REAL kernel sources executed on the host -- same
+    inputs, same bars.  A GPU test that rots (a renamed argument, a changed shape) or a kernel-source change that breaks parity fails HERE,
+    not in the next GPU session."""
+    import os
+    import subprocess
+    import sys
+    if hostexec.library() is None:
+        pytest.skip('the host-executed library needs the ROCm clang++')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ids = [l.strip() for l in open(os.path.join(root, 'tests', 'rehearsed_on_host.txt')) if l.strip() and not l.startswith('#')]
+    assert len(ids) >= 100
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-m', 'gpu', '--runxfail', '-p', 'no:cacheprovider', '-p', 'no:xdist'] + ids, cwd=root,
+                       env=dict(os.environ, UNFLOW_TESTS_ON_HOST='1'), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and ('%d passed' % len(ids)) in r.stdout, r.stdout[-4000:]
