@@ -16,7 +16,7 @@ CSRC = os.path.join(ROOT, 'unopticalflow_amd', 'csrc')
 OUT = os.environ.get('UNFLOW_HOSTEXEC_DIR') or os.path.join(HERE, '_build')
 LIB = os.path.join(OUT, 'libunflow_hostexec.so')
 CLANG = '/opt/rocm/lib/llvm/bin/clang++'
-FLAGS = ['-O2', '-std=c++20', '-fPIC', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-Wno-unknown-attributes', '-Wno-unknown-pragmas', '-Wno-pass-failed',
+FLAGS = (os.environ.get('UNFLOW_HOSTEXEC_FLAGS', '-O2').split()) + ['-std=c++20', '-fPIC', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-Wno-unknown-attributes', '-Wno-unknown-pragmas', '-Wno-pass-failed',
          '-I', HERE, '-I', CSRC]
 SOURCES = [os.path.join(CSRC, f) for f in ('photo.hip', 'ssim.hip', 'warp.hip', 'corr.hip', 'warp_corr.hip', 'elementwise.hip', 'elementwise_bf16.hip', 'prepare.hip', 'optim.hip')]
 
@@ -45,7 +45,7 @@ def build(verbose=False):
         err = p.communicate()[1]
         if p.returncode != 0:
             raise RuntimeError('%s:\n%s' % (src, err[-3000:]))
-    subprocess.run([CLANG, '-shared', '-o', LIB] + objs, check=True)
+    subprocess.run([CLANG, '-shared', '-o', LIB] + [f for f in FLAGS if f.startswith('-fsanitize')] + objs, check=True)
     return LIB
 
 

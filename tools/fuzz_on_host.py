@@ -1,7 +1,7 @@
 """Randomised shapes through the operators that have not run on a GPU yet, on the build host -- TEST INFRASTRUCTURE (oracle + host-executed
 kernel library: tests/hostexec.py; nothing of the product imports this).
 
-    python tools/fuzz_on_host.py [--minutes M] [--seed S] [--what ms,warp,mfma2,corr]
+    python tools/fuzz_on_host.py [--minutes M] [--seed S] [--what ms,warp,mfma2,corr,fused]
 
 For M minutes draws shapes and checks, over the product's own autograd wrappers (ops.py) and the REAL kernel sources executed with lanes as
 fibers:
@@ -11,6 +11,12 @@ fibers:
   mfma2  the pixel-pair matrix-core cost-volume backward (ops.set_corr_backward('mfma2'), never run on a GPU) against the oracle's autograd of
          corr_naive at the GPU test's bar, at shapes the dispatch serves (W % 4 == 0, C % 16 == 0, >= 8192 pixels, H >= 4 d), d = 4 and 8
   corr   the fp32 cost volume through its dispatch at random shapes (any W, C), d in {1, 2, 4, 8}, against the oracle at the GPU tests' bars
+  fused  ops.warp_corr (the fused warp + cost volume, W % 4 == 0) against corr_naive(f1, warp_flow(f2, flow)) forward and backward, five flow kinds
+Under AddressSanitizer + UBSan (every global and LDS access of every lane, random shapes): build the host library instrumented into a directory
+of its own and preload the runtime --
+    export UNFLOW_HOSTEXEC_DIR=/tmp/hxasan UNFLOW_HOSTEXEC_FLAGS="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined -shared-libsan"
+    LD_PRELOAD=$(/opt/rocm/lib/llvm/bin/clang++ -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 \
+        python tools/fuzz_on_host.py --minutes 30
 Prints one line per failure (with the draw that reproduces it) and a summary; exit code = number of failures (capped at 100)."""
 import argparse
 import contextlib
@@ -158,13 +164,40 @@ def fuzz_corr(rng):
                                       lambda amax: max(5e-6, (1e-5 if d == 8 else 1e-6) * max(amax, 1.0 if d == 8 else 0.0)))
 
 
+def fuzz_fused(rng):
+    C = int(rng.integers(1, 40))
+    big = rng.random() < 0.3
+    h, w = (int(rng.integers(40, 70)), 4 * int(rng.integers(24, 60))) if big else (int(rng.integers(1, 30)), 4 * int(rng.integers(2, 24)))
+    B = max(1, int(rng.integers(100000, 140000)) // (h * w)) if big and rng.random() < 0.5 else int(rng.integers(1, 4))
+    ac = bool(rng.integers(0, 2))
+    kind = ('smooth', 'mixed', 'edge', 'outside', 'noise')[int(rng.integers(0, 5))]
+    draw = 'fused [%d,%d,%d,%d] ac=%d %s' % (B, C, h, w, ac, kind)
+    f1c, f2c = tensor(rng, (B, C, h, w)).requires_grad_(), tensor(rng, (B, C, h, w)).requires_grad_()
+    fc = flow_of(rng, B, h, w, kind).requires_grad_()
+    cvr = R.corr_naive(f1c, R.warp_flow(f2c, fc, False, ac), 4)
+    g = tensor(rng, tuple(cvr.shape))
+    cvr.backward(g)
+    f1, f2, f = (t.detach().clone().requires_grad_() for t in (f1c, f2c, fc))
+    if not ops.warp_corr_supported(f1, 4):
+        return draw, 'not served'
+    cv = ops.warp_corr(f1, f2, f, 4, align_corners=ac)
+    cv.backward(g)
+    amax = max(float(f1c.grad.abs().max()), float(f2c.grad.abs().max()), 1e-6)
+    scale = max(float(fc.grad.abs().max()), 1e-6)
+    for name, got, ref, rtol, atol in (('cv', cv.detach(), cvr.detach(), 1e-5, 2e-6), ('gf1', f1.grad, f1c.grad, 1e-4, max(5e-6, 2e-6 * amax)),
+                                       ('gf2', f2.grad, f2c.grad, 1e-4, max(2e-5, 2e-6 * amax)), ('gflow', f.grad, fc.grad, 1e-4, 2e-5 * scale)):
+        if not np.allclose(got.numpy(), ref.numpy(), rtol=rtol, atol=atol):
+            return draw, '%s off by %g (bar %g + %g rel)' % (name, float((got - ref).abs().max()), atol, rtol)
+    return draw, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--minutes', type=float, default=2.0)
     ap.add_argument('--seed', type=int, default=0)
-    ap.add_argument('--what', default='ms,warp,mfma2,corr')
+    ap.add_argument('--what', default='ms,warp,mfma2,corr,fused')
     a = ap.parse_args()
-    fns = {'ms': fuzz_ms, 'warp': fuzz_warp, 'mfma2': fuzz_mfma2, 'corr': fuzz_corr}
+    fns = {'ms': fuzz_ms, 'warp': fuzz_warp, 'mfma2': fuzz_mfma2, 'corr': fuzz_corr, 'fused': fuzz_fused}
     which = [fns[k] for k in a.what.split(',')]
     t_end = time.time() + 60 * a.minutes
     runs, fails, k = {f.__name__: 0 for f in which}, 0, 0
