@@ -45,6 +45,7 @@ def patched(ops):
         import pytest
         pytest.skip('the host-executed library needs the ROCm clang++ (vector extensions, __bf16)')
     old = (_lib._lib, ops._dev, ops._stream, ops._on, ops.on_device)
+    capturing = torch.cuda.is_current_stream_capturing
 
     def dev(*tensors):
         for t in tensors:
@@ -52,7 +53,9 @@ def patched(ops):
                 raise TypeError('unopticalflow_amd ops compute in fp32; got %s' % t.dtype)
         return torch.device('cpu')
     _lib._lib, ops._dev, ops._stream, ops._on, ops.on_device = lib, dev, (lambda: None), (lambda d: contextlib.nullcontext()), (lambda t: True)
+    torch.cuda.is_current_stream_capturing = lambda: False          # (the trainer asks before it checks what a backward pass left; no device here)
     try:
         yield lib
     finally:
         _lib._lib, ops._dev, ops._stream, ops._on, ops.on_device = old
+        torch.cuda.is_current_stream_capturing = capturing

@@ -290,3 +290,73 @@ def test_gpu_op_tests_rehearsed_on_host_kernels():
     r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-m', 'gpu', '--runxfail', '-p', 'no:cacheprovider', '-p', 'no:xdist'] + ids, cwd=root,
                        env=dict(os.environ, UNFLOW_TESTS_ON_HOST='1'), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and ('%d passed' % len(ids)) in r.stdout, r.stdout[-4000:]
+
+
+def _product_rank(rank, world, port, steps, out_path):
+    """One rank of the data-parallel train step with the PRODUCT on it: unopticalflow_amd.Model_flow over the host-executed kernels, FlowTrainer as
+    bench.py / train.py build it for several ranks (flat gradient buffer, pieces all-reduced from hooks during backward, bias gradients
+    deferred to the end of the pass, the one-launch Adam of csrc/optim.hip) -- over gloo, since the ranks have no GPU."""
+    import os
+    from unopticalflow_amd import get_model, ops as _ops
+    from unopticalflow_amd.parallel import init_distributed, shard_batch
+    from unopticalflow_amd.trainer import FlowTrainer
+    import torch.distributed as dist
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    init_distributed('gloo')
+    with hostexec.patched(_ops):
+        cfg = R.default_cfg()
+        model = get_model('flow')(cfg)
+        model.load_state_dict(R.seeded_state_dict(model, 1234 if rank == 0 else 999, 0.25))       # rank 0's weights must win
+        trainer = FlowTrainer(cfg, model, distributed=True)
+        assert type(trainer.optimizer).__name__ == 'FlowAdam' and trainer._defer_bias_grads and trainer.grads.overlap
+        x = R.synthetic_triplets(2 * world, 64, 128, seed=5, structured=True)
+        for _ in range(steps):
+            loss, _ = trainer.step(shard_batch(x, rank, world))
+        assert trainer.optimizer.native_steps == steps                                            # the kernel stepped, not torch's Adam
+        trainer.grads.check_views()
+        if rank == 0:
+            torch.save({'grad': trainer.grads.vector(), 'params': [p.detach().clone() for p in model.parameters()]}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('steps', [1, 2])
+def test_two_ranks_of_the_product_step_on_host_kernels(tmp_path, steps):
+    """SURVEY 8(e) with the product's own model on the ranks: two gloo ranks, each running Model_flow over the host-executed kernel sources on its
+    half of the batch, exchange the flat gradient piece by piece during backward and step the one-launch Adam; rank 0's averaged gradient
+    and its parameters after two steps equal the ORACLE's single-process steps on the whole batch (train.py:137-152 with DataParallel's
+    batch split, train.py:36-37).  tests/test_data_parallel.py makes the same comparison with the oracle's model on the ranks."""
+    import socket
+    import torch.multiprocessing as mp
+    from unopticalflow_amd.trainer import FlowTrainer
+    if hostexec.library() is None:
+        pytest.skip('the host-executed library needs the ROCm clang++')
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    world = 2
+    out = str(tmp_path / 'rank0.pt')
+    mp.spawn(_product_rank, args=(world, port, steps, out), nprocs=world, join=True)
+    got = torch.load(out)
+    cfg = R.default_cfg()
+    ref = R.Model_flow(cfg)
+    ref.load_state_dict(R.seeded_state_dict(ref, 1234, 0.25))
+    trainer = FlowTrainer(cfg, ref, distributed=False, fused_adam=False)
+    x = R.synthetic_triplets(2 * world, 64, 128, seed=5, structured=True)
+    for _ in range(steps):
+        trainer.step(x)
+    g_ref = trainer.grads.vector()
+    pa, pb = torch.cat([a.reshape(-1) for a in got['params']]), torch.cat([b.detach().reshape(-1) for b in ref.parameters()])
+    if steps == 1:
+        # one step: the averaged gradient element by element (the GPU suite's bar for a whole-model gradient), the parameters inside Adam's step
+        np.testing.assert_allclose(got['grad'].numpy(), g_ref.numpy(), rtol=1e-3, atol=2e-5 * g_ref.abs().max().item())
+        # Adam's first update is lr * sign(g) whatever |g|: an element whose gradient is zero to rounding may step the other way (2 lr apart)
+        off = (pa - pb).abs()
+        assert float(off.max()) <= 2.1e-4 and float((off > 2e-5).float().mean()) < 1e-4, (float(off.max()), float((off > 2e-5).float().mean()))
+    else:
+        # two steps: the second starts from parameters 2e-4 apart in those few elements -- the comparison is by norm and by share, as in test_hip_model.py
+        rel = float((got['grad'] - g_ref).norm() / g_ref.norm())
+        assert rel < 2e-3, rel
+        off = (pa - pb).abs()
+        assert float(off.max()) <= 4.2e-4 and float((off > 2e-5).float().mean()) < 2e-3, (float(off.max()), float((off > 2e-5).float().mean()))

@@ -11,7 +11,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 
 
 class _Slot(ctypes.Structure):
@@ -89,7 +89,7 @@ class FlowAdam(torch.optim.Adam):
         and host-to-device copies made DURING a capture would become graph nodes (every replay would reset the moments and the
         step counters) or fail the capture outright."""
         params = self._params()
-        if not params or not all(p.is_cuda and p.dtype == torch.float32 for p in params) or len(params) > 128:
+        if not params or not all(ops.on_device(p) and p.dtype == torch.float32 for p in params) or len(params) > 128:
             return False
         self._init_state(params)
         self._build_tables(params)
@@ -114,7 +114,7 @@ class FlowAdam(torch.optim.Adam):
             return False
         dev = params[0].device
         for p in params:
-            if not p.is_cuda or p.device != dev or p.dtype != torch.float32 or p.grad is None or p.grad.is_sparse:
+            if not ops.on_device(p) or p.device != dev or p.dtype != torch.float32 or p.grad is None or p.grad.is_sparse:
                 return False
             if not _dense_like(p.grad, p) or not _dense(p):
                 return False
@@ -146,11 +146,11 @@ class FlowAdam(torch.optim.Adam):
         grads = (ctypes.c_void_p * len(params))(*[p.grad.data_ptr() for p in params])
         g = self.param_groups[0]
         lib = _lib.load()
-        with torch.cuda.device(params[0].device):
+        with ops._on(params[0].device):
             rc = lib.unflow_adam_multi(ctypes.c_void_p(slots.data_ptr()), ctypes.c_void_p(cmap.data_ptr()), nchunks, grads, len(params),
                                        ctypes.c_void_p(self._steps.data_ptr()),
                                        ctypes.c_float(g['lr']), ctypes.c_float(g['betas'][0]), ctypes.c_float(g['betas'][1]),
-                                       ctypes.c_float(g['eps']), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                       ctypes.c_float(g['eps']), ops._stream())
         _lib.check(rc, 'unflow_adam_multi')
         self.native_steps += 1
         return None

@@ -12,6 +12,12 @@ import torch
 from .core.config import generate_loss_weights_dict
 from .parallel import FlatGradients, PlainGradients, broadcast_parameters
 
+
+def _on_device(t):
+    """ops.on_device (a tensor the kernels can take: a HIP tensor), asked lazily -- a CPU oracle model never imports the operator layer"""
+    from . import ops
+    return ops.on_device(t)
+
 _PROCESS_GC_FROZEN = False
 
 
@@ -31,7 +37,7 @@ class FlowTrainer:
         if distributed:
             self.grads = FlatGradients(params, chunks=allreduce_chunks, overlap=not use_graph,
                                        single_rank_collectives=single_rank_collectives, pack=True)
-            if params[0].is_cuda:
+            if _on_device(params[0]):
                 # bias gradients are finished by one batched launch at the END of a backward pass (ops.deferred_bias_grads); a piece
                 # packed from a hook in the middle of the pass must see finished values
                 from . import ops
@@ -43,13 +49,13 @@ class FlowTrainer:
         else:
             self.grads = PlainGradients(params)
         self.distributed = distributed
-        self._defer_bias_grads = params[0].is_cuda if defer_bias_grads is None else bool(defer_bias_grads)
+        self._defer_bias_grads = _on_device(params[0]) if defer_bias_grads is None else bool(defer_bias_grads)
         self._defer_checks = 2
         kw = {}
         if fused_adam is None:
-            fused_adam = params[0].is_cuda
+            fused_adam = _on_device(params[0])
         if own_adam is None:
-            own_adam = fused_adam and params[0].is_cuda
+            own_adam = fused_adam and _on_device(params[0])
         if own_adam:
             # torch.optim.Adam whose step is one HIP launch over all tensors (optim.FlowAdam; same state layout and state_dict)
             from .optim import FlowAdam
@@ -81,7 +87,7 @@ class FlowTrainer:
     def total_loss(self, loss_pack):
         """train.py:147-150; on the GPU one launch each way (ops.weighted_mean_sum) instead of a mean, a multiply and an add per key"""
         terms = list(loss_pack.values())
-        if self.fused_total_loss and 1 <= len(terms) <= 8 and all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 1 and
+        if self.fused_total_loss and 1 <= len(terms) <= 8 and all(_on_device(t) and t.dtype == torch.float32 and t.dim() == 1 and
                                                                    t.shape == terms[0].shape for t in terms):
             from . import ops
             return ops.weighted_mean_sum(terms, [self.loss_weights[k] for k in loss_pack])
