@@ -292,7 +292,7 @@ def test_gpu_op_tests_rehearsed_on_host_kernels():
     assert r.returncode == 0 and ('%d passed' % len(ids)) in r.stdout, r.stdout[-4000:]
 
 
-def _product_rank(rank, world, port, steps, out_path):
+def _product_rank(rank, world, port, steps, out_path, flat=False):
     """One rank of the data-parallel train step with the PRODUCT on it: unopticalflow_amd.Model_flow over the host-executed kernels, FlowTrainer as
     bench.py / train.py build it for several ranks (flat gradient buffer, pieces all-reduced from hooks during backward, bias gradients
     deferred to the end of the pass, the one-launch Adam of csrc/optim.hip) -- over gloo, since the ranks have no GPU."""
@@ -308,11 +308,21 @@ def _product_rank(rank, world, port, steps, out_path):
         cfg = R.default_cfg()
         model = get_model('flow')(cfg)
         model.load_state_dict(R.seeded_state_dict(model, 1234 if rank == 0 else 999, 0.25))       # rank 0's weights must win
-        trainer = FlowTrainer(cfg, model, distributed=True)
-        assert type(trainer.optimizer).__name__ == 'FlowAdam' and trainer._defer_bias_grads and trainer.grads.overlap
+        trainer = FlowTrainer(cfg, model, distributed=True, use_graph=flat)
+        assert type(trainer.optimizer).__name__ == 'FlowAdam' and trainer._defer_bias_grads and trainer.grads.overlap == (not flat)
         x = R.synthetic_triplets(2 * world, 64, 128, seed=5, structured=True)
         for _ in range(steps):
-            loss, _ = trainer.step(shard_batch(x, rank, world))
+            if not flat:
+                loss, _ = trainer.step(shard_batch(x, rank, world))
+                continue
+            # the replayed multi-rank step's exchange without its graphs (they need a GPU): backward assigns, pack_all copies every piece into
+            # the flat buffer (what graph A ends with), ONE all-reduce of the buffer, Adam on the buffer's views (graph B)
+            trainer.grads.zero()
+            trainer._backward(trainer.total_loss(trainer.model(shard_batch(x, rank, world))))
+            assert trainer.grads.launched_early == 0
+            trainer.grads.pack_all()
+            trainer.grads.all_reduce_flat()
+            trainer.optimizer.step()
         assert trainer.optimizer.native_steps == steps                                            # the kernel stepped, not torch's Adam
         trainer.grads.check_views()
         if rank == 0:
@@ -321,9 +331,9 @@ def _product_rank(rank, world, port, steps, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('steps', [1, 2])
-def test_two_ranks_of_the_product_step_on_host_kernels(tmp_path, steps):
-    """SURVEY 8(e) with the product's own model on the ranks: two gloo ranks, each running Model_flow over the host-executed kernel sources on its
+@pytest.mark.parametrize('world,steps,flat', [(2, 1, False), (2, 2, False), (8, 1, True)])
+def test_ranks_of_the_product_step_on_host_kernels(tmp_path, world, steps, flat):
+    """SURVEY 8(e) with the product's own model on the ranks: two gloo ranks (and eight, with the one-all-reduce exchange of the replayed step), each running Model_flow over the host-executed kernel sources on its
     half of the batch, exchange the flat gradient piece by piece during backward and step the one-launch Adam; rank 0's averaged gradient
     and its parameters after two steps equal the ORACLE's single-process steps on the whole batch (train.py:137-152 with DataParallel's
     batch split, train.py:36-37).  tests/test_data_parallel.py makes the same comparison with the oracle's model on the ranks."""
@@ -335,9 +345,8 @@ def test_two_ranks_of_the_product_step_on_host_kernels(tmp_path, steps):
     with socket.socket() as so:
         so.bind(('127.0.0.1', 0))
         port = so.getsockname()[1]
-    world = 2
     out = str(tmp_path / 'rank0.pt')
-    mp.spawn(_product_rank, args=(world, port, steps, out), nprocs=world, join=True)
+    mp.spawn(_product_rank, args=(world, port, steps, out, flat), nprocs=world, join=True)
     got = torch.load(out)
     cfg = R.default_cfg()
     ref = R.Model_flow(cfg)
