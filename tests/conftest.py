@@ -20,6 +20,7 @@ if os.environ.get('UNFLOW_LIB_PATH'):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'own_process: a -m gpu test that runs its body in a child pytest (tests/test_zz_round5_gpu.py)')
 
 
 @pytest.fixture(scope='session')

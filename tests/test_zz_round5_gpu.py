@@ -20,16 +20,50 @@ from oracle_cache import corr_case
 pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason='added in round 5 after the GPU lease closed: never run on an MI355X yet')]
 
 
+own_process = pytest.mark.own_process
+_batch = {}
+
+
+def _child(ids, timeout, junit=None):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, '-m', 'pytest', '-q', '-m', 'gpu', '--runxfail', '-p', 'no:cacheprovider'] + (['--junitxml', junit] if junit else ['-x']) + list(ids)
+    try:
+        return subprocess.run(cmd, cwd=root, env=dict(os.environ, UNFLOW_ZZ_CHILD='1'), capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired as e:
+        return subprocess.CompletedProcess(cmd, 124, stdout=(e.stdout or b'').decode(errors='replace') if isinstance(e.stdout, bytes) else (e.stdout or ''), stderr='timed out')
+
+
 def _ran_in_a_child(request):
-    """Tests that launch device code which has NEVER run (the `_ms` kernels of csrc/multiscale.h) do it in a pytest process of their own:
-    a GPU fault there fails this one test instead of taking the validated suite's process down with it.  -> True when the child ran the
-    test (and passed: a failure is raised here); False inside the child, where the body runs."""
+    """Tests that launch device code which has NEVER run (the `_ms` kernels of csrc/multiscale.h, csrc/corr_mfma2.h) do it outside the pytest
+    process of the validated suite: a GPU fault there fails these tests instead of taking that process down.  All `own_process` tests of
+    the session run in ONE child (a process start, torch import and library load once, not a dozen times); a test the child did not get to
+    (it died on the way) is run again in a child of its own.  -> True when a child ran the test (and it passed: a failure is raised here);
+    False inside the child, where the body runs."""
     if os.environ.get('UNFLOW_ZZ_CHILD'):
         return False
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, '-m', 'pytest', request.node.nodeid, '-q', '-x', '-m', 'gpu', '--runxfail', '-p', 'no:cacheprovider'],
-                       cwd=root, env=dict(os.environ, UNFLOW_ZZ_CHILD='1'), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
+    me = request.node.nodeid
+    if not _batch:
+        import tempfile
+        import xml.etree.ElementTree as ET
+        ids = [it.nodeid for it in request.session.items if it.get_closest_marker('own_process')] or [me]
+        with tempfile.TemporaryDirectory() as tmp:
+            junit = os.path.join(tmp, 'isolated.xml')
+            r = _child(ids, 2400, junit)
+            _batch['log'] = (r.stdout[-3000:], r.stderr[-1500:])
+            if os.path.exists(junit):
+                for case in ET.parse(junit).getroot().iter('testcase'):
+                    bad = [c for c in case if c.tag in ('failure', 'error')]
+                    skipped = any(c.tag == 'skipped' for c in case)
+                    _batch[case.get('name')] = ('failed', (bad[0].get('message') or '')[:300] + '\n' + (bad[0].text or '')[-2500:]) if bad else (('skipped', '') if skipped else ('passed', ''))
+    name = me.split('::')[-1]
+    if name in _batch:
+        state, why = _batch[name]
+        if state == 'skipped':
+            pytest.skip('skipped in the child process')
+        assert state == 'passed', why
+        return True
+    r = _child([me], 900)                                  # the batch never reached this test: on its own
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:], 'batch: %s' % (_batch.get('log'),))
     return True
 
 
@@ -148,6 +182,7 @@ def test_corr_backward_on_the_matrix_cores_ragged_d8(ops, d, B, C, h, w):
     _matrix_core_backward_case(ops, d, B, C, h, w)
 
 
+@own_process
 @pytest.mark.parametrize('B,h,w', [(2, 64, 208), (3, 60, 104), (8, 256, 832)])
 def test_multiscale_losses_are_the_same_bits(ops, B, h, w, request):
     """Round 5 (csrc/multiscale.h, C ABI 11): every loss of the scale loop as ONE launch over the three scales -- the `_ms` kernels
@@ -201,6 +236,7 @@ def test_multiscale_losses_are_the_same_bits(ops, B, h, w, request):
             assert torch.equal(a, b), (form, k, float((a - b).abs().max()))
 
 
+@own_process
 def test_multiscale_losses_in_the_model(ops, request):
     """Model_flow.multiscale_losses: the same loss pack and the same loss-side gradients (the flows' and the warped images' come out of the
     loss kernels; compared here through the total gradient norm, which also crosses MIOpen's run-to-run level) as the per-scale loop."""
@@ -223,6 +259,7 @@ def test_multiscale_losses_in_the_model(ops, request):
     assert abs(norms[0] - norms[1]) <= 1e-3 * norms[0], norms
 
 
+@own_process
 @pytest.mark.parametrize('ac', [False, True])
 def test_multiscale_image_warps_are_the_same_bits(ops, ac, request):
     """ops.warp_flow_masked_pyramid (C ABI 11: unflow_warp_fwd_ms / unflow_warp_bwd_ms) against ops.warp_flow(use_mask=True) per scale:
@@ -318,6 +355,7 @@ def _loss_section_flow_gradients(g, dtype):
     return [torch.cat((fb[s].grad, ff[s].grad)).double().numpy() for s in range(3)]
 
 
+@own_process
 @pytest.mark.parametrize('ms', [False, True])
 def test_loss_section_against_the_reference_fixture(ops, golden, monkeypatch, request, ms):
     """g5_loss_section.npz -- the REFERENCE's own run of model_flow_paper.py:227-251 from given flows, on frames with saturated / dark
@@ -353,6 +391,7 @@ def test_loss_section_against_the_reference_fixture(ops, golden, monkeypatch, re
     assert fl[3].grad is None
 
 
+@own_process
 @pytest.mark.parametrize('d,B,C,h,w', [(4, 16, 32, 64, 208), (4, 4, 48, 21, 100), (8, 12, 64, 32, 104), (8, 6, 16, 37, 44)])
 def test_corr_backward_pixel_pair_form(ops, request, d, B, C, h, w):
     """ops.set_corr_backward('mfma2') (csrc/corr_mfma2.h: the pixel-pair variant of the matrix-core backward; executed and checked on the build
