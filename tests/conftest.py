@@ -35,37 +35,11 @@ def golden():
 
 
 if os.environ.get('UNFLOW_TESTS_ON_HOST') == '1':
-    # A REHEARSAL of the -m gpu tests without a GPU (test infrastructure, off unless asked for):
-    #     UNFLOW_TESTS_ON_HOST=1 python -m pytest tests/test_zz_round5_gpu.py -m gpu -k "..."
-    # runs the GPU tests' own code on CPU tensors over the host-executed build of the kernel sources (tests/hostexec.py) -- `.cuda()` and
-    # `.to('cuda')` keep the tensor where it is, every test body sits inside hostexec.patched(ops).  It finds mistakes in TEST code (shapes,
-    # expectations, argument order) before a GPU session pays for them, and re-checks the kernels' arithmetic; what only a device has --
-    # MIOpen's convolutions (torch's CPU convolutions stand in), the kernel timer's events, hipGraphs, a second process's GPU -- it
-    # cannot answer, and tests that need those fail here by design.  Nothing in the default runs (`-m "not gpu"`, `-m gpu`) sees any of this.
-    import torch
-
-    torch.Tensor.cuda = lambda self, *a, **k: self.clone()          # (a copy, differentiable like the real host-to-device copy: no aliasing)
-    _to = torch.Tensor.to
-
-    def _to_host(self, *a, **k):
-        n = len(a) + len(k)
-        a = tuple(x for x in a if not (isinstance(x, (str, torch.device)) and str(x).startswith('cuda')))
-        if str(k.get('device', '')).startswith('cuda'):
-            k.pop('device')
-        moved = len(a) + len(k) < n
-        out = _to(self, *a, **k) if (a or k) else self
-        return out.clone() if (moved and out is self) else out
-    torch.Tensor.to = _to_host
-    for _name in ('zeros', 'ones', 'empty', 'full', 'rand', 'randn', 'randint', 'arange', 'tensor', 'as_tensor', 'zeros_like', 'empty_like', 'ones_like'):
-        def _on_host(*a, _f=getattr(torch, _name), **k):              # torch.zeros(..., device='cuda') -> the same tensor in host memory
-            if str(k.get('device', '')).startswith('cuda'):
-                k.pop('device')
-            return _f(*a, **k)
-        setattr(torch, _name, _on_host)
-    torch.cuda.is_available = lambda: True
-    torch.cuda.synchronize = lambda *a, **k: None
-    torch.cuda.is_current_stream_capturing = lambda: False
-    torch.nn.Module.cuda = lambda self, *a, **k: self
+    # the -m gpu tests rehearsed without a GPU (tests/rehearsal.py: what it is for and what it cannot answer); with UNFLOW_REHEARSAL_TIMES=file
+    # one line per test: wall seconds and the seconds spent outside the host-executed kernels (oracle + torch)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import rehearsal
+    rehearsal.install()
 
     @pytest.fixture(autouse=True)
     def _over_host_executed_kernels():

@@ -369,3 +369,23 @@ def test_ranks_of_the_product_step_on_host_kernels(tmp_path, world, steps, flat)
         assert rel < 2e-3, rel
         off = (pa - pb).abs()
         assert float(off.max()) <= 4.2e-4 and float((off > 2e-5).float().mean()) < 2e-3, (float(off.max()), float((off > 2e-5).float().mean()))
+
+
+def test_smoke_entry_rehearsed_on_host_kernels():
+    """__graft_entry__.smoke() -- the driver's round-end check: one train step of the product on `cuda:0` against the oracle -- with ITS OWN code on
+    CPU tensors (tests/rehearsal.py) over the host-executed kernels, in a process of its own: the losses inside 1e-4, the gradient norm inside
+    2e-4 of the oracle's, as on the device."""
+    import os
+    import subprocess
+    import sys
+    if hostexec.library() is None:
+        pytest.skip('the host-executed library needs the ROCm clang++')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "import rehearsal, hostexec; rehearsal.install()\n"
+            "from unopticalflow_amd import ops\n"
+            "import __graft_entry__ as g\n"
+            "with hostexec.patched(ops):\n"
+            "    g.smoke()\n") % (root, os.path.join(root, 'tests'))
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'smoke ok' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
