@@ -206,3 +206,67 @@ def test_fused_warp_corr_levels_are_a_config_key():
     for kw, want in ((dict(fused_warp_corr_levels='4,5'), {4, 5}), (dict(fused_warp_corr_levels=5), {5}), (dict(fused_warp_corr_levels=(3, 5)), {3, 5}),
                      (dict(fused_warp_corr=True), {2, 3, 4, 5}), (dict(), set())):
         assert get_model('flow')(R.default_cfg(**kw)).pwc_model.fused_levels == want, kw
+
+
+def test_no_undefined_names_in_python_sources():
+    """A typo in a branch only a GPU run takes (bench.py's roofline legs, a recipe's probe, a `-m gpu` test) would cost a GPU session to find.
+    Every name LOADED inside a function of the product, bench.py, tools/ and tests/ is a builtin, a module-level name, or bound somewhere in
+    the function (arguments, assignments, imports, nested definitions, enclosing class attributes) -- a crude scope model (no flow analysis),
+    enough for misspelt and forgotten names."""
+    import ast
+    import builtins
+    import glob
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def check(path):
+        tree = ast.parse(open(path).read())
+        mod = set(dir(builtins)) | {'__file__', '__name__', '__doc__'}
+        for n in tree.body:
+            for x in (ast.walk(n) if isinstance(n, (ast.If, ast.Try, ast.With, ast.For)) else [n]):
+                if isinstance(x, (ast.Import, ast.ImportFrom)):
+                    mod.update((a.asname or a.name).split('.')[0] for a in x.names)
+                elif isinstance(x, (ast.FunctionDef, ast.ClassDef)):
+                    mod.add(x.name)
+                elif isinstance(x, (ast.Assign, ast.AugAssign, ast.AnnAssign, ast.For, ast.With)):
+                    mod.update(y.id for y in ast.walk(x) if isinstance(y, ast.Name) and isinstance(y.ctx, ast.Store))
+        for x in ast.walk(tree):
+            if isinstance(x, ast.Global):
+                mod.update(x.names)
+
+        def bound(fn):
+            s = set()
+            for x in ast.walk(fn):
+                if isinstance(x, ast.Name) and isinstance(x.ctx, (ast.Store, ast.Del)):
+                    s.add(x.id)
+                elif isinstance(x, (ast.FunctionDef, ast.ClassDef, ast.AsyncFunctionDef)):
+                    s.add(x.name)
+                elif isinstance(x, (ast.Import, ast.ImportFrom)):
+                    s.update((a.asname or a.name).split('.')[0] for a in x.names)
+                elif isinstance(x, ast.ExceptHandler) and x.name:
+                    s.add(x.name)
+                elif isinstance(x, ast.arg):
+                    s.add(x.arg)
+            return s
+        bad = set()
+
+        def visit(node, outer):
+            for n in ast.iter_child_nodes(node):
+                if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef, ast.Lambda)):
+                    local = outer | bound(n)
+                    bad.update((x.id, x.lineno) for x in ast.walk(n) if isinstance(x, ast.Name) and isinstance(x.ctx, ast.Load) and x.id not in local and x.id not in mod)
+                elif isinstance(n, ast.ClassDef):
+                    cls = {y.name for y in n.body if isinstance(y, (ast.FunctionDef, ast.ClassDef))}
+                    for y in n.body:
+                        if isinstance(y, (ast.Assign, ast.AnnAssign)):
+                            cls.update(z.id for z in ast.walk(y) if isinstance(z, ast.Name) and isinstance(z.ctx, ast.Store))
+                    visit(n, outer | cls)
+                else:
+                    visit(n, outer)
+        visit(tree, set())
+        return sorted(bad)
+    files = (glob.glob(os.path.join(ROOT, 'unopticalflow_amd', '**', '*.py'), recursive=True) + glob.glob(os.path.join(ROOT, 'tools', '**', '*.py'), recursive=True)
+             + glob.glob(os.path.join(ROOT, 'tests', '*.py')) + glob.glob(os.path.join(ROOT, 'tests', 'host_check', '*.py')) + glob.glob(os.path.join(ROOT, 'oracle', '*.py'))
+             + [os.path.join(ROOT, 'bench.py'), os.path.join(ROOT, '__graft_entry__.py')])
+    assert len(files) > 60
+    findings = {os.path.relpath(f, ROOT): check(f) for f in files}
+    assert not any(findings.values()), {f: b for f, b in findings.items() if b}
