@@ -270,3 +270,22 @@ def test_no_undefined_names_in_python_sources():
     assert len(files) > 60
     findings = {os.path.relpath(f, ROOT): check(f) for f in files}
     assert not any(findings.values()), {f: b for f, b in findings.items() if b}
+
+
+def test_gpu_recipes_parse_and_name_existing_files():
+    """tools/*.sh are what a GPU session runs first: each parses (`bash -n`) and every repository path a recipe names -- tools/..., tests/...,
+    bench.py, csrc files -- exists (a renamed probe would otherwise surface as a lost recipe on the GPU box)."""
+    import glob
+    import re
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scripts = sorted(glob.glob(os.path.join(ROOT, 'tools', '*.sh')))
+    assert scripts
+    for sh in scripts:
+        r = subprocess.run(['bash', '-n', sh], capture_output=True, text=True)
+        assert r.returncode == 0, (sh, r.stderr)
+    text = open(os.path.join(ROOT, 'tools', 'gpu_r5.sh')).read()
+    named = set(re.findall(r'(?<![\w/$}])((?:tools|tests|unopticalflow_amd|oracle)/[\w/.]+\.(?:py|sh|cpp|hip|h))\b', text)) | set(re.findall(r'(?<![\w/])(bench\.py|__graft_entry__\.py)\b', text))
+    assert len(named) >= 10
+    missing = sorted(p for p in named if not os.path.exists(os.path.join(ROOT, p)))
+    assert not missing, missing
