@@ -36,6 +36,62 @@ def install():
             return _f(*a, **k)
         setattr(torch, _name, _on_host)
     torch.cuda.is_available = lambda: True
+    torch.cuda.device_count = lambda: 1
+    torch.cuda.set_device = lambda *a, **k: None
+    torch.cuda.current_device = lambda: 0
+    torch.cuda.empty_cache = lambda: None
+    torch.cuda.get_device_name = lambda *a, **k: 'host rehearsal'
+
+    class _Event:                                                       # everything is in order on the host: events and streams have nothing to do
+        def __init__(self, *a, **k): pass
+        def record(self, *a, **k): pass
+        def synchronize(self): pass
+        def wait(self, *a, **k): pass
+        def query(self): return True
+        def elapsed_time(self, other): return 0.0
+
+    class _Stream:
+        cuda_stream = 0
+        def __init__(self, *a, **k): pass
+        def wait_stream(self, *a, **k): pass
+        def wait_event(self, *a, **k): pass
+        def record_event(self, e=None): return e or _Event()
+        def synchronize(self): pass
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+    import contextlib
+    torch.cuda.Event, torch.cuda.Stream = _Event, _Stream
+    torch.cuda.current_stream = lambda *a, **k: _Stream()
+    torch.cuda.default_stream = lambda *a, **k: _Stream()
+    torch.cuda.stream = lambda s: contextlib.nullcontext()
+
+    class _Device:                                                      # (a class: torch.serialization asks isinstance(x, torch.cuda.device))
+        def __init__(self, *a, **k): pass
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+    torch.cuda.device = _Device
+    _load = torch.load
+
+    def _load_on_host(f, *a, **k):
+        if a and str(a[0]).startswith('cuda'):
+            a = ('cpu',) + tuple(a[1:])
+        if str(k.get('map_location', '')).startswith('cuda'):
+            k['map_location'] = 'cpu'
+        return _load(f, *a, **k)
+    torch.load = _load_on_host
+    torch.Tensor.pin_memory = lambda self, *a, **k: self
+    torch.Tensor.record_stream = lambda self, *a, **k: None
+    # hipGraphs cannot be rehearsed (a capture records device work): a trainer asked to replay its step steps eagerly here
+    from unopticalflow_amd import trainer as _trainer
+    _init = _trainer.FlowTrainer.__init__
+
+    def _eager_init(self, *a, **k):
+        k['use_graph'] = False
+        _init(self, *a, **k)
+    _trainer.FlowTrainer.__init__ = _eager_init
+    torch.cuda.memory_allocated = lambda *a, **k: 0
+    torch.cuda.max_memory_allocated = lambda *a, **k: 0
+    torch.cuda.reset_peak_memory_stats = lambda *a, **k: None
     torch.cuda.synchronize = lambda *a, **k: None
     torch.cuda.is_current_stream_capturing = lambda: False
     torch.nn.Module.cuda = lambda self, *a, **k: self
