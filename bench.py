@@ -562,8 +562,9 @@ def main():
                            if (world > 1 or args.force_ddp) else 'hipGraph replay') if args.graph else
                           ('eager, gradient pieces all-reduced from hooks during backward' if (world > 1 or args.force_ddp) else 'eager')),
             'config': {'workload': '%dx%d triplets, bs=%d per GPU, %s, corr d=4 + warp + occlusion losses, '
-                                   'fwd+bwd+Adam (BASELINE configs[%d])' % (fw, fh, args.batch, args.precision,
-                                                                            (1 if args.precision == 'fp32' else 2) if (fh, fw) == (H, W) else 3),
+                                   'fwd+bwd+Adam (%s)' % (fw, fh, args.batch, args.precision,
+                                                          'BASELINE configs[%d]' % (1 if args.precision == 'fp32' else 2) if (fh, fw, args.batch) == (H, W, B_PER_GPU)
+                                                          else 'BASELINE configs[3]' if (fh, fw, args.batch) == (448, 1024, 4) else 'not a BASELINE configuration'),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                        'conv_memory_format': 'channels_last' if cfg.channels_last else 'NCHW',
                        'triplets_per_s': round(pairs / 2 / dt, 2),

@@ -170,8 +170,8 @@ typedef void* hipEvent_t;
 typedef int hipError_t;
 #define hipSuccess 0
 static inline int hipGetLastError() { return 0; }
-static inline int hipEventCreate(hipEvent_t* e) { static char token; *e = &token; return 0; }      // (non-null: an armed timing slot counts its launches, the time is 0)
-static inline int hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
+static inline int hipEventCreate(hipEvent_t* e) { static char token; *e = &token; return 0; }      // (non-null: an armed timing slot counts its launches; the time is a made-up 1 us)
+static inline int hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.001f; return 0; }      // (1 us: time means nothing here, but a rate computed from it must not divide by zero)
 
 // a fiber switch without system calls (ucontext's swapcontext saves the signal mask: a syscall per switch): callee-saved registers on the
 // old stack, stack pointers exchanged (x86-64 System V)

@@ -41,6 +41,14 @@ def install():
     torch.cuda.current_device = lambda: 0
     torch.cuda.empty_cache = lambda: None
     torch.cuda.get_device_name = lambda *a, **k: 'host rehearsal'
+    _Generator = torch.Generator
+
+    class _HostGenerator(_Generator):                                  # torch.Generator(device='cuda') -> the host generator (still a type: annotations use it)
+        def __new__(cls, *a, **k):
+            return _Generator.__new__(cls)
+    torch.Generator = _HostGenerator
+    import types
+    torch.cuda.get_device_properties = lambda *a, **k: types.SimpleNamespace(gcnArchName='host:rehearsal', multi_processor_count=0, name='host rehearsal', total_memory=0)
 
     class _Event:                                                       # everything is in order on the host: events and streams have nothing to do
         def __init__(self, *a, **k): pass
@@ -48,7 +56,7 @@ def install():
         def synchronize(self): pass
         def wait(self, *a, **k): pass
         def query(self): return True
-        def elapsed_time(self, other): return 0.0
+        def elapsed_time(self, other): return 1.0                       # (a made-up millisecond: rates computed from it must not divide by zero)
 
     class _Stream:
         cuda_stream = 0

@@ -389,3 +389,37 @@ def test_smoke_entry_rehearsed_on_host_kernels():
             "    g.smoke()\n") % (root, os.path.join(root, 'tests'))
     r = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'smoke ok' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_bench_line_rehearsed_on_host_kernels():
+    """bench.py's OWN code (tests/bench_on_host.py: CPU tensors, host-executed kernels, made-up timer values) with the switches that have not been
+    measured yet: the step loop, the kernel-timer bookkeeping and the JSON assembly run through and the LAST stdout line is the contract's
+    object -- metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config
+    {workload} / roofline {bound, achieved, peak, unit, frac, traffic} (+ aggregate, losses) / cpu_baseline -- with the one-launch-per-loss
+    entries in the loss section (10 loss launches per step, 36 -> 12 counting the image warps).  No number in it means anything."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if hostexec.library() is None:
+        pytest.skip('the host-executed library needs the ROCm clang++')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tests', 'bench_on_host.py'), '--steps', '2', '--warmup', '1', '--batch', '1', '--hw', '64', '128',
+                        '--graph', '0', '--no-cpu-baseline', '--multiscale-losses', '1', '--split-handoff', '1'], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['unit'] == 'pairs/s' and d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['higher_is_better'] is True and d['scaling'] == 'weak'
+    assert d['vs_baseline'] is None and d['dtype'] == 'f32' and d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
+    assert d['config']['loss_launch_form'] == 'one per loss over the scales' and 'not a BASELINE configuration' in d['config']['workload']
+    roof = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'aggregate', 'losses'):
+        assert k in roof, k
+    assert roof['bound'] == 'hbm' and roof['peak'] == 8000.0 and roof['unit'] == 'GB/s'
+    entries = {e['entry'] for e in roof['losses']['per_entry']}
+    assert entries == {'unflow_%s_ms' % n for n in ('occ_weight_fwd', 'masked_mean_fwd', 'ssim_loss_fwd', 'smooth2_fwd', 'consis_fwd', 'consis_bwd', 'smooth2_bwd',
+                                                     'ssim_loss_bwd', 'masked_mean_bwd', 'absdiff_bwd')}, entries
+    assert roof['losses']['launches_per_step'] == 10.0
+    warps = {e['entry'] for e in roof['aggregate']['per_level']}
+    assert {'unflow_warp_fwd_ms', 'unflow_warp_bwd_ms'} <= warps
