@@ -433,10 +433,11 @@ def test_cost_volume_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
     sources = [os.path.join(csrc, 'corr.hip'), os.path.join(csrc, 'warp_corr.hip'), os.path.join(csrc, 'warp.hip'), os.path.join(ROOT, 'tests', 'host_check', 'corr_check.cpp')]
     common = ['-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-Wno-unknown-attributes', '-Wno-unknown-pragmas', '-Wno-pass-failed',
               '-I', os.path.join(ROOT, 'tests', 'host_check'), '-I', csrc]
-    san = ['-O1', '-g', '-fsanitize=address,undefined', '-fno-omit-frame-pointer', '-fno-sanitize-recover=undefined']
+    san = ['-O1', '-gline-tables-only', '-fsanitize=address,undefined', '-fno-omit-frame-pointer', '-fno-sanitize-recover=undefined']
     # both programs (plain -O2 and AddressSanitizer + UBSan, see _sanitized) at once, a compiler process per translation unit
     jobs = []
-    for tag, flags in (('plain', ['-O2']), ('san', san)):
+    long = os.environ.get('UNFLOW_HOST_CHECK_SANITIZE') == 'all'           # (then also a plain -O2 build, whose bytes must equal the instrumented -O1 build's)
+    for tag, flags in ((('plain', ['-O2']),) if long else ()) + (('san', san),):
         for src in sources:
             obj = str(tmp_path / ('%s_%s.o' % (tag, os.path.basename(src))))
             jobs.append((tag, obj, subprocess.Popen([clang, *flags, *common, '-x', 'c++', '-c', src, '-o', obj], stderr=subprocess.PIPE, text=True)))
@@ -444,7 +445,8 @@ def test_cost_volume_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
         err = pr.communicate()[1]
         assert pr.returncode == 0, err[-3000:]
     exe, exe_san = str(tmp_path / 'corr_check'), str(tmp_path / 'corr_check_asan')
-    subprocess.run([clang, '-o', exe] + [o for t, o, _ in jobs if t == 'plain'], check=True)
+    if long:
+        subprocess.run([clang, '-o', exe] + [o for t, o, _ in jobs if t == 'plain'], check=True)
     subprocess.run([clang, '-fsanitize=address,undefined', '-o', exe_san] + [o for t, o, _ in jobs if t == 'san'], check=True)
     rng = np.random.default_rng(5)
     data = []
@@ -462,14 +464,17 @@ def test_cost_volume_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
             f.write(struct.pack('8i', kind, d, B, C, H, W, ac, mode))
             for t in ((f1, f2, flow, g) if kind else (f1, f2, g)):
                 f.write(t.numpy().tobytes())
-    sanitized = subprocess.Popen([exe_san, fin, str(tmp_path / 'san.bin')], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                                 env=dict(os.environ, ASAN_OPTIONS='detect_stack_use_after_return=0:detect_leaks=0'))       # (the lanes' stacks are heap blocks switched by hand)
-    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=3000, env=dict(os.environ, HIP_ON_HOST_TRACE='1'))
-    assert r.returncode == 0 and 'OK' in r.stdout, (r.stdout[-2000:], r.stderr[-500:])
-    launches = [l.split()[1] for l in r.stderr.splitlines() if l.startswith('launch ')]
+    # the program under AddressSanitizer + UBSan (the lanes' stacks are heap blocks switched by hand: no stack-use-after-return tracking), launch trace on
+    sanitized = subprocess.Popen([exe_san, fin, fout], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                 env=dict(os.environ, ASAN_OPTIONS='detect_stack_use_after_return=0:detect_leaks=0', HIP_ON_HOST_TRACE='1'))
+    if long:
+        r = subprocess.run([exe, fin, str(tmp_path / 'plain.bin')], capture_output=True, text=True, timeout=3000)
+        assert r.returncode == 0 and 'OK' in r.stdout, (r.stdout[-2000:], r.stderr[-500:])
     so, se = sanitized.communicate(timeout=3000)
     assert sanitized.returncode == 0 and 'OK' in so and 'ERROR' not in se and 'runtime error' not in se, (so[-1500:], se[-3000:])
-    assert open(fout, 'rb').read() == open(str(tmp_path / 'san.bin'), 'rb').read()              # -O1 and -O2, with and without instrumentation: the same bytes
+    launches = [l.split()[1] for l in se.splitlines() if l.startswith('launch ')]
+    if long:
+        assert open(fout, 'rb').read() == open(str(tmp_path / 'plain.bin'), 'rb').read()        # -O1 and -O2, with and without instrumentation: the same bytes
     raw = np.fromfile(fout, dtype=np.float32)
     pos = 0
     at = 0

@@ -95,7 +95,7 @@ def test_multiscale_losses_are_the_same_bits_and_the_oracles_values(ops):
         close(got[4 + n + s], fl[s].grad, rtol=1e-4, atol=2e-5 * float(fl[s].grad.abs().max()), what='flow gradient %d' % s)
 
 
-@pytest.mark.parametrize('ac,cl,switches', [(0, False, {}), (0, True, {}), (1, True, {}), (0, True, {'multiscale_losses': True, 'split_handoff': True}),
+@pytest.mark.parametrize('ac,cl,switches', [(0, False, {}), (1, True, {}), (0, True, {'multiscale_losses': True, 'split_handoff': True}),
                                             (1, False, {'multiscale_losses': True})])
 def test_module_128_golden_on_host_kernels(golden, ops, ac, cl, switches):
     """tests/test_hip_model.py::test_module_128_golden on the CPU tier: the product's Model_flow over the host-executed kernel sources (convolutions:
@@ -331,9 +331,9 @@ def _product_rank(rank, world, port, steps, out_path, flat=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,steps,flat', [(2, 1, False), (2, 2, False), (8, 1, True)])
+@pytest.mark.parametrize('world,steps,flat', [(2, 1, False), (8, 1, True)] + ([(2, 2, False)] if __import__('os').environ.get('UNFLOW_HOST_CHECK_SANITIZE') == 'all' else []))
 def test_ranks_of_the_product_step_on_host_kernels(tmp_path, world, steps, flat):
-    """SURVEY 8(e) with the product's own model on the ranks: two gloo ranks (and eight, with the one-all-reduce exchange of the replayed step), each running Model_flow over the host-executed kernel sources on its
+    """SURVEY 8(e) with the product's own model on the ranks: two gloo ranks (and eight, with the one-all-reduce exchange of the replayed step; a two-step case with UNFLOW_HOST_CHECK_SANITIZE=all), each running Model_flow over the host-executed kernel sources on its
     half of the batch, exchange the flat gradient piece by piece during backward and step the one-launch Adam; rank 0's averaged gradient
     and its parameters after two steps equal the ORACLE's single-process steps on the whole batch (train.py:137-152 with DataParallel's
     batch split, train.py:36-37).  tests/test_data_parallel.py makes the same comparison with the oracle's model on the ranks."""
