@@ -112,7 +112,7 @@ def parse():
     ap.add_argument('--split-handoff', type=int, default=0, help='1: the pyramid hand-off returns both decoder inputs itself (Model_flow.split_handoff: no split, no gradient concatenation; A/B)')
     ap.add_argument('--multiscale-losses', type=int, default=0, help='1: every loss of the scale loop as one launch over the three scales (A/B; Model_flow.multiscale_losses, off until GPU-validated)')
     ap.add_argument('--deferred-loss-sums', type=int, default=1, help='0: one second-stage launch per loss reduction instead of one per forward pass (A/B; Model_flow.deferred_loss_sums)')
-    ap.add_argument('--corr-bwd', default='auto', choices=['auto', 'fp32', 'mfma', 'mfma2'], help='cost-volume backward arithmetic (ops.set_corr_backward): mfma = the matrix-core form at d = 4 too, mfma2 = its pixel-pair variant (A/B)')
+    ap.add_argument('--corr-bwd', default='auto', choices=['auto', 'fp32', 'mfma', 'mfma2'], help='cost-volume backward arithmetic, per call (PWC_tf.corr_backward -> unflow_corr_bwd_ex): mfma = the matrix-core form at d = 4 too, mfma2 = its pixel-pair variant (A/B)')
     ap.add_argument('--gc-freeze', type=int, default=1, help='0: leave Python\'s cyclic collector alone; 1: FlowTrainer(gc_freeze_after=2), what train.py asks for too (gc.freeze() after the second step, once per process)')
     ap.add_argument('--contended-host', action='store_true', help='experiment (profiles/r4_multirank_step_mode.md): for the TIMED steps confine this process to one core and run a busy-loop child on the same core -- what a slow or shared host does to the step mode')
     ap.add_argument('--force-ddp', action='store_true', help='N = 1 only: run the step through the RCCL data-parallel path with a one-rank communicator')
@@ -295,7 +295,6 @@ def main():
 
     _lib.load()                                   # no HIP library -> fail loudly, never fall back
     ops.fused_warp_bwd = bool(args.fused_warp_bwd)
-    ops.set_corr_backward(args.corr_bwd)
     # one rank per GPU over RCCL.  UNFLOW_BENCH_ONE_GPU=1 is a rehearsal mode for boxes with a single GPU: every rank
     # shares device 0 and the collectives go through gloo (RCCL refuses two ranks on one device) -- it exercises the
     # multi-rank plumbing, its numbers mean nothing.
@@ -330,6 +329,7 @@ def main():
     model.fused_loss_sums = bool(args.fused_loss_sums)
     model.deferred_loss_sums = bool(args.deferred_loss_sums)
     model.multiscale_losses = bool(args.multiscale_losses)
+    model.pwc_model.corr_backward = args.corr_bwd
     model.split_handoff = bool(args.split_handoff)
     model.dup_centre = bool(args.dup_centre)
     trainer = FlowTrainer(cfg, model, distributed=(world > 1 or args.force_ddp), use_graph=bool(args.graph),
@@ -368,6 +368,7 @@ def main():
             model.fused_loss_sums = bool(args.fused_loss_sums)
             model.deferred_loss_sums = bool(args.deferred_loss_sums)
             model.multiscale_losses = bool(args.multiscale_losses)
+            model.pwc_model.corr_backward = args.corr_bwd
             model.split_handoff = bool(args.split_handoff)
             model.dup_centre = bool(args.dup_centre)
             trainer = FlowTrainer(cfg, model, distributed=(world > 1 or args.force_ddp), use_graph=False,

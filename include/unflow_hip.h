@@ -36,7 +36,7 @@ extern "C" {
 /* ABI version of this header (bumped on any signature change).  The library returns the value it was BUILT with; a C user
  * compares `unflow_abi_version() == UNFLOW_ABI_VERSION` (tools/capi_bench.cpp), the Python binding reads this very line
  * (unopticalflow_amd/_lib.py). */
-#define UNFLOW_ABI_VERSION 11
+#define UNFLOW_ABI_VERSION 12
 int unflow_abi_version(void);
 
 /* ---- kernel-exact timing (bench.py's roofline legs; nothing in the reference corresponds) ----
@@ -64,13 +64,25 @@ int unflow_corr_fwd(const float* f1, const float* f2, float* cv,
 /* autograd of the above: gcv [B,(2d+1)^2,H,W] -> gf1, gf2 [B,C,H,W] (both written in full). */
 int unflow_corr_bwd(const float* f1, const float* f2, const float* gcv, float* gf1, float* gf2,
                     int B, int C, int H, int W, int d, void* stream);
-/* Which arithmetic unflow_corr_bwd uses where both exist (round 5; process-wide): 0 (default) = the matrix-core form -- banded
- * bf16 hi/lo split products, fp32 accumulation, ~4e-6 of the largest gradient away from the fp32 sums, deterministic -- where it
- * measured faster (d = 8 on maps of >= 8192 pixels with C % 16 == 0, W % 4 == 0); 1 = fp32 FMA kernels everywhere (the results of
- * ABI <= 9, bit for bit); 2 = the matrix-core form wherever the shape is served (d = 4 too); 3 = its pixel-pair variant (csrc/corr_mfma2.h:
- * 11 instead of 27 gradient-load instructions per step at d = 4; same arithmetic; executed and checked on the build host, not measured on a
- * GPU yet) wherever served.  Returns the previous mode, or UNFLOW_EINVAL.  The reference has one arithmetic (ATen's fp32 sums, pwc_tf.py:97-106); both forms hold its 1e-4 bar. */
-int unflow_corr_set_backward(int mode);
+/* (ABI 12) The same backward with the ARITHMETIC chosen per call -- the library keeps no process-wide mode (the setter of ABI 10-11,
+ * unflow_corr_set_backward, is gone: two models in one process could not differ).  The reference has one arithmetic (ATen's fp32 sums,
+ * pwc_tf.py:97-106 through autograd); every form below holds its 1e-4 bar.
+ *   UNFLOW_CORR_BWD_AUTO   what unflow_corr_bwd() runs: per shape, the fastest kernel that has passed a complete GPU parity run;
+ *   UNFLOW_CORR_BWD_FP32   fp32 FMA kernels everywhere (the results of ABI <= 9, bit for bit);
+ *   UNFLOW_CORR_BWD_MFMA   banded products on the matrix cores (v_mfma_f32_16x16x32_bf16, both operands split into bf16 hi + lo parts, fp32
+ *                          accumulation: ~4e-6 of the largest gradient away from the fp32 sums, deterministic) wherever the shape is served
+ *                          (d = 4 or 8, >= 8192 pixels, C % 16 == 0, W % 4 == 0, H >= 4 d, 16-byte aligned tensors), the fp32 kernels elsewhere.
+ *                          Difference a caller can see besides rounding: for gf2 the kernel multiplies weights read at displaced pixels
+ *                          (neighbouring rows / planes of gcv) with exact-zero features outside the image, so an Inf or NaN anywhere in gcv
+ *                          reaches border outputs that the fp32 kernels leave finite;
+ *   UNFLOW_CORR_BWD_MFMA2  the pixel-pair variant of the matrix-core form (csrc/corr_mfma2.h; same arithmetic, fewer load instructions).
+ * UNFLOW_EINVAL for any other value. */
+#define UNFLOW_CORR_BWD_AUTO 0
+#define UNFLOW_CORR_BWD_FP32 1
+#define UNFLOW_CORR_BWD_MFMA 2
+#define UNFLOW_CORR_BWD_MFMA2 3
+int unflow_corr_bwd_ex(const float* f1, const float* f2, const float* gcv, float* gf1, float* gf2,
+                       int B, int C, int H, int W, int d, int arithmetic, void* stream);
 
 /* ---- flow warp: warp_flow, core/networks/structures/net_utils.py:16-54 ----
  * out[b,c,y,x] = bilinear sample of src[b,c] at (x+u, y+v) through the reference's

@@ -88,6 +88,28 @@ def gen_corr():
     save('g1_corr.npz', out)
 
 
+# ------------------------------------------------------------------ G6: corr at shapes the matrix-core backward serves
+def gen_corr_served():
+    """g1_corr's cases are too small to reach the matrix-core backward (csrc/corr_mfma.h serves >= 8192 pixels, C % 16 == 0,
+    W % 4 == 0, H >= 4 d), so nothing from the REFERENCE pinned it.  The reference's own corr_naive + autograd (pwc_tf.py:97-106) at three served
+    shapes: d = 8 on a 64 x 128 map, d = 8 with a ragged last 16-pixel segment (116 = 7 x 16 + 4) and a row count that is no multiple of the
+    kernel's chunk, d = 4 (the form on request).  Inputs and the upstream gradient come from the seeds stored here (tests re-draw them with the
+    same numpy PCG64 streams); the file holds only the reference's two gradients per case and a strided sample of its cost volume."""
+    out = {}
+    pwc = PWC_tf()
+    cases = [(8, 1, 16, 64, 128), (8, 1, 16, 72, 116), (4, 1, 16, 64, 128)]
+    out['cases'] = np.array(cases, np.int64)
+    out['seeds'] = np.array([[1100 + k, 1200 + k, 1300 + k] for k in range(len(cases))], np.int64)
+    for k, (d, B, C, h, w) in enumerate(cases):
+        f1 = rnd(1100 + k, (B, C, h, w)).requires_grad_()
+        f2 = rnd(1200 + k, (B, C, h, w)).requires_grad_()
+        cv = pwc.corr_naive(f1, f2, d=d)
+        g = rnd(1300 + k, tuple(cv.shape))
+        cv.backward(g)
+        out.update({'cv_s_%d' % k: npy(cv)[:, :, ::8, ::8].copy(), 'gf1_%d' % k: npy(f1.grad), 'gf2_%d' % k: npy(f2.grad)})
+    save('g6_corr_served.npz', out)
+
+
 # ------------------------------------------------------------------ G1: warp
 def gen_warp():
     out = {}
@@ -356,8 +378,12 @@ if __name__ == '__main__':
     if sys.argv[1:] == ['loss_section']:
         gen_loss_section()
         sys.exit(0)
+    if sys.argv[1:] == ['corr_served']:
+        gen_corr_served()
+        sys.exit(0)
     torch.manual_seed(0)
     gen_corr()
+    gen_corr_served()
     gen_warp()
     gen_losses()
     gen_loss_section()

@@ -6,7 +6,7 @@
 //
 //   corr_check in.bin out.bin
 // in : int32 ncases; per case int32 kind (0: cost volume, 1: fused warp + cost volume), d, B, C, H, W, align_corners, backward mode
-//      (unflow_corr_set_backward); float f1[B,C,H,W], f2[B,C,H,W], flow[B,2,H,W] (kind 1 only), g[B,(2d+1)^2,H,W]
+//      (unflow_corr_bwd_ex's arithmetic); float f1[B,C,H,W], f2[B,C,H,W], flow[B,2,H,W] (kind 1 only), g[B,(2d+1)^2,H,W]
 // out: per case cv[B,(2d+1)^2,H,W], gf1[B,C,H,W], gf2[B,C,H,W], gflow[B,2,H,W] (kind 1 only)
 #include <cstdio>
 #include <cstdlib>
@@ -43,11 +43,10 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < ng; ++i) cv[i] = -7.f;
         for (size_t i = 0; i < n; ++i) gf1[i] = gf2[i] = -7.f;
         for (size_t i = 0; i < nf; ++i) gflow[i] = -7.f;
-        unflow_corr_set_backward(mode);
         int rc;
         if (kind == 0) {
             rc = unflow_corr_fwd(f1, f2, cv, B, C, H, W, d, nullptr);
-            if (rc == 0) rc = unflow_corr_bwd(f1, f2, g, gf1, gf2, B, C, H, W, d, nullptr);
+            if (rc == 0) rc = unflow_corr_bwd_ex(f1, f2, g, gf1, gf2, B, C, H, W, d, mode, nullptr);
         } else {
             if (!unflow_warp_corr_supported(C, H, W, d)) { printf("case %d: not served\n", k); return 1; }
             rc = unflow_warp_corr_fwd(f1, f2, flow, cv, B, C, H, W, d, ac, nullptr);

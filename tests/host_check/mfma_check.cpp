@@ -1,5 +1,5 @@
 // The cost-volume backward on the matrix cores -- csrc/corr_mfma.h (shipped: the default at d = 8) and csrc/corr_mfma2.h (the
-// pixel-pair form that has never run on a GPU: behind unflow_corr_set_backward(3)) -- compiled for the build host with the ROCm clang++ and EXECUTED with lanes as fibers
+// pixel-pair form that has never run on a GPU: behind UNFLOW_CORR_BWD_MFMA2) -- compiled for the build host with the ROCm clang++ and EXECUTED with lanes as fibers
 // (tests/host_check/hip_on_host.h; TEST INFRASTRUCTURE, tests/test_kernels_on_host.py).  The matrix instruction is a function there that
 // gathers the 64 lanes' A / B fragments by the lane layouts of the CDNA4 ISA and forms the 16 x 16 x 32 product in fp32; buffer loads /
 // stores range-check like the hardware (the kernels' predicate); LDS is a static array.

@@ -165,15 +165,19 @@ def test_fp32_cost_volume_kernels_are_the_validated_ones():
 
 
 def test_round5_host_entry_points_without_gpu():
-    """The host-only entry points of ABI 10: the backward-arithmetic switch returns the previous mode and rejects unknown ones; the
+    """The host-only entry points of ABI 10-12: the per-call backward arithmetic of the cost volume rejects unknown values (and the process-wide
+    setter of ABI 10-11 is gone); the
     partial-sum counts that ``unflow_loss_finalize_batch`` jobs are described with follow the kernels' tilings (masked mean /
     consistency: 2048 pixels per workgroup; smoothness: 64 x 8 tiles; SSIM loss: 124-column strips x 8- or 16-row chunks when every
     tensor is 8-byte aligned and the width even) and never exceed the scratch ``unflow_partials_per_sample`` sizes."""
     from unopticalflow_amd import _lib
     lib = ctypes.CDLL(_lib.LIB_PATH)
-    assert lib.unflow_corr_set_backward(2) == 0 and lib.unflow_corr_set_backward(1) == 2 and lib.unflow_corr_set_backward(0) == 1
-    assert lib.unflow_corr_set_backward(3) == 0 and lib.unflow_corr_set_backward(0) == 3                     # (3: the pixel-pair matrix-core form)
-    assert lib.unflow_corr_set_backward(4) == -22 and lib.unflow_corr_set_backward(-1) == -22 and lib.unflow_corr_set_backward(0) == 0
+    assert not hasattr(lib, 'unflow_corr_set_backward')          # ABI 12: the arithmetic is an argument of unflow_corr_bwd_ex, the library keeps no mode
+    one = ctypes.c_void_p(16)                                      # (argument checks come before any launch: a non-NULL dummy pointer is never touched)
+    lib.unflow_corr_bwd_ex.argtypes = _lib.SIGNATURES['unflow_corr_bwd_ex']
+    for bad in (-1, 4, 7):
+        assert lib.unflow_corr_bwd_ex(one, one, one, one, one, 1, 16, 8, 8, 4, bad, None) == -22
+    assert lib.unflow_corr_bwd_ex(None, one, one, one, one, 1, 16, 8, 8, 4, 0, None) == -22
     cdiv = lambda a, b: (a + b - 1) // b
     for H, W in ((256, 832), (128, 416), (64, 208), (33, 57), (448, 1024), (1, 1)):
         per_sample = lib.unflow_partials_per_sample(H, W) // 2

@@ -53,6 +53,31 @@ def test_corr_golden(ops, golden):
         close(f2.grad, g['gf2_%d' % k], rtol=1e-5, atol=2e-6, what='corr gf2 case %d' % k)
 
 
+@pytest.mark.parametrize('backward', ['auto', 'fp32', 'mfma'])
+@pytest.mark.parametrize('k', [0, 1, 2])
+def test_corr_golden_at_matrix_core_shapes(ops, golden, k, backward):
+    """the REFERENCE's gradients (tests/golden/g6_corr_served.npz, gen_golden.py corr_served: pwc_tf.py:97-106 through autograd)
+    at shapes the matrix-core backward serves -- d = 8 [1,16,64,128], d = 8 with a ragged last segment [1,16,72,116], d = 4 [1,16,64,128] -- for
+    every arithmetic a caller can ask for.  Bars: the fp32 kernels at test_corr_golden's; the matrix-core form at north_star's 1e-4 relative + 1e-5
+    of the fixture's largest gradient (a sum of (2d+1)^2 signed products cancels: an element near zero has no relative accuracy in ANY fp32 order)."""
+    g = golden('g6_corr_served.npz')
+    d, B, C, h, w = (int(v) for v in g['cases'][k])
+    s1, s2, s3 = (int(v) for v in g['seeds'][k])
+    f1, f2 = dev(rnd(s1, (B, C, h, w))).requires_grad_(), dev(rnd(s2, (B, C, h, w))).requires_grad_()
+    cv = ops.corr(f1, f2, d, backward=backward)
+    close(cv[:, :, ::8, ::8], g['cv_s_%d' % k], rtol=1e-5, atol=2e-6, what='corr fwd case %d' % k)
+    cv.backward(dev(rnd(s3, tuple(cv.shape))))
+    amax = max(float(np.abs(g['gf1_%d' % k]).max()), float(np.abs(g['gf2_%d' % k]).max()))
+    rtol, atol = (1e-4, 1e-5 * amax) if backward == 'mfma' else (1e-5, 5e-6)
+    if backward == 'auto':                       # whatever the library picks by itself holds the tighter bar or is the matrix-core form
+        ref1 = dev(rnd(s1, (B, C, h, w))).requires_grad_(); ref2 = dev(rnd(s2, (B, C, h, w))).requires_grad_()
+        ops.corr(ref1, ref2, d, backward='fp32').backward(dev(rnd(s3, tuple(cv.shape))))
+        if not (torch.equal(ref1.grad, f1.grad) and torch.equal(ref2.grad, f2.grad)):
+            rtol, atol = 1e-4, 1e-5 * amax
+    close(f1.grad, g['gf1_%d' % k], rtol=rtol, atol=atol, what='corr gf1 case %d (%s)' % (k, backward))
+    close(f2.grad, g['gf2_%d' % k], rtol=rtol, atol=atol, what='corr gf2 case %d (%s)' % (k, backward))
+
+
 @pytest.mark.parametrize('d,C,h,w', [(4, 32, 64, 208), (4, 64, 32, 104), (4, 96, 16, 52), (4, 128, 8, 26),
                                      (4, 196, 4, 13), (8, 32, 32, 104), (3, 6, 10, 70), (2, 9, 17, 130),
                                      (1, 4, 5, 5), (0, 3, 4, 6), (4, 3, 23, 97), (4, 17, 9, 129)])
@@ -142,34 +167,29 @@ def test_corr_small_map_backward(ops, B, C, h, w):
                                        (4, 4, 48, 21, 100), (8, 16, 32, 64, 208), (8, 12, 64, 32, 104)])          # (two more d = 8 shapes: tests/test_zz_round5_gpu.py)
 def test_corr_backward_on_the_matrix_cores(ops, d, B, C, h, w):
     """Round 5 (csrc/corr_mfma.h): the cost-volume backward as banded bf16 hi/lo split products on v_mfma_f32_16x16x32_bf16 -- the
-    default at d = 8, on request at d = 4 -- against the oracle's autograd of corr_naive (pwc_tf.py:97-106) at the pyramid shapes of
+    chosen per call (ops.corr(..., backward='mfma') -> unflow_corr_bwd_ex) -- against the oracle's autograd of corr_naive (pwc_tf.py:97-106) at the pyramid shapes of
     832x256 and 1024x448, ragged last segments (w % 16 != 0), row counts that are not a multiple of the chunk, 16 / 48 channels.
     Bars: north_star's 1e-4 relative (+ 1e-5 of the largest gradient: a sum of (2d+1)^2 signed products cancels); the kernel is
-    measured at ~4e-6 of the largest gradient from the fp32 sums.  Deterministic: two launches agree bit for bit; 'fp32' mode
-    restores the fp32 kernels' bits."""
+    measured at ~4e-6 of the largest gradient from the fp32 sums.  Deterministic: two launches agree bit for bit; backward='fp32'
+    gives the fp32 kernels' bits."""
     o = corr_case(d, B, C, h, w)          # (the case of test_corr_large_map_paths / test_corr_d8_large_map_paths where the shapes coincide: one oracle evaluation)
     f1c, f2c, gout = o['f1'], o['f2'], o['gout']
     amax = max(o['gf1'].abs().max().item(), o['gf2'].abs().max().item())
-    lib = __import__('unopticalflow_amd._lib', fromlist=['load']).load()
-    prev = ops.set_corr_backward('mfma')
-    try:
-        runs = []
-        for _ in range(2):
-            f1, f2 = dev(f1c).requires_grad_(), dev(f2c).requires_grad_()
-            ops.corr(f1, f2, d).backward(dev(gout))
-            close(f1.grad, o['gf1'], rtol=1e-4, atol=1e-5 * amax, what='gf1')
-            close(f2.grad, o['gf2'], rtol=1e-4, atol=1e-5 * amax, what='gf2')
-            runs.append((f1.grad.clone(), f2.grad.clone()))
-        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
-        # the split keeps ~16 bits per factor: clearly away from the fp32 kernels' bits, clearly inside a tenth of the bar
-        assert ops.set_corr_backward('fp32') == 'mfma'
+    runs = []
+    for _ in range(2):
         f1, f2 = dev(f1c).requires_grad_(), dev(f2c).requires_grad_()
-        ops.corr(f1, f2, d).backward(dev(gout))
-        err = max((f1.grad - runs[0][0]).abs().max().item(), (f2.grad - runs[0][1]).abs().max().item())
-        assert 0 < err < 1e-5 * amax, (err, amax)
-    finally:
-        ops.set_corr_backward(prev)
-    assert lib.unflow_corr_set_backward(7) == -22
+        ops.corr(f1, f2, d, backward='mfma').backward(dev(gout))
+        close(f1.grad, o['gf1'], rtol=1e-4, atol=1e-5 * amax, what='gf1')
+        close(f2.grad, o['gf2'], rtol=1e-4, atol=1e-5 * amax, what='gf2')
+        runs.append((f1.grad.clone(), f2.grad.clone()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    # the split keeps ~16 bits per factor: clearly away from the fp32 kernels' bits, clearly inside a tenth of the bar
+    f1, f2 = dev(f1c).requires_grad_(), dev(f2c).requires_grad_()
+    ops.corr(f1, f2, d, backward='fp32').backward(dev(gout))
+    err = max((f1.grad - runs[0][0]).abs().max().item(), (f2.grad - runs[0][1]).abs().max().item())
+    assert 0 < err < 1e-5 * amax, (err, amax)
+    with pytest.raises(ValueError):
+        ops.corr(f1, f2, d, backward='fp16')
 
 
 def test_corr_shape_mismatch_asserts(ops):

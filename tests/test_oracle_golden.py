@@ -28,6 +28,25 @@ def test_corr_values_and_grads(golden):
         close(f2.grad, g['gf2_%d' % k])
 
 
+def _rnd(seed, shape):
+    return T(np.random.default_rng(int(seed)).standard_normal(shape).astype(np.float32))
+
+
+@pytest.mark.parametrize('k', [0, 1, 2])
+def test_corr_at_matrix_core_shapes(golden, k):
+    """g6_corr_served.npz: the reference's corr_naive + autograd (pwc_tf.py:97-106) at shapes the matrix-core backward serves (d = 8 and 4, >= 8192
+    pixels, 16 channels, a ragged last segment); inputs re-drawn from the stored seeds.  The oracle reproduces the reference to rounding."""
+    g = golden('g6_corr_served.npz')
+    d, B, C, h, w = (int(v) for v in g['cases'][k])
+    s1, s2, s3 = g['seeds'][k]
+    f1, f2 = _rnd(s1, (B, C, h, w)).requires_grad_(), _rnd(s2, (B, C, h, w)).requires_grad_()
+    cv = R.corr_naive(f1, f2, d)
+    close(cv[:, :, ::8, ::8], g['cv_s_%d' % k])
+    cv.backward(_rnd(s3, tuple(cv.shape)))
+    close(f1.grad, g['gf1_%d' % k], atol=2e-6)
+    close(f2.grad, g['gf2_%d' % k], atol=2e-6)
+
+
 def test_corr_shape_mismatch_asserts():
     with pytest.raises(AssertionError):          # pwc_tf.py:99
         R.corr_naive(torch.zeros(1, 2, 4, 4), torch.zeros(1, 2, 4, 5))

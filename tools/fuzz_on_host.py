@@ -8,7 +8,7 @@ fibers:
   ms     ops.multiscale_losses (1-4 scales, B 1-3, even widths 4-90, heights 3-40, flat / zeroed regions, both consistency forms, inside and
          outside deferred_loss_sums) == the scale-by-scale operators BIT FOR BIT in every loss, saved sum and gradient
   warp   ops.warp_flow_masked_pyramid == ops.warp_flow_masked per scale bit for bit, forward and flow gradient, both conventions, five flow kinds
-  mfma2  the pixel-pair matrix-core cost-volume backward (ops.set_corr_backward('mfma2'), never run on a GPU) against the oracle's autograd of
+  mfma2  the pixel-pair matrix-core cost-volume backward (ops.corr(..., backward='mfma2'), never run on a GPU) against the oracle's autograd of
          corr_naive at the GPU test's bar, at shapes the dispatch serves (W % 4 == 0, C % 16 == 0, >= 8192 pixels, H >= 4 d), d = 4 and 8
   corr   the fp32 cost volume through its dispatch at random shapes (any W, C), d in {1, 2, 4, 8}, against the oracle at the GPU tests' bars
   fused  ops.warp_corr (the fused warp + cost volume, W % 4 == 0) against corr_naive(f1, warp_flow(f2, flow)) forward and backward, five flow kinds
@@ -123,13 +123,9 @@ def _corr_against_oracle(rng, d, B, C, h, w, mode, rtol, atol_of):
     cv_ref = R.corr_naive(f1c, f2c, d)
     gout = tensor(rng, tuple(cv_ref.shape), 0.05 if mode else 1.0)
     cv_ref.backward(gout)
-    prev = ops.set_corr_backward(mode or 'auto')
-    try:
-        f1, f2 = f1c.detach().clone().requires_grad_(), f2c.detach().clone().requires_grad_()
-        cv = ops.corr(f1, f2, d)
-        cv.backward(gout)
-    finally:
-        ops.set_corr_backward(prev)
+    f1, f2 = f1c.detach().clone().requires_grad_(), f2c.detach().clone().requires_grad_()
+    cv = ops.corr(f1, f2, d, backward=mode or 'auto')
+    cv.backward(gout)
     amax = max(float(f1c.grad.abs().max()), float(f2c.grad.abs().max()))
     if not np.allclose(cv.detach().numpy(), cv_ref.detach().numpy(), rtol=1e-5, atol=2e-6):
         return 'forward off by %g' % float((cv - cv_ref).abs().max())

@@ -197,9 +197,8 @@ def corr_bwd_mf(B=16):
             ref = {}
 
             def run(tag, mode):
-                lib.unflow_corr_set_backward(mode)
                 gf1.fill_(float('nan')); gf2.fill_(float('nan'))
-                tb = timeit(lambda: lib.unflow_corr_bwd(P(f1), P(f2), P(g), P(gf1), P(gf2), Bq, C, h, w, d, ops._stream()), n=30)
+                tb = timeit(lambda: lib.unflow_corr_bwd_ex(P(f1), P(f2), P(g), P(gf1), P(gf2), Bq, C, h, w, d, mode, ops._stream()), n=30)
                 if not ref:
                     ref['a'], ref['b'] = gf1.clone(), gf2.clone()
                 err = max((gf1 - ref['a']).abs().max().item(), (gf2 - ref['b']).abs().max().item())
@@ -210,7 +209,6 @@ def corr_bwd_mf(B=16):
                 _sweep([{'UNFLOW_CORR_MF_ROWS': r} for r in (8, 16, 32, 64)], lambda tag: run('mfma ' + tag, 2))
             else:
                 run('mfma (shipped pick)', 2)
-            lib.unflow_corr_set_backward(0)
 
 
 def ablate(B=16):

@@ -24,7 +24,7 @@ SIGNATURES = {
     'unflow_partials_per_sample': [_I, _I],
     'unflow_corr_fwd': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     'unflow_corr_bwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    'unflow_corr_set_backward': [_I],
+    'unflow_corr_bwd_ex': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'unflow_warp_fwd': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'unflow_warp_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'unflow_warp_bwd_det': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -124,7 +124,7 @@ class UnflowLibraryError(RuntimeError):
 # The ABI this file's SIGNATURES table was written for.  Bump it together with UNFLOW_ABI_VERSION of include/unflow_hip.h whenever an
 # entry point changes: load() wants library == header == this number, so a header bump + rebuild with a stale ctypes table is caught
 # (reading the number from the header alone only detects a stale .so).
-BINDING_ABI = 11
+BINDING_ABI = 12
 
 
 def _abi_version():

@@ -30,6 +30,7 @@ class PWC_tf(nn.Module):
         self.fused_head = True            # flow heads: bias + NHWC -> NCHW + residual as one kernel each way (ops.flow_head)
         self.fused_upsample = True        # flow up-sampling + its scale factor as one kernel each way (ops.upsample_bilinear_scaled)
         self.corr = self.corr_naive
+        self.corr_backward = 'auto'       # arithmetic of the cost volume's backward pass, per module (ops.CORR_BACKWARD_MODES; bench.py --corr-bwd)
         # True: warp + cost volume of a level as ONE kernel (ops.warp_corr; the warped features never reach HBM).
         # Measured on MI355X (profiles/r2_v1_bench_fused1.json): at parity with the two separate kernels at level 2 and
         # slower below it -- the cost-volume kernel is LDS/VALU-bound, so the warp stage adds to the bound resource --
@@ -94,7 +95,7 @@ class PWC_tf(nn.Module):
     def corr_naive(self, input1, input2, d=4):
         """Same contract as the reference's corr_naive (pwc_tf.py:97-106); one HIP kernel (fp32 accumulation;
         bf16 features of an autocast run are widened first)."""
-        return ops.corr(input1.float(), input2.float(), d)
+        return ops.corr(input1.float(), input2.float(), d, backward=self.corr_backward)
 
     def _decoder(self, lvl, x, residual=None):
         """``x``: the tuple of tensors the reference concatenates into the decoder input.

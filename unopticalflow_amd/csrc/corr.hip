@@ -21,7 +21,6 @@
 #include "corr_ring.h"
 #include "corr_mfma.h"
 #include "corr_mfma2.h"
-#include <atomic>
 #include <stdlib.h>
 #include <utility>
 
@@ -1446,9 +1445,8 @@ static inline int forced_groups() { return 0; }
 
 static inline bool mid_size(int variant) { return variant == 9 || variant == 12 || variant == 13; }   // levels 3, 4
 
-// The backward on the matrix cores (corr_mfma.h): 0 = where it measured faster (d = 8), 1 = never (fp32 kernels, bit-identical to
-// rounds 1-4), 2 = wherever the shape is served (d = 4 too).  Process-wide, read once per call.
-static std::atomic<int> g_bwd_mfma_mode{0};
+// The backward on the matrix cores (corr_mfma.h) is chosen PER CALL (unflow_corr_bwd_ex's `arithmetic`, include/unflow_hip.h): the library keeps
+// no mode of its own.  UNFLOW_CORR_BWD_AUTO = what passed a whole `-m gpu` run on an MI355X for the shape.
 static bool mfma_served(const float* f1, const float* f2, const float* g, const float* gf1, const float* gf2, int B, int C, int H, int W, int R) {
     return (W & 3) == 0 && (C & 15) == 0 && (long)B * H * W >= 8192 && W >= 16 && H >= 4 * R      // (level 4 at d = 8, 16 rows: 50 us against 47 for the fp32 kernel)
            && ((((size_t)f1 | (size_t)f2 | (size_t)g | (size_t)gf1 | (size_t)gf2) & 15) == 0) && mf_offsets_fit(C, H, W, R);
@@ -1541,9 +1539,14 @@ extern "C" int unflow_corr_fwd(const float* f1, const float* f2, float* cv, int 
     return unflow_launch_status();
 }
 
-extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gcv, float* gf1, float* gf2,
-                               int B, int C, int H, int W, int d, void* stream) {
+// d = 8 under UNFLOW_CORR_BWD_AUTO: the matrix-core kernel where it is served (round 5: 150-158 us against 245-272 at level 2).  false until the
+// kernel has passed a complete `-m gpu` run at the reference-generated fixture (tests/golden/g6_corr_d8.npz); UNFLOW_CORR_BWD_MFMA asks for it.
+static constexpr bool kAutoMatrixCoresAtD8 = false;
+
+extern "C" int unflow_corr_bwd_ex(const float* f1, const float* f2, const float* gcv, float* gf1, float* gf2,
+                                  int B, int C, int H, int W, int d, int arithmetic, void* stream) {
     UNFLOW_REQUIRE(f1 && f2 && gcv && gf1 && gf2 && B > 0 && C > 0 && H > 0 && W > 0 && d >= 0);
+    UNFLOW_REQUIRE(arithmetic >= UNFLOW_CORR_BWD_AUTO && arithmetic <= UNFLOW_CORR_BWD_MFMA2);
     hipStream_t s = (hipStream_t)stream;
     int variant = 4;
     switch (d) {
@@ -1552,11 +1555,11 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
         case 4: {
                 variant = pick_variant(B, C, H, W);
                 // matrix-core form (corr_mfma.h): at d = 4 level 2 it measures level with the fp32 row-streamed kernel back to back
-                // (59 vs 57 us), so it is taken only on request (unflow_corr_set_backward(2))
-                if (g_bwd_mfma_mode.load(std::memory_order_relaxed) == 2 && mfma_served(f1, f2, gcv, gf1, gf2, B, C, H, W, 4))
+                // (59 vs 57 us), so it is taken only on request (UNFLOW_CORR_BWD_MFMA)
+                if (arithmetic == UNFLOW_CORR_BWD_MFMA && mfma_served(f1, f2, gcv, gf1, gf2, B, C, H, W, 4))
                     return launch_bwd_mf<4, 2, 1, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, mfma_rows(B, C, H, W, 2, 4), s);
                 // (3: the pixel-pair form of the same sums, corr_mfma2.h -- 11 instead of 27 load instructions per step; host-checked, NOT measured)
-                if (g_bwd_mfma_mode.load(std::memory_order_relaxed) == 3 && mfma_served(f1, f2, gcv, gf1, gf2, B, C, H, W, 4))
+                if (arithmetic == UNFLOW_CORR_BWD_MFMA2 && mfma_served(f1, f2, gcv, gf1, gf2, B, C, H, W, 4))
                     return launch_bwd_mf2<4, 2, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, mfma_rows(B, C, H, W, 2, 4), s);
                 const bool ring_ok = (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0)     // LDS-DMA moves aligned 16-byte pieces
                                      && gs_offsets_fit(C, H, W, 4);
@@ -1607,9 +1610,9 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
         case 8: variant = pick_variant(B, C, H, W);
                 // round 5: banded bf16x3 products on the matrix cores: level 2 149 us against 271 for the fp32 row-streamed kernel
                 // (tools/proto/corr_bwd_mfma.hip); ~4e-6 of the largest gradient away from the fp32 sums
-                if (g_bwd_mfma_mode.load(std::memory_order_relaxed) == 3 && mfma_served(f1, f2, gcv, gf1, gf2, B, C, H, W, 8))
+                if (arithmetic == UNFLOW_CORR_BWD_MFMA2 && mfma_served(f1, f2, gcv, gf1, gf2, B, C, H, W, 8))
                     return launch_bwd_mf2<8, 2, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, mfma_rows(B, C, H, W, 2, 8), s);
-                if (g_bwd_mfma_mode.load(std::memory_order_relaxed) != 1 && mfma_served(f1, f2, gcv, gf1, gf2, B, C, H, W, 8))
+                if ((arithmetic == UNFLOW_CORR_BWD_MFMA || (arithmetic == UNFLOW_CORR_BWD_AUTO && kAutoMatrixCoresAtD8)) && mfma_served(f1, f2, gcv, gf1, gf2, B, C, H, W, 8))
                     return launch_bwd_mf<8, 2, 2, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, mfma_rows(B, C, H, W, 2, 8), s);
                 if (variant == 4 || (long)B * H * W < 8192) break;      // small maps: one lane per element (117 / 57 us at levels 5 / 6, tile kernel 283 / 378)
                 if ((variant == 7 || mid_size(variant)) && (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0) && gs_offsets_fit(C, H, W, 8)) {
@@ -1625,7 +1628,7 @@ extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gc
     return unflow_launch_status();
 }
 
-extern "C" int unflow_corr_set_backward(int mode) {
-    if (mode < 0 || mode > 3) return UNFLOW_EINVAL;
-    return g_bwd_mfma_mode.exchange(mode, std::memory_order_relaxed);
+extern "C" int unflow_corr_bwd(const float* f1, const float* f2, const float* gcv, float* gf1, float* gf2,
+                               int B, int C, int H, int W, int d, void* stream) {
+    return unflow_corr_bwd_ex(f1, f2, gcv, gf1, gf2, B, C, H, W, d, UNFLOW_CORR_BWD_AUTO, stream);
 }

@@ -69,11 +69,11 @@ def _dev(*tensors):
     return dev
 
 
-def _call(name, *args, nbytes=0, shape=None):
+def _call(name, *args, nbytes=0, shape=None, label=None):
     """Call one C entry point.  ``nbytes`` = algorithmic HBM bytes of the launch (include/unflow_hip.h,
-    DESIGN.md section 3); only used when bench.py's kernel timing is on."""
+    DESIGN.md section 3); only used when bench.py's kernel timing is on (``label``: the row the launch is timed under, default the name)."""
     lib = _lib.load()
-    if kernel_timer.names is not None and (kernel_timer.names is True or name in kernel_timer.names):
+    if kernel_timer.names is not None and (kernel_timer.names is True or (label or name) in kernel_timer.names):
         slot = lib.unflow_timing_begin()
         if slot < 0:
             raise RuntimeError('unflow_timing_begin failed (%d)' % slot)
@@ -81,7 +81,7 @@ def _call(name, *args, nbytes=0, shape=None):
             _lib.check(getattr(lib, name)(*args), name)
         finally:
             lib.unflow_timing_end()
-        kernel_timer.table.setdefault((name, shape), []).append((slot, nbytes))
+        kernel_timer.table.setdefault((label or name, shape), []).append((slot, nbytes))
         return
     _lib.check(getattr(lib, name)(*args), name)
 
@@ -309,9 +309,16 @@ def _partials(B, H, W, dev):
 # ------------------------------------------------------------------------------------------
 # cost volume
 # ------------------------------------------------------------------------------------------
+# arithmetic of the cost-volume backward, chosen PER CALL (include/unflow_hip.h UNFLOW_CORR_BWD_*; the library keeps no mode): 'auto' = per
+# shape, the fastest kernel that has passed a complete GPU parity run; 'fp32' = the fp32 FMA kernels everywhere; 'mfma' = banded bf16 hi/lo
+# split products on the matrix cores (fp32 accumulation; ~4e-6 of the largest gradient away from the fp32 sums, deterministic) wherever the
+# shape is served; 'mfma2' = its pixel-pair variant (csrc/corr_mfma2.h)
+CORR_BACKWARD_MODES = {'auto': 0, 'fp32': 1, 'mfma': 2, 'mfma2': 3}
+
+
 class _Corr(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, f1, f2, d):
+    def forward(ctx, f1, f2, d, arithmetic=0):
         _dev(f1, f2)
         f1, f2 = f1.contiguous(), f2.contiguous()
         B, C, H, W = f1.shape
@@ -321,6 +328,7 @@ class _Corr(torch.autograd.Function):
                   nbytes=4 * B * H * W * (2 * C + (2 * d + 1) ** 2), shape=(B, C, H, W))          # f1, f2 once, write cv once
         ctx.save_for_backward(f1, f2)
         ctx.d = d
+        ctx.arithmetic = arithmetic
         return cv
 
     @staticmethod
@@ -330,30 +338,22 @@ class _Corr(torch.autograd.Function):
         g = g.contiguous()
         gf1, gf2 = torch.empty_like(f1), torch.empty_like(f2)
         with _on(f1.device):
-            _call('unflow_corr_bwd', _ptr(f1), _ptr(f2), _ptr(g), _ptr(gf1), _ptr(gf2), B, C, H, W, ctx.d,
-                  _stream(), nbytes=4 * B * H * W * (4 * C + (2 * ctx.d + 1) ** 2), shape=(B, C, H, W))
-        return gf1, gf2, None
+            if ctx.arithmetic == 0:
+                _call('unflow_corr_bwd', _ptr(f1), _ptr(f2), _ptr(g), _ptr(gf1), _ptr(gf2), B, C, H, W, ctx.d,
+                      _stream(), nbytes=4 * B * H * W * (4 * C + (2 * ctx.d + 1) ** 2), shape=(B, C, H, W))
+            else:
+                _call('unflow_corr_bwd_ex', _ptr(f1), _ptr(f2), _ptr(g), _ptr(gf1), _ptr(gf2), B, C, H, W, ctx.d, ctx.arithmetic,
+                      _stream(), nbytes=4 * B * H * W * (4 * C + (2 * ctx.d + 1) ** 2), shape=(B, C, H, W), label='unflow_corr_bwd')
+        return gf1, gf2, None, None
 
 
-CORR_BACKWARD_MODES = {'auto': 0, 'fp32': 1, 'mfma': 2, 'mfma2': 3}
-
-
-def set_corr_backward(mode):
-    """Which arithmetic the cost-volume backward uses where two exist (unflow_corr_set_backward; process-wide): 'auto' = the
-    matrix-core form (banded bf16 hi/lo split products, fp32 accumulation; ~4e-6 of the largest gradient away from the fp32 sums,
-    deterministic) where it measured faster (d = 8); 'fp32' = the fp32 FMA kernels everywhere; 'mfma' = the matrix-core form
-    wherever the shape is served; 'mfma2' = its pixel-pair variant (csrc/corr_mfma2.h; checked on the build host, not measured yet) wherever served.
-    Returns the previous mode's name."""
-    prev = _lib.load().unflow_corr_set_backward(CORR_BACKWARD_MODES[mode])
-    if prev < 0:
-        raise ValueError(mode)
-    return {v: k for k, v in CORR_BACKWARD_MODES.items()}[prev]
-
-
-def corr(input1, input2, d=4):
-    """Cost volume, PWC_tf.corr_naive (pwc_tf.py:97-106): [B,C,H,W] x2 -> [B,(2d+1)^2,H,W]."""
+def corr(input1, input2, d=4, backward='auto'):
+    """Cost volume, PWC_tf.corr_naive (pwc_tf.py:97-106): [B,C,H,W] x2 -> [B,(2d+1)^2,H,W].  ``backward``: the arithmetic of THIS
+    call's backward pass (CORR_BACKWARD_MODES; ValueError for an unknown name)."""
     assert (input1.shape == input2.shape)            # pwc_tf.py:99
-    return _Corr.apply(input1, input2, int(d))
+    if backward not in CORR_BACKWARD_MODES:
+        raise ValueError('backward must be one of %s, got %r' % (sorted(CORR_BACKWARD_MODES), backward))
+    return _Corr.apply(input1, input2, int(d), CORR_BACKWARD_MODES[backward])
 
 
 # ------------------------------------------------------------------------------------------
