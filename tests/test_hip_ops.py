@@ -95,23 +95,26 @@ def test_corr_vs_oracle(ops, d, C, h, w):
     close(f2.grad, f2c.grad, rtol=1e-5, atol=5e-6)
 
 
+@pytest.mark.parametrize('backward', ['auto', 'mfma'])
 @pytest.mark.parametrize('C,h,w', [(32, 64, 208), (64, 32, 104), (96, 16, 52), (128, 8, 26), (196, 4, 13)])
-def test_corr_d8_full_pyramid(ops, C, h, w):
+def test_corr_d8_full_pyramid(ops, C, h, w, backward):
     """BASELINE config 5: d=8 cost volume (289 planes) on every pyramid-level shape of 832x256."""
     f1c, f2c = rnd(8, (2, C, h, w)).requires_grad_(), rnd(9, (2, C, h, w)).requires_grad_()
     cv_ref = R.corr_naive(f1c, f2c, 8)
     gout = rnd(10, tuple(cv_ref.shape))
     cv_ref.backward(gout)
     f1, f2 = dev(f1c.detach()).requires_grad_(), dev(f2c.detach()).requires_grad_()
-    cv = ops.corr(f1, f2, 8)
+    cv = ops.corr(f1, f2, 8, backward=backward)
     assert cv.shape[1] == 289
     close(cv, cv_ref, rtol=1e-5, atol=2e-6)
     cv.backward(dev(gout))
-    # round 5: maps of >= 8192 pixels with C % 16 == 0 take the matrix-core backward (bf16 hi/lo split products, ~4e-6 of the LARGEST
-    # gradient from the fp32 sums -- a sum of 289 signed products cancels, so the absolute part of the bar scales with that largest value)
+    # 'auto' (what Model_flow runs): the bar of rounds 1-4.  'mfma': maps of >= 8192 pixels with C % 16 == 0 take the matrix-core backward (bf16
+    # hi/lo split products, ~4e-6 of the LARGEST gradient from the fp32 sums -- a sum of 289 signed products cancels, so the absolute part of that
+    # arithmetic's bar scales with the largest value; the round-5 GPU run had 1 of 851,968 elements at 1.16e-5 absolute under the fixed 1e-5)
     amax = max(1.0, f1c.grad.abs().max().item(), f2c.grad.abs().max().item())
-    close(f1.grad, f1c.grad, rtol=1e-4, atol=1e-5 * amax)
-    close(f2.grad, f2c.grad, rtol=1e-4, atol=1e-5 * amax)
+    atol = 1e-5 * amax if backward == 'mfma' else 1e-5
+    close(f1.grad, f1c.grad, rtol=1e-4, atol=atol)
+    close(f2.grad, f2c.grad, rtol=1e-4, atol=atol)
 
 
 @pytest.mark.parametrize('B,C,h,w', [(16, 32, 64, 208), (8, 32, 112, 256), (5, 7, 100, 268), (12, 64, 32, 104),
@@ -133,18 +136,20 @@ def test_corr_large_map_paths(ops, B, C, h, w):
     close(f2.grad, o['gf2'], rtol=1e-5, atol=max(5e-6, 1e-6 * amax))
 
 
+@pytest.mark.parametrize('backward', ['auto', 'mfma'])
 @pytest.mark.parametrize('B,C,h,w', [(16, 32, 64, 208), (5, 7, 100, 268), (3, 2, 40, 72), (12, 64, 32, 104), (16, 96, 16, 52)])
-def test_corr_d8_large_map_paths(ops, B, C, h, w):
+def test_corr_d8_large_map_paths(ops, B, C, h, w, backward):
     """d=8 (BASELINE config 5) at the batch the step uses (2B=16): the LDS-DMA ring forward with 17 displacement
     rows split over workgroups (4 or 3 rows each, the last group partial), ragged tiles, odd channel counts."""
     o = corr_case(8, B, C, h, w)
     f1, f2 = dev(o['f1']).requires_grad_(), dev(o['f2']).requires_grad_()
-    cv = ops.corr(f1, f2, 8)
+    cv = ops.corr(f1, f2, 8, backward=backward)
     close(cv, o['cv'], rtol=1e-5, atol=2e-6)
     cv.backward(dev(o['gout']))
     amax = max(1.0, o['gf1'].abs().max().item(), o['gf2'].abs().max().item())      # (as in test_corr_d8_full_pyramid)
-    close(f1.grad, o['gf1'], rtol=1e-4, atol=1e-5 * amax)
-    close(f2.grad, o['gf2'], rtol=1e-4, atol=1e-5 * amax)
+    atol = 1e-5 * amax if backward == 'mfma' else 1e-5
+    close(f1.grad, o['gf1'], rtol=1e-4, atol=atol)
+    close(f2.grad, o['gf2'], rtol=1e-4, atol=atol)
 
 
 @pytest.mark.parametrize('B,C,h,w', [(16, 128, 8, 26), (16, 196, 4, 13), (3, 5, 7, 11), (1, 2, 30, 34), (2, 1, 3, 3), (4, 128, 14, 32)])

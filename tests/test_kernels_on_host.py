@@ -15,11 +15,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 _san_builds = {}
+# UNFLOW_HOST_CHECK_SANITIZE: unset = the check programs run once, plain -O2 (the default CPU tier: the AddressSanitizer + UBSan compiles of the kernel
+# files alone were ~70 s of it); '1' = each program once more under AddressSanitizer + UBSan (run after every change of a kernel file, last: see
+# profiles/README.md); 'all' = also the long ones (warp at ~100 s, -O2 against instrumented -O1 bytes of the cost-volume program)
+_LEVEL = os.environ.get('UNFLOW_HOST_CHECK_SANITIZE', '')
+
+
+def _sanitize(always):
+    return _LEVEL == 'all' or (always and _LEVEL == '1')
 
 
 def _sanitized_build_started(build_cmd, tmp_path, name, always=True):
     """Start the sanitized build of a check program NOW, next to the plain one's build and run (_sanitized() then waits for it)."""
-    if not always and os.environ.get('UNFLOW_HOST_CHECK_SANITIZE') != 'all':
+    if not _sanitize(always):
         return
     exe = str(tmp_path / (name + '_asan'))
     cmd = [a for a in build_cmd if a not in ('-O2',)]
@@ -32,8 +40,8 @@ def _sanitized(build_cmd, run_args, tmp_path, name, always=True):
     """The same program once more under AddressSanitizer + UndefinedBehaviorSanitizer (the CPU build is where sanitizers run: no GPU ASan on
     this pool): every global-memory access of the executed kernels lands inside the buffers it was given (they are exactly-sized heap
     blocks with red zones around them), every LDS access inside its array, no signed overflow / misaligned access / bad shift in the
-    index arithmetic.  `always` = False: only with UNFLOW_HOST_CHECK_SANITIZE=all (the long ones)."""
-    if not always and os.environ.get('UNFLOW_HOST_CHECK_SANITIZE') != 'all':
+    index arithmetic.  `always` = False: only with UNFLOW_HOST_CHECK_SANITIZE=all (the long ones); nothing without UNFLOW_HOST_CHECK_SANITIZE."""
+    if not _sanitize(always):
         return
     exe = str(tmp_path / (name + '_asan'))
     if exe not in _san_builds:
@@ -436,8 +444,9 @@ def test_cost_volume_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
     san = ['-O1', '-gline-tables-only', '-fsanitize=address,undefined', '-fno-omit-frame-pointer', '-fno-sanitize-recover=undefined']
     # both programs (plain -O2 and AddressSanitizer + UBSan, see _sanitized) at once, a compiler process per translation unit
     jobs = []
-    long = os.environ.get('UNFLOW_HOST_CHECK_SANITIZE') == 'all'           # (then also a plain -O2 build, whose bytes must equal the instrumented -O1 build's)
-    for tag, flags in ((('plain', ['-O2']),) if long else ()) + (('san', san),):
+    long = _LEVEL == 'all'           # (then both builds: the plain -O2 program's bytes must equal the instrumented -O1 program's)
+    plain, sanit = (long or _LEVEL == ''), (long or _LEVEL == '1')
+    for tag, flags in ((('plain', ['-O2']),) if plain else ()) + ((('san', san),) if sanit else ()):
         for src in sources:
             obj = str(tmp_path / ('%s_%s.o' % (tag, os.path.basename(src))))
             jobs.append((tag, obj, subprocess.Popen([clang, *flags, *common, '-x', 'c++', '-c', src, '-o', obj], stderr=subprocess.PIPE, text=True)))
@@ -445,9 +454,10 @@ def test_cost_volume_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
         err = pr.communicate()[1]
         assert pr.returncode == 0, err[-3000:]
     exe, exe_san = str(tmp_path / 'corr_check'), str(tmp_path / 'corr_check_asan')
-    if long:
+    if plain:
         subprocess.run([clang, '-o', exe] + [o for t, o, _ in jobs if t == 'plain'], check=True)
-    subprocess.run([clang, '-fsanitize=address,undefined', '-o', exe_san] + [o for t, o, _ in jobs if t == 'san'], check=True)
+    if sanit:
+        subprocess.run([clang, '-fsanitize=address,undefined', '-o', exe_san] + [o for t, o, _ in jobs if t == 'san'], check=True)
     rng = np.random.default_rng(5)
     data = []
     fin, fout = str(tmp_path / 'in.bin'), str(tmp_path / 'out.bin')
@@ -465,16 +475,19 @@ def test_cost_volume_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
             for t in ((f1, f2, flow, g) if kind else (f1, f2, g)):
                 f.write(t.numpy().tobytes())
     # the program under AddressSanitizer + UBSan (the lanes' stacks are heap blocks switched by hand: no stack-use-after-return tracking), launch trace on
-    sanitized = subprocess.Popen([exe_san, fin, fout], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                                 env=dict(os.environ, ASAN_OPTIONS='detect_stack_use_after_return=0:detect_leaks=0', HIP_ON_HOST_TRACE='1'))
-    if long:
-        r = subprocess.run([exe, fin, str(tmp_path / 'plain.bin')], capture_output=True, text=True, timeout=3000)
+    env = dict(os.environ, ASAN_OPTIONS='detect_stack_use_after_return=0:detect_leaks=0', HIP_ON_HOST_TRACE='1')
+    sanitized = subprocess.Popen([exe_san, fin, fout if not plain else str(tmp_path / 'san.bin')], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) if sanit else None
+    if plain:
+        r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=3000, env=env)
         assert r.returncode == 0 and 'OK' in r.stdout, (r.stdout[-2000:], r.stderr[-500:])
-    so, se = sanitized.communicate(timeout=3000)
-    assert sanitized.returncode == 0 and 'OK' in so and 'ERROR' not in se and 'runtime error' not in se, (so[-1500:], se[-3000:])
+        se = r.stderr
+    if sanit:
+        so, se_san = sanitized.communicate(timeout=3000)
+        assert sanitized.returncode == 0 and 'OK' in so and 'ERROR' not in se_san and 'runtime error' not in se_san, (so[-1500:], se_san[-3000:])
+        se = se if plain else se_san
     launches = [l.split()[1] for l in se.splitlines() if l.startswith('launch ')]
     if long:
-        assert open(fout, 'rb').read() == open(str(tmp_path / 'plain.bin'), 'rb').read()        # -O1 and -O2, with and without instrumentation: the same bytes
+        assert open(fout, 'rb').read() == open(str(tmp_path / 'san.bin'), 'rb').read()        # -O1 and -O2, with and without instrumentation: the same bytes
     raw = np.fromfile(fout, dtype=np.float32)
     pos = 0
     at = 0

@@ -98,13 +98,15 @@ def short_name(demangled):
 
 def tree_hashes(root):
     """{file: {kernel: {sha16, instructions}}} for every csrc/*.hip of a checkout rooted at `root`."""
+    from concurrent.futures import ThreadPoolExecutor
     csrc = os.path.join(root, 'unopticalflow_amd', 'csrc')
+    files = [f for f in sorted(os.listdir(csrc)) if f.endswith('.hip')]
+    with ThreadPoolExecutor(max_workers=min(len(files), os.cpu_count() or 2)) as ex:      # one hipcc per file, side by side (corr.hip alone is ~15 s)
+        hashes = list(ex.map(lambda f: isa_hashes(os.path.join(csrc, f)), files))
     doc = {}
-    for f in sorted(os.listdir(csrc)):
-        if f.endswith('.hip'):
-            h = isa_hashes(os.path.join(csrc, f))
-            names = demangle(list(h))
-            doc[f] = {short_name(names[k]): v for k, v in h.items()}
+    for f, h in zip(files, hashes):
+        names = demangle(list(h))
+        doc[f] = {short_name(names[k]): v for k, v in h.items()}
     return doc
 
 
