@@ -124,9 +124,7 @@ ROUND5_DEVICE_CODE = {
                           'occ_weight_fwd_ms_kernel', 'absdiff_bwd_ms_kernel', 'masked_mean_partial_ms_kernel', 'masked_mean_bwd_ms_kernel',
                           'smooth2_fwd_tile_ms_kernel', 'smooth2_bwd_stage_ms_kernel', 'consis_partial_ms_kernel', 'consis_bwd_ms_kernel'}},
     'warp.hip': {'new': {'warp_fwd_ms_kernel', 'warp_bwd_ms_kernel'}},                                # the masked image warps of a pyramid; never run, off by default
-    'ssim.hip': {'new': {'ssim2_fwd_ms_kernel<false>', 'ssim2_bwd_ms_kernel'},
-                 'changed': {'ssim2_fwd_kernel<8, false>', 'ssim2_fwd_kernel<16, false>', 'ssim2_fwd_kernel<32, false>',
-                             'ssim2_bwd_kernel<8>', 'ssim2_bwd_kernel<16>', 'ssim2_bwd_kernel<32>'}},     # pair_factors: fma forms
+    'ssim.hip': {'new': {'ssim2_fwd_ms_kernel<false>', 'ssim2_bwd_ms_kernel'}},     # (round 5's fma forms of pair_factors were taken back in round 6: the six ssim2 kernels hash to round 4's)
 }
 
 
@@ -281,13 +279,13 @@ def test_pmc_traffic_carries_over_to_byte_identical_kernels(tmp_path):
     """bench.py's `roofline.traffic` comes from a committed rocprofv3 --pmc capture.  The capture names the kernels that served each entry
     and the hash of each one's instruction stream; a later build is served by it exactly when hipcc still emits those kernels byte for
     byte (the round-5 sources differ from the capture's in comments and pruned templates only: the level-2 cost-volume backward keeps its
-    measured 211.3 MB) -- and not otherwise (the SSIM kernels changed: null), nor when a hash in the file does not match."""
+    measured 211.3 MB, the SSIM loss its 113.2 MB) -- and not when a hash in the file does not match."""
     import json
     import bench
     got, note = bench.measured_traffic('unflow_corr_bwd', [16, 32, 64, 208])
     assert got == 211299925 and 'byte-identical' in note and 'corr_bwd_rs_mixed_kernel<4, 16, 2>' in note, (got, note)
-    got, note = bench.measured_traffic('unflow_ssim_loss_fwd', [16, 3, 256, 832])
-    assert got is None and 'differs' in note, (got, note)
+    got, note = bench.measured_traffic('unflow_ssim_loss_fwd', [16, 3, 256, 832])          # (round 6 took the SSIM kernels back to round 4's machine code)
+    assert got == 113197141 and 'byte-identical' in note and 'ssim2_fwd_kernel<16, false>' in note, (got, note)
     d = json.load(open(os.path.join(ROOT, 'profiles', 'r4_pmc_traffic.json')))
     d['kernel_isa']['kernels']['corr_bwd_rs_mixed_kernel<4, 16, 2>']['sha16'] = '0' * 16
     p = tmp_path / 'tampered.json'

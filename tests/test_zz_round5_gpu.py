@@ -1,6 +1,7 @@
 """GPU parity tests added in round 5 that have not yet run on an MI355X (the GPU lease was closed from outside the build before they
-could) -- kept in a file that sorts LAST so that a first run under ``-x`` reaches them after everything that has
-been validated.  Same helpers, bars and oracle as tests/test_hip_ops.py."""
+could, and stayed closed through round 6) -- kept in a file that sorts LAST so that a first run under ``-x`` reaches
+them after everything that has been validated.  Same helpers, bars and oracle as tests/test_hip_ops.py.  Tests of what the DEFAULT path
+runs (round-4 kernels under new test code) carry no mark and fail hard; tests of off-by-default paths carry test_hip_ops.UNVALIDATED."""
 import os
 import subprocess
 import sys
@@ -10,7 +11,7 @@ import pytest
 import torch
 
 from oracle import ref_cpu as R
-from test_hip_ops import T, close, dev, ops, rnd, _structured_flow      # noqa: F401  (``ops`` is the module-scoped fixture)
+from test_hip_ops import T, close, dev, ops, rnd, _structured_flow, UNVALIDATED      # noqa: F401  (``ops`` is the module-scoped fixture)
 from test_hip_ops import test_corr_backward_on_the_matrix_cores as _matrix_core_backward_case
 from oracle_cache import corr_case
 
@@ -145,6 +146,7 @@ def test_ssim_loss_flat_patches_and_edges(ops, shape):
         close(ops.ssim_loss(dev(img), dev(wp), dev(m)), R.ssim_loss(img, wp, m), rtol=1e-4, atol=5e-5, what='patch at %d, %d' % (y0, x0))
 
 
+@UNVALIDATED
 def test_deferred_loss_sums_are_the_same_bits(ops):
     """Round 5: inside ``with ops.deferred_loss_sums:`` the four per-sample loss reductions stop after their partial sums and ONE
     ``unflow_loss_finalize_batch`` launch (triggered by loss_combine, their reader) finishes all of them: values and gradients equal the
@@ -172,6 +174,7 @@ def test_deferred_loss_sums_are_the_same_bits(ops):
             assert torch.equal(a, b)
 
 
+@UNVALIDATED
 @pytest.mark.parametrize('d,B,C,h,w', [(8, 16, 96, 32, 52), (8, 6, 16, 37, 44)])
 def test_corr_backward_on_the_matrix_cores_ragged_d8(ops, d, B, C, h, w):
     """The d = 8 shapes of test_hip_ops.py::test_corr_backward_on_the_matrix_cores that had not run when the lease closed: a last
@@ -179,6 +182,7 @@ def test_corr_backward_on_the_matrix_cores_ragged_d8(ops, d, B, C, h, w):
     _matrix_core_backward_case(ops, d, B, C, h, w)
 
 
+@UNVALIDATED
 @own_process
 @pytest.mark.parametrize('B,h,w', [(2, 64, 208), (3, 60, 104), (8, 256, 832)])
 def test_multiscale_losses_are_the_same_bits(ops, B, h, w, request):
@@ -233,6 +237,7 @@ def test_multiscale_losses_are_the_same_bits(ops, B, h, w, request):
             assert torch.equal(a, b), (form, k, float((a - b).abs().max()))
 
 
+@UNVALIDATED
 @own_process
 def test_multiscale_losses_in_the_model(ops, request):
     """Model_flow.multiscale_losses: the same loss pack and the same loss-side gradients (the flows' and the warped images' come out of the
@@ -256,6 +261,7 @@ def test_multiscale_losses_in_the_model(ops, request):
     assert abs(norms[0] - norms[1]) <= 1e-3 * norms[0], norms
 
 
+@UNVALIDATED
 @own_process
 @pytest.mark.parametrize('ac', [False, True])
 def test_multiscale_image_warps_are_the_same_bits(ops, ac, request):
@@ -282,6 +288,7 @@ def test_multiscale_image_warps_are_the_same_bits(ops, ac, request):
         assert all(torch.equal(a, b) for a, b in zip(ops.warp_flow_masked_pyramid(imgs, flows0, ac), [p[0] for p in per]))
 
 
+@UNVALIDATED
 def test_fused_warp_corr_at_level_4_only(ops):
     """cfg.fused_warp_corr_levels = '4': only the 16 x 52 level takes the fused warp + cost-volume kernel (the op of
     test_fused_warp_corr_model_matches_golden, chosen per level; level 5's width 26 is not a multiple of 4, the fused kernel does not
@@ -302,6 +309,7 @@ def test_fused_warp_corr_at_level_4_only(ops):
         close(packs[1][k], packs[0][k], rtol=1e-5, what=k)
 
 
+@UNVALIDATED
 def test_pyramid_handoff_as_two_tensors_on_the_gpu(ops):
     """ops.to_nchw_split (validated kernels behind a new autograd node; wiring checked on the CPU in tests/test_ops_plumbing_cpu.py):
     values and the gradient against cat + split in torch at a pyramid level's shape, fp32 and bf16; and Model_flow.split_handoff gives
@@ -353,7 +361,7 @@ def _loss_section_flow_gradients(g, dtype):
 
 
 @own_process
-@pytest.mark.parametrize('ms', [False, True])
+@pytest.mark.parametrize('ms', [False, pytest.param(True, marks=UNVALIDATED)])
 def test_loss_section_against_the_reference_fixture(ops, golden, monkeypatch, request, ms):
     """g5_loss_section.npz -- the REFERENCE's own run of model_flow_paper.py:227-251 from given flows, on frames with saturated / dark
     flat patches and a step edge -- against Model_flow.forward from the flows on, i.e. the HIP image pyramid, masked warps, occlusion
@@ -388,6 +396,7 @@ def test_loss_section_against_the_reference_fixture(ops, golden, monkeypatch, re
     assert fl[3].grad is None
 
 
+@UNVALIDATED
 @own_process
 @pytest.mark.parametrize('d,B,C,h,w', [(4, 16, 32, 64, 208), (4, 4, 48, 21, 100), (8, 12, 64, 32, 104), (8, 6, 16, 37, 44)])
 def test_corr_backward_pixel_pair_form(ops, request, d, B, C, h, w):

@@ -43,7 +43,10 @@ class Model_flow(nn.Module):
         self.weight_shadow_groups = int(getattr(cfg, 'weight_shadow_groups', 1))     # cast nodes of the bf16 option (net_utils.WeightShadows)
         self.dup_centre = True           # the pyramid hand-off writes the centre features twice (False: torch.cat((c, c)); A/B)
         self.fused_loss_sums = True      # the sums over scales and directions of forward() as one launch each way (False: eager adds; tests compare)
-        self.deferred_loss_sums = True   # the second stage of the per-sample loss reductions as one launch in front of loss_combine (False: one per reduction; same bits)
+        # True: the second stage of the per-sample loss reductions as ONE launch in front of loss_combine (False: one per reduction; same bits on the
+        # build host).  Round 5's GPU evidence for it is smoke() + bench lines, no complete `-m gpu` run, so it is off until one has passed
+        # (tests/test_zz_round5_gpu.py::test_deferred_loss_sums_are_the_same_bits; bench.py --deferred-loss-sums 1)
+        self.deferred_loss_sums = bool(getattr(cfg, 'deferred_loss_sums', False))
         # every loss of the scale loop as ONE launch over the scales per direction of the pass (ops.multiscale_losses, csrc/multiscale.h): same kernel
         # bodies, same bits, 30 loss launches -> 10.  Off until its GPU tests have run (written after the round-5 GPU lease closed); bench.py
         # --multiscale-losses 1 / tests/test_zz_round5_gpu.py switch it on
