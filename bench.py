@@ -523,9 +523,11 @@ def main():
             limited = None
             if top['entry'] == 'unflow_corr_bwd':
                 limited = ('valu: packed fp32 FMA issue (15.0 M VALU instructions in 51 M wave-cycles at level 2, LDS array busy 26 %, VALU issuing 41 % of all SIMD cycles, no bank '
-                           'conflicts: profiles/r5_corr_bwd_mfma/pmc_sq_counters.txt; the matrix-core form of the same sums, csrc/corr_mfma.h, is the '
-                           'default only at d = 8: profiles/r5_corr_bwd_mfma.md)')
-            roof = {'bound': 'hbm', 'limited_by': limited, 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
+                           'conflicts: profiles/r5_corr_bwd_mfma/pmc_sq_counters.txt; the matrix-core form of the same sums, csrc/corr_mfma.h, lost in the step at d = 4 '
+                           '(81.2 vs 70.5 us) and is opt-in at d = 8: profiles/r5_corr_bwd_mfma.md)')
+            # `bound` stays the contract's roofline ('hbm': `peak` and `frac` are HBM figures); `limiter` is the machine-readable name of what
+            # the counters say actually holds this kernel ('valu' for the level-2 cost-volume backward), `limited_by` the evidence in words
+            roof = {'bound': 'hbm', 'limiter': ('valu' if limited else None), 'limited_by': limited, 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
                     'traffic': traffic, 'traffic_source': traffic_note,
                     'kernel': '%s %s: the cost-volume / warp entry point with the largest time per step' % (top['entry'], top['shape']),
                     'measured_in': ('%d eager steps right behind the timed region (the timed region replays a hipGraph, which cannot carry per-launch events; --graph 0 times them inside it)' % int(roofline_steps)

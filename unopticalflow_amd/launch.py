@@ -46,14 +46,26 @@ def rank_env(rank, world, port, base=None):
     return env
 
 
-def _die_with_parent():
-    """preexec hook of a rank (runs in the child between fork and exec): SIGKILL when the launcher dies -- a launcher killed with
-    SIGKILL (OOM killer, ``timeout -s KILL``) cannot forward anything, and orphaned ranks would keep the GPUs and the port."""
+def _libc_prctl():
+    """libc's prctl, resolved ONCE at import: the hook below runs in the forked child between fork and exec, where an import or a dlopen could
+    deadlock on a lock some other thread of the parent held at the fork (pump threads of an earlier spawn_ranks call, torch's pools)."""
     try:
         import ctypes
-        ctypes.CDLL('libc.so.6', use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)          # PR_SET_PDEATHSIG
-    except Exception:                                              # not Linux / no libc: the forwarding below still covers SIGTERM / SIGHUP
-        pass
+        return ctypes.CDLL('libc.so.6', use_errno=True).prctl
+    except Exception:                                              # not Linux / no libc: the signal forwarding still covers SIGTERM / SIGHUP
+        return None
+
+
+_PRCTL = _libc_prctl()
+_SIGKILL = int(signal.SIGKILL)
+
+
+def _die_with_parent():
+    """preexec hook of a rank: SIGKILL when the launcher dies -- a launcher killed with SIGKILL (OOM killer, ``timeout -s KILL``) cannot
+    forward anything, and orphaned ranks would keep the GPUs and the port.  One call into an already-resolved C function: no import, no
+    allocation.  PR_SET_PDEATHSIG follows the forking THREAD, which is why spawn_ranks insists on the main thread."""
+    if _PRCTL is not None:
+        _PRCTL(1, _SIGKILL, 0, 0, 0)                               # PR_SET_PDEATHSIG
 
 
 def spawn_ranks(argv, world, poll_s=0.2, grace_s=10.0, out=None, err=None):
@@ -78,14 +90,17 @@ def spawn_ranks(argv, world, poll_s=0.2, grace_s=10.0, out=None, err=None):
     def on_signal(signum, frame):
         stop['sig'] = signum
     old = {}
-    if threading.current_thread() is threading.main_thread():      # (signal.signal is main-thread only; elsewhere the defaults stay)
+    # signal.signal is main-thread only, and PR_SET_PDEATHSIG is tied to the forking THREAD (the ranks would be killed when a helper thread that
+    # called us returns): from another thread the defaults stay and the ranks get no parent-death signal
+    on_main = threading.current_thread() is threading.main_thread()
+    if on_main:
         for sg in (signal.SIGTERM, signal.SIGHUP):
             old[sg] = signal.signal(sg, on_signal)
     procs = []
     try:
         for r in range(world):
             procs.append(subprocess.Popen(list(argv), env=rank_env(r, world, port), stdout=subprocess.PIPE,
-                                          stderr=None, text=True, bufsize=1, preexec_fn=_die_with_parent))
+                                          stderr=None, text=True, bufsize=1, preexec_fn=_die_with_parent if on_main else None))
 
         def pump(p, sink):
             for line in p.stdout:
@@ -133,7 +148,7 @@ def spawn_ranks(argv, world, poll_s=0.2, grace_s=10.0, out=None, err=None):
             if p.poll() is None:
                 p.kill()
         for sg, h in old.items():
-            signal.signal(sg, h)
+            signal.signal(sg, h if h is not None else signal.SIG_DFL)      # (None: the previous handler was installed from C)
     if interrupted:
         raise KeyboardInterrupt
     if forwarded is not None:

@@ -157,6 +157,7 @@ class _DeferredBiasGrads:
         self.jobs = []                 # (partials tensor, gbias storage, gbias address, n, C, mode)
         self.queued = False
         self.last_addresses = ()       # gbias addresses of the last flush (adopted())
+        self.last_storages = []        # ... and their storages, kept until the next pass: a freed address could be handed to a later gradient and pass adopted() by accident
         import threading
         self.lock = threading.Lock()
         self._depth = 0
@@ -179,6 +180,7 @@ class _DeferredBiasGrads:
             if not self.queued:
                 self.queued = True
                 self.last_addresses = ()
+                self.last_storages = []
                 torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
 
     def _end_of_backward(self):
@@ -192,6 +194,7 @@ class _DeferredBiasGrads:
         if not jobs:
             return
         self.last_addresses = tuple(self.last_addresses) + tuple(j[2] for j in jobs)
+        self.last_storages.extend(j[1] for j in jobs)          # (a few KB: bias gradients)
         by_dev = {}
         for j in jobs:
             by_dev.setdefault(j[3], []).append(j)
@@ -210,7 +213,9 @@ class _DeferredBiasGrads:
         """True when every bias gradient finished by the last pass IS some parameter's ``.grad`` (autograd adopted the tensors it
         was handed: nothing was cloned or accumulated before the deferred launch wrote them).  ``extra``: addresses of gradients
         that were already copied elsewhere and re-pointed (the data-parallel trainer packs all-reduce pieces during the pass:
-        ``FlatGradients.seen_sources``)."""
+        ``FlatGradients.seen_sources``, which keeps those tensors alive until the check).  Addresses are compared, so both sides hold their
+        memory until then: the finished gradients' storages stay referenced here (``last_storages``) -- an address freed in between could be
+        handed to a later gradient and match by accident."""
         have = {p.grad.data_ptr() for p in params if p.grad is not None}
         have.update(extra)
         return all(a in have for a in self.last_addresses)
@@ -783,9 +788,12 @@ def _ints(vals):
 
 def multiscale_supported(imgs, warped):
     """True when the `_ms` entries serve these scales (what the single-scale fast paths serve: even widths -- the SSIM column pairs --,
-    maps of at least 3 x 3 -- the smoothness tiles --, at most 4 scales)."""
+    maps of at least 3 x 3 -- the smoothness tiles --, 8-byte aligned tensors -- ssim2_ok of csrc/ssim.hip: a view with an odd storage offset would
+    come back as UNFLOW_EINVAL from unflow_ssim_loss_*_ms --, at most 4 scales).  The occlusion weights the SSIM pair also reads are allocated
+    inside the op (aligned)."""
     return (0 < len(imgs) <= 4 and all(on_device(t) and t.shape[-1] % 2 == 0 and t.shape[-1] >= 3 and t.shape[-2] >= 3 for t in imgs)
-            and all(w.shape[0] <= 65535 for w in warped))
+            and all(w.shape[0] <= 65535 for w in warped)
+            and all(t.data_ptr() % 8 == 0 and t.is_contiguous() for t in list(imgs) + list(warped)))
 
 
 def _register_sums(jobs):

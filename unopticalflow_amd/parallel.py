@@ -103,6 +103,7 @@ class FlatGradients:
         self._sources = None                              # gradient tensors of a captured hipGraph (remember_sources)
         self.track_sources = False                        # first passes of a trainer: remember where the packed gradients came from
         self.seen_sources = set()                         # ... (addresses; ops.deferred_bias_grads.adopted(extra=...))
+        self._seen_tensors = []                           # ... and the tensors, alive until zero(): the allocator cannot hand a seen address to a later gradient
         self.before_pack = None                           # called before gradients are READ (ops.deferred_bias_grads.flush on the GPU)
         self.launched_early = 0                           # pieces sent from a hook during the last backward
         self.overlap = False
@@ -141,6 +142,7 @@ class FlatGradients:
                 dst.append(self.views[i]); src.append(g)
                 if self.track_sources:
                     self.seen_sources.add(g.data_ptr())
+                    self._seen_tensors.append(g)
         if dst:
             torch._foreach_copy_(dst, src)
         for i in range(a, b):
@@ -229,6 +231,7 @@ class FlatGradients:
         self._packed = [False] * self.chunks
         self.launched_early = 0
         self.seen_sources.clear()
+        self._seen_tensors = []
 
     def vector(self):
         """The gradients as one vector in LOGICAL element order, parameter by parameter (a copy).  ``flat`` itself is
