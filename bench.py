@@ -112,7 +112,7 @@ def parse():
     ap.add_argument('--split-handoff', type=int, default=0, help='1: the pyramid hand-off returns both decoder inputs itself (Model_flow.split_handoff: no split, no gradient concatenation; A/B)')
     ap.add_argument('--multiscale-losses', type=int, default=0, help='1: every loss of the scale loop as one launch over the three scales (A/B; Model_flow.multiscale_losses, off until GPU-validated)')
     ap.add_argument('--deferred-loss-sums', type=int, default=0, help='1: ONE second-stage launch per forward pass for all per-sample loss reductions instead of one per reduction (A/B; Model_flow.deferred_loss_sums, off until a complete GPU suite has covered it)')
-    ap.add_argument('--corr-bwd', default='auto', choices=['auto', 'fp32', 'mfma', 'mfma2'], help='cost-volume backward arithmetic, per call (PWC_tf.corr_backward -> unflow_corr_bwd_ex): mfma = the matrix-core form at d = 4 too, mfma2 = its pixel-pair variant (A/B)')
+    ap.add_argument('--corr-bwd', default='auto', choices=['auto', 'fp32', 'mfma', 'fp32_next'], help='cost-volume backward arithmetic, per call (PWC_tf.corr_backward -> unflow_corr_bwd_ex): mfma = the matrix-core form at d = 4 too')
     ap.add_argument('--gc-freeze', type=int, default=1, help='0: leave Python\'s cyclic collector alone; 1: FlowTrainer(gc_freeze_after=2), what train.py asks for too (gc.freeze() after the second step, once per process)')
     ap.add_argument('--contended-host', action='store_true', help='experiment (profiles/r4_multirank_step_mode.md): for the TIMED steps confine this process to one core and run a busy-loop child on the same core -- what a slow or shared host does to the step mode')
     ap.add_argument('--force-ddp', action='store_true', help='N = 1 only: run the step through the RCCL data-parallel path with a one-rank communicator')

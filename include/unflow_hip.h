@@ -75,12 +75,15 @@ int unflow_corr_bwd(const float* f1, const float* f2, const float* gcv, float* g
  *                          Difference a caller can see besides rounding: for gf2 the kernel multiplies weights read at displaced pixels
  *                          (neighbouring rows / planes of gcv) with exact-zero features outside the image, so an Inf or NaN anywhere in gcv
  *                          reaches border outputs that the fp32 kernels leave finite;
- *   UNFLOW_CORR_BWD_MFMA2  the pixel-pair variant of the matrix-core form (csrc/corr_mfma2.h; same arithmetic, fewer load instructions).
+ *   UNFLOW_CORR_BWD_FP32_NEXT  fp32 FMA kernels, taking the kernels written in round 6 that no GPU has run yet where one exists (executed and checked
+ *                          on the build host only): the small-map backward with the gradient rows passing through registers (csrc/corr_small_rows.h)
+ *                          for maps of <= 1024 pixels at d = 8 -- where _AUTO runs one lane per output element -- and at d = 4.  Same sums in another
+ *                          fp32 order, deterministic.  The candidate for _AUTO once measured.
  * UNFLOW_EINVAL for any other value. */
 #define UNFLOW_CORR_BWD_AUTO 0
 #define UNFLOW_CORR_BWD_FP32 1
 #define UNFLOW_CORR_BWD_MFMA 2
-#define UNFLOW_CORR_BWD_MFMA2 3
+#define UNFLOW_CORR_BWD_FP32_NEXT 3
 int unflow_corr_bwd_ex(const float* f1, const float* f2, const float* gcv, float* gf1, float* gf2,
                        int B, int C, int H, int W, int d, int arithmetic, void* stream);
 

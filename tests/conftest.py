@@ -12,7 +12,7 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 if os.environ.get('UNFLOW_LIB_PATH'):
-    # a variant build of the library under test (python -m unopticalflow_amd.build --tuning with UNFLOW_TUNING_TAG; tools/gpu_r5.sh
+    # a variant build of the library under test (python -m unopticalflow_amd.build --tuning with UNFLOW_TUNING_TAG; tools/gpu_r6.sh
     # loss_pending): test infrastructure only -- the product always loads libunflow_hip.so next to the package
     from unopticalflow_amd import _lib as _unflow_lib
     _unflow_lib.LIB_PATH = os.environ['UNFLOW_LIB_PATH']

@@ -1,5 +1,5 @@
-// The cost-volume backward on the matrix cores -- csrc/corr_mfma.h (shipped: the default at d = 8) and csrc/corr_mfma2.h (the
-// pixel-pair form that has never run on a GPU: behind UNFLOW_CORR_BWD_MFMA2) -- compiled for the build host with the ROCm clang++ and EXECUTED with lanes as fibers
+// The cost-volume backward on the matrix cores -- csrc/corr_mfma.h (shipped, on request: UNFLOW_CORR_BWD_MFMA) and, built with -DWITH_PROTO, the
+// never-run pixel-pair prototype tools/proto/corr_mfma2.h -- compiled for the build host with the ROCm clang++ and EXECUTED with lanes as fibers
 // (tests/host_check/hip_on_host.h; TEST INFRASTRUCTURE, tests/test_kernels_on_host.py).  The matrix instruction is a function there that
 // gathers the 64 lanes' A / B fragments by the lane layouts of the CDNA4 ISA and forms the 16 x 16 x 32 product in fp32; buffer loads /
 // stores range-check like the hardware (the kernels' predicate); LDS is a static array.
@@ -8,7 +8,9 @@
 // in : int32 ncases; per case int32 R, B, C, H, W, rows, which (0: corr_mfma.h, 1: corr_mfma2.h); float f1[B,C,H,W], f2[B,C,H,W], g[B,(2R+1)^2,H,W]
 // out: per case gf1[B,C,H,W], gf2[B,C,H,W]
 #include "corr_mfma.h"
+#ifdef WITH_PROTO
 #include "corr_mfma2.h"
+#endif
 
 UnflowTimingArm& unflow_timing_arm() { static UnflowTimingArm arm = {nullptr, nullptr, false}; return arm; }
 
@@ -30,8 +32,10 @@ int main(int argc, char** argv) {
         int rc = -1;
         if (which == 0 && R == 4) rc = launch_bwd_mf<4, 2, 1, 1>(f1.data(), f2.data(), g.data(), gf1.data(), gf2.data(), B, C, H, W, rows, nullptr);
         if (which == 0 && R == 8) rc = launch_bwd_mf<8, 2, 2, 1>(f1.data(), f2.data(), g.data(), gf1.data(), gf2.data(), B, C, H, W, rows, nullptr);
+#ifdef WITH_PROTO
         if (which == 1 && R == 4) rc = launch_bwd_mf2<4, 2, 1>(f1.data(), f2.data(), g.data(), gf1.data(), gf2.data(), B, C, H, W, rows, nullptr);
         if (which == 1 && R == 8) rc = launch_bwd_mf2<8, 2, 1>(f1.data(), f2.data(), g.data(), gf1.data(), gf2.data(), B, C, H, W, rows, nullptr);
+#endif
         if (rc != 0) { printf("case %d: rc %d\n", k, rc); return 1; }
         fwrite(gf1.data(), 4, n, o); fwrite(gf2.data(), 4, n, o);
     }

@@ -36,7 +36,7 @@ def test_library_builds_loads_and_exports_every_header_symbol():
 
 
 def test_variant_libraries_in_the_tree_are_not_stale():
-    """Variant builds (libunflow_hip_tuning*.so: tools/ and the gpu_r5.sh A/B recipes load them through UNFLOW_LIB_PATH) travel to the GPU
+    """Variant builds (libunflow_hip_tuning*.so: tools/ and the gpu_r6.sh A/B recipes load them through UNFLOW_LIB_PATH) travel to the GPU
     box with the tree: one that was built before the header grew would fail there, not here.  Every one present exports every symbol
     the header declares and reports the header's ABI version."""
     pkg = os.path.join(ROOT, 'unopticalflow_amd')
@@ -103,7 +103,7 @@ def test_dma_ring_kernels_do_not_spill():
     assert len(names) == len(scratch) and names
     checked = 0
     for n, s in zip(names, scratch):
-        if 'ring_kernel' in n or 'ring_mixed_kernel' in n or 'gs_kernel' in n or 'rs_kernel' in n or 'rs_mixed_kernel' in n or 'mf_kernel' in n or 'mf2_kernel' in n:      # (row-streamed backward: counted vmcnt behind its LDS-DMA too; matrix-core backward: two request sets in flight)
+        if 'ring_kernel' in n or 'ring_mixed_kernel' in n or 'gs_kernel' in n or 'rs_kernel' in n or 'rs_mixed_kernel' in n or 'mf_kernel' in n:      # (row-streamed backward: counted vmcnt behind its LDS-DMA too; matrix-core backward: two request sets in flight)
             assert s == 0, (n, s)
             checked += 1
     assert checked >= 3      # ring<9 rows>, ring<3 rows>, group-split backward
@@ -113,8 +113,9 @@ def test_dma_ring_kernels_do_not_spill():
 # Every other kernel the library ships is, instruction for instruction, one that suite exercised.  What is listed here has its own
 # GPU evidence from round 5: see DESIGN.md section 7.
 ROUND5_DEVICE_CODE = {
-    'corr.hip': {'new': {'corr_bwd_mf_kernel<4, 2, 1, 1>', 'corr_bwd_mf_kernel<8, 2, 2, 1>',         # csrc/corr_mfma.h
-                         'corr_bwd_mf2_kernel<4, 2, 1>', 'corr_bwd_mf2_kernel<8, 2, 1>'},            # csrc/corr_mfma2.h: never run on a GPU, mode 3 only
+    'corr.hip': {'new': {'corr_bwd_mf_kernel<4, 2, 1, 1>', 'corr_bwd_mf_kernel<8, 2, 2, 1>',         # csrc/corr_mfma.h (on request: UNFLOW_CORR_BWD_MFMA)
+                         # round 6, csrc/corr_small_rows.h: never run on a GPU, UNFLOW_CORR_BWD_FP32_NEXT only
+                         'corr_bwd_smallrows_kernel<4, 3, 4>', 'corr_bwd_smallrows_kernel<4, 3, 8>', 'corr_bwd_smallrows_kernel<8, 3, 4>', 'corr_bwd_smallrows_kernel<8, 3, 8>'},
                  'renamed': {'corr_bwd_rs_kernel<4, 16, 8, 2>': 'corr_bwd_rs_kernel<4, 16, 8, 2, 0, 1, 1>',
                              'corr_bwd_rs_kernel<4, 8, 8, 2>': 'corr_bwd_rs_kernel<4, 8, 8, 2, 0, 1, 1>',
                              'corr_bwd_rs_kernel<8, 8, 8, 1>': 'corr_bwd_rs_kernel<8, 8, 8, 1, 0, 1, 1>'},

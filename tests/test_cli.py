@@ -102,7 +102,7 @@ def test_bench_starts_its_own_ranks(tmp_path):
 
 
 @pytest.mark.skipif(os.environ.get('UNFLOW_RUN_EIGHT_RANKS') != '1',
-                    reason='nine HIP contexts on one GPU (eight ranks + this process): run on its own, `bash tools/gpu_r5.sh ranks8` '
+                    reason='nine HIP contexts on one GPU (eight ranks + this process): run on its own, `bash tools/gpu_r6.sh ranks8` '
                            '(once in three runs inside the whole suite the runtime aborted THIS process while the ranks started)')
 @pytest.mark.gpu
 def test_bench_eight_ranks_rehearsal_and_a_killed_rank(tmp_path):

@@ -284,7 +284,7 @@ def test_gpu_recipes_parse_and_name_existing_files():
     for sh in scripts:
         r = subprocess.run(['bash', '-n', sh], capture_output=True, text=True)
         assert r.returncode == 0, (sh, r.stderr)
-    text = open(os.path.join(ROOT, 'tools', 'gpu_r5.sh')).read()
+    text = open(os.path.join(ROOT, 'tools', 'gpu_r6.sh')).read()
     named = set(re.findall(r'(?<![\w/$}])((?:tools|tests|unopticalflow_amd|oracle)/[\w/.]+\.(?:py|sh|cpp|hip|h))\b', text)) | set(re.findall(r'(?<![\w/])(bench\.py|__graft_entry__\.py)\b', text))
     assert len(named) >= 10
     missing = sorted(p for p in named if not os.path.exists(os.path.join(ROOT, p)))

@@ -25,6 +25,45 @@ def _sanitize(always):
     return _LEVEL == 'all' or (always and _LEVEL == '1')
 
 
+def _sources_key():
+    """sha256 over everything a check program is made of: csrc/ (kernel files, headers, bodies), tests/host_check/ sources and tools/proto headers."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in (os.path.join(ROOT, 'unopticalflow_amd', 'csrc'), os.path.join(ROOT, 'unopticalflow_amd', 'csrc', 'bodies'),
+              os.path.join(ROOT, 'tests', 'host_check'), os.path.join(ROOT, 'tools', 'proto'), os.path.join(ROOT, 'include')):
+        for f in sorted(os.listdir(d)):
+            if f.endswith(('.h', '.hip', '.inc', '.cpp')):
+                h.update(f.encode()); h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:20]
+
+
+def _build_cached(build_cmd, builder=None):
+    """Run a check program's compile command -- or copy the program from tests/host_check/_build/programs/ when this very command was already run on
+    these very sources (a second pass over an unchanged tree then skips ~25 s of compiling corr.hip / warp.hip for the host).  The command's output
+    path is its `-o` argument; the key is the command with the temporary directory taken out + _sources_key().  -> CompletedProcess-like (returncode, stderr)."""
+    import hashlib
+    import shutil
+    import types
+    exe = build_cmd[build_cmd.index('-o') + 1]
+    tmp = os.path.dirname(exe)
+    norm = ' '.join(a.replace(tmp, '@') for a in build_cmd)
+    key = hashlib.sha256((norm + _sources_key()).encode()).hexdigest()[:24]
+    store = os.path.join(ROOT, 'tests', 'host_check', '_build', 'programs')
+    hit = os.path.join(store, key)
+    if os.path.exists(hit):
+        shutil.copy2(hit, exe)
+        return types.SimpleNamespace(returncode=0, stderr='')
+    r = builder() if builder is not None else subprocess.run(build_cmd, capture_output=True, text=True)      # (builder: several compilers side by side + a link, described by build_cmd for the key)
+    if r.returncode == 0:
+        os.makedirs(store, exist_ok=True)
+        old = sorted((os.path.getmtime(os.path.join(store, f)), f) for f in os.listdir(store))
+        for _, f in old[:-40]:                                   # (keep the store bounded)
+            os.remove(os.path.join(store, f))
+        shutil.copy2(exe, hit + '.tmp%d' % os.getpid())
+        os.replace(hit + '.tmp%d' % os.getpid(), hit)
+    return r
+
+
 def _sanitized_build_started(build_cmd, tmp_path, name, always=True):
     """Start the sanitized build of a check program NOW, next to the plain one's build and run (_sanitized() then waits for it)."""
     if not _sanitize(always):
@@ -65,7 +104,7 @@ def test_flat_ms_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
     build = ['g++', '-O1', '-std=c++17', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'),
                         os.path.join(ROOT, 'tests', 'host_check', 'ms_flat_check.cpp'), '-o', exe]
     _sanitized_build_started(build, tmp_path, 'ms_flat_check')
-    r = subprocess.run(build, capture_output=True, text=True)
+    r = _build_cached(build)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe, out], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'OK: 0 mismatches' in r.stdout, r.stdout[-2000:]          # one launch over the scales == three launches, bit for bit
@@ -135,7 +174,7 @@ def test_input_stage_kernel_runs_on_the_host_bit_exact(tmp_path):
     exe = str(tmp_path / 'prepare_check')
     build = ['g++', '-O1', '-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-I', os.path.join(ROOT, 'tests', 'host_check'),
              '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'), os.path.join(ROOT, 'tests', 'host_check', 'prepare_check.cpp'), '-o', exe]
-    r = subprocess.run(build, capture_output=True, text=True)
+    r = _build_cached(build)
     assert r.returncode == 0, r.stderr[-3000:]
     rng = np.random.default_rng(11)
     for (H, W), swap in (((64, 128), 0), ((32, 52), 1)):
@@ -168,7 +207,7 @@ def test_loss_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
     build = ['g++', '-O1', '-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-I', os.path.join(ROOT, 'tests', 'host_check'),
                         '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'), os.path.join(ROOT, 'tests', 'host_check', 'photo_check.cpp'), '-o', exe]
     _sanitized_build_started(build, tmp_path, 'photo_check')
-    r = subprocess.run(build, capture_output=True, text=True)
+    r = _build_cached(build)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe, out], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'OK: 0 mismatches' in r.stdout, r.stdout[-2000:]
@@ -178,7 +217,7 @@ def test_loss_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
     exe5, out5 = str(tmp_path / 'photo_check_r5b'), str(tmp_path / 'out_r5b.bin')
     build5 = ['g++', '-O1', '-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-DUNFLOW_LOSS_R5B', '-I', os.path.join(ROOT, 'tests', 'host_check'),
                         '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'), os.path.join(ROOT, 'tests', 'host_check', 'photo_check.cpp'), '-o', exe5]
-    r = subprocess.run(build5, capture_output=True, text=True)
+    r = _build_cached(build5)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe5, out5], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'OK: 0 mismatches' in r.stdout, r.stdout[-2000:]
@@ -237,7 +276,7 @@ def test_ssim_kernels_run_on_the_host_on_flat_patches(tmp_path):
                         '-I', os.path.join(ROOT, 'tests', 'host_check'), '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'),
                         os.path.join(ROOT, 'tests', 'host_check', 'ssim_check.cpp'), '-o', exe]
     _sanitized_build_started(build, tmp_path, 'ssim_check')
-    r = subprocess.run(build, capture_output=True, text=True)
+    r = _build_cached(build)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe, out], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and 'OK: 0 mismatches' in r.stdout, r.stdout[-2000:]
@@ -293,14 +332,14 @@ def test_warp_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
     exe = str(tmp_path / 'warp_check')
     build = ['g++', '-O2', '-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-I', os.path.join(ROOT, 'tests', 'host_check'),
                         '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'), os.path.join(ROOT, 'tests', 'host_check', 'warp_check.cpp'), '-o', exe]
-    r = subprocess.run(build, capture_output=True, text=True)
+    r = _build_cached(build)
     assert r.returncode == 0, r.stderr[-3000:]
     rng = np.random.default_rng(5)
     cases = []                                                              # (B, C, H, W, masked, ac, flow kind)
     cases.append((8, 32, 64, 208, 0, 0, 'smooth'))                         # level 2 of the step at B = 4 pairs: the one-pass backward is picked (supported == 2)
     for kind in ('mixed', 'outside', 'edge', 'noise'):
-        cases.append((3, 32, 64, 208, 0, 0, kind))
-    cases += [(8, 64, 32, 104, 0, 0, 'smooth'), (3, 64, 32, 104, 0, 1, 'mixed'), (2, 96, 16, 52, 0, 0, 'smooth'), (2, 128, 8, 26, 0, 0, 'edge'),
+        cases.append((2, 32, 64, 208, 0, 0, kind))
+    cases += [(3, 64, 32, 104, 0, 0, 'smooth'), (2, 64, 32, 104, 0, 1, 'mixed'), (2, 96, 16, 52, 0, 0, 'smooth'), (2, 128, 8, 26, 0, 0, 'edge'),
               (2, 9, 17, 130, 0, 1, 'noise'), (2, 20, 40, 72, 0, 0, 'mixed')]
     cases += [(3, 3, 40, 100, 1, 0, 'mixed'), (3, 3, 20, 50, 1, 0, 'edge'), (3, 3, 10, 25, 1, 0, 'noise')]      # an image pyramid: masked, no source gradient
     data = []
@@ -356,8 +395,8 @@ def test_warp_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
 def test_matrix_core_backward_runs_on_the_host(tmp_path):
     """The cost-volume backward on the matrix cores compiled for the host (ROCm clang++) and executed with lanes as fibers: the matrix
     instruction as a function that gathers the wave's A / B fragments by the CDNA4 lane layouts, range-checked buffer accesses, LDS tables.
-    csrc/corr_mfma.h -- the shipped kernel, the default at d = 8 -- and csrc/corr_mfma2.h -- the pixel-pair form (mode 3 of the switch) that has NEVER
-    run on a GPU -- against the oracle's autograd of corr_naive (pwc_tf.py:97-106) at the GPU test's bar (rtol 1e-4 + 1e-5 of the largest
+    csrc/corr_mfma.h -- the shipped kernel (on request: ops.corr(..., backward='mfma')); with UNFLOW_HOST_CHECK_PROTO=1 also the never-run pixel-pair
+    prototype tools/proto/corr_mfma2.h -- against the oracle's autograd of corr_naive (pwc_tf.py:97-106) at the GPU test's bar (rtol 1e-4 + 1e-5 of the largest
     gradient): both radii, ragged last segments, a partial channel group, chunks that do not divide the rows, one row chunk and several."""
     import struct
     clang = '/opt/rocm/lib/llvm/bin/clang++'
@@ -368,12 +407,15 @@ def test_matrix_core_backward_runs_on_the_host(tmp_path):
     build = [clang, '-O2', '-std=c++20', '-ffp-contract=off', '-DUNFLOW_HOST_CHECK', '-Wno-unknown-attributes', '-Wno-unknown-pragmas', '-Wno-pass-failed',
                         '-I', os.path.join(ROOT, 'tests', 'host_check'), '-I', os.path.join(ROOT, 'unopticalflow_amd', 'csrc'),
                         os.path.join(ROOT, 'tests', 'host_check', 'mfma_check.cpp'), '-o', exe]
+    proto = os.environ.get('UNFLOW_HOST_CHECK_PROTO') == '1'
+    if proto:
+        build[-3:-3] = ['-DWITH_PROTO', '-I', os.path.join(ROOT, 'tools', 'proto')]
     _sanitized_build_started(build, tmp_path, 'mfma_check')
-    r = subprocess.run(build, capture_output=True, text=True)
+    r = _build_cached(build)
     assert r.returncode == 0, r.stderr[-3000:]
     rng = np.random.default_rng(3)
     shapes = [(4, 2, 32, 12, 48, 8), (4, 1, 48, 21, 100, 16), (4, 2, 16, 9, 36, 4), (8, 1, 32, 20, 48, 16), (8, 1, 16, 37, 44, 32)]       # R, B, C, H, W, rows per wave
-    cases = [(s, which) for which in (0, 1) for s in shapes]
+    cases = [(s, which) for which in ((0, 1) if proto else (0,)) for s in shapes]
     data = []
     fin, fout = str(tmp_path / 'in.bin'), str(tmp_path / 'out.bin')
     with open(fin, 'wb') as f:
@@ -419,6 +461,12 @@ _COST_VOLUME_CASES = [
     ((0, 1, 2, 5, 9, 37, 0, 0), ('corr_fwd_kernel', 'corr_bwd_kernel')),
     ((0, 2, 2, 5, 9, 37, 0, 0), ('corr_fwd_kernel', 'corr_bwd_kernel')),
     ((0, 3, 1, 4, 7, 9, 0, 0), ('corr_fwd_generic', 'corr_bwd_generic')),                         # a radius no tuned kernel exists for
+    # round 6, UNFLOW_CORR_BWD_FP32_NEXT (3): the small-map backward with the gradient rows passing through registers (csrc/corr_small_rows.h; no GPU has run it)
+    ((0, 8, 2, 24, 8, 26, 0, 3), ('corr_bwd_smallrows_kernel',)),                                 # level-5 class at d = 8: all lanes pixels, 8 channels per lane, three chunks; the short last row group
+    ((0, 8, 3, 21, 4, 13, 0, 3), ('corr_bwd_smallrows_kernel',)),                                 # level-6 class at d = 8: four channel phases x 4 channels, a ragged second chunk
+    ((0, 8, 1, 5, 14, 32, 0, 3), ('corr_bwd_smallrows_kernel',)),                                 # two pixel blocks, fewer channels than a chunk
+    ((0, 4, 2, 20, 8, 26, 0, 3), ('corr_bwd_smallrows_kernel',)),                                 # d = 4 (three full row groups)
+    ((0, 4, 2, 19, 5, 7, 0, 3), ('corr_bwd_smallrows_kernel',)),                                  # a tiny map: dead lanes in every phase
     ((1, 4, 10, 5, 64, 208, 0, 0), ('warp_corr_fwd_kernel',)),                                    # fused warp + cost volume, 81 displacements per workgroup
     ((1, 4, 3, 24, 16, 52, 1, 0), ('warp_corr_fwd_kernel',)),                                     # ... three displacement rows per workgroup, align_corners
     ((1, 4, 2, 5, 23, 72, 0, 0), ('warp_corr_fwd_kernel',)),
@@ -443,21 +491,26 @@ def test_cost_volume_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
               '-I', os.path.join(ROOT, 'tests', 'host_check'), '-I', csrc]
     san = ['-O1', '-gline-tables-only', '-fsanitize=address,undefined', '-fno-omit-frame-pointer', '-fno-sanitize-recover=undefined']
     # both programs (plain -O2 and AddressSanitizer + UBSan, see _sanitized) at once, a compiler process per translation unit
-    jobs = []
     long = _LEVEL == 'all'           # (then both builds: the plain -O2 program's bytes must equal the instrumented -O1 program's)
     plain, sanit = (long or _LEVEL == ''), (long or _LEVEL == '1')
-    for tag, flags in ((('plain', ['-O2']),) if plain else ()) + ((('san', san),) if sanit else ()):
+    exe, exe_san = str(tmp_path / 'corr_check'), str(tmp_path / 'corr_check_asan')
+
+    def program(tag, flags, link_flags, out):
+        """a compiler process per translation unit, side by side, then the link"""
+        import types
+        jobs = []
         for src in sources:
             obj = str(tmp_path / ('%s_%s.o' % (tag, os.path.basename(src))))
-            jobs.append((tag, obj, subprocess.Popen([clang, *flags, *common, '-x', 'c++', '-c', src, '-o', obj], stderr=subprocess.PIPE, text=True)))
-    for tag, obj, pr in jobs:
-        err = pr.communicate()[1]
-        assert pr.returncode == 0, err[-3000:]
-    exe, exe_san = str(tmp_path / 'corr_check'), str(tmp_path / 'corr_check_asan')
-    if plain:
-        subprocess.run([clang, '-o', exe] + [o for t, o, _ in jobs if t == 'plain'], check=True)
-    if sanit:
-        subprocess.run([clang, '-fsanitize=address,undefined', '-o', exe_san] + [o for t, o, _ in jobs if t == 'san'], check=True)
+            jobs.append((obj, subprocess.Popen([clang, *flags, *common, '-x', 'c++', '-c', src, '-o', obj], stderr=subprocess.PIPE, text=True)))
+        for obj, pr in jobs:
+            err = pr.communicate()[1]
+            if pr.returncode != 0:
+                return types.SimpleNamespace(returncode=pr.returncode, stderr=err)
+        return subprocess.run([clang, *link_flags, '-o', out] + [o for o, _ in jobs], capture_output=True, text=True)
+    for want, tag, flags, link_flags, out in ((plain, 'plain', ['-O2'], [], exe), (sanit, 'san', san, ['-fsanitize=address,undefined'], exe_san)):
+        if want:
+            r = _build_cached([clang, *flags, *common, *sources, '-o', out], builder=lambda: program(tag, flags, link_flags, out))
+            assert r.returncode == 0, r.stderr[-3000:]
     rng = np.random.default_rng(5)
     data = []
     fin, fout = str(tmp_path / 'in.bin'), str(tmp_path / 'out.bin')

@@ -394,24 +394,3 @@ def test_loss_section_against_the_reference_fixture(ops, golden, monkeypatch, re
         got = fl[s].grad.detach().cpu().double().numpy()
         assert float(np.abs(got - truth[s]).max()) <= allowance, (s, float(np.abs(got - truth[s]).max()) / big, allowance / big)
     assert fl[3].grad is None
-
-
-@UNVALIDATED
-@own_process
-@pytest.mark.parametrize('d,B,C,h,w', [(4, 16, 32, 64, 208), (4, 4, 48, 21, 100), (8, 12, 64, 32, 104), (8, 6, 16, 37, 44)])
-def test_corr_backward_pixel_pair_form(ops, request, d, B, C, h, w):
-    """ops.corr(..., backward='mfma2') (csrc/corr_mfma2.h: the pixel-pair variant of the matrix-core backward; executed and checked on the build
-    host, never on a GPU) against the oracle at the matrix-core test's bar, in a process of its own."""
-    if _ran_in_a_child(request):
-        return
-    o = corr_case(d, B, C, h, w)          # (the oracle's answer for this case is on file from test_hip_ops.py's tests: tests/oracle_cache.py)
-    f1c, f2c, gout = o['f1'], o['f2'], o['gout']
-    amax = max(o['gf1'].abs().max().item(), o['gf2'].abs().max().item())
-    runs = []
-    for _ in range(2):
-        f1, f2 = dev(f1c).requires_grad_(), dev(f2c).requires_grad_()
-        ops.corr(f1, f2, d, backward='mfma2').backward(dev(gout))
-        close(f1.grad, o['gf1'], rtol=1e-4, atol=1e-5 * amax, what='gf1')
-        close(f2.grad, o['gf2'], rtol=1e-4, atol=1e-5 * amax, what='gf2')
-        runs.append((f1.grad.clone(), f2.grad.clone()))
-    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])          # deterministic

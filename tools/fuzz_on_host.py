@@ -1,14 +1,14 @@
 """Randomised shapes through the operators that have not run on a GPU yet, on the build host -- TEST INFRASTRUCTURE (oracle + host-executed
 kernel library: tests/hostexec.py; nothing of the product imports this).
 
-    python tools/fuzz_on_host.py [--minutes M] [--seed S] [--what ms,warp,mfma2,corr,fused]
+    python tools/fuzz_on_host.py [--minutes M] [--seed S] [--what ms,warp,mfma,corr,fused]
 
 For M minutes draws shapes and checks, over the product's own autograd wrappers (ops.py) and the REAL kernel sources executed with lanes as
 fibers:
   ms     ops.multiscale_losses (1-4 scales, B 1-3, even widths 4-90, heights 3-40, flat / zeroed regions, both consistency forms, inside and
          outside deferred_loss_sums) == the scale-by-scale operators BIT FOR BIT in every loss, saved sum and gradient
   warp   ops.warp_flow_masked_pyramid == ops.warp_flow_masked per scale bit for bit, forward and flow gradient, both conventions, five flow kinds
-  mfma2  the pixel-pair matrix-core cost-volume backward (ops.corr(..., backward='mfma2'), never run on a GPU) against the oracle's autograd of
+  mfma   the matrix-core cost-volume backward (ops.corr(..., backward='mfma')) against the oracle's autograd of
          corr_naive at the GPU test's bar, at shapes the dispatch serves (W % 4 == 0, C % 16 == 0, >= 8192 pixels, H >= 4 d), d = 4 and 8
   corr   the fp32 cost volume through its dispatch at random shapes (any W, C), d in {1, 2, 4, 8}, against the oracle at the GPU tests' bars
   fused  ops.warp_corr (the fused warp + cost volume, W % 4 == 0) against corr_naive(f1, warp_flow(f2, flow)) forward and backward, five flow kinds
@@ -135,15 +135,15 @@ def _corr_against_oracle(rng, d, B, C, h, w, mode, rtol, atol_of):
     return None
 
 
-def fuzz_mfma2(rng):
+def fuzz_mfma(rng):
     d = 4 if rng.random() < 0.6 else 8
     C = 16 * int(rng.integers(1, 5))
     w = 4 * int(rng.integers(4, 40))
     h = int(rng.integers(4 * d, 4 * d + 40))
     B = max(1, -(-8192 // (h * w)))
     B += int(rng.integers(0, 2))
-    draw = 'mfma2 d=%d [%d,%d,%d,%d]' % (d, B, C, h, w)
-    return draw, _corr_against_oracle(rng, d, B, C, h, w, 'mfma2', 1e-4, lambda amax: 1e-5 * amax)
+    draw = 'mfma d=%d [%d,%d,%d,%d]' % (d, B, C, h, w)
+    return draw, _corr_against_oracle(rng, d, B, C, h, w, 'mfma', 1e-4, lambda amax: 1e-5 * amax)
 
 
 def fuzz_corr(rng):
@@ -191,9 +191,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--minutes', type=float, default=2.0)
     ap.add_argument('--seed', type=int, default=0)
-    ap.add_argument('--what', default='ms,warp,mfma2,corr,fused')
+    ap.add_argument('--what', default='ms,warp,mfma,corr,fused')
     a = ap.parse_args()
-    fns = {'ms': fuzz_ms, 'warp': fuzz_warp, 'mfma2': fuzz_mfma2, 'corr': fuzz_corr, 'fused': fuzz_fused}
+    fns = {'ms': fuzz_ms, 'warp': fuzz_warp, 'mfma': fuzz_mfma, 'corr': fuzz_corr, 'fused': fuzz_fused}
     which = [fns[k] for k in a.what.split(',')]
     t_end = time.time() + 60 * a.minutes
     runs, fails, k = {f.__name__: 0 for f in which}, 0, 0

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-5 GPU recipes (the current set; rounds 3 / 4 keep their experiment scripts, their end-of-round scripts are folded in here).
-# One or more recipes per call:   gpurun -- bash tools/gpu_r5.sh <recipe> [<recipe> ...]        outputs under gpurun_out/r5/
+# Round-6 GPU recipes (the current set, grown out of round 5's; rounds 3 / 4 keep their experiment scripts, their end-of-round scripts are folded in here).
+# One or more recipes per call:   gpurun -- bash tools/gpu_r6.sh <recipe> [<recipe> ...]        outputs under gpurun_out/r6/
 #   suite        the whole -m gpu suite (no -x) + smoke()
 #   headline     the driver's exact bench command, twice
 #   configs      the other BASELINE configurations on one GPU: bf16 conv stacks, 1024x448 bs 4, one-rank RCCL, eager
@@ -12,16 +12,16 @@
 #   mfma_harness tools/proto/corr_bwd_mfma.hip built and run: matrix-core cost-volume backward variants vs the shipped entry
 #   mfma_pmc     SQ counter passes over that harness (three --pmc passes, no trace domains)
 #   mfma_sweep   microbench corr_bwd_mf on the tuning library: rows-per-wave sweep at levels 2-4, d = 4 and 8
-#   instep_ab    bench.py --corr-bwd {auto, mfma, fp32} and --deferred-loss-sums {1, 0}: in-step A/B of this round's switches
-#   loss_pending the loss-kernel changes written after the lease closed (-DUNFLOW_LOSS_R5B, libunflow_hip_tuning_lossr5b.so built on the
-#                build host): the loss tests against that library, kernel-exact loss times and the bench line, each next to the shipped one
+#   instep_ab    bench.py --corr-bwd {auto, mfma, fp32} and --deferred-loss-sums {0, 1}: in-step A/B of the opt-in switches
 #   multiscale   one launch per loss / image warp over the scales (ABI 11): its bit-identity tests, then bench --multiscale-losses 0 / 1
+#   smallrows    microbench corr_small: the round-6 small-map cost-volume backward (UNFLOW_CORR_BWD_FP32_NEXT) against today's kernels at levels 5 / 6, d = 4 and 8,
+#                its GPU tests, and bench --corr-bwd fp32_next in the step
 #   fused_levels bench --fused-levels 4 / 3,4: the fused warp + cost-volume kernel at chosen decoder levels only
 #   reopen       what to run FIRST when the lease comes back, most valuable first, so that a cut-off call still leaves the important half:
-#                suite, multiscale, mfma_harness, headline, instep_ab (incl. the never-run --corr-bwd mfma2), ranks8, profile_fp32, traffic, loss_pending, fused_levels, configs, profile_bf16, corr8, capi
+#                suite, headline, multiscale, instep_ab, smallrows, ranks8, profile_fp32, traffic, fused_levels, configs, profile_bf16, corr8, capi, mfma_harness
 #   final        everything that gets recorded for one source state: suite, headline, configs, ranks8, profile_fp32, profile_bf16, traffic, corr8, capi
 cd $GRAFT_REPO_ROOT
-out=gpurun_out/r5
+out=gpurun_out/r6
 mkdir -p $out
 line() { python3 - "$@" <<'PY'
 import json, sys
@@ -48,12 +48,12 @@ profile() {   # $1 = fp32 | bf16
   ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $M -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing $extra > $M/run.log 2>&1 )
   CC=$(ls $M/*/*counter_collection.csv | head -1)
   peak=157.3; [ $w = bf16 ] && peak=2500
-  python3 tools/summarize_mfma.py $CC $OUT/timed_region_stats.csv $out/r5_conv_mfma_$w.json --steps 9 --peak $peak && rm -f $CC
+  python3 tools/summarize_mfma.py $CC $OUT/timed_region_stats.csv $out/r6_conv_mfma_$w.json --steps 9 --peak $peak && rm -f $CC
 }
 for r in "$@"; do
 case $r in
   suite)
-    timeout 2400 python3 -m pytest tests -m gpu -q -p no:cacheprovider --timeout 900 --durations=30 > $out/suite.log 2>&1; echo "suite rc=$?"; tail -25 $out/suite.log
+    timeout 1500 python3 -m pytest tests -m gpu -q -rxX -p no:cacheprovider --timeout 600 --durations=30 > $out/suite.log 2>&1; echo "suite rc=$?"; tail -45 $out/suite.log
     python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
   headline)
     for i in a b; do python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_n1_$i.json 2> $out/bench_n1_$i.err; done
@@ -104,17 +104,9 @@ PY
     ;;
   mfma_sweep) UNFLOW_MICROBENCH_TUNING=1 timeout 600 python3 tools/microbench.py corr_bwd_mf 2>&1 | tee $out/corr_bwd_mf_tuning.txt | tail -60 ;;
   instep_ab)
-    for m in auto mfma mfma2 fp32; do python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --corr-bwd $m > $out/ab_corr_bwd_$m.json 2>> $out/ab.err; done
+    for m in auto mfma fp32; do python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --corr-bwd $m > $out/ab_corr_bwd_$m.json 2>> $out/ab.err; done
     for v in 1 0; do python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --deferred-loss-sums $v > $out/ab_deferred_loss_sums_$v.json 2>> $out/ab.err; done
     line $out/ab_*.json ;;
-  loss_pending)
-    V=$GRAFT_REPO_ROOT/unopticalflow_amd/libunflow_hip_tuning_lossr5b.so
-    UNFLOW_LIB_PATH=$V timeout 900 python3 -m pytest tests/test_hip_ops.py tests/test_zz_round5_gpu.py -x -q -m gpu -p no:cacheprovider -k "loss or smooth or occ or reductions or stacked or deferred or golden" > $out/loss_pending_tests.log 2>&1; echo "variant tests rc=$?"; tail -4 $out/loss_pending_tests.log
-    echo "== shipped"; timeout 200 python3 tools/probes/loss_kernel_times.py 2>&1 | tee $out/loss_times_shipped.txt | grep -E "smooth|absdiff|masked" | head -20
-    echo "== variant"; UNFLOW_LIB_PATH=$V timeout 200 python3 tools/probes/loss_kernel_times.py 2>&1 | tee $out/loss_times_lossr5b.txt | grep -E "smooth|absdiff|masked" | head -20
-    python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $out/ab_loss_shipped.json 2>> $out/ab.err
-    UNFLOW_LIB_PATH=$V python3 tools/bench_with_lib.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $out/ab_loss_lossr5b.json 2>> $out/ab.err
-    line $out/ab_loss_shipped.json $out/ab_loss_lossr5b.json ;;
   multiscale)
     # one launch per loss over the three scales (csrc/multiscale.h, written after the lease closed): its bit-identity tests, then the step A/B
     timeout 900 python3 -m pytest tests/test_zz_round5_gpu.py -q -m gpu -p no:cacheprovider -k "multiscale or handoff" > $out/multiscale_tests.log 2>&1; echo "multiscale tests rc=$?"; tail -4 $out/multiscale_tests.log
@@ -126,13 +118,18 @@ PY
 import json
 for v in (0, 1):
     try:
-        d = json.loads(open('gpurun_out/r5/ab_multiscale_losses_%d.json' % v).read().strip().splitlines()[-1])
+        d = json.loads(open('gpurun_out/r6/ab_multiscale_losses_%d.json' % v).read().strip().splitlines()[-1])
         l = d['roofline']['losses']
         print('multiscale_losses=%d: %.1f pairs/s, loss section %.1f us in %d launches, frac %.3f' % (v, d['value'], l['us_per_step'], l['launches_per_step'], l['frac']))
     except Exception as e:
         print('multiscale_losses=%d: no line (%s)' % (v, e))
 PY
     ;;
+  smallrows)
+    timeout 300 python3 tools/microbench.py corr_small 2>&1 | tee $out/corr_small_microbench.txt | tail -20
+    timeout 600 python3 -m pytest tests/test_hip_ops.py -q -m gpu --runxfail -p no:cacheprovider -k "fp32_next" > $out/smallrows_tests.log 2>&1; echo "fp32_next tests rc=$?"; tail -4 $out/smallrows_tests.log
+    python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --corr-bwd fp32_next > $out/ab_corr_bwd_fp32_next.json 2>> $out/ab.err
+    line $out/ab_corr_bwd_fp32_next.json ;;
   fused_levels)
     # the fused warp + cost-volume kernel at chosen levels only (it lost with all of 2-4 fused; level 5's width 26 is not served)
     for lv in none 4 3,4; do
@@ -140,8 +137,8 @@ PY
       python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline $a > $out/ab_fused_levels_$lv.json 2>> $out/ab.err
     done
     line $out/ab_fused_levels_*.json ;;
-  reopen) bash tools/gpu_r5.sh suite multiscale mfma_harness headline instep_ab ranks8 profile_fp32 traffic loss_pending fused_levels configs profile_bf16 corr8 capi ;;
-  final) bash tools/gpu_r5.sh suite headline configs ranks8 profile_fp32 profile_bf16 traffic corr8 capi ;;
+  reopen) bash tools/gpu_r6.sh suite headline multiscale instep_ab smallrows ranks8 profile_fp32 traffic fused_levels configs profile_bf16 corr8 capi mfma_harness ;;
+  final) bash tools/gpu_r6.sh suite headline configs ranks8 profile_fp32 profile_bf16 traffic corr8 capi ;;
   *) echo "unknown recipe $r" ;;
 esac
 done

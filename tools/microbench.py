@@ -211,6 +211,32 @@ def corr_bwd_mf(B=16):
                 run('mfma (shipped pick)', 2)
 
 
+def corr_small(B=16):
+    """Round 6: the small-map cost-volume backward with the gradient rows through registers (csrc/corr_small_rows.h, UNFLOW_CORR_BWD_FP32_NEXT = 3,
+    never run on a GPU) against what unflow_corr_bwd runs today at levels 5 / 6 of 832x256 and 1024x448, d = 4 (corr_bwd_small_kernel) and d = 8
+    (one lane per output element: 119 / 57 us in round 5)."""
+    lib = _lib.load()
+    P = ops._ptr
+    shapes = [('L5', B, 128, 8, 26), ('L6', B, 196, 4, 13), ('S5', B // 2, 128, 14, 32), ('S6', B // 2, 196, 7, 16)]
+    for d in (8, 4):
+        D2 = (2 * d + 1) ** 2
+        for name, Bq, C, h, w in shapes:
+            f1 = torch.randn(Bq, C, h, w, device='cuda')
+            f2 = torch.randn(Bq, C, h, w, device='cuda')
+            g = torch.randn(Bq, D2, h, w, device='cuda') * 0.05
+            gf1, gf2 = torch.empty_like(f1), torch.empty_like(f2)
+            bb = 4 * Bq * h * w * (4 * C + D2)
+            ref = {}
+            for tag, mode in (('today (fp32)', 1), ('rows through registers', 3)):
+                gf1.fill_(float('nan')); gf2.fill_(float('nan'))
+                tb = timeit(lambda: lib.unflow_corr_bwd_ex(P(f1), P(f2), P(g), P(gf1), P(gf2), Bq, C, h, w, d, mode, ops._stream()), n=50)
+                if not ref:
+                    ref['a'], ref['b'] = gf1.clone(), gf2.clone()
+                err = max((gf1 - ref['a']).abs().max().item(), (gf2 - ref['b']).abs().max().item())
+                print('corr_bwd d=%d %s [%d,%d,%d,%d] %-24s %7.1f us (%6.0f GB/s = %.3f of 8 TB/s)  max|diff vs today| %.2e (max|ref| %.2f)' % (
+                    d, name, Bq, C, h, w, tag, tb, bb / tb / 1e3, bb / tb / 1e3 / 8000.0, err, ref['a'].abs().max().item()), flush=True)
+
+
 def ablate(B=16):
     """Phase ablations at level 2 (tuning library; results are wrong by construction, only the times matter)."""
     lib = _lib.load()

@@ -3,7 +3,7 @@
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude tools/proto/corr_bwd_mfma.hip -o tools/proto/corr_bwd_mfma
 //   tools/proto/corr_bwd_mfma [B C H W [iters]]
 #include "../../unopticalflow_amd/csrc/corr.hip"
-#include "../../unopticalflow_amd/csrc/corr_mfma2.h"
+#include "corr_mfma2.h"
 #include <cstdio>
 #include <cstring>
 #include <cmath>

@@ -1,4 +1,4 @@
-// NOT MEASURED YET (in libunflow_hip.so behind unflow_corr_bwd_ex(UNFLOW_CORR_BWD_MFMA2) only): the matrix-core cost-volume backward of csrc/corr_mfma.h with TWO PIXELS PER LANE
+// PROTOTYPE, NEVER RUN ON A GPU (round 6 moved it out of libunflow_hip.so and its C ABI; tools/proto/corr_bwd_mfma.hip is its harness): the matrix-core cost-volume backward of csrc/corr_mfma.h with TWO PIXELS PER LANE
 // in the upstream-gradient stage.  What the counters of the shipped form say (profiles/r5_corr_bwd_mfma.md): at d = 4 the
 // vector-memory path carries 27 dword-load instructions per source-row step and wave for 81 x 16 gradients -- four 64-byte pieces per
 // instruction -- and a second request set in flight does not help: throughput, not latency.  Here a lane is (pixel PAIR p, displacement

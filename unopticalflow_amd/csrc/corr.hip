@@ -20,7 +20,7 @@
 #include "common.h"
 #include "corr_ring.h"
 #include "corr_mfma.h"
-#include "corr_mfma2.h"
+#include "corr_small_rows.h"
 #include <stdlib.h>
 #include <utility>
 
@@ -1546,7 +1546,7 @@ static constexpr bool kAutoMatrixCoresAtD8 = false;
 extern "C" int unflow_corr_bwd_ex(const float* f1, const float* f2, const float* gcv, float* gf1, float* gf2,
                                   int B, int C, int H, int W, int d, int arithmetic, void* stream) {
     UNFLOW_REQUIRE(f1 && f2 && gcv && gf1 && gf2 && B > 0 && C > 0 && H > 0 && W > 0 && d >= 0);
-    UNFLOW_REQUIRE(arithmetic >= UNFLOW_CORR_BWD_AUTO && arithmetic <= UNFLOW_CORR_BWD_MFMA2);
+    UNFLOW_REQUIRE(arithmetic >= UNFLOW_CORR_BWD_AUTO && arithmetic <= UNFLOW_CORR_BWD_FP32_NEXT);
     hipStream_t s = (hipStream_t)stream;
     int variant = 4;
     switch (d) {
@@ -1558,9 +1558,6 @@ extern "C" int unflow_corr_bwd_ex(const float* f1, const float* f2, const float*
                 // (59 vs 57 us), so it is taken only on request (UNFLOW_CORR_BWD_MFMA)
                 if (arithmetic == UNFLOW_CORR_BWD_MFMA && mfma_served(f1, f2, gcv, gf1, gf2, B, C, H, W, 4))
                     return launch_bwd_mf<4, 2, 1, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, mfma_rows(B, C, H, W, 2, 4), s);
-                // (3: the pixel-pair form of the same sums, corr_mfma2.h -- 11 instead of 27 load instructions per step; host-checked, NOT measured)
-                if (arithmetic == UNFLOW_CORR_BWD_MFMA2 && mfma_served(f1, f2, gcv, gf1, gf2, B, C, H, W, 4))
-                    return launch_bwd_mf2<4, 2, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, mfma_rows(B, C, H, W, 2, 4), s);
                 const bool ring_ok = (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0)     // LDS-DMA moves aligned 16-byte pieces
                                      && gs_offsets_fit(C, H, W, 4);
                 const int fb = forced_bwd();
@@ -1600,6 +1597,11 @@ extern "C" int unflow_corr_bwd_ex(const float* f1, const float* f2, const float*
                 if (fb == 6 || variant == 1 || variant == 7) return launch_bwd<4, 2, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
                 if (variant == 2 || variant == 3 || (mid_size(variant) && (long)B * H * W >= 32768))
                     return launch_bwd<4, 1, 9, 8>(f1, f2, gcv, gf1, gf2, B, C, H, W, s);
+                if (arithmetic == UNFLOW_CORR_BWD_FP32_NEXT && fb == 0) {      // round 6, not measured: gradient rows through registers, 4 / 8 channels per lane
+                    bool launched = false;
+                    const int rc = launch_bwd_smallrows<4, 3>(f1, f2, gcv, gf1, gf2, B, C, H, W, s, &launched);
+                    if (launched) return rc;
+                }
                 if (fb != 2) {                           // small maps (levels 5, 6): whole-map kernel; UNFLOW_CORR_BWD=2: per-element
                     bool launched = false;
                     const int rc = launch_bwd_small<4>(f1, f2, gcv, gf1, gf2, B, C, H, W, s, &launched);
@@ -1610,10 +1612,13 @@ extern "C" int unflow_corr_bwd_ex(const float* f1, const float* f2, const float*
         case 8: variant = pick_variant(B, C, H, W);
                 // round 5: banded bf16x3 products on the matrix cores: level 2 149 us against 271 for the fp32 row-streamed kernel
                 // (tools/proto/corr_bwd_mfma.hip); ~4e-6 of the largest gradient away from the fp32 sums
-                if (arithmetic == UNFLOW_CORR_BWD_MFMA2 && mfma_served(f1, f2, gcv, gf1, gf2, B, C, H, W, 8))
-                    return launch_bwd_mf2<8, 2, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, mfma_rows(B, C, H, W, 2, 8), s);
                 if ((arithmetic == UNFLOW_CORR_BWD_MFMA || (arithmetic == UNFLOW_CORR_BWD_AUTO && kAutoMatrixCoresAtD8)) && mfma_served(f1, f2, gcv, gf1, gf2, B, C, H, W, 8))
                     return launch_bwd_mf<8, 2, 2, 1>(f1, f2, gcv, gf1, gf2, B, C, H, W, mfma_rows(B, C, H, W, 2, 8), s);
+                if (arithmetic == UNFLOW_CORR_BWD_FP32_NEXT && (variant == 4 || (long)B * H * W < 8192)) {      // round 6, not measured: levels 5 / 6 at d = 8
+                    bool launched = false;
+                    const int rc = launch_bwd_smallrows<8, 3>(f1, f2, gcv, gf1, gf2, B, C, H, W, s, &launched);
+                    if (launched) return rc;
+                }
                 if (variant == 4 || (long)B * H * W < 8192) break;      // small maps: one lane per element (117 / 57 us at levels 5 / 6, tile kernel 283 / 378)
                 if ((variant == 7 || mid_size(variant)) && (W & 3) == 0 && ((((size_t)f1 | (size_t)f2) & 15) == 0) && gs_offsets_fit(C, H, W, 8)) {
                     // round 3: row-streamed, 8 channels per item: 290 / 117 / 49 us at levels 2 / 3 / 4 (group-split ring kernel 343 / 129 / 85)

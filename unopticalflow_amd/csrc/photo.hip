@@ -33,19 +33,6 @@ __global__ void absdiff_bwd_kernel(const float* __restrict__ img, const float* _
 #include "bodies/absdiff_bwd.inc"
 }
 
-#ifdef UNFLOW_LOSS_R5B
-// the same, four pixels per lane (HW % 4 == 0, 16-byte aligned planes): grid (ceil(HW / 1024), 3, B) -- no 64-bit divisions, 16-byte accesses
-__global__ __launch_bounds__(256) void absdiff_bwd4_kernel(const float* __restrict__ img, const float* __restrict__ from,
-                                                           const float* __restrict__ gdiff, float* __restrict__ gfrom, int HW, int img_b) {
-    const int b = blockIdx.z, c = blockIdx.y, p = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (p >= HW) return;
-    const size_t o = ((size_t)b * 3 + c) * HW + p, oi = ((size_t)(b % img_b) * 3 + c) * HW + p;
-    const float4 i4 = *reinterpret_cast<const float4*>(img + oi), f4 = *reinterpret_cast<const float4*>(from + o);
-    const float4 g4 = *reinterpret_cast<const float4*>(gdiff + (size_t)b * HW + p);
-    auto one = [](float i, float f, float g) { const float d = i - f; const float sg = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f); return -(g / 3.0f) * sg; };
-    *reinterpret_cast<float4*>(gfrom + o) = make_float4(one(i4.x, f4.x, g4.x), one(i4.y, f4.y, g4.y), one(i4.z, f4.z, g4.z), one(i4.w, f4.w, g4.w));
-}
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // compute_loss_with_mask, model_flow_paper.py:93-97 (one scale)
@@ -76,16 +63,6 @@ __global__ void masked_mean_bwd_kernel(const float* __restrict__ w, const float*
 #include "bodies/masked_mean_bwd.inc"
 }
 
-#ifdef UNFLOW_LOSS_R5B
-__global__ __launch_bounds__(256) void masked_mean_bwd4_kernel(const float* __restrict__ w, const float* __restrict__ sums,
-                                                               const float* __restrict__ gloss, float* __restrict__ gdiff, int HW) {
-    const int b = blockIdx.y, p = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (p >= HW) return;
-    const float k = gloss[b] / (float)HW / (sums[b * 2 + 1] / (float)HW + 1e-12f);
-    const float4 w4 = *reinterpret_cast<const float4*>(w + (size_t)b * HW + p);
-    *reinterpret_cast<float4*>(gdiff + (size_t)b * HW + p) = make_float4(k * w4.x, k * w4.y, k * w4.z, k * w4.w);
-}
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // cal_grad2_error / compute_loss_flow_smooth, model_flow_paper.py:152-177 (one scale)
@@ -221,35 +198,6 @@ __global__ __launch_bounds__(256) void smooth2_bwd_tile_kernel(const float* __re
 constexpr int SG_W = SM_TW + 4, SG_H = SM_TH + 4, SG_N = SG_W * SG_H;
 struct SmoothStage { float f0[SG_N], f1[SG_N], i0[SG_N], i1[SG_N], i2[SG_N]; };
 
-#ifdef UNFLOW_LOSS_R5B     // written after the GPU lease closed in round 5: never run, compiled out of the shipped library (tools/gpu_r5.sh loss_pending)
-// (round 5: all of a thread's loads are issued before the first value is used -- as a loop of load -> divide -> LDS store every one of
-// the four passes waited for its own loads, 4 x a memory latency per 512-pixel workgroup; positions outside the image read element 0
-// and are zeroed by a select, so nothing is branched over)
-__device__ __forceinline__ void smooth_stage(SmoothStage& t, const float* __restrict__ f, const float* __restrict__ im, int HW,
-                                             int H, int W, int x0, int y0) {
-    constexpr int IT = (SG_N + 255) / 256;
-    float a[IT], b[IT], c0[IT], c1[IT], c2[IT];
-    bool in[IT];
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int i = it * 256 + (int)threadIdx.x;
-        const int ry = i / SG_W, rx = i - ry * SG_W;
-        const int y = y0 - 2 + ry, x = x0 - 2 + rx;
-        in[it] = (i < SG_N) & (x >= 0) & (x < W) & (y >= 0) & (y < H);
-        const int q = in[it] ? y * W + x : 0;
-        a[it] = f[q]; b[it] = f[HW + q];
-        c0[it] = im[q]; c1[it] = im[HW + q]; c2[it] = im[2 * HW + q];
-    }
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int i = it * 256 + (int)threadIdx.x;
-        if (i < SG_N) {
-            t.f0[i] = in[it] ? a[it] / 20.0f : 0.f; t.f1[i] = in[it] ? b[it] / 20.0f : 0.f;
-            t.i0[i] = in[it] ? c0[it] : 0.f; t.i1[i] = in[it] ? c1[it] : 0.f; t.i2[i] = in[it] ? c2[it] : 0.f;
-        }
-    }
-}
-#else
 __device__ __forceinline__ void smooth_stage(SmoothStage& t, const float* __restrict__ f, const float* __restrict__ im, int HW,
                                              int H, int W, int x0, int y0) {
     for (int i = threadIdx.x; i < SG_N; i += 256) {
@@ -264,7 +212,6 @@ __device__ __forceinline__ void smooth_stage(SmoothStage& t, const float* __rest
         t.f0[i] = a; t.f1[i] = b; t.i0[i] = c0; t.i1[i] = c1; t.i2[i] = c2;
     }
 }
-#endif
 
 // edge_w() between two staged positions
 __device__ __forceinline__ float stage_edge_w(const SmoothStage& t, int j0, int j1) {
@@ -650,13 +597,6 @@ extern "C" int unflow_absdiff_bwd(const float* img, const float* from, const flo
                                   int B, int H, int W, int img_batch, void* stream) {
     UNFLOW_REQUIRE(img && from && gdiff && gfrom && B > 0 && H > 0 && W > 0 && img_batch > 0 && B % img_batch == 0);
     hipStream_t s = (hipStream_t)stream;
-#ifdef UNFLOW_LOSS_R5B
-    const int HW = H * W;
-    if ((HW & 3) == 0 && B <= 65535 && ((((size_t)img | (size_t)from | (size_t)gdiff | (size_t)gfrom) & 15) == 0)) {
-        UNFLOW_LAUNCH(absdiff_bwd4_kernel, dim3(ceil_div(HW, 1024), 3, B), dim3(256), 0, s, img, from, gdiff, gfrom, HW, img_batch);
-        return unflow_launch_status();
-    }
-#endif
     UNFLOW_LAUNCH(absdiff_bwd_kernel, dim3(flat_blocks((size_t)B * 3 * H * W)), dim3(256), 0, s, img, from,
                        gdiff, gfrom, B, H * W, img_batch);
     return unflow_launch_status();
@@ -678,12 +618,6 @@ extern "C" int unflow_masked_mean_bwd(const float* w, const float* sums, const f
                                       int B, int H, int W, void* stream) {
     UNFLOW_REQUIRE(w && sums && gloss && gdiff && B > 0 && H > 0 && W > 0);
     hipStream_t s = (hipStream_t)stream;
-#ifdef UNFLOW_LOSS_R5B
-    if (((H * W) & 3) == 0 && B <= 65535 && ((((size_t)w | (size_t)gdiff) & 15) == 0)) {
-        UNFLOW_LAUNCH(masked_mean_bwd4_kernel, dim3(ceil_div(H * W, 1024), B), dim3(256), 0, s, w, sums, gloss, gdiff, H * W);
-        return unflow_launch_status();
-    }
-#endif
     UNFLOW_LAUNCH(masked_mean_bwd_kernel, dim3(flat_blocks((size_t)B * H * W)), dim3(256), 0, s, w, sums,
                        gloss, gdiff, B, H * W);
     return unflow_launch_status();

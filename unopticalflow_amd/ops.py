@@ -317,8 +317,8 @@ def _partials(B, H, W, dev):
 # arithmetic of the cost-volume backward, chosen PER CALL (include/unflow_hip.h UNFLOW_CORR_BWD_*; the library keeps no mode): 'auto' = per
 # shape, the fastest kernel that has passed a complete GPU parity run; 'fp32' = the fp32 FMA kernels everywhere; 'mfma' = banded bf16 hi/lo
 # split products on the matrix cores (fp32 accumulation; ~4e-6 of the largest gradient away from the fp32 sums, deterministic) wherever the
-# shape is served; 'mfma2' = its pixel-pair variant (csrc/corr_mfma2.h)
-CORR_BACKWARD_MODES = {'auto': 0, 'fp32': 1, 'mfma': 2, 'mfma2': 3}
+# shape is served; 'fp32_next' = the fp32 kernels incl. the round-6 ones no GPU has run yet (small maps: csrc/corr_small_rows.h)
+CORR_BACKWARD_MODES = {'auto': 0, 'fp32': 1, 'mfma': 2, 'fp32_next': 3}
 
 
 class _Corr(torch.autograd.Function):
