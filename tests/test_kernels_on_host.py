@@ -336,10 +336,10 @@ def test_warp_kernels_run_on_the_host_and_match_the_oracle(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     rng = np.random.default_rng(5)
     cases = []                                                              # (B, C, H, W, masked, ac, flow kind)
-    cases.append((8, 32, 64, 208, 0, 0, 'smooth'))                         # level 2 of the step at B = 4 pairs: the one-pass backward is picked (supported == 2)
+    cases.append((8, 16, 64, 208, 0, 0, 'smooth'))                         # level 2 of the step at B = 4 pairs (half its channels): the one-pass backward is picked (supported == 2)
     for kind in ('mixed', 'outside', 'edge', 'noise'):
-        cases.append((2, 32, 64, 208, 0, 0, kind))
-    cases += [(3, 64, 32, 104, 0, 0, 'smooth'), (2, 64, 32, 104, 0, 1, 'mixed'), (2, 96, 16, 52, 0, 0, 'smooth'), (2, 128, 8, 26, 0, 0, 'edge'),
+        cases.append((2, 32 if kind == 'mixed' else 16, 64, 208, 0, 0, kind))
+    cases += [(3, 32, 32, 104, 0, 0, 'smooth'), (2, 64, 32, 104, 0, 1, 'mixed'), (2, 96, 16, 52, 0, 0, 'smooth'), (2, 128, 8, 26, 0, 0, 'edge'),
               (2, 9, 17, 130, 0, 1, 'noise'), (2, 20, 40, 72, 0, 0, 'mixed')]
     cases += [(3, 3, 40, 100, 1, 0, 'mixed'), (3, 3, 20, 50, 1, 0, 'edge'), (3, 3, 10, 25, 1, 0, 'noise')]      # an image pyramid: masked, no source gradient
     data = []
