@@ -159,8 +159,53 @@ static inline hip_on_host_v4f hip_on_host_mfma_16x16x32_bf16(hip_on_host_bf16x8 
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) hip_on_host_mfma_16x16x32_bf16(a, b, c)
 #endif
 
+// ---- the host forms of csrc/device_forms.h (the product's one header of gfx950-only forms: common.h includes THIS file instead of it in the test
+// build, so every name defined there is defined here).  Register pins and counted waits mean nothing -- every load has landed when its call
+// returns --, the occupancy attribute is dropped, address-space pointers are plain pointers, and a wave's lock step needs marking because the
+// lanes of a wave run one after the other.
+#define UNFLOW_PIN_VGPR(x) ((void)(x))
+#define UNFLOW_PIN_SGPR(x) ((void)(x))
+#define UNFLOW_WAIT_LGKMCNT0()
+#define UNFLOW_WAIT_VMCNT0()
+#define UNFLOW_WAVES_PER_EU(n)
+#define UNFLOW_WAVE_LOCKSTEP() __syncthreads()
+typedef const void* wgas_ptr;
+typedef void* wlds_ptr;
+namespace {
+typedef const float lds_cfloat;
+typedef const float gfloat;
+typedef const void* gas_ptr;
+typedef void* lds_ptr;
+inline __attribute__((aligned(16))) float kZeroLine[4] = {0.f, 0.f, 0.f, 0.f};
+static inline gfloat* zero_line() { return kZeroLine; }
+template <int N> static inline void lds_wait() {}
+template <int N> static inline void vm_wait() {}
+// the wave shift by one lane is an exchange between the fibers (0 enters at the wave's ends)
+static inline float from_lane_below(float v) { const float r = __shfl_up(v, 1, 64); return (threadIdx.x & 63) == 0 ? 0.f : r; }
+static inline float from_lane_above(float v) { const float r = __shfl_down(v, 1, 64); return (threadIdx.x & 63) == 63 ? 0.f : r; }
+// a 32-bit "LDS address" is the low half of the host address (lds_at() finds the object again): the hand-issued reads and writes are plain
+// loads and stores at the same addresses
+static inline void lds_write_b32(unsigned addr, float v) { memcpy(hip_on_host::lds_at(addr, 4), &v, 4); }
+#if defined(__clang__)
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef const v2f lds_cfloat2;
+template <int OFF>
+static inline v2f lds_read_b64(unsigned addr) { v2f v; memcpy(&v, hip_on_host::lds_at(addr + OFF, 8), 8); return v; }
+template <int OFF0, int OFF1>
+static inline v2f lds_read2_b32(unsigned addr) {
+    float lo, hi;
+    memcpy(&lo, hip_on_host::lds_at(addr + 4 * OFF0, 4), 4);
+    memcpy(&hi, hip_on_host::lds_at(addr + 4 * OFF1, 4), 4);
+    return v2f{lo, hi};
+}
+template <int OFF>
+static inline void lds_write_b64(unsigned addr, v2f v) { memcpy(hip_on_host::lds_at(addr + OFF, 8), &v, 8); }
+#endif
+}  // namespace
+
 // dynamic LDS (common.h: UNFLOW_DYNAMIC_LDS): one block of the size of a CU's LDS; raising a kernel's dynamic-LDS limit is a no-op
 namespace hip_on_host { alignas(16) inline unsigned char dynamic_lds[160 * 1024]; }
+#define UNFLOW_DYNAMIC_LDS(T, name) T* name = reinterpret_cast<T*>(hip_on_host::dynamic_lds)
 #define hipFuncAttributeMaxDynamicSharedMemorySize 0
 static inline int hipFuncSetAttribute(const void*, int, int) { return 0; }
 

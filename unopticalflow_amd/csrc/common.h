@@ -1,34 +1,16 @@
 // Shared device helpers for the gfx950 kernels of libunflow_hip.so.
 #pragma once
-#ifdef UNFLOW_HOST_CHECK            // tests/host_check/: this header and the loss kernels compiled with g++, lanes as threads of the build host
-#include "hip_on_host.h"
+#include <stdint.h>
+#include "../../include/unflow_hip.h"
+#ifdef UNFLOW_HOST_CHECK            // the TEST build (tests/host_check/: kernel sources compiled for the build host, lanes as fibers): that header holds
+#include "hip_on_host.h"            // the host form of every name device_forms.h defines -- the one place csrc/ knows about it
 #else
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include "device_forms.h"
 #endif
-#include <stdint.h>
-#include "../../include/unflow_hip.h"
 
 #define UNFLOW_WAVE 64
-
-// a kernel's dynamic LDS array (`extern __shared__ T name[]`; on the build host -- tests/host_check/ -- one static block stands for it)
-#ifdef UNFLOW_HOST_CHECK
-#define UNFLOW_DYNAMIC_LDS(T, name) T* name = reinterpret_cast<T*>(hip_on_host::dynamic_lds)
-#else
-#define UNFLOW_DYNAMIC_LDS(T, name) extern __shared__ T name[]
-#endif
-
-// hipcc idioms that mean nothing on the build host: keep a value in a vector / scalar register where it is (an empty asm the
-// optimiser cannot see through), drain this wave's LDS / scalar-memory counter
-#ifdef UNFLOW_HOST_CHECK
-#define UNFLOW_PIN_VGPR(x) ((void)(x))
-#define UNFLOW_PIN_SGPR(x) ((void)(x))
-#define UNFLOW_WAIT_LGKMCNT0()
-#else
-#define UNFLOW_PIN_VGPR(x) asm volatile("" : "+v"(x))
-#define UNFLOW_PIN_SGPR(x) asm volatile("" : "+s"(x))
-#define UNFLOW_WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#endif
 
 #define UNFLOW_REQUIRE(cond) do { if (!(cond)) return UNFLOW_EINVAL; } while (0)
 

@@ -689,14 +689,6 @@ template <int GL, int N, int... Es>
 __device__ __forceinline__ void slab_read(v2f (&q)[N], unsigned addr, std::integer_sequence<int, Es...>) {
     ((q[Es] = lds_read_b64<Es * GL * 8>(addr)), ...);
 }
-template <int OFF>
-__device__ __forceinline__ void lds_write_b64(unsigned addr, v2f v) {
-#ifdef UNFLOW_HOST_CHECK
-    memcpy(hip_on_host::lds_at(addr + OFF, 8), &v, 8);
-#else
-    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
-#endif
-}
 template <int GL, int CC, int... Cs>
 __device__ __forceinline__ void slab_write(unsigned addr, const v2f (&v)[CC], std::integer_sequence<int, Cs...>) {
     (lds_write_b64<Cs * GL * 8>(addr, v[Cs]), ...);

@@ -25,19 +25,7 @@
 // Results are deterministic (no atomics) but not bit-identical to the fp32 kernels.
 #pragma once
 #define UNFLOW_CORR_MFMA_INCLUDED 1
-#ifdef UNFLOW_HOST_CHECK            // (tests/host_check/mfma_check.cpp: this header compiled for the build host -- the matrix instruction, the buffer
-#include "common.h"                 // accesses and the LDS address space have host forms in tests/host_check/hip_on_host.h)
-#else
 #include "corr_ring.h"
-#endif
-
-// A wave executes its LDS accesses in program order for all 64 lanes at once: the table writes of a round are complete before any lane reads its
-// fragment, with no barrier.  Lanes that run one after the other (the host check) need the point marked; on the device it is nothing.
-#ifdef UNFLOW_HOST_CHECK
-#define UNFLOW_WAVE_LOCKSTEP() __syncthreads()
-#else
-#define UNFLOW_WAVE_LOCKSTEP()
-#endif
 
 namespace {
 

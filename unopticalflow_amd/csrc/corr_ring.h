@@ -7,63 +7,7 @@
 
 namespace {
 
-#ifdef UNFLOW_HOST_CHECK
-// On the build host (tests/host_check/: lanes as fibers) LDS is ordinary static memory: the address-space typedefs are plain pointers, a
-// 32-bit "LDS address" is the low half of the host address (hip_on_host::lds_at() finds the object again), the hand-issued reads and
-// writes are plain loads and stores, and the counted waits mean nothing -- every load has landed when its call returns.
-typedef const float lds_cfloat;
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef const v2f lds_cfloat2;
-typedef const float gfloat;
-typedef const void* gas_ptr;
-typedef void* lds_ptr;
-inline __attribute__((aligned(16))) float kZeroLine[4] = {0.f, 0.f, 0.f, 0.f};
-static inline gfloat* zero_line() { return kZeroLine; }
-template <int OFF>
-static inline v2f lds_read_b64(unsigned addr) { v2f v; memcpy(&v, hip_on_host::lds_at(addr + OFF, 8), 8); return v; }
-template <int N> static inline void lds_wait() {}
-template <int N> static inline void vm_wait() {}
-#else
-typedef __attribute__((address_space(3))) const float lds_cfloat;
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) const v2f lds_cfloat2;
-
-__device__ __attribute__((aligned(16))) float kZeroLine[4] = {0.f, 0.f, 0.f, 0.f};    // source of out-of-image DMA slots
-
-// Its address, fetched ONCE per wave into a scalar register pair.  Naming kZeroLine at the point of use makes hipcc
-// re-derive it there every time (s_getpc + s_load through the GOT + s_waitcnt lgkmcnt(0)) and, since that is expensive,
-// wrap each `ok ? p : kZeroLine` in an EXEC-masked branch: 58 scalar-memory round trips and 56 branches in the
-// gradient gather of the group-split backward alone.
-typedef __attribute__((address_space(1))) const float gfloat;       // explicit global address space: a laundered generic
-__device__ __forceinline__ gfloat* zero_line() {                     // pointer would turn every load behind it into flat_load
-    gfloat* z = (gfloat*)kZeroLine;
-    UNFLOW_PIN_SGPR(z);
-    return z;
-}
-
-typedef __attribute__((address_space(1))) const void* gas_ptr;
-typedef __attribute__((address_space(3))) void* lds_ptr;
-
-// Hand-issued LDS reads with hand-counted waits.  hipcc tracks its own ds_reads with lgkmcnt(0)
-// whenever a register buffer is re-used, which exposes the full LDS latency every few rows at two
-// waves per SIMD; here the row stream is software-pipelined PF row-steps deep and every step waits
-// only for its own rows (lgkmcnt is a 4-bit in-order counter: <= 15 reads are kept in flight).
-template <int OFF>
-__device__ __forceinline__ v2f lds_read_b64(unsigned addr) {
-    v2f v;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-template <int N>
-__device__ __forceinline__ void lds_wait() {
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-    __builtin_amdgcn_sched_barrier(0);      // nothing that consumes the rows may move above the wait
-}
-
-template <int N>
-__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-#endif
+// (address-space typedefs, zero_line(), the hand-issued ds_read / ds_write forms and the counted waits: device_forms.h through common.h)
 
 // the lane's own f1 pixels of the stage's CC channels (channel stride CH_BYTES)
 template <int CH_BYTES, int CC, int... Cs>

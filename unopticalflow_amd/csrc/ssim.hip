@@ -308,22 +308,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define SSIM2_ROWS 0             // output rows per wave: 0 = by map height (16 from 128 rows up, else 8)
 #endif
 
-#ifdef UNFLOW_HOST_CHECK
-#define UNFLOW_WAVES_PER_EU(n)
-#else
-#define UNFLOW_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
-#endif
-#ifdef UNFLOW_HOST_CHECK            // (tests/host_check/ssim_check.cpp: lanes are fibers of the build host, the wave shift an exchange between them)
-__device__ __forceinline__ float from_lane_below(float v) { const float r = __shfl_up(v, 1, 64); return (threadIdx.x & 63) == 0 ? 0.f : r; }
-__device__ __forceinline__ float from_lane_above(float v) { const float r = __shfl_down(v, 1, 64); return (threadIdx.x & 63) == 63 ? 0.f : r; }
-#else
-__device__ __forceinline__ float from_lane_below(float v) {       // lane i <- lane i-1 (0 into lane 0)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float from_lane_above(float v) {       // lane i <- lane i+1 (0 into lane 63)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
-}
-#endif
+// (from_lane_below / from_lane_above -- lane i <- lane i -+ 1, 0 at the wave's ends -- are DPP wave shifts: device_forms.h)
 // the column pair one to the left / right of this lane's pair
 __device__ __forceinline__ f2 pair_left(f2 c) { f2 r; r.x = from_lane_below(c.y); r.y = c.x; return r; }
 __device__ __forceinline__ f2 pair_right(f2 c) { f2 r; r.x = c.y; r.y = from_lane_above(c.x); return r; }

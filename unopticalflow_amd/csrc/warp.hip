@@ -130,15 +130,6 @@ __device__ __forceinline__ void tile_setup(TileCtx<PPT>& k, const float* __restr
     k.wh = by1 >= by0 ? by1 - by0 + 1 : 0;
 }
 
-#ifdef UNFLOW_HOST_CHECK            // (tests/host_check/warp_check.cpp: the file compiled for the build host, lanes as fibers; LDS-DMA is a memcpy there)
-typedef const void* wgas_ptr;
-typedef void* wlds_ptr;
-#define UNFLOW_WAIT_VMCNT0()
-#else
-typedef __attribute__((address_space(1))) const void* wgas_ptr;
-typedef __attribute__((address_space(3))) void* wlds_ptr;
-#define UNFLOW_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#endif
 
 // The source window in LDS: rows [wy0, wy0+wh) x [wxa, wxa+rs) of a channel plane, packed with row stride `rs`
 // (runtime: the window is as wide as this tile's flow makes it), channel stride WIN floats.

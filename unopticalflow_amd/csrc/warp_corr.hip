@@ -22,27 +22,6 @@
 
 namespace {
 
-template <int OFF0, int OFF1>
-__device__ __forceinline__ v2f lds_read2_b32(unsigned addr) {
-    v2f v;
-#ifdef UNFLOW_HOST_CHECK            // (tests/host_check/: the two dwords at addr + 4 OFF0 and addr + 4 OFF1, plain loads)
-    float lo, hi;
-    memcpy(&lo, hip_on_host::lds_at(addr + 4 * OFF0, 4), 4);
-    memcpy(&hi, hip_on_host::lds_at(addr + 4 * OFF1, 4), 4);
-    v = v2f{lo, hi};
-#else
-    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(OFF0), "n"(OFF1));
-#endif
-    return v;
-}
-__device__ __forceinline__ void lds_write_b32(unsigned addr, float v) {
-#ifdef UNFLOW_HOST_CHECK
-    memcpy(hip_on_host::lds_at(addr, 4), &v, 4);
-#else
-    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
-#endif
-}
-
 __device__ __forceinline__ int wave_min_i32(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
