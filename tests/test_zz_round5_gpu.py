@@ -32,7 +32,7 @@ def _child(ids, timeout, junit=None):
 
 
 def _ran_in_a_child(request):
-    """Tests that launch device code which has NEVER run (the `_ms` kernels of csrc/multiscale.h, csrc/corr_mfma2.h) do it outside the pytest
+    """Tests that launch device code which has NEVER run (the `_ms` kernels of csrc/multiscale.h) do it outside the pytest
     process of the validated suite: a GPU fault there fails these tests instead of taking that process down.  All `own_process` tests of
     the session run in ONE child (a process start, torch import and library load once, not a dozen times); a test the child did not get to
     (it died on the way) is run again in a child of its own.  -> True when a child ran the test (and it passed: a failure is raised here);
