@@ -31,12 +31,17 @@ def _child(ids, timeout, junit=None):
         return subprocess.CompletedProcess(cmd, 124, stdout=(e.stdout or b'').decode(errors='replace') if isinstance(e.stdout, bytes) else (e.stdout or ''), stderr='timed out')
 
 
+_CHILD_BUDGET_S = [600.0]        # wall seconds all child processes of a session may take together (the driver caps the whole suite at 1200 s)
+
+
 def _ran_in_a_child(request):
     """Tests that launch device code which has NEVER run (the `_ms` kernels of csrc/multiscale.h) do it outside the pytest
     process of the validated suite: a GPU fault there fails these tests instead of taking that process down.  All `own_process` tests of
     the session run in ONE child (a process start, torch import and library load once, not a dozen times); a test the child did not get to
-    (it died on the way) is run again in a child of its own.  -> True when a child ran the test (and it passed: a failure is raised here);
-    False inside the child, where the body runs."""
+    (it died on the way) is run again in a child of its own -- as long as the session's child budget lasts: a child that hangs costs its
+    300 s once, not once per test.  -> True when a child ran the test (and it passed: a failure is raised here); False inside the child,
+    where the body runs."""
+    import time
     if os.environ.get('UNFLOW_ZZ_CHILD'):
         return False
     me = request.node.nodeid
@@ -46,10 +51,17 @@ def _ran_in_a_child(request):
         ids = [it.nodeid for it in request.session.items if it.get_closest_marker('own_process')] or [me]
         with tempfile.TemporaryDirectory() as tmp:
             junit = os.path.join(tmp, 'isolated.xml')
+            t0 = time.monotonic()
             r = _child(ids, 300, junit)
+            _CHILD_BUDGET_S[0] -= time.monotonic() - t0
             _batch['log'] = (r.stdout[-3000:], r.stderr[-1500:])
+            _batch['timed_out'] = r.returncode == 124
             if os.path.exists(junit):
-                for case in ET.parse(junit).getroot().iter('testcase'):
+                try:
+                    cases = list(ET.parse(junit).getroot().iter('testcase'))
+                except ET.ParseError:                                   # (a child killed while it wrote the report)
+                    cases = []
+                for case in cases:
                     bad = [c for c in case if c.tag in ('failure', 'error')]
                     skipped = any(c.tag == 'skipped' for c in case)
                     _batch[case.get('name')] = ('failed', (bad[0].get('message') or '')[:300] + '\n' + (bad[0].text or '')[-2500:]) if bad else (('skipped', '') if skipped else ('passed', ''))
@@ -60,7 +72,12 @@ def _ran_in_a_child(request):
             pytest.skip('skipped in the child process')
         assert state == 'passed', why
         return True
-    r = _child([me], 300)                                  # the batch never reached this test: on its own
+    # the batch never reached this test
+    assert not _batch.get('timed_out'), 'the shared child process timed out before this test ran: %s' % (_batch.get('log'),)
+    assert _CHILD_BUDGET_S[0] > 60.0, 'no child-process time left in this session (batch: %s)' % (_batch.get('log'),)
+    t0 = time.monotonic()
+    r = _child([me], int(min(300.0, _CHILD_BUDGET_S[0])))
+    _CHILD_BUDGET_S[0] -= time.monotonic() - t0
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:], 'batch: %s' % (_batch.get('log'),))
     return True
 
