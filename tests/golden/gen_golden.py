@@ -339,8 +339,9 @@ def eval_inputs(seed=11, n=3, H=37, W=61):
 
 def gen_eval():
     """core/evaluation/evaluate_flow.py imported unmodified: calculate_error_rate (:85-90) and eval_flow_avg (:93-174).
-    Harness shims: empty ``png`` module (flowlib.py:11 imports it; read_flow_png is not called), ``cv2.resize`` that only
-    accepts the identity case.  The PNG decode and the real bilinear resize stay unpinned (no pypng / cv2 in the image)."""
+    Harness shims: a ``png`` module whose Reader serves pixel rows from an array (flowlib.py:11 imports pypng; read_flow_png, flowlib.py:107-127,
+    runs over it: the arithmetic after the decode is the reference's), ``cv2.resize`` that only accepts the identity case.  The PNG byte decode
+    itself and the real bilinear resize stay unpinned (no pypng / cv2 in the image)."""
     sys.modules.setdefault('png', types.ModuleType('png'))
     cv2 = sys.modules['cv2']
 
@@ -364,6 +365,24 @@ def gen_eval():
         rates.append([EF.calculate_error_rate(epe, g[:, :, :2], g[:, :, 2]), EF.calculate_error_rate(epe, g[:, :, :2], g[:, :, 2] * m),
                       EF.calculate_error_rate(epe, g[:, :, :2], g[:, :, 2] * (1.0 - m)), EF.calculate_error_rate(epe, g[:, :, :2], n_)])
     out['error_rates'] = np.array(rates, np.float64)
+    # flowlib.read_flow_png (flowlib.py:107-127), the reference's own function, over a stand-in for the third-party decoder it calls: pypng's
+    # Reader(...).asDirect() hands it (w, h, rows of 3 w flat uint16 values, info); the stand-in serves those rows from an array instead of a
+    # file, so what is pinned here is everything AFTER the PNG decode: channel order, (v - 2^15) / 64, the validity channel, zeros where invalid
+    import flowlib
+    rng = np.random.default_rng(23)
+    raw = rng.integers(0, 65536, (29, 47, 3), dtype=np.uint16)
+    raw[:, :, 2] = rng.integers(0, 2, (29, 47))                   # validity: 0 / 1 as in KITTI
+    raw[3, 5] = (2 ** 15, 2 ** 15, 1); raw[4, 6] = (0, 65535, 1); raw[5, 7] = (12345, 54321, 0)
+
+    class _Reader:
+        def __init__(self, filename=None):
+            pass
+
+        def asDirect(self):
+            return raw.shape[1], raw.shape[0], iter([row.reshape(-1) for row in raw]), {'size': (raw.shape[1], raw.shape[0])}
+    flowlib.png.Reader = _Reader
+    out['flowpng_raw'] = raw
+    out['flowpng_flow'] = flowlib.read_flow_png('unused')
     out['result_plain'] = np.array(EF.eval_flow_avg(gt, noc, pred, cfg))
     out['result_moving'] = np.array(EF.eval_flow_avg(gt, noc, pred, cfg, moving_masks=move))
     # un-rounded per-metric averages, recomputed from the reference's own formulas' pieces (the strings carry 4 decimals)
@@ -371,7 +390,50 @@ def gen_eval():
     print(out['result_plain']); print(out['result_moving'])
 
 
+def gen_prepare():
+    """core/dataset/kitti_prepared.py imported unmodified: KITTI_Prepared.preprocess_img (:91-99: resize_img :63-76, random_flip_img :78-82, / 255.0)
+    and the tail of __getitem__ (:146-148,154: transpose(2, 0, 1), torch.from_numpy(img).float()) on a decoded stacked triplet at its NATIVE size.
+    Harness shims for the third-party calls: ``cv2.resize`` accepts only the identity case (OpenCV's same-size resize is a copy), ``cv2.flip(img, 1)``
+    is the horizontal mirror it documents.  So the frame split, the flip, the scaling, the channel / layout order and the float32 rounding are the
+    reference's own; OpenCV's fixed-point bilinear at other sizes stays unpinned (no cv2 in the image; oracle/prepare_cpu.py restates it)."""
+    cv2 = sys.modules['cv2']
+
+    def resize(img, size, interpolation=None):
+        assert (img.shape[1], img.shape[0]) == tuple(size), 'fixture is native-resolution only'
+        return np.copy(img)
+    cv2.resize, cv2.flip, cv2.INTER_LINEAR = resize, (lambda img, code: np.ascontiguousarray(img[:, ::-1]) if code == 1 else None), 1
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('kitti_prepared', '/root/reference/core/dataset/kitti_prepared.py')
+    KP = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(KP)
+    ds = object.__new__(KP.KITTI_Prepared)                 # (no train.txt to read: only the image path of __getitem__ is exercised)
+    h, w = 24, 40
+    ds.img_hw = (h, w)
+    rng = np.random.default_rng(31)
+    img = rng.integers(0, 256, (3 * h, w, 3), dtype=np.uint8)
+    img[0, 0] = (0, 255, 1); img[h, 1] = (254, 127, 128)
+    out = {'img': img, 'img_hw': np.array([h, w])}
+    seen = {}
+    for seed in range(64):                                   # the reference draws the flip from numpy's global generator (:79)
+        np.random.seed(seed)
+        flipped = np.random.rand() > 0.5
+        if flipped in seen:
+            continue
+        np.random.seed(seed)
+        x = ds.preprocess_img(img.copy(), ds.img_hw)
+        x = torch.from_numpy(x.transpose(2, 0, 1)).float()
+        seen[flipped] = True
+        out['out_flip%d' % int(flipped)] = x.numpy()
+        if len(seen) == 2:
+            break
+    assert len(seen) == 2
+    save('g7_prepare.npz', out)
+
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['prepare']:
+        gen_prepare()
+        sys.exit(0)
     if sys.argv[1:] == ['eval']:
         gen_eval()
         sys.exit(0)
@@ -390,3 +452,4 @@ if __name__ == '__main__':
     gen_module('g2_module_128.npz', 2, 128, 128, steps=3, full_flows=True, mask_flow_scales=(0, 1, 2, 3), full_grads=True)
     gen_module('g3_kitti_256x832.npz', 1, 256, 832, steps=1, full_flows=False, mask_flow_scales=(1, 2, 3))
     gen_eval()
+    gen_prepare()

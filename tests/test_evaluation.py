@@ -44,6 +44,19 @@ def test_flow_png_encoding(tmp_path):
     assert raw.dtype == np.uint16 and raw[0, 0, 0] == int(np.clip(fl[0, 0, 0] * 64 + 2 ** 15, 0, 65535))
 
 
+def test_flow_png_matches_the_references_own_reader(tmp_path, golden):
+    """g4_eval.npz holds what the REFERENCE's flowlib.read_flow_png (flowlib.py:107-127, imported unmodified) returns for given 16-bit RGB pixel
+    rows (its third-party decoder, pypng, replaced by a stand-in that serves the rows: tests/golden/gen_golden.py eval).  The same pixels written as a
+    real PNG and read back by this package's reader: the float64 flow and the validity channel bit for bit -- everything after the byte decode is
+    pinned on the reference; the decode itself on PIL where PIL can read the format (test_png_codec_against_pil) and on the round trip here."""
+    g = golden('g4_eval.npz')
+    raw = g['flowpng_raw']
+    E.write_png(str(tmp_path / 'k.png'), raw)
+    assert np.array_equal(E.read_png(str(tmp_path / 'k.png')), raw)
+    got = E.read_flow_png(str(tmp_path / 'k.png'))
+    assert got.dtype == np.float64 and np.array_equal(got, g['flowpng_flow'])
+
+
 def _make_kitti(root, n, H=48, W=160, flow=(4.0, -2.0)):
     for d in ('flow_occ', 'flow_noc', 'obj_map', 'image_2'):
         os.makedirs(os.path.join(root, d), exist_ok=True)

@@ -195,6 +195,21 @@ def test_input_stage_kernel_runs_on_the_host_bit_exact(tmp_path):
         for i, im in enumerate(images):
             src = im[:, :, ::-1] if swap else im                              # swap_rb: an RGB-decoded source lands in cv2's BGR planes
             np.testing.assert_array_equal(out[i], prepare_triplet(src, (H, W), flips[i]), err_msg='image %d, %dx%d' % (i, H, W))
+    # ... and against the REFERENCE's own input pipeline (tests/golden/g7_prepare.npz: KITTI_Prepared.preprocess_img + the tail of __getitem__,
+    # kitti_prepared.py:63-99,146-154, at the image's native size): the kernel source leaves its bytes, flipped and not
+    g = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'g7_prepare.npz')))
+    H, W = (int(v) for v in g['img_hw'])
+    with open(fin, 'wb') as f:
+        f.write(struct.pack('4i', 2, H, W, 0))
+        for fl in (0, 1):
+            f.write(struct.pack('3i', g['img'].shape[0], g['img'].shape[1], fl))
+        for _ in (0, 1):
+            f.write(np.ascontiguousarray(g['img']).tobytes())
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'OK' in r.stdout, (r.stdout, r.stderr)
+    out = np.fromfile(fout, dtype=np.float32).reshape(2, 3, 3 * H, W)
+    for fl in (0, 1):
+        np.testing.assert_array_equal(out[fl], g['out_flip%d' % fl], err_msg='reference fixture, flip %d' % fl)
 
 
 def test_loss_kernels_run_on_the_host_and_match_the_oracle(tmp_path):

@@ -50,8 +50,30 @@ def test_prepare_triplet_layout_and_flip():
     np.testing.assert_array_equal(prepare_triplet(img, (64, 128), True), out[:, :, ::-1])
 
 
+def test_prepare_triplet_matches_the_references_own_pipeline(golden):
+    """g7_prepare.npz: the REFERENCE's KITTI_Prepared.preprocess_img and the tail of its __getitem__ (kitti_prepared.py:63-99,146-154, imported
+    unmodified; cv2.resize in its identity case, cv2.flip as the mirror it documents) on a decoded stacked triplet at its native size, with and
+    without the flip.  The restatement gives the same float32 bytes: frame split, flip, / 255.0 in float64 then .float(), HWC -> CHW."""
+    g = golden('g7_prepare.npz')
+    hw = tuple(int(v) for v in g['img_hw'])
+    for flip in (0, 1):
+        np.testing.assert_array_equal(prepare_triplet(g['img'], hw, bool(flip)), g['out_flip%d' % flip])
+
+
 # ----------------------------------------------------------------------------------------------------------
 gpu = pytest.mark.gpu
+
+
+@gpu
+def test_prepare_triplets_kernel_matches_the_references_own_pipeline(golden):
+    """The HIP input-stage kernel against the reference fixture g7_prepare.npz (see the CPU test above), bit for bit."""
+    from unopticalflow_amd import ops
+    g = golden('g7_prepare.npz')
+    hw = tuple(int(v) for v in g['img_hw'])
+    out = ops.prepare_triplets([g['img'], g['img']], hw, [False, True], 'cuda:0', src_is_rgb=False)
+    torch.cuda.synchronize()
+    for flip in (0, 1):
+        np.testing.assert_array_equal(out[flip].cpu().numpy(), g['out_flip%d' % flip])
 
 
 @gpu
