@@ -427,6 +427,19 @@ def gen_prepare():
         if len(seen) == 2:
             break
     assert len(seen) == 2
+    # the test-time loader: KITTI_2012.__getitem__ (kitti_2012.py:38-55: two frames read, stacked, preprocess_img_origin(is_test=True) --
+    # kitti_prepared.py:51-61,101-109 -- transpose, .float()) with ``cv2.imread`` serving the two decoded frames
+    sys.modules.setdefault('png', types.ModuleType('png'))
+    spec = importlib.util.spec_from_file_location('kitti_2012', '/root/reference/core/dataset/kitti_2012.py')
+    K12 = importlib.util.module_from_spec(spec)
+    sys.path.insert(0, '/root/reference/core/dataset')
+    spec.loader.exec_module(K12)
+    a, b = rng.integers(0, 256, (h, w, 3), dtype=np.uint8), rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    ds12 = K12.KITTI_2012('/data', img_hw=(h, w))
+    frames = {ds12.data_list[0]['img1_dir']: a, ds12.data_list[0]['img2_dir']: b}
+    K12.cv2.imread = lambda path, *args: np.copy(frames[path])
+    out['eval_img1'], out['eval_img2'] = a, b
+    out['eval_out'] = ds12[0].numpy()
     save('g7_prepare.npz', out)
 
 

@@ -60,6 +60,57 @@ def test_prepare_triplet_matches_the_references_own_pipeline(golden):
         np.testing.assert_array_equal(prepare_triplet(g['img'], hw, bool(flip)), g['out_flip%d' % flip])
 
 
+def test_product_host_resize_is_the_restated_opencv_arithmetic():
+    """unopticalflow_amd.data.resize_linear_u8 (the host-side twin of the kernel's resize: `--host_input 1` training, the KITTI evaluation loaders)
+    against the oracle's restatement of OpenCV's 8-bit INTER_LINEAR, bit for bit: KITTI's native sizes down to 256x832, up-scaling, odd sizes,
+    the exact-half reduction, the identity."""
+    from unopticalflow_amd.data import resize_linear_u8
+    rng = np.random.default_rng(17)
+    for (h, w), (H, W) in (((375, 1242), (256, 832)), ((370, 1224), (256, 832)), ((436, 1024), (448, 1024)), ((90, 300), (256, 832)),
+                           ((31, 57), (64, 64)), ((128, 192), (64, 96)), ((24, 40), (24, 40)), ((5, 7), (3, 2))):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        np.testing.assert_array_equal(resize_linear_u8(img, W, H), cv2_resize_linear_u8(img, W, H), err_msg='%dx%d -> %dx%d' % (h, w, H, W))
+    with pytest.raises(ValueError):
+        resize_linear_u8(np.zeros((4, 4, 3), np.float32), 2, 2)
+
+
+def test_host_input_path_and_eval_loader_match_the_reference(tmp_path, golden):
+    """The all-CPU input path (`data.PreparedTriplets`, train.py --host_input 1) and the evaluation loader (`evaluation.KITTI_2012`, test.py --task
+    kitti_flow) read PNG files and must hand the network what the reference's loaders do.  At native size against the reference's own output
+    (g7_prepare.npz: KITTI_Prepared / KITTI_2012 `__getitem__`, imported unmodified, cv2.imread serving the decoded frames), bit for bit; at
+    another size against the oracle (OpenCV's resize restated) -- the reference resizes the uint8 frame BEFORE the division by 255."""
+    from unopticalflow_amd.data import PreparedTriplets
+    from unopticalflow_amd.evaluation import KITTI_2012, write_png
+    g = golden('g7_prepare.npz')
+    hw = tuple(int(v) for v in g['img_hw'])
+    os.makedirs(tmp_path / 'seq')
+    write_png(str(tmp_path / 'seq' / '0.png'), np.ascontiguousarray(g['img'][:, :, ::-1]))        # the file holds RGB, cv2.imread hands out BGR
+    (tmp_path / 'train.txt').write_text('seq/0.png seq/0_cam.txt\n')
+    ds = PreparedTriplets(str(tmp_path), img_hw=hw)
+    seen = set()
+    for seed in range(64):
+        np.random.seed(seed)
+        flip = int(np.random.rand() > 0.5)
+        if flip in seen:
+            continue
+        seen.add(flip)
+        np.random.seed(seed)
+        np.testing.assert_array_equal(ds[0].numpy(), g['out_flip%d' % flip])
+    assert seen == {0, 1}
+    ds2 = PreparedTriplets(str(tmp_path), img_hw=(16, 36))                                        # another size: the restated resize
+    np.random.seed(3)
+    flip = bool(np.random.rand() > 0.5)
+    np.random.seed(3)
+    np.testing.assert_array_equal(ds2[0].numpy(), prepare_triplet(g['img'], (16, 36), flip))
+    os.makedirs(tmp_path / 'image_2')
+    write_png(str(tmp_path / 'image_2' / '000000_10.png'), np.ascontiguousarray(g['eval_img1'][:, :, ::-1]))
+    write_png(str(tmp_path / 'image_2' / '000000_11.png'), np.ascontiguousarray(g['eval_img2'][:, :, ::-1]))
+    np.testing.assert_array_equal(KITTI_2012(str(tmp_path), hw, 1)[0].numpy(), g['eval_out'])
+    got = KITTI_2012(str(tmp_path), (16, 36), 1)[0].numpy()
+    want = np.concatenate([cv2_resize_linear_u8(g['eval_img1'], 36, 16), cv2_resize_linear_u8(g['eval_img2'], 36, 16)], 0) / 255.0
+    np.testing.assert_array_equal(got, want.transpose(2, 0, 1).astype(np.float32))
+
+
 # ----------------------------------------------------------------------------------------------------------
 gpu = pytest.mark.gpu
 

@@ -3,8 +3,8 @@
 ``SyntheticTriplets`` generates batches on the device (bench / smoke / --synthetic training).
 ``PreparedTriplets`` reads the stacked-triplet PNGs + train.txt that the reference's
 ``KITTI_RAW.prepare_data_mp`` / ``SINTEL_RAW.prepare_data_mp`` write (kitti_prepared.py:10-42,133-153)
-with PIL instead of cv2 (resize to img_hw, random horizontal flip, /255, channel order BGR so the
-published checkpoints see what they were trained on), everything on the CPU like the reference.
+with PIL's decoder instead of cv2's (then OpenCV's 8-bit resize arithmetic restated in ``resize_linear_u8``, random horizontal flip, / 255,
+channel order BGR so the published checkpoints see what they were trained on), everything on the CPU like the reference.
 ``DecodedTriplets`` + ``DeviceTripletLoader`` are the MI355X input stage:
 the workers only decode the PNG; resize / flip / scaling / layout run on the GPU in
 ``unflow_prepare_triplets`` with OpenCV's 8-bit arithmetic, on a side stream one batch ahead of the step.
@@ -14,6 +14,41 @@ import os
 import numpy as np
 import torch
 import torch.utils.data
+
+
+def _linear_taps(dst_n, src_n, columns):
+    """Tap indices and 11-bit fixed-point coefficients of OpenCV's INTER_LINEAR for one axis (cv::resize, resize.cpp: half-pixel centres,
+    ``f = float((d + 0.5) * scale - 0.5)``; a column tap that leaves the row snaps to the border pixel with weight 1, a row tap is clamped
+    and keeps its fraction; coefficients ``short(rint(c * 2048))``)."""
+    scale = 1.0 / (float(dst_n) / float(src_n))
+    f = ((np.arange(dst_n, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    if columns:
+        lo, hi = s < 0, s >= src_n - 1
+        f = np.where(lo | hi, np.float32(0), f)
+        s = np.where(lo, 0, np.where(hi, src_n - 1, s))
+    i0, i1 = np.clip(s, 0, src_n - 1), np.clip(s + 1, 0, src_n - 1)
+    return i0, i1, np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64), np.rint(f * np.float32(2048)).astype(np.int64)
+
+
+def resize_linear_u8(img, W, H):
+    """``cv2.resize(img, (W, H))`` for a uint8 [h, w, C] image -- what the reference applies to every frame it loads (kitti_prepared.py:51-76,
+    kitti_2012.py:50-52): OpenCV's 8-bit INTER_LINEAR is integer arithmetic (horizontal pass in int32 with 11-bit coefficients, vertical pass
+    ``(((b0 (S0 >> 4)) >> 16) + ((b1 (S1 >> 4)) >> 16) + 2) >> 2``), and its uint8 result is what the network sees.  The host-side twin of
+    ``unflow_prepare_triplets``'s resize (csrc/prepare.hip); equal sizes are a copy."""
+    img = np.asarray(img)
+    if img.dtype != np.uint8 or img.ndim != 3:
+        raise ValueError('resize_linear_u8 takes a uint8 [h, w, C] image, got %s %s' % (img.dtype, img.shape))
+    h, w = img.shape[:2]
+    if (h, w) == (H, W):
+        return img.copy()
+    x0, x1, a0, a1 = _linear_taps(W, w, True)
+    y0, y1, b0, b1 = _linear_taps(H, h, False)
+    p = img.astype(np.int64)
+    rows = p[:, x0] * a0[None, :, None] + p[:, x1] * a1[None, :, None]
+    out = (((b0[:, None, None] * (rows[y0] >> 4)) >> 16) + ((b1[:, None, None] * (rows[y1] >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8)
 
 
 class SyntheticTriplets:
@@ -51,16 +86,14 @@ class PreparedTriplets(torch.utils.data.Dataset):
         from PIL import Image
         if self.num_iterations is not None:
             idx = self.rand_num(idx)
-        img = Image.open(self.files[idx]).convert('RGB')
-        w, h3 = img.size
-        h = h3 // 3
-        frames = [img.crop((0, k * h, w, (k + 1) * h)).resize((self.img_hw[1], self.img_hw[0]), Image.BILINEAR)
-                  for k in range(3)]
-        arr = np.concatenate([np.asarray(f) for f in frames], 0)[:, :, ::-1]     # RGB -> BGR (cv2 order)
-        if np.random.rand() > 0.5:
+        img = np.asarray(Image.open(self.files[idx]).convert('RGB'))[:, :, ::-1]     # RGB -> BGR (what cv2.imread hands the reference)
+        h = int(img.shape[0] / 3)                                                     # kitti_prepared.py:69
+        frames = [resize_linear_u8(img[k * h:(k + 1) * h], self.img_hw[1], self.img_hw[0]) for k in range(3)]
+        arr = np.concatenate(frames, 0)
+        if np.random.rand() > 0.5:                                                   # kitti_prepared.py:79-81
             arr = arr[:, ::-1]
-        arr = np.ascontiguousarray(arr.transpose(2, 0, 1)).astype(np.float32) / 255.0
-        return torch.from_numpy(arr)
+        arr = arr / 255.0                                                             # float64, then .float() (kitti_prepared.py:96,154)
+        return torch.from_numpy(np.ascontiguousarray(arr.transpose(2, 0, 1))).float()
 
 
 class DecodedTriplets(torch.utils.data.Dataset):

@@ -190,16 +190,21 @@ class KITTI_2012(torch.utils.data.Dataset):
         return self.num_total
 
     def _load(self, path):
+        """One frame as ``cv2.imread`` + ``cv2.resize`` leave it (kitti_2012.py:47-52 through kitti_prepared.py:51-61): uint8 BGR, resized with
+        OpenCV's 8-bit fixed-point INTER_LINEAR -- the reference resizes BEFORE it divides by 255, so the network sees quantised grey levels."""
+        from .data import resize_linear_u8
         img = read_png(path)
         if img.ndim == 2:
             img = np.repeat(img[:, :, None], 3, 2)
-        img = img[:, :, ::-1].astype(np.float64)                          # RGB file order -> BGR (cv2.imread)
-        return resize_bilinear(img, self.img_hw[1], self.img_hw[0]) / 255.0
+        if img.dtype != np.uint8:                                         # (a 16-bit frame: cv2.imread's default flag reads it as 8 bits)
+            img = (img >> 8).astype(np.uint8)
+        return resize_linear_u8(np.ascontiguousarray(img[:, :, ::-1]), self.img_hw[1], self.img_hw[0])      # RGB file order -> BGR
 
     def __getitem__(self, idx):
         a = self._load(os.path.join(self.data_dir, 'image_2', str(idx).zfill(6) + '_10.png'))
         b = self._load(os.path.join(self.data_dir, 'image_2', str(idx).zfill(6) + '_11.png'))
-        return torch.from_numpy(np.concatenate([a, b], 0).transpose(2, 0, 1)).float()
+        img = np.concatenate([a, b], 0) / 255.0                           # float64 (kitti_prepared.py:107), then .float() (kitti_2012.py:55)
+        return torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1))).float()
 
 
 class KITTI_2015(KITTI_2012):
