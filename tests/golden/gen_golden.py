@@ -443,7 +443,31 @@ def gen_prepare():
     save('g7_prepare.npz', out)
 
 
+def gen_config():
+    """The reference's hyper-parameter files and its loss weighting: config/kitti.yaml and config/sintel.yaml as yaml reads them (minus machine
+    paths) and what core/config/config_utils.py:3-9 ``generate_loss_weights_dict`` (imported unmodified) makes of them -- a JSON file, since these
+    are names and scalars."""
+    import importlib.util
+    import json
+    import yaml
+    spec = importlib.util.spec_from_file_location('config_utils', '/root/reference/core/config/config_utils.py')
+    CU = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(CU)
+    doc = {}
+    for name in ('kitti', 'sintel'):
+        cfg = yaml.safe_load(open('/root/reference/config/%s.yaml' % name))
+        keep = {k: v for k, v in cfg.items() if not (isinstance(v, str) and v.startswith('/'))}
+        doc[name] = {'yaml': keep, 'loss_weights': CU.generate_loss_weights_dict(types.SimpleNamespace(**cfg))}
+    path = os.path.join(HERE, 'g8_config.json')
+    with open(path, 'w') as f:
+        json.dump(doc, f, indent=1, sort_keys=True)
+    print('%-22s %8.1f KB' % ('g8_config.json', os.path.getsize(path) / 1024))
+
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['config']:
+        gen_config()
+        sys.exit(0)
     if sys.argv[1:] == ['prepare']:
         gen_prepare()
         sys.exit(0)
@@ -466,3 +490,4 @@ if __name__ == '__main__':
     gen_module('g3_kitti_256x832.npz', 1, 256, 832, steps=1, full_flows=False, mask_flow_scales=(1, 2, 3))
     gen_eval()
     gen_prepare()
+    gen_config()

@@ -124,6 +124,31 @@ def test_total_loss_off_the_gpu_is_the_reference_formula():
     torch.testing.assert_close(tr.total_loss(pack), want, rtol=1e-6, atol=0)
 
 
+def test_configs_and_loss_weights_are_the_references():
+    """tests/golden/g8_config.json: the reference's config/kitti.yaml and config/sintel.yaml as yaml reads them and what its own
+    generate_loss_weights_dict (core/config/config_utils.py:3-9, imported unmodified by gen_golden.py) makes of them.  The package's yaml files carry
+    the same value under every key they share (the flow stage's keys; machine paths aside), and the package's and the oracle's weighting give the
+    reference's four numbers bit for bit (train.py:147-150 multiplies the batch means by exactly these)."""
+    import json
+    import types
+    import yaml
+    from oracle import ref_cpu as R
+    from unopticalflow_amd import generate_loss_weights_dict
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = json.load(open(os.path.join(root, 'tests', 'golden', 'g8_config.json')))
+    for name in ('kitti', 'sintel'):
+        ours = yaml.safe_load(open(os.path.join(root, 'unopticalflow_amd', 'config', name + '.yaml')))
+        ref = doc[name]['yaml']
+        shared = [k for k in ours if k in ref]
+        assert {'dataset', 'img_hw', 'num_scales', 'num_iterations', 'w_ssim', 'w_flow_smooth', 'w_flow_consis', 'h_flow_consist_alpha',
+                'h_flow_consist_beta'} <= set(shared), (name, shared)
+        for k in shared:
+            assert ours[k] == ref[k], (name, k, ours[k], ref[k])
+        cfg = types.SimpleNamespace(**ours)
+        assert generate_loss_weights_dict(cfg) == doc[name]['loss_weights'] == R.generate_loss_weights_dict(cfg)
+        assert list(generate_loss_weights_dict(cfg)) == ['loss_pixel', 'loss_ssim', 'loss_flow_smooth', 'loss_flow_consis']      # (insertion order: the loss pack's)
+
+
 def test_weight_shadow_groups_split_the_cast_nodes():
     """WeightShadows(groups=k): k cast nodes over consecutive convolutions, so the eager data-parallel step's all-reduce pieces do
     not all wait for the end of backward; same values and gradients as one node."""
