@@ -157,7 +157,7 @@ def train(cfg):
                                     'package: run the reference\'s prepare_data_mp once, or use --synthetic)'.format(data_dir))
         ds = (PreparedTriplets if cfg.host_input else DecodedTriplets)(data_dir, cfg.num_scales, cfg.img_hw, n_items)
         sampler = torch.utils.data.distributed.DistributedSampler(ds, world, rank, shuffle=True) if world > 1 else None
-        if cfg.host_input:                                             # the reference's all-CPU pipeline (PIL resize)
+        if cfg.host_input:                                             # the reference's all-CPU pipeline (PIL decode, OpenCV's 8-bit resize restated: data.resize_linear_u8)
             loader = torch.utils.data.DataLoader(ds, batch_size=per_rank, shuffle=(sampler is None), sampler=sampler,
                                                  num_workers=cfg.num_workers, drop_last=False, pin_memory=True)
             batches = (b.to(dev, non_blocking=True) for b in loader)
