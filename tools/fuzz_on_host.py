@@ -1,7 +1,7 @@
 """Randomised shapes through the operators that have not run on a GPU yet, on the build host -- TEST INFRASTRUCTURE (oracle + host-executed
 kernel library: tests/hostexec.py; nothing of the product imports this).
 
-    python tools/fuzz_on_host.py [--minutes M] [--seed S] [--what ms,warp,mfma,corr,fused]
+    python tools/fuzz_on_host.py [--minutes M] [--seed S] [--what ms,warp,mfma,corr,fused,smallrows]
 
 For M minutes draws shapes and checks, over the product's own autograd wrappers (ops.py) and the REAL kernel sources executed with lanes as
 fibers:
@@ -12,6 +12,7 @@ fibers:
          corr_naive at the GPU test's bar, at shapes the dispatch serves (W % 4 == 0, C % 16 == 0, >= 8192 pixels, H >= 4 d), d = 4 and 8
   corr   the fp32 cost volume through its dispatch at random shapes (any W, C), d in {1, 2, 4, 8}, against the oracle at the GPU tests' bars
   fused  ops.warp_corr (the fused warp + cost volume, W % 4 == 0) against corr_naive(f1, warp_flow(f2, flow)) forward and backward, five flow kinds
+  smallrows  round 6's small-map cost-volume backward (ops.corr(..., backward='fp32_next'), csrc/corr_small_rows.h) against the oracle, maps of <= 1024 pixels
 Under AddressSanitizer + UBSan (every global and LDS access of every lane, random shapes): build the host library instrumented into a directory
 of its own and preload the runtime --
     export UNFLOW_HOSTEXEC_DIR=/tmp/hxasan UNFLOW_HOSTEXEC_FLAGS="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined -shared-libsan"
@@ -146,6 +147,19 @@ def fuzz_mfma(rng):
     return draw, _corr_against_oracle(rng, d, B, C, h, w, 'mfma', 1e-4, lambda amax: 1e-5 * amax)
 
 
+def fuzz_smallrows(rng):
+    """round 6: the small-map cost-volume backward with the gradient rows through registers (backward='fp32_next', csrc/corr_small_rows.h): maps of
+    <= 1024 pixels, any channel count, d = 4 and 8 -- pixel blocks, channel phases, ragged chunks and dead lanes as the draw has them."""
+    d = 8 if rng.random() < 0.6 else 4
+    h = int(rng.integers(1, 33))
+    w = int(rng.integers(1, max(2, min(96, 1024 // h) + 1)))
+    C = int(rng.integers(1, 70))
+    B = int(rng.integers(1, 4))
+    draw = 'smallrows d=%d [%d,%d,%d,%d]' % (d, B, C, h, w)
+    return draw, _corr_against_oracle(rng, d, B, C, h, w, 'fp32_next', 1e-4 if d == 8 else 1e-5,
+                                      lambda amax: max(5e-6, (1e-5 if d == 8 else 1e-6) * max(amax, 1.0 if d == 8 else 0.0)))
+
+
 def fuzz_corr(rng):
     d = (1, 2, 4, 4, 4, 8)[int(rng.integers(0, 6))]
     C = int(rng.integers(1, 40))
@@ -193,7 +207,7 @@ def main():
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--what', default='ms,warp,mfma,corr,fused')
     a = ap.parse_args()
-    fns = {'ms': fuzz_ms, 'warp': fuzz_warp, 'mfma': fuzz_mfma, 'corr': fuzz_corr, 'fused': fuzz_fused}
+    fns = {'ms': fuzz_ms, 'warp': fuzz_warp, 'mfma': fuzz_mfma, 'corr': fuzz_corr, 'fused': fuzz_fused, 'smallrows': fuzz_smallrows}
     which = [fns[k] for k in a.what.split(',')]
     t_end = time.time() + 60 * a.minutes
     runs, fails, k = {f.__name__: 0 for f in which}, 0, 0
