@@ -13,6 +13,7 @@ import torch
 from oracle import ref_cpu as R
 from test_hip_ops import T, close, dev, ops, rnd, _structured_flow, UNVALIDATED      # noqa: F401  (``ops`` is the module-scoped fixture)
 from test_hip_ops import test_corr_backward_on_the_matrix_cores as _matrix_core_backward_case
+from test_hip_ops import test_corr_small_map_backward as _small_map_case, test_corr_d8_full_pyramid as _d8_pyramid_case
 from oracle_cache import corr_case
 
 pytestmark = [pytest.mark.gpu]
@@ -411,3 +412,19 @@ def test_loss_section_against_the_reference_fixture(ops, golden, monkeypatch, re
         got = fl[s].grad.detach().cpu().double().numpy()
         assert float(np.abs(got - truth[s]).max()) <= allowance, (s, float(np.abs(got - truth[s]).max()) / big, allowance / big)
     assert fl[3].grad is None
+
+
+@UNVALIDATED
+@own_process
+@pytest.mark.parametrize('d,B,C,h,w', [(4, 16, 128, 8, 26), (4, 16, 196, 4, 13), (4, 3, 5, 7, 11), (4, 1, 2, 30, 34), (4, 2, 1, 3, 3), (4, 4, 128, 14, 32),
+                                       (8, 2, 128, 8, 26), (8, 2, 196, 4, 13)])
+def test_corr_small_map_backward_rows_through_registers(ops, request, d, B, C, h, w):
+    """Round 6, csrc/corr_small_rows.h (``ops.corr(..., backward='fp32_next')``: maps of <= 1024 pixels at any radius -- levels 5 / 6 at d = 8 ran one
+    lane per output element): the bodies and bars of test_corr_small_map_backward (d = 4) and test_corr_d8_full_pyramid (d = 8) of
+    tests/test_hip_ops.py with that arithmetic, in a process of its own -- the kernel has been executed on the build host only."""
+    if _ran_in_a_child(request):
+        return
+    if d == 4:
+        _small_map_case(ops, B, C, h, w, backward='fp32_next')
+    else:
+        _d8_pyramid_case(ops, C, h, w, 'fp32_next')

@@ -127,7 +127,7 @@ PY
     ;;
   smallrows)
     timeout 300 python3 tools/microbench.py corr_small 2>&1 | tee $out/corr_small_microbench.txt | tail -20
-    timeout 600 python3 -m pytest tests/test_hip_ops.py -q -m gpu --runxfail -p no:cacheprovider -k "fp32_next" > $out/smallrows_tests.log 2>&1; echo "fp32_next tests rc=$?"; tail -4 $out/smallrows_tests.log
+    timeout 600 python3 -m pytest tests/test_zz_round5_gpu.py -q -m gpu --runxfail -p no:cacheprovider -k "rows_through_registers" > $out/smallrows_tests.log 2>&1; echo "fp32_next tests rc=$?"; tail -4 $out/smallrows_tests.log
     python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --corr-bwd fp32_next > $out/ab_corr_bwd_fp32_next.json 2>> $out/ab.err
     line $out/ab_corr_bwd_fp32_next.json ;;
   fused_levels)
