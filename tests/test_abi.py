@@ -91,16 +91,17 @@ def test_get_model_unknown_mode():
 def test_dma_ring_kernels_do_not_spill():
     """The LDS-DMA ring kernels wait with counted s_waitcnt vmcnt(N); scratch (spill) traffic shares that
     counter, so a spilling build would under-wait.  Guard: those kernels must compile without scratch."""
-    import subprocess
+    import sys
     from unopticalflow_amd import build as b
-    src = os.path.join(b.CSRC, 'corr.hip')
-    flags = [f for f in b.FLAGS if f not in ('-shared', '-fPIC')]
-    out = subprocess.run([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), *flags, '--cuda-device-only', '-c', src,
-                          '-o', os.devnull, '-Rpass-analysis=kernel-resource-usage'],
-                         capture_output=True, text=True).stderr
-    names = re.findall(r'Function Name: (\S+)', out)
-    scratch = [int(x) for x in re.findall(r'ScratchSize \[bytes/lane\]: (\d+)', out)]
-    assert len(names) == len(scratch) and names
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    try:
+        import isa_hashes
+    finally:
+        sys.path.pop(0)
+    # (the build's flags, one compile per file and process: shared with the instruction-stream hashes of the tests below)
+    table = isa_hashes.isa_scratch(os.path.join(b.CSRC, 'corr.hip'))
+    names, scratch = list(table), list(table.values())
+    assert names
     checked = 0
     for n, s in zip(names, scratch):
         if 'ring_kernel' in n or 'ring_mixed_kernel' in n or 'gs_kernel' in n or 'rs_kernel' in n or 'rs_mixed_kernel' in n or 'mf_kernel' in n:      # (row-streamed backward: counted vmcnt behind its LDS-DMA too; matrix-core backward: two request sets in flight)

@@ -57,6 +57,22 @@ def kernel_streams(asm_text):
 
 
 _STREAMS = {}
+_SCRATCH = {}
+
+
+def kernel_scratch(asm_text):
+    """{mangled kernel name: scratch bytes per lane} from the `; Kernel info:` comment blocks of the same listing (`; ScratchSize: N`)."""
+    out, cur = {}, None
+    for line in asm_text.splitlines():
+        m = re.match(r'^(_Z\S+):', line)
+        if m:
+            cur = m.group(1)
+            continue
+        m = re.match(r'^; ScratchSize: (\d+)', line)
+        if m and cur is not None:
+            out[cur] = int(m.group(1))
+            cur = None
+    return out
 
 
 def isa_streams(src, hipcc=HIPCC, extra=()):
@@ -69,8 +85,16 @@ def isa_streams(src, hipcc=HIPCC, extra=()):
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(r.stderr[-2000:])
-            _STREAMS[key] = kernel_streams(open(asm).read())
+            text = open(asm).read()
+            _STREAMS[key] = kernel_streams(text)
+            _SCRATCH[key] = kernel_scratch(text)
     return _STREAMS[key]
+
+
+def isa_scratch(src, hipcc=HIPCC, extra=()):
+    """{mangled kernel name: scratch bytes per lane} of one source file, from the same (cached) compile as isa_streams()."""
+    isa_streams(src, hipcc, extra)
+    return _SCRATCH[(os.path.abspath(src), os.path.getmtime(src), tuple(extra))]
 
 
 def isa_hashes(src, hipcc=HIPCC, extra=()):
